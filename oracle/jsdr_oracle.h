@@ -1,0 +1,130 @@
+/*
+ * jsdr_oracle.h -- CPU oracle for the java-sdr FFT / FIR / BPSK-demod hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
+ * library.  The product (java-sdr_amd/csrc, libjsdr_hip.so) never links or calls it.
+ *
+ * Every function is a plain-C restatement of the reference's arithmetic with Java
+ * numeric semantics (IEEE double/float, no FMA contraction: build with
+ * -ffp-contract=off; (int) casts truncate; int arithmetic wraps).  Each cites the
+ * reference file:line it follows (paths relative to /root/reference).
+ *
+ * Parity pinning status:
+ *   - FECDecoder, FUNcubeBPSKDemod (tune mode), fir, phase, sample conversion:
+ *     pinned by the reference's own constant tables (digests in tests/golden) and by
+ *     the internal-consistency / round-trip KATs of SURVEY.md section 8c.
+ *   - Anything that crosses JTransforms 2.4 (FloatFFT_1D / DoubleFFT_1D, absent from
+ *     /root/reference): PARITY UNPINNED -- a radix-2 FFT stands in, checked against an
+ *     exact float64 DFT.
+ */
+#ifndef JSDR_ORACLE_H
+#define JSDR_ORACLE_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- JavaAudio.java:276-293 : int16 LE -> float, with I/Q DC correction ------- */
+void jo_convert_i16(const int16_t *raw, int nframes, int chns, int ic, int qc, float *out);
+
+/* ---- FFT stand-ins for JTransforms (third-party, absent) ------------------------ */
+/* in-place, interleaved re/im, n a power of two.  sign=-1 forward, +1 inverse
+ * (inverse optionally scaled by 1/n, as complexInverse(a,true)).                   */
+void jo_fft_f32(float *a, int n);
+void jo_fft_f64(double *a, int n, int inverse, int scale);
+/* twiddle table used by jo_fft_f64 (and uploaded verbatim to the GPU by tests that
+ * want bit-identical double FFTs): w[2k]=cos(2 pi k/n), w[2k+1]=-sin(2 pi k/n), k<n/2 */
+void jo_fft_twiddles_f64(double *w, int n);
+/* exact O(n^2) float64 DFT of float input (reference for the 1e-5 tolerance tests) */
+void jo_dft_exact(const float *in, int n, double *out);
+
+/* ---- fft.java:190-228 : receive() -> psd[n+2] ------------------------------------ */
+void jo_fft_receive(const float *buf, int n, int rate, float *psd);
+/* the PSD / argmax / Hz rule alone, applied to a given complex spectrum (float) */
+void jo_fft_psd_from_spectrum(const float *spec, int n, int rate, float *psd);
+
+/* ---- fir.java:169-228 --------------------------------------------------------- */
+typedef struct {
+    double wfir[21];
+    int    fir[21];
+    int    fof;
+} jo_fir_t;
+void jo_fir_init(jo_fir_t *f);                                   /* fir.java:30-32 */
+void jo_fir_weights(jo_fir_t *f, int f1, int f2, float sample_rate); /* :169-195 */
+int  jo_fir_filter(jo_fir_t *f, int in);                         /* :198-211 */
+void jo_fir_complex_gen(int sig[2], int wav[2], float sample_rate); /* :221-228 */
+void jo_fir_complex_mod(const int s1[2], const int s2[2], int out[2]); /* :214-218 */
+
+/* ---- phase.java:75-116 --------------------------------------------------------- */
+float jo_phase_maxabs(const float *dpy, int len);                /* :75-80 */
+/* column means: returns number of columns emitted; pix[c], avgi[c], avgq[c]      */
+int   jo_phase_columns(const float *dpy, int len, int bx, int *pix, float *avgi, float *avgq);
+
+/* ---- FECDecoder.java ----------------------------------------------------------- */
+int  jo_fec_decode(const uint8_t raw[5200], uint8_t out[256]);   /* :703-852 */
+void jo_fec_encode(const uint8_t data[256], uint8_t sym[5200]);  /* :538-688 (encode_FEC40) */
+/* table access for digest tests: which = "ALPHA_TO","INDEX_OF","Partab","Syms",
+ * "Scrambler","mettab","RS_poly".  returns element count, fills out (as int32)     */
+int  jo_fec_table(const char *which, int32_t *out, int cap);
+int  jo_viterbi27(uint8_t *data, const uint8_t *symbols, int nbits); /* :203-278 */
+int  jo_decode_rs_8(uint8_t *data, int *eras_pos, int no_eras);  /* :325-519 */
+
+/* ---- FUNcubeBPSKDemod.java ----------------------------------------------------- */
+typedef struct jo_bpsk jo_bpsk_t;
+jo_bpsk_t *jo_bpsk_new(int rate, int blen, int size, int tuning, int do_fft, int do_up);
+void jo_bpsk_free(jo_bpsk_t *d);
+void jo_bpsk_receive(jo_bpsk_t *d, const float *buf);            /* :357-364 */
+/* convenience: convert int16 (JavaAudio rule) frame by frame and receive()       */
+void jo_bpsk_receive_i16(jo_bpsk_t *d, const int16_t *raw, int nframes_total, int ic, int qc);
+/* counters: cntRaw,cntDS,cntBit,cntFEC,cntDec,dmErrBits,dmCorr,dmMaxCorr,decodeOK,centreBin */
+void jo_bpsk_counters(const jo_bpsk_t *d, int32_t out[10]);
+/* log of sliced bits (+1/-1) since creation; returns total count, copies up to cap */
+int64_t jo_bpsk_bits(const jo_bpsk_t *d, int8_t *out, int64_t cap);
+/* log of FECDecode calls: each entry = int32 rc, int64 bit index, 256 bytes       */
+int  jo_bpsk_fec_count(const jo_bpsk_t *d);
+int  jo_bpsk_fec_get(const jo_bpsk_t *d, int idx, int32_t *rc, int64_t *bitidx, uint8_t out[256]);
+void jo_bpsk_decoded(const jo_bpsk_t *d, uint8_t out[256]);
+/* optional trace of matched-filter outputs (fi,fq) at 9600 Hz: enable before receive */
+void jo_bpsk_trace_enable(jo_bpsk_t *d, int64_t cap_pairs);
+int64_t jo_bpsk_trace(const jo_bpsk_t *d, double *out, int64_t cap_pairs);
+/* optional trace of down-sampler outputs (after x HOWARD_FUDGE_FACTOR)           */
+int64_t jo_bpsk_trace_ds(const jo_bpsk_t *d, double *out, int64_t cap_pairs);
+/* scalar state snapshot (doubles): tuPhase,vcoPhase,dmBitPhase,dmEnergyOut,energy1,
+ * energy2,avePeakPower,aveCentreBin, dmEnergy[0..7], dmLastIQ[0..1]  (18 values)    */
+void jo_bpsk_state(const jo_bpsk_t *d, double out[18]);
+/* integer state: dsPos,dsCnt,dmPos,dmBitPos,dmPeakPos,dmNewPeak (6 values)          */
+void jo_bpsk_istate(const jo_bpsk_t *d, int32_t out[6]);
+/* filter taps (for digest tests): which=0 dsFilter[27], 1 dmFilter[130], 2 SYNC_VECTOR[65] (as doubles) */
+int  jo_bpsk_table(int which, double *out, int cap);
+/* sin/cos tables as built by the ctor (FUNcubeBPSKDemod.java:159-162)              */
+void jo_bpsk_sincos(double sin_tab[256], double cos_tab[256]);
+
+/* ---- synthetic signal generator (NOT from the reference; spec in DESIGN.md) ------ */
+/* Integer-only so that the HIP generator (jsdr_synth_*) is bit-identical.         */
+uint64_t jo_mix64(uint64_t z);
+void jo_synth_payload(uint64_t seed, int stream, int frame, uint8_t out[256]);
+/* differential sign sequence from symbols (1 = no phase change, 0 = reversal)     */
+void jo_synth_diffsign(const uint8_t *sym, int64_t nsym, int8_t *dsign, int8_t start);
+/* amplitude-scaled carrier tables: tab[k]=round(amp*cos(2 pi k/1024)), sin alike   */
+void jo_synth_tables(int amp, int16_t cos_tab[1024], int16_t sin_tab[1024]);
+/* n0 = global index of first sample; samples n0..n0+n-1 written interleaved I,Q   */
+void jo_synth_dbpsk(int16_t *out, int64_t n0, int64_t n, const int8_t *dsign, int64_t nsym,
+                    int samples_per_sym, uint32_t phase0, uint32_t phase_inc,
+                    const int16_t *cos_tab, const int16_t *sin_tab,
+                    int noise_gain, uint64_t noise_key);
+/* tones+noise frames for the FFT workload: up to 3 tones per frame chosen by hash  */
+void jo_synth_tones(int16_t *out, int64_t frame0, int64_t nframes, int n,
+                    const int16_t *cos_tab, int noise_gain, uint64_t key);
+
+/* ---- CPU baseline helpers (bench.py cpu_baseline leg) --------------------------- */
+/* run fft.receive restatement over nframes frames of n int16 IQ samples            */
+void jo_bench_fft(const int16_t *raw, int64_t nframes, int n, int rate, float *psd_last);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

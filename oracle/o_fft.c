@@ -1,0 +1,229 @@
+/*
+ * o_fft.c -- oracle: sample conversion, FFT stand-ins, fft.java receive().
+ * TEST INFRASTRUCTURE (see jsdr_oracle.h).  Build with -ffp-contract=off.
+ */
+#include "jsdr_oracle.h"
+#include <math.h>
+#include <float.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define JO_PI 3.14159265358979323846 /* == java.lang.Math.PI */
+
+/* JavaAudio.java:276-293.  `short s = cnv.getShort(); s += (short)m_ic;` wraps mod 2^16,
+ * then `(float)s/(float)Short.MAX_VALUE` is a float division.  Mono => Q = 0.        */
+void jo_convert_i16(const int16_t *raw, int nframes, int chns, int ic, int qc, float *out)
+{
+    const float fmax = (float)32767;
+    for (int f = 0; f < nframes; f++) {
+        int16_t s = raw[f * chns];
+        s = (int16_t)(s + (int16_t)ic);
+        out[2 * f] = (float)s / fmax;
+        if (chns > 1) {
+            s = raw[f * chns + 1];
+            s = (int16_t)(s + (int16_t)qc);
+            out[2 * f + 1] = (float)s / fmax;
+        } else {
+            out[2 * f + 1] = 0;
+        }
+    }
+}
+
+static unsigned bitrev(unsigned x, int bits)
+{
+    unsigned r = 0;
+    for (int i = 0; i < bits; i++) {
+        r = (r << 1) | (x & 1u);
+        x >>= 1;
+    }
+    return r;
+}
+
+static int ilog2(int n)
+{
+    int b = 0;
+    while ((1 << b) < n) b++;
+    return b;
+}
+
+void jo_fft_twiddles_f64(double *w, int n)
+{
+    for (int k = 0; k < n / 2; k++) {
+        double ang = 2.0 * JO_PI * (double)k / (double)n;
+        w[2 * k] = cos(ang);
+        w[2 * k + 1] = -sin(ang);
+    }
+    /* exact values on the axes so that trivial twiddles stay trivial */
+    w[0] = 1.0;
+    w[1] = -0.0;
+    if (n >= 4) {
+        w[2 * (n / 4)] = 0.0;
+        w[2 * (n / 4) + 1] = -1.0;
+    }
+}
+
+/* Stand-in for JTransforms DoubleFFT_1D.complexForward / complexInverse(a,true)
+ * (call sites FUNcubeBPSKDemod.java:422-423,459).  Radix-2 decimation in time:
+ * bit-reversal permutation, then log2(n) stages; butterfly
+ *     t = w*b  (tr = wr*br - wi*bi ; ti = wr*bi + wi*br, every product and sum rounded)
+ *     a' = a + t ; b' = a - t
+ * The HIP double FFT (csrc/bpsk_fft.hip) performs the same butterflies on the same
+ * twiddle table, so both are bit-identical.  PARITY UNPINNED vs JTransforms.          */
+void jo_fft_f64(double *a, int n, int inverse, int scale)
+{
+    int bits = ilog2(n);
+    double *w = (double *)malloc(sizeof(double) * (size_t)n);
+    jo_fft_twiddles_f64(w, n);
+    for (int i = 0; i < n; i++) {
+        int j = (int)bitrev((unsigned)i, bits);
+        if (j > i) {
+            double tr = a[2 * i], ti = a[2 * i + 1];
+            a[2 * i] = a[2 * j];
+            a[2 * i + 1] = a[2 * j + 1];
+            a[2 * j] = tr;
+            a[2 * j + 1] = ti;
+        }
+    }
+    for (int half = 1; half < n; half <<= 1) {
+        int step = n / (2 * half);
+        for (int base = 0; base < n; base += 2 * half) {
+            for (int j = 0; j < half; j++) {
+                double wr = w[2 * (j * step)];
+                double wi = w[2 * (j * step) + 1];
+                if (inverse) wi = -wi;
+                int ia = base + j, ib = base + j + half;
+                double br = a[2 * ib], bi = a[2 * ib + 1];
+                double p1 = wr * br, p2 = wi * bi, p3 = wr * bi, p4 = wi * br;
+                double tr = p1 - p2;
+                double ti = p3 + p4;
+                double ar = a[2 * ia], ai = a[2 * ia + 1];
+                a[2 * ia] = ar + tr;
+                a[2 * ia + 1] = ai + ti;
+                a[2 * ib] = ar - tr;
+                a[2 * ib + 1] = ai - ti;
+            }
+        }
+    }
+    if (inverse && scale) {
+        double norm = 1.0 / (double)n;
+        for (int i = 0; i < 2 * n; i++) a[i] *= norm;
+    }
+    free(w);
+}
+
+/* Stand-in for JTransforms FloatFFT_1D.complexForward (call site fft.java:194-195).
+ * Same radix-2 network in float; twiddles rounded from double.  PARITY UNPINNED.    */
+void jo_fft_f32(float *a, int n)
+{
+    int bits = ilog2(n);
+    float *w = (float *)malloc(sizeof(float) * (size_t)n);
+    for (int k = 0; k < n / 2; k++) {
+        double ang = 2.0 * JO_PI * (double)k / (double)n;
+        w[2 * k] = (float)cos(ang);
+        w[2 * k + 1] = (float)(-sin(ang));
+    }
+    for (int i = 0; i < n; i++) {
+        int j = (int)bitrev((unsigned)i, bits);
+        if (j > i) {
+            float tr = a[2 * i], ti = a[2 * i + 1];
+            a[2 * i] = a[2 * j];
+            a[2 * i + 1] = a[2 * j + 1];
+            a[2 * j] = tr;
+            a[2 * j + 1] = ti;
+        }
+    }
+    for (int half = 1; half < n; half <<= 1) {
+        int step = n / (2 * half);
+        for (int base = 0; base < n; base += 2 * half) {
+            for (int j = 0; j < half; j++) {
+                float wr = w[2 * (j * step)], wi = w[2 * (j * step) + 1];
+                int ia = base + j, ib = base + j + half;
+                float br = a[2 * ib], bi = a[2 * ib + 1];
+                float tr = wr * br - wi * bi;
+                float ti = wr * bi + wi * br;
+                float ar = a[2 * ia], ai = a[2 * ia + 1];
+                a[2 * ia] = ar + tr;
+                a[2 * ia + 1] = ai + ti;
+                a[2 * ib] = ar - tr;
+                a[2 * ib + 1] = ai - ti;
+            }
+        }
+    }
+    free(w);
+}
+
+/* exact reference DFT, X[k] = sum x[t] e^{-2 pi i k t / n}, accumulated in long double */
+void jo_dft_exact(const float *in, int n, double *out)
+{
+    long double *c = (long double *)malloc(sizeof(long double) * (size_t)n);
+    long double *s = (long double *)malloc(sizeof(long double) * (size_t)n);
+    for (int k = 0; k < n; k++) {
+        long double ang = 2.0L * 3.14159265358979323846264338327950288L * (long double)k / (long double)n;
+        c[k] = cosl(ang);
+        s[k] = sinl(ang);
+    }
+    for (int k = 0; k < n; k++) {
+        long double re = 0, im = 0;
+        for (int t = 0; t < n; t++) {
+            int idx = (int)(((long long)k * t) % n);
+            long double xr = in[2 * t], xi = in[2 * t + 1];
+            /* (xr + i xi)(c - i s) */
+            re += xr * c[idx] + xi * s[idx];
+            im += xi * c[idx] - xr * s[idx];
+        }
+        out[2 * k] = (double)re;
+        out[2 * k + 1] = (double)im;
+    }
+    free(c);
+    free(s);
+}
+
+/* fft.java:196-224 -- PSD in dBFS, first strictly-greater maximum, bin -> Hz in Java int
+ * arithmetic (wrapping multiply, truncating divide).                                  */
+void jo_fft_psd_from_spectrum(const float *dat, int n, int rate, float *psd)
+{
+    int datlen = 2 * n;
+    float cf = 2.0f / (float)(datlen / 2);
+    cf = cf * cf;
+    float m = -FLT_MAX;
+    int p = -1;
+    for (int s = 0; s < datlen - 1; s += 2) {
+        float pw = ((dat[s] * dat[s]) + (dat[s + 1] * dat[s + 1])) * cf;
+        psd[s / 2] = 10.0f * (float)log10((double)pw);
+        if (m < psd[s / 2]) {
+            m = psd[s / 2];
+            p = s;
+        }
+    }
+    if (p < datlen / 2) {
+        p = (int32_t)((uint32_t)p * (uint32_t)rate) / datlen;
+    } else {
+        p -= datlen;
+        p = (int32_t)((uint32_t)p * (uint32_t)rate) / datlen;
+    }
+    psd[n] = (float)p;
+    psd[n + 1] = m;
+}
+
+/* fft.java:190-228 receive(): copy, complex forward FFT, PSD rule.                 */
+void jo_fft_receive(const float *buf, int n, int rate, float *psd)
+{
+    float *dat = (float *)malloc(sizeof(float) * 2 * (size_t)n);
+    memcpy(dat, buf, sizeof(float) * 2 * (size_t)n);
+    jo_fft_f32(dat, n);
+    jo_fft_psd_from_spectrum(dat, n, rate, psd);
+    free(dat);
+}
+
+void jo_bench_fft(const int16_t *raw, int64_t nframes, int n, int rate, float *psd_last)
+{
+    float *buf = (float *)malloc(sizeof(float) * 2 * (size_t)n);
+    float *psd = (float *)malloc(sizeof(float) * ((size_t)n + 2));
+    for (int64_t f = 0; f < nframes; f++) {
+        jo_convert_i16(raw + f * 2 * n, n, 2, 0, 0, buf);
+        jo_fft_receive(buf, n, rate, psd);
+    }
+    if (psd_last) memcpy(psd_last, psd, sizeof(float) * ((size_t)n + 2));
+    free(buf);
+    free(psd);
+}

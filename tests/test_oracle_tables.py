@@ -1,0 +1,90 @@
+"""Pin the oracle's constant tables to the reference's literal tables (by digest) and check
+the internal-consistency KATs of SURVEY.md section 8c."""
+import hashlib
+import json
+import os
+import struct
+
+import numpy as np
+
+import oracle_lib as O
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "table_digests.json")))
+
+
+def dig_ints(vals):
+    return hashlib.sha256(b"".join(struct.pack("<i", int(v)) for v in vals)).hexdigest()
+
+
+def dig_f64(vals):
+    return hashlib.sha256(b"".join(struct.pack("<d", float(v)) for v in vals)).hexdigest()
+
+
+def test_fec_tables_match_reference_digests():
+    for name in ["ALPHA_TO", "INDEX_OF", "Partab", "Syms", "Scrambler", "RS_poly", "mettab"]:
+        t = O.fec_table(name)
+        assert t.size == GOLD[name]["n"], name
+        assert dig_ints(t) == GOLD[name]["sha256"], name
+
+
+def test_filter_tables_match_reference_digests():
+    ds = O.bpsk_table(0)
+    dm = O.bpsk_table(1)
+    sv = O.bpsk_table(2)
+    assert ds.size == 27 and dm.size == 130 and sv.size == 65
+    assert dig_f64(ds) == GOLD["dsFilter"]["sha256"]
+    assert dig_f64(dm) == GOLD["dmFilter"]["sha256"]
+    assert dig_ints(sv.astype(np.int32)) == GOLD["SYNC_VECTOR"]["sha256"]
+
+
+def test_kat_gf256_tables():
+    a = O.fec_table("ALPHA_TO")
+    idx = O.fec_table("INDEX_OF")
+    x = 1
+    for i in range(255):
+        assert a[i] == x
+        assert idx[x] == i
+        x <<= 1
+        if x & 0x100:
+            x ^= 0x187
+    assert a[255] == 0 and idx[0] == 255
+
+
+def test_kat_partab_syms_scrambler():
+    p = O.fec_table("Partab")
+    assert all(p[i] == bin(i).count("1") % 2 for i in range(256))
+    s = O.fec_table("Syms")
+    for i in range(128):
+        assert s[i] == (p[i & 0x4F] << 1) | (1 - p[i & 0x6D])
+    sc = O.fec_table("Scrambler")
+    assert list(sc[:5]) == [0xFF, 0x48, 0x0E, 0xC0, 0x9A]
+    assert np.array_equal(sc[:65], sc[255:320])
+
+
+def test_kat_mettab_irregular_entries():
+    m = O.fec_table("mettab").reshape(2, 256)
+    assert m[1][2] == -338 and m[0][253] == -337
+    assert m[1][8] == -321 and m[0][247] == -320
+    mirror = m[0][::-1].copy()
+    diff = np.nonzero(mirror != m[1])[0]
+    assert list(diff) == [2, 8]
+
+
+def test_kat_filters():
+    ds = O.bpsk_table(0)
+    dm = O.bpsk_table(1)
+    assert np.array_equal(ds, ds[::-1])
+    assert np.array_equal(dm[:65], dm[65:])
+    assert np.array_equal(dm[:65], dm[:65][::-1])
+    assert np.all(ds == ds.astype(np.float32).astype(np.float64))
+    assert np.all(dm == dm.astype(np.float32).astype(np.float64))
+    assert abs(ds.sum() - 1.000366) < 1e-6
+    assert abs(dm[:65].sum() - 8.003885) < 1e-6
+    assert abs(dm[32] - 1.1366118) < 1e-7
+
+
+def test_fixture_files_intact(golden_dir):
+    for fn in ["sine4410.raw", "sine4410-short.raw"]:
+        data = open(os.path.join(golden_dir, fn), "rb").read()
+        assert len(data) == GOLD[fn]["n"]
+        assert hashlib.md5(data).hexdigest() == GOLD[fn]["md5"]
