@@ -1,0 +1,266 @@
+#!/usr/bin/env python3
+"""bench.py -- IQ Msamples/s through FFT + FIR + BPSK demod on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W [--workload pipeline|fft|bpsk] [--streams S] [--samples L]
+
+One STEP = one pass of the hot path over one HBM-resident batch of synthetic input:
+    S streams x L int16 IQ samples (96 kHz FUNcube-style DBPSK carrying valid FEC frames, generated on
+    the device) -> fft.java waterfall PSD of every 2048-sample frame  +  FUNcubeBPSKDemod (tuner, 27-tap
+    /10, VCO, 65-tap matched filter, slicer, sync correlation) + FECDecoder of every synchronised frame.
+N > 1: one rank per GPU (torch.distributed, backend nccl == RCCL), streams are sharded S per rank (weak
+scaling: BASELINE config 5 is 8 x 1024 streams), and every step ends with one all-gather of the fixed-size
+per-stream result slots over xGMI.  value = samples processed by all ranks / max-over-ranks time.
+
+The JSON line also carries
+    roofline     : dominant kernel (HIP events recorded on the launch stream inside the timed region)
+    cpu_baseline : the plain-C oracle (oracle/, a restatement of the Java arithmetic: kind "port") on the
+                   host cores, bounded sample, rank 0 at N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# algorithmic HBM bytes per IQ sample: 4 B int16 pair read; fft writes 4 B psd (+8 B/frame);
+# the demodulator writes ~0.0125 B of bits
+BYTES_PER_SAMPLE = {"fft": 4.0 + 4.0 * 2050.0 / 2048.0, "bpsk": 4.0125, "pipeline": 4.0 + 4.0 * 2050.0 / 2048.0 + 0.0125}
+N_FFT = 2048
+RATE = 96000
+SEED = 20020109
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="pipeline", choices=["pipeline", "fft", "bpsk"])
+    ap.add_argument("--streams", type=int, default=1024, help="streams per GPU")
+    ap.add_argument("--samples", type=int, default=1048576, help="IQ samples per stream per step")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-validate", action="store_true")
+    return ap.parse_args()
+
+
+def make_inputs(J, O, S, L, stream0):
+    """DBPSK streams stream0..stream0+S-1 on the device; returns (d_iq, payloads_dev, nframes)"""
+    sps = RATE // 1200
+    nfr = -(-L // (5200 * sps)) + 1
+    pay = J.synth_payloads(SEED, stream0, S, nfr)
+    d_sym = J.DeviceBuffer(S * nfr * 5200)
+    if J.lib().jsdr_fec_encode_batch(pay.ptr, S * nfr, d_sym.ptr, None) != 0:
+        raise RuntimeError(J.lib().jsdr_last_error())
+    d_ds = J.DeviceBuffer(S * nfr * 5200)
+    J.synth_diffsign(d_sym, nfr * 5200, S, d_ds)
+    ct, st = O.synth_tables(3000)
+    keys = np.array([O.mix64((SEED * 0x9E3779B1 + stream0 + s) ^ 0xA5A5A5A5) for s in range(S)], np.uint64)
+    d_iq = J.DeviceBuffer(S * L * 4)
+    gain = int(round(1500.0 / 37837.0 * 32768.0))
+    J.synth_dbpsk(d_iq, 2 * L, S, 0, L, d_ds, nfr * 5200, sps, 0, O.phase_inc_u32(13200.0, RATE),
+                  J.DeviceBuffer.from_host(ct), J.DeviceBuffer.from_host(st), gain, J.DeviceBuffer.from_host(keys))
+    J.binding.stream_sync(None)
+    return d_iq, pay, nfr
+
+
+def cpu_baseline(O, workload, L, seconds):
+    """the oracle on the host cores: one stream per thread (ctypes releases the GIL), repeated until
+    ~`seconds` of wall time; same signal family, same frame size."""
+    cores = os.cpu_count() or 1
+    Lc = min(L, 1048576)
+    streams = [O.make_dbpsk_stream(SEED, s, Lc)[0] for s in range(cores)]
+    nframes = Lc // N_FFT
+    psd = np.empty(N_FFT + 2, np.float32)
+
+    def one_pass(s, dem):
+        if workload in ("pipeline", "fft"):
+            O.lib().jo_bench_fft(streams[s].ctypes.data, nframes, N_FFT, RATE, psd.ctypes.data if s == 0 else None)
+        if workload in ("pipeline", "bpsk"):
+            dem.receive_i16(streams[s])
+
+    # calibrate on one thread
+    dem0 = O.Bpsk()
+    t0 = time.perf_counter()
+    one_pass(0, dem0)
+    t1 = time.perf_counter() - t0
+    reps = max(1, int(seconds / max(t1, 1e-3)))
+    dems = [O.Bpsk() for _ in range(cores)]
+
+    def worker(s):
+        for _ in range(reps):
+            one_pass(s, dems[s])
+
+    th = [threading.Thread(target=worker, args=(s,)) for s in range(cores)]
+    t0 = time.perf_counter()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    dt = time.perf_counter() - t0
+    total = cores * reps * Lc
+    return {"value": round(total / dt / 1e6, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "sample": f"{cores} streams x {reps} passes x {Lc} samples ({workload}), 1 thread/stream, "
+                      f"{dt:.1f} s wall; single-thread {Lc / t1 / 1e6:.2f} Msamples/s"}
+
+
+def main():
+    a = parse()
+    N = a.gpus
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    torch = None
+    if N > 1:
+        if world != N:
+            raise SystemExit(f"--gpus {N} needs WORLD_SIZE={N} (launch with torch.distributed.run); got {world}")
+        import torch  # noqa: F811  (first, so libjsdr_hip.so binds to the same HIP runtime)
+        import torch.distributed as dist  # noqa: F811
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    import java_sdr_amd as J
+    import oracle_lib as O  # input tables + cpu_baseline leg only
+
+    if not J.have_gpu():
+        raise SystemExit("bench.py: no HIP device (libjsdr_hip.so has no CPU fallback)")
+    if J.lib().jsdr_set_device(local_rank if N > 1 else 0) != 0:
+        raise SystemExit(J.lib().jsdr_last_error())
+
+    S, L = a.streams, a.samples
+    if L % N_FFT:
+        raise SystemExit("--samples must be a multiple of 2048")
+    d_iq, pay, nfr = make_inputs(J, O, S, L, rank * S)
+    nframes = S * L // N_FFT
+    fft = J.Fft(N_FFT, RATE) if a.workload in ("pipeline", "fft") else None
+    d_psd = J.DeviceBuffer(nframes * (N_FFT + 2) * 4) if fft else None
+    dem = J.Bpsk(rate=RATE, blen=4 * N_FFT, tuning=12000, nstreams=S, max_batch_samples=L) \
+        if a.workload in ("pipeline", "bpsk") else None
+    slots = gathered = None
+    if dem is not None and N > 1:
+        info = dem.slot_info()
+        slots = torch.empty(S * info["slot_bytes"], dtype=torch.uint8, device="cuda")
+        gathered = torch.empty(N * S * info["slot_bytes"], dtype=torch.uint8, device="cuda")
+
+    fft_timer = [J.Timer() for _ in range(a.steps)] if fft else []
+
+    def step(i, timed):
+        if fft is not None:
+            if timed:
+                fft_timer[i].start(None)
+            fft.batch_i16(d_iq, nframes, d_psd)
+            if timed:
+                fft_timer[i].stop(None)
+        if dem is not None:
+            dem.batch_i16(d_iq, 2 * L, L)
+            if N > 1:
+                dem.pack_slots(slots.data_ptr())
+                dist.all_gather_into_tensor(gathered, slots)
+
+    def sync():
+        if N > 1:
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+        else:
+            J.binding.stream_sync(None)
+
+    for i in range(a.warmup):
+        step(i, False)
+    sync()
+    if dem is not None:
+        dem.profile_read()
+        dem.profile_enable(True)
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(i, True)
+    sync()
+    dt = time.perf_counter() - t0
+    if dem is not None:
+        dem.profile_enable(False)
+    if N > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    # ---- per-kernel durations measured inside the timed region
+    kern = {}
+    if fft is not None:
+        ms = [t.elapsed_ms() for t in fft_timer]
+        kern["k_fft"] = (float(np.sum(ms)), len(ms), BYTES_PER_SAMPLE["fft"])
+    if dem is not None:
+        for name, (ms, cnt) in dem.profile_read().items():
+            if cnt:
+                kern[name] = (ms, cnt, BYTES_PER_SAMPLE["bpsk"])
+    dom = max(kern, key=lambda k: kern[k][0])
+    dom_ms = kern[dom][0] / kern[dom][1]
+    alg_bytes = kern[dom][2] * S * L
+    achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc):
+        try:
+            traffic = json.load(open(pmc)).get(dom, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "avg_launch_ms": round(dom_ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes),
+                "kernels_ms_per_step": {k: round(v[0] / v[1], 4) for k, v in sorted(kern.items())}}
+
+    # ---- validation outside the timed region: every sampled stream decodes what it was sent
+    validated = None
+    if dem is not None and not a.no_validate:
+        payloads = pay.to_host(np.uint8).reshape(S, nfr, 256)
+        ok = True
+        for s in sorted(set([0, S // 2, S - 1])):
+            fr = dem.fec_results(s)
+            ok = ok and len(fr) >= 1 and all(r[0] >= 0 for r in fr)
+            ok = ok and all(any(np.array_equal(r[2], payloads[s, f]) for f in range(nfr)) for r in fr)
+        validated = bool(ok)
+
+    if rank == 0:
+        total = float(N) * S * L * a.steps
+        out = {
+            "metric": "IQ Msamples/s through FFT+FIR+BPSK demod, 2048-pt frames",
+            "value": round(total / dt / 1e6, 3),
+            "unit": "Msamples/s",
+            "n_gpus": N,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64" if a.workload != "fft" else "f32",
+            "data": "synthetic",
+            "config": {"workload": {"pipeline": "fft.java PSD of every 2048-sample frame + FUNcubeBPSKDemod "
+                                                "(tune mode) + FECDecoder, same HBM-resident IQ",
+                                    "fft": "batched 2048-pt waterfall FFT+PSD (BASELINE config 2)",
+                                    "bpsk": "FUNcubeBPSKDemod tune mode + FECDecoder (BASELINE config 4)"}[a.workload],
+                       "streams_per_gpu": S, "samples_per_stream": L, "rate_hz": RATE, "frame": N_FFT,
+                       "input_bytes_per_gpu": S * L * 4, "variant": "exact-order FP64 (bit-exact bits/bytes)",
+                       "parallelism": f"streams sharded over {N} GPU(s)" + (", RCCL all-gather of result slots" if N > 1 else "")},
+            "roofline": roofline,
+            "hbm_read_roofline_frac": round(total / dt * 4.0 / (N * HBM_PEAK_GBS * 1e9), 4),
+            "validated": validated,
+        }
+        if N == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(O, a.workload, L, a.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if N > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

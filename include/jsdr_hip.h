@@ -1,0 +1,160 @@
+/*
+ * jsdr_hip.h -- C ABI of libjsdr_hip.so: the MI355X (gfx950) implementation of java-sdr's
+ * FFT / FIR / BPSK-demod hot path.
+ *
+ * This is the drop-in boundary.  java-sdr itself defines no native ABI (it is pure Java); each
+ * entry point below replaces the arithmetic of one reference method and is what a JNI shim
+ * for that class binds (INTEGRATION.md shows the stubs).  Citations are file:line in the
+ * reference tree.
+ *
+ * Conventions:
+ *   - every function returns JSDR_OK (0) or JSDR_ERR (-1)  (cf. FCD.OK/ERR, FCD.java:46-47);
+ *     on error jsdr_last_error() returns a thread-local message.  Nothing throws or aborts.
+ *   - handles are opaque; one handle is used by one thread at a time (the reference calls
+ *     every handler from its single audio thread, JavaAudio.java:298-304).
+ *   - "_host" buffers are caller-owned host memory, read/written before the call returns (the
+ *     reference re-uses its frame buffers every iteration, JavaAudio.java:220-224).
+ *   - "_dev" buffers are device (HBM) pointers valid on the current device; `stream` is a
+ *     hipStream_t passed as void* (NULL = default stream); batch calls are asynchronous on it.
+ *   - there is NO CPU fallback: without a usable HIP device every compute call fails.
+ */
+#ifndef JSDR_HIP_H
+#define JSDR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JSDR_OK 0
+#define JSDR_ERR (-1)
+
+/* ------------------------------------------------------------------ runtime */
+const char *jsdr_last_error(void);
+int jsdr_version(void);                       /* ABI version, currently 1 */
+int jsdr_device_count(int *count);
+int jsdr_set_device(int device);
+int jsdr_device_name(char *buf, int cap);     /* gcnArchName of the current device */
+int jsdr_malloc(void **dev, size_t bytes);
+int jsdr_free(void *dev);
+int jsdr_memset(void *dev, int value, size_t bytes);
+int jsdr_memcpy_h2d(void *dev, const void *host, size_t bytes);
+int jsdr_memcpy_d2h(void *host, const void *dev, size_t bytes);
+int jsdr_stream_sync(void *stream);
+/* HIP-event timing on `stream` (what bench.py brackets kernels with) */
+int jsdr_timer_create(void **timer);
+int jsdr_timer_destroy(void *timer);
+int jsdr_timer_start(void *timer, void *stream);
+int jsdr_timer_stop(void *timer, void *stream);
+int jsdr_timer_elapsed_ms(void *timer, float *ms); /* synchronises on the stop event */
+
+/* ------------------------------------------------------------------ sample conversion
+ * JavaAudio.java:276-293: short s = LE16; s += (short)ic (wraps); f = (float)s/32767f; mono => Q=0.
+ * Fused into every *_i16 kernel below; exposed on its own for parity tests.                */
+int jsdr_convert_i16(const int16_t *raw_dev, int64_t nframes, int chns, int ic, int qc,
+                     float *iq_dev, void *stream);
+
+/* ------------------------------------------------------------------ fft.java
+ * fft.receive (fft.java:190-228): complex forward FFT (replaces JTransforms FloatFFT_1D,
+ * fft.java:194-195), psd[k]=10*log10((re^2+im^2)*(2/n)^2), first strict maximum, bin->Hz in
+ * Java int arithmetic; output float[n+2] = what the reference publishes as "fft-psd".
+ * n = blen/size (fft.java:67); supported: powers of two 64..8192 (2048 is the tuned size).   */
+typedef struct jsdr_fft jsdr_fft;
+int jsdr_fft_create(jsdr_fft **h, int n, int rate);
+int jsdr_fft_destroy(jsdr_fft *h);
+int jsdr_fft_receive_f32(jsdr_fft *h, const float *iq_host, float *psd_host);      /* IAudioHandler.receive(float[]) */
+int jsdr_fft_receive_i16(jsdr_fft *h, const int16_t *raw_host, int ic, int qc,
+                         float *psd_host);                                          /* IRawHandler.receive(byte[]) + a0 */
+int jsdr_fft_batch_f32(jsdr_fft *h, const float *iq_dev, int64_t nframes, float *psd_dev, void *stream);
+int jsdr_fft_batch_i16(jsdr_fft *h, const int16_t *raw_dev, int64_t nframes, int ic, int qc,
+                       float *psd_dev, void *stream);
+/* complex spectrum only (float2[n] per frame), for the 1e-5 FFT parity tests */
+int jsdr_fft_spectrum_f32(jsdr_fft *h, const float *iq_dev, int64_t nframes, float *spec_dev, void *stream);
+
+/* ------------------------------------------------------------------ phase.java
+ * phase.java:75-80 max|x| over the 2n floats of a frame; :93-116 per-pixel-column means of I and Q
+ * for a panel `bx` pixels wide.  cols_dev = int32[ncol_cap] pixel indices, avg*_dev float[ncol_cap].  */
+int jsdr_phase_maxabs(const float *iq_dev, int64_t nframes, int n, float *max_dev, void *stream);
+int jsdr_phase_columns(const float *iq_dev, int n, int bx, int32_t *pix_host, float *avgi_host,
+                       float *avgq_host, int cap, int *ncol);
+
+/* ------------------------------------------------------------------ fir.java
+ * weights (fir.java:169-195) is setup arithmetic (host); filter (:198-211) runs on the GPU over a
+ * block of samples with carried delay line; complex_gen/complex_mod (:214-228) likewise.      */
+typedef struct jsdr_fir jsdr_fir;
+int jsdr_fir_create(jsdr_fir **h, float sample_rate);
+int jsdr_fir_destroy(jsdr_fir *h);
+int jsdr_fir_weights(jsdr_fir *h, int f1, int f2, double w_out[21]);
+int jsdr_fir_filter(jsdr_fir *h, const int32_t *in_host, int32_t *out_host, int64_t n);
+int jsdr_fir_complex_gen(jsdr_fir *h, int freq, int start, int32_t *sig_host /*[n][2]*/, int64_t n);
+int jsdr_fir_complex_mod(jsdr_fir *h, const int32_t *a_host, const int32_t *b_host, int32_t *out_host, int64_t n);
+
+/* ------------------------------------------------------------------ FECDecoder.java
+ * FECDecode (FECDecoder.java:703-852): 5200 soft symbols -> 256 bytes, return -1 or channel errors.
+ * encode_FEC40 (:677-688) is the (private) re-encoder, exposed for test-vector generation.     */
+int jsdr_fec_decode(const uint8_t raw_host[5200], uint8_t out_host[256], int *rc);
+int jsdr_fec_encode(const uint8_t data_host[256], uint8_t sym_host[5200]);
+int jsdr_fec_decode_batch(const uint8_t *raw_dev, int64_t nblocks, uint8_t *out_dev, int32_t *rc_dev, void *stream);
+int jsdr_fec_encode_batch(const uint8_t *data_dev, int64_t nblocks, uint8_t *sym_dev, void *stream);
+
+/* ------------------------------------------------------------------ FUNcubeBPSKDemod.java
+ * One handle = `nstreams` independent demodulators with identical configuration that advance in
+ * lock-step (stream-major batches).  nstreams=1 + receive_* is the IAudioHandler drop-in.
+ *   rate, blen/size : AudioDescriptor (FUNcubeBPSKDemod.java:193-194)
+ *   tuning_hz       : "bpsk-tuning" (:195), do_fft "bpsk-dofft" (:199), do_up "bpsk-upper" (:200)  */
+typedef struct jsdr_bpsk jsdr_bpsk;
+int jsdr_bpsk_create(jsdr_bpsk **h, int rate, int nsamples_per_frame, int tuning_hz, int do_fft,
+                     int do_up, int nstreams, int64_t max_batch_samples);
+int jsdr_bpsk_destroy(jsdr_bpsk *h);
+/* receive(float[]) / raw form for stream 0 of a 1-stream handle (:357-364) */
+int jsdr_bpsk_receive_f32(jsdr_bpsk *h, const float *iq_host);
+int jsdr_bpsk_receive_i16(jsdr_bpsk *h, const int16_t *raw_host, int ic, int qc);
+/* batched: raw_dev[s*stream_stride + 2*t .. +1] = I,Q of sample t of stream s; nsamples must be a
+ * multiple of nsamples_per_frame in FFT mode; asynchronous on `stream`.                        */
+int jsdr_bpsk_batch_i16(jsdr_bpsk *h, const int16_t *raw_dev, int64_t stream_stride_i16,
+                        int64_t nsamples, int ic, int qc, void *stream);
+/* results (synchronise the handle's stream first) */
+enum { JSDR_BPSK_NCOUNTERS = 10 };
+/* cntRaw,cntDS,cntBit,cntFEC,cntDec,dmErrBits,dmCorr,dmMaxCorr,decodeOK,centreBin (:110-115,:405,:498) */
+int jsdr_bpsk_get_counters(jsdr_bpsk *h, int stream, int32_t out[JSDR_BPSK_NCOUNTERS]);
+/* bits sliced during the LAST batch/receive call, +1/-1 each (:545-554) */
+int jsdr_bpsk_get_bits(jsdr_bpsk *h, int stream, int8_t *bits_host, int cap, int *nbits);
+/* FECDecode calls made during the last call: rc + index (1-based, within the call) of the bit that triggered */
+int jsdr_bpsk_get_fec(jsdr_bpsk *h, int stream, int idx, int32_t *rc, int32_t *bit_index, uint8_t out_host[256]);
+int jsdr_bpsk_get_fec_count(jsdr_bpsk *h, int stream, int *count);
+int jsdr_bpsk_get_decoded(jsdr_bpsk *h, int stream, uint8_t out_host[256]);   /* decoded[] (:111) */
+/* matched-filter outputs (fi,fq) of the last call, double[npairs][2] (:518-531) */
+int jsdr_bpsk_get_trace(jsdr_bpsk *h, int stream, double *out_host, int64_t cap_pairs, int64_t *npairs);
+/* scalar state, same 18-value layout as the oracle: tuPhase,vcoPhase,dmBitPhase,dmEnergyOut,energy1,
+ * energy2,avePeakPower,aveCentreBin,dmEnergy[8],dmLastIQ[2]                                       */
+int jsdr_bpsk_get_state(jsdr_bpsk *h, int stream, double out[18]);
+/* per-kernel HIP-event timing of the batch pipeline (events recorded on the caller's stream around each
+ * launch while enabled).  profile_read sums and clears what was recorded since the last read.          */
+int jsdr_bpsk_profile_enable(jsdr_bpsk *h, int on);
+int jsdr_bpsk_profile_count(void);                 /* number of kernels in the pipeline */
+const char *jsdr_bpsk_profile_name(int k);
+int jsdr_bpsk_profile_read(jsdr_bpsk *h, double *ms_total, int *launches);
+/* device-resident result slots for the multi-GPU all-gather: per stream
+ * int32 header[16] = {nbits, nfec, counters[10], 0...} followed by int8 bits[slot_bits] and
+ * nfec_max x {int32 rc, int32 bit_index, uint8 data[256]}.  Layout constants via slot_info.      */
+int jsdr_bpsk_slot_info(jsdr_bpsk *h, int64_t *slot_bytes, int64_t *bits_offset, int64_t *fec_offset,
+                        int *slot_bits, int *nfec_max);
+int jsdr_bpsk_pack_slots(jsdr_bpsk *h, uint8_t *slots_dev, void *stream);
+
+/* ------------------------------------------------------------------ synthetic inputs (bench / tests)
+ * Integer-only generators, bit-identical to oracle/o_synth.c.  Not part of the reference.        */
+int jsdr_synth_diffsign(const uint8_t *sym_dev, int64_t nsym, int nstreams, int8_t *dsign_dev, void *stream);
+int jsdr_synth_dbpsk(int16_t *out_dev, int64_t stream_stride_i16, int nstreams, int64_t n0, int64_t n,
+                     const int8_t *dsign_dev, int64_t nsym, int samples_per_sym, uint32_t phase0,
+                     uint32_t phase_inc, const int16_t *cos_tab_dev, const int16_t *sin_tab_dev,
+                     int noise_gain, const uint64_t *noise_keys_dev, void *stream);
+int jsdr_synth_tones(int16_t *out_dev, int64_t frame0, int64_t nframes, int n, const int16_t *cos_tab_dev,
+                     int noise_gain, uint64_t key, void *stream);
+int jsdr_synth_payloads(uint64_t seed, int stream0, int nstreams, int nframes, uint8_t *out_dev, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JSDR_HIP_H */

@@ -1,0 +1,1322 @@
+// bpsk.hip -- FUNcubeBPSKDemod.receive() chain for batches of independent streams, exact-order FP64.
+//
+// Reference: FUNcubeBPSKDemod.java:357-595 (receive -> doBufferTune -> RxMixTuner -> RxDownSample ->
+// RxDemodulate), constants :26-96, tables :159-162.  This translation unit is compiled with
+// -ffp-contract=off: every double product and sum is rounded separately, in the reference's order, so
+// the slicer bits are bit-identical to the Java arithmetic by construction (tests compare with the
+// oracle's restatement).
+//
+// Pipeline per batch of L input samples x S streams (all on one HIP stream):
+//   host        : input-independent schedules (tuner / VCO table indices per sample) in exact double,
+//                 cached while the phase state repeats (it is an exact 8-cycle at 12 kHz / 96 kHz)
+//   k_front     : int16 -> float -> double, tuner mix, 27-tap low-pass at the decimated instants
+//                 (newest-first order, :479-483), x HOWARD_FUDGE_FACTOR, VCO mix  -> dm[s][64+j]
+//   k_matched   : 65-tap matched filter in RING-SLOT order with rotated taps (:519-523) -> y[s][j]=(fi,fq)
+//   k_tail      : bit-energy IIRs, peak tracking, differential slicer (:534-593) -> bits
+//   k_sync      : 65-symbol sync correlation at stride 80 over the 5200-bit window (:556-560)
+//   k_sync_fin  : trigger ordering, dmCorr / dmMaxCorr bookkeeping (:567-572)
+//   k_fec_bpsk  : FECDecode of every triggered window (fec.hip)
+// DESIGN.md has the lane/LDS mapping of each kernel and its roofline.
+#include "bpsk_fec.h"
+#include <math.h>
+#include <vector>
+
+namespace jsdr {
+
+enum { DS_N = 27, DM_N = 65, HIST_BITS = 5200, MAX_TRIG = 8, SYNC_N = 65 };
+
+// FUNcubeBPSKDemod.java:27-55, float literals widened (symmetric, first 14)
+static const float h_ds_half[14] = {-6.103515625000e-004F, -1.220703125000e-004F, +2.380371093750e-003F,
+                                    +6.164550781250e-003F, +7.324218750000e-003F, +7.629394531250e-004F,
+                                    -1.464843750000e-002F, -3.112792968750e-002F, -3.225708007813e-002F,
+                                    -1.617431640625e-003F, +6.463623046875e-002F, +1.502380371094e-001F,
+                                    +2.231445312500e-001F, +2.518310546875e-001F};
+// FUNcubeBPSKDemod.java:58-77 (symmetric, first 33)
+static const float h_dm_half[33] = {
+    -0.0101130691F, -0.0086975143F, -0.0038246093F, +0.0033563764F, +0.0107237026F, +0.0157790936F, +0.0164594107F,
+    +0.0119213911F, +0.0030315224F, -0.0076488191F, -0.0164594107F, -0.0197184277F, -0.0150109226F, -0.0023082460F,
+    +0.0154712381F, +0.0327423589F, +0.0424493086F, +0.0379940454F, +0.0154712381F, -0.0243701991F, -0.0750320094F,
+    -0.1244834076F, -0.1568500423F, -0.1553748911F, -0.1061032953F, -0.0015013786F, +0.1568500423F, +0.3572048240F,
+    +0.5786381191F, +0.7940228249F, +0.9744923010F, +1.0945250059F, +1.1366117829F};
+
+struct BpskConst {
+    double ds_taps[32];   // [27] used
+    double dm_taps[96];   // [65] used, zero beyond (edge steps of the register-blocked loops read past 64)
+    signed char sync[72]; // [65] used, +1/-1
+};
+__constant__ BpskConst c_bpsk;
+
+// per-stream demodulator state that depends on the data (FUNcubeBPSKDemod.java:497-503)
+struct TailState {
+    double dmEnergy[8];
+    double dmEnergyOut;
+    double lastI, lastQ;
+    double energy1, energy2;
+    int peakPos, newPeak;
+    int dmCorr, dmMaxCorr;
+    int cntBit, cntFEC, cntDec, dmErrBits, decodeOK;
+    int nbits_prev;  // bits sliced in the previous call (locates the 5200-bit history in the other bitlog)
+    int overflow;    // sticky: more than MAX_TRIG sync hits in one call
+    int pad;
+};
+
+// ------------------------------------------------------------------------------------------- k_front
+// One wave = one chunk of 64 decimated outputs of one stream.  The wave converts and tuner-mixes the
+// 26 + 64*D input samples its outputs need, parks them as double2 in LDS, then every lane runs the 27-tap
+// filter for its own output.  LDS element e sits at e + PADK*(e/D): the lane stride of the FIR reads is
+// then D+PADK, an odd number of 16-byte slots -> ds_read_b128 conflict-free.
+template <int D>
+struct FrontGeom {
+    static constexpr int PADK = (D & 1) ? 2 : 1;
+    static constexpr int NIN = 26 + 63 * D + 1;             // samples per chunk
+    static constexpr int NLDS = NIN + PADK * (NIN / D + 1);  // padded elements per wave
+};
+
+struct FrontArgs {
+    const int *raw;            // int16 pairs as dwords, [S][stride] (null when rawf is used)
+    const float2 *rawf;        // alternative input: the float frame of IAudioHandler.receive, [S][stride]
+    long long stride_pairs;
+    long long nsamples;        // L
+    int ic, qc;
+    const short *ktu;          // [L] tuner table index or -1 (no mix: tuPhase <= 0, :388)
+    const unsigned char *kvco; // [nds]
+    const double *sincos;      // cos[256], sin[256]
+    const double2 *hist_in;    // [S][32]: the 26 samples fed to RxDownSample before this call (time order)
+    double2 *dm;               // [S][dm_stride]: 64 history + nds VCO-mixed samples
+    long long dm_stride;
+    double2 *ds_dbg;           // optional [S][nds] down-sampler outputs (after HOWARD), may be null
+    long long nds;
+    int first_out;             // input index whose arrival completes output 0 (= D-1-dsCnt0)
+};
+
+template <int D>
+__global__ __launch_bounds__(256) void k_front(FrontArgs a)
+{
+    using G = FrontGeom<D>;
+    extern __shared__ __align__(16) unsigned char smem[];
+    double *sc = reinterpret_cast<double *>(smem);                            // [512]
+    double2 *lds_all = reinterpret_cast<double2 *>(smem + 512 * sizeof(double));
+    for (int i = threadIdx.x; i < 512; i += 256) sc[i] = a.sincos[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double2 *x = lds_all + wave * G::NLDS;
+    const int s = blockIdx.y;
+    const long long nchunks = (a.nds + 63) / 64;
+    const double HOWARD = 0.9 * 32768.0;  // :469
+    for (long long chunk = (long long)blockIdx.x * 4 + wave; chunk < nchunks; chunk += (long long)gridDim.x * 4) {
+        const long long j0 = chunk * 64;
+        const long long lo = (long long)a.first_out + (long long)D * j0 - 26;  // first input index needed
+        const int *raw = a.raw + (long long)s * a.stride_pairs;
+        // ---- stage the mixed samples
+#pragma unroll
+        for (int it = 0; it < (G::NIN + 63) / 64; it++) {
+            int e = it * 64 + lane;
+            if (e < G::NIN) {
+                long long n = lo + e;
+                double2 v;
+                if (n < 0) {
+                    v = a.hist_in[(long long)s * 32 + (26 + n)];
+                } else if (n < a.nsamples) {
+                    double di, dq;
+                    if (a.rawf) {
+                        float2 f = a.rawf[(long long)s * a.stride_pairs + n];
+                        di = (double)f.x;  // (double)buf[n*2]   :372
+                        dq = (double)f.y;
+                    } else {
+                        int w = raw[n];
+                        int si = java_short_add((int)(short)(w & 0xffff), a.ic);
+                        int sq = java_short_add(w >> 16, a.qc);
+                        di = (double)i16_to_float_java(si);
+                        dq = (double)i16_to_float_java(sq);
+                    }
+                    int k = a.ktu[n];
+                    if (k >= 0) {  // :388-390 component-wise, not a complex multiply
+                        di = di * sc[k];
+                        dq = dq * sc[256 + k];
+                    }
+                    v = make_double2(di, dq);
+                } else {
+                    v = make_double2(0.0, 0.0);
+                }
+                x[e + G::PADK * (e / D)] = v;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- 27-tap low-pass for output j0+lane: newest sample first (:479-483)
+        const long long j = j0 + lane;
+        double fi = 0.0, fq = 0.0;
+        const double2 *xl = x + (D + G::PADK) * lane;
+#pragma unroll
+        for (int n = 0; n < DS_N; n++) {
+            constexpr int dummy = 0;
+            (void)dummy;
+            const int d = 26 - n;                       // element offset of the sample of age n
+            const int dp = d + G::PADK * (d / D);       // folded at compile time after unrolling
+            double2 v = xl[dp];
+            double t = c_bpsk.ds_taps[n];
+            fi += v.x * t;
+            fq += v.y * t;
+        }
+        if (j < a.nds) {
+            double oi = fi * HOWARD, oq = fq * HOWARD;  // :486
+            if (a.ds_dbg) a.ds_dbg[(long long)s * a.nds + j] = make_double2(oi, oq);
+            int kv = a.kvco[j];
+            a.dm[(long long)s * a.dm_stride + 64 + j] = make_double2(oi * sc[kv], oq * sc[256 + kv]);  // :515-516
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// the 26 most recent samples fed to RxDownSample, for the next call (new history), one lane each
+struct HistArgs {
+    const int *raw;
+    const float2 *rawf;
+    long long stride_pairs, nsamples;
+    int ic, qc;
+    const short *ktu;
+    const double *sincos;
+    const double2 *hist_old;
+    double2 *hist_new;
+    int nstreams;
+};
+__global__ void k_hist_in(HistArgs a)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    int s = t >> 5, i = t & 31;
+    if (s >= a.nstreams || i >= 26) return;
+    long long n = a.nsamples - 26 + i;
+    double2 v;
+    if (n < 0) {
+        v = a.hist_old[(long long)s * 32 + (26 + n)];
+    } else {
+        double di, dq;
+        if (a.rawf) {
+            float2 f = a.rawf[(long long)s * a.stride_pairs + n];
+            di = (double)f.x;
+            dq = (double)f.y;
+        } else {
+            int w = a.raw[(long long)s * a.stride_pairs + n];
+            di = (double)i16_to_float_java(java_short_add((int)(short)(w & 0xffff), a.ic));
+            dq = (double)i16_to_float_java(java_short_add(w >> 16, a.qc));
+        }
+        int k = a.ktu[n];
+        if (k >= 0) {
+            di = di * a.sincos[k];
+            dq = dq * a.sincos[256 + k];
+        }
+        v = make_double2(di, dq);
+    }
+    a.hist_new[(long long)s * 32 + i] = v;
+}
+
+// ------------------------------------------------------------------------------------------- k_matched
+// 65-tap matched filter, summed in ring-slot order n=0..64 with tap 65-dmPos+n (:519-523).  In time
+// terms (g = global index of a 9600 Hz sample, slot(g) = (64-g) mod 65): the window [g-64, g] holds one
+// sample s0 with slot 0; the reference adds s0, s0-1, .., g-64 (ages g-s0 .. 64) and then g, g-1, .., s0+1
+// (ages 0 .. g-s0-1).  All outputs g = s0+u, u = 0..64, share s0.  Lane l of a workgroup owns the block
+// s0 = G + 65 l; wave w computes R consecutive u for all 64 blocks with R accumulators per rail held in
+// registers: at every step all lanes need the SAME taps (scalar loads) and one double2 from LDS
+// (stride 65 elements -> conflict-free), which is then used 4R times.  Edge steps where an output has
+// run out of taps are peeled at compile time, so exactly 65 products are summed per output, in order.
+struct MatchedArgs {
+    const double2 *dm;   // [S][dm_stride], index 64 + (g - g_first)
+    long long dm_stride;
+    double2 *y;          // [S][y_stride]
+    long long y_stride;
+    long long nds;
+    long long g_first;   // global 9600 Hz index of dm[64] (= samples demodulated before this call)
+    long long tile0;     // global index of the first block of tile 0 (== 64 mod 65, <= g_first)
+};
+
+template <int R>
+__device__ __forceinline__ void matched_block(const double2 *xl /* &X[s0] of this lane */, int u0, double (&ai)[R],
+                                              double (&aq)[R])
+{
+    const double *f = c_bpsk.dm_taps;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        ai[r] = 0.0;
+        aq[r] = 0.0;
+    }
+    // phase 1: s = s0 - i, ages u+i.  main part: every output still has a tap
+    const int n1 = 66 - u0 - R;
+    for (int i = 0; i < n1; i++) {
+        double2 v = xl[-i];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            double t = f[u0 + i + r];
+            ai[r] += v.x * t;
+            aq[r] += v.y * t;
+        }
+    }
+    // phase 1 tail: outputs drop out from the top (age would exceed 64)
+#pragma unroll
+    for (int q = 0; q < R - 1; q++) {
+        const int i = n1 + q;
+        double2 v = xl[-i];
+#pragma unroll
+        for (int r = 0; r < R - 1 - q; r++) {
+            double t = f[u0 + i + r];
+            ai[r] += v.x * t;
+            aq[r] += v.y * t;
+        }
+    }
+    // phase 2 head: s = s0 + u0 + R-1-q, only outputs with u >= s-s0 take part, age = u-(s-s0)
+#pragma unroll
+    for (int q = 0; q < R - 1; q++) {
+        double2 v = xl[u0 + R - 1 - q];
+#pragma unroll
+        for (int r = R - 1 - q; r < R; r++) {
+            double t = f[r - (R - 1 - q)];
+            ai[r] += v.x * t;
+            aq[r] += v.y * t;
+        }
+    }
+    // phase 2 main: s = s0 + u0 - m, m = 0..u0-1, age = r + m
+    for (int m = 0; m < u0; m++) {
+        double2 v = xl[u0 - m];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            double t = f[r + m];
+            ai[r] += v.x * t;
+            aq[r] += v.y * t;
+        }
+    }
+}
+
+__global__ __launch_bounds__(512) void k_matched(MatchedArgs a)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    double2 *X = reinterpret_cast<double2 *>(smem);  // [64 + 4160]: X[i] = sample (G - 64 + i)
+    const int s = blockIdx.y;
+    const long long G = a.tile0 + 4160LL * blockIdx.x;
+    const double2 *dm = a.dm + (long long)s * a.dm_stride;
+    for (int i = threadIdx.x; i < 64 + 4160; i += 512) {
+        long long rel = (G - 64 + i) - a.g_first;  // index relative to the first new sample
+        double2 v = make_double2(0.0, 0.0);
+        if (rel >= -64 && rel < a.nds) v = dm[64 + rel];
+        X[i] = v;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const double2 *xl = X + 64 + 65 * lane;  // &X[s0]
+    const long long s0 = G + 65LL * lane;
+    double2 *y = a.y + (long long)s * a.y_stride;
+    if (wave == 0) {
+        double ai[9], aq[9];
+        matched_block<9>(xl, 0, ai, aq);
+#pragma unroll
+        for (int r = 0; r < 9; r++) {
+            long long rel = s0 + r - a.g_first;
+            if (rel >= 0 && rel < a.nds) y[rel] = make_double2(ai[r], aq[r]);
+        }
+    } else {
+        const int u0 = 9 + 8 * (wave - 1);
+        double ai[8], aq[8];
+        matched_block<8>(xl, u0, ai, aq);
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            long long rel = s0 + u0 + r - a.g_first;
+            if (rel >= 0 && rel < a.nds) y[rel] = make_double2(ai[r], aq[r]);
+        }
+    }
+}
+
+// keep the last 64 VCO-mixed samples as the next call's history (one wave per stream; loads before stores)
+__global__ __launch_bounds__(64) void k_dm_history(double2 *dm, long long dm_stride, long long nds, int nstreams)
+{
+    int s = blockIdx.x;
+    if (s >= nstreams) return;
+    double2 *p = dm + (long long)s * dm_stride;
+    double2 v = p[nds + threadIdx.x];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    p[threadIdx.x] = v;
+}
+
+// ------------------------------------------------------------------------------------------- k_tail
+// One wave per stream, the 9600 Hz tail (:534-593) in chunks of 64 bit periods (512 samples).
+// The bit clock is input independent and exactly periodic (bitPos == g mod 8, a new peak is measured
+// after every g == 7 mod 8; verified on the host at create time).  Per chunk:
+//   parallel : lane = bit period: load its 8 (fi,fq), energy1 = fi*fi+fq*fq                  (:534)
+//   serial   : per period -- scalar peak logic (:537,:577-579), then ONE vector update in which lanes 0..7
+//              advance the eight dmEnergy IIRs (:535) and lane 8 advances dmEnergyOut (:538), then an
+//              8-lane argmax with first-maximum-wins (:586-592)
+//   parallel : lane = decision: differential detector, sqrt, threshold, bit (:539-545), compaction
+struct TailArgs {
+    const double2 *y;
+    long long y_stride;
+    long long nds;
+    long long g_first;
+    TailState *st;
+    signed char *bitlog_new;        // [S][stride]: 5200 history + new bits
+    const signed char *bitlog_old;
+    long long bitlog_stride;
+    int *nbits;                     // [S] bits sliced in this call
+    int max_bits;
+    int nstreams;
+};
+
+__global__ __launch_bounds__(64) void k_tail(TailArgs a)
+{
+    __shared__ double2 yL[64][8];
+    __shared__ double enL[64][8];
+    __shared__ unsigned char maskL[64];
+    __shared__ short declist[136];
+    const int lane = threadIdx.x;
+    const int s = blockIdx.x;
+    if (s >= a.nstreams) return;
+    TailState st = a.st[s];
+    const double2 *y = a.y + (long long)s * a.y_stride;
+    signed char *blog = a.bitlog_new + (long long)s * a.bitlog_stride;
+    // carry the 5200-bit shift register (dmFECCorr, :503) over from the previous call's log
+    {
+        const signed char *old = a.bitlog_old + (long long)s * a.bitlog_stride + st.nbits_prev;
+        for (int i = lane; i < HIST_BITS; i += 64) blog[i] = old[i];
+    }
+    const double K1 = 1.0 - 1.0 / 200.0, S1 = 1.0 / 200.0;  // BIT_SMOOTH1 (:89)
+    const double K2 = 1.0 - 1.0 / 800.0, S2 = 1.0 / 800.0;  // BIT_SMOOTH2 (:90)
+    // lanes 0..7 carry dmEnergy[lane], lane 8 carries dmEnergyOut
+    double e = (lane < 8) ? st.dmEnergy[lane] : st.dmEnergyOut;
+    const double Kc = (lane < 8) ? K1 : K2, Sc = (lane < 8) ? S1 : S2;
+    int peakPos = st.peakPos, newPeak = st.newPeak;
+    double lastI = st.lastI, lastQ = st.lastQ, energy1 = st.energy1, energy2 = st.energy2;
+    int nbits = 0;
+    const long long g_end = a.g_first + a.nds;
+    const long long M_first = a.g_first >> 3, M_last = (g_end - 1) >> 3;
+    for (long long MB = M_first; MB <= M_last && a.nds > 0; MB += 64) {
+        // ---------------- parallel: load + energy
+        {
+            const long long M = MB + lane;
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                long long g = 8 * M + c;
+                double2 v = make_double2(0.0, 0.0);
+                if (g >= a.g_first && g < g_end) v = y[g - a.g_first];
+                yL[lane][c] = v;
+                enL[lane][c] = v.x * v.x + v.y * v.y;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---------------- serial over the periods of this chunk
+        int nper = (int)((M_last - MB + 1) < 64 ? (M_last - MB + 1) : 64);
+        for (int p = 0; p < nper; p++) {
+            const long long gbase = 8 * (MB + p);
+            // sample validity of this period (only the first / last period of a call can be partial)
+            int cfirst = (gbase < a.g_first) ? (int)(a.g_first - gbase) : 0;
+            int clast = (gbase + 7 >= g_end) ? (int)(g_end - 1 - gbase) : 7;
+            // scalar peak logic: which samples are decision points (:537), half-bit hand-over (:577-578)
+            int mask = 0, c1 = -1, c2 = -1;
+            for (int c = cfirst; c <= clast; c++) {
+                if (c == peakPos) {
+                    mask |= 1 << c;
+                    if (c1 < 0) c1 = c; else c2 = c;
+                }
+                if (c == ((peakPos + 4) & 7)) peakPos = newPeak;  // dmHalfTable = {4,5,6,7,0,1,2,3} (:500)
+            }
+            // vector update: lanes 0..7 their IIR, lane 8 dmEnergyOut at the (first) decision point
+            {
+                int idx = (lane < 8) ? lane : (c1 < 0 ? 0 : c1);
+                bool on = (lane < 8) ? (lane >= cfirst && lane <= clast) : (lane == 8 && c1 >= 0);
+                double xv = enL[p][idx & 7];
+                double ne = (e * Kc) + (xv * Sc);
+                if (on) e = ne;
+                if (c2 >= 0) {  // two decision points in one period (peak moved forward): rare
+                    double xv2 = enL[p][c2];
+                    double ne2 = (e * Kc) + (xv2 * Sc);
+                    if (lane == 8) e = ne2;
+                }
+            }
+            if (lane == 0) maskL[p] = (unsigned char)mask;
+            // new peak measurement after the sample with bitPos 7 (:582-593): first maximum wins
+            if (clast == 7) {
+                double bv = e;
+                int bi = lane;
+#pragma unroll
+                for (int off = 1; off < 8; off <<= 1) {
+                    double ov = __shfl_xor(bv, off, 8);
+                    int oi = __shfl_xor(bi, off, 8);
+                    if (ov > bv || (ov == bv && oi < bi)) {
+                        bv = ov;
+                        bi = oi;
+                    }
+                }
+                newPeak = __builtin_amdgcn_readfirstlane(bi);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---------------- decision list of the chunk, in time order
+        int mymask = (lane < nper) ? (int)maskL[lane] : 0;
+        int mycnt = __popc(mymask);
+        int pre = mycnt;  // inclusive prefix sum over lanes
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            int o = __shfl_up(pre, off, 64);
+            if (lane >= off) pre += o;
+        }
+        int nd = __shfl(pre, 63, 64);
+        {
+            int pos = pre - mycnt;
+            int m = mymask;
+            while (m) {
+                int c = __ffs(m) - 1;
+                m &= m - 1;
+                declist[pos++] = (short)(lane * 8 + c);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---------------- parallel: differential detector per decision (:539-545)
+        for (int d0 = 0; d0 < nd; d0 += 64) {
+            int d = d0 + lane;
+            bool have = d < nd;
+            double2 cur = make_double2(0.0, 0.0), prv = make_double2(lastI, lastQ);
+            if (have) {
+                int pc = declist[d];
+                cur = yL[pc >> 3][pc & 7];
+                if (d > 0) {
+                    int pp = declist[d - 1];
+                    prv = yL[pp >> 3][pp & 7];
+                }
+            }
+            double di = -((prv.x * cur.x) + (prv.y * cur.y));
+            double dq = (prv.x * cur.y) - (prv.y * cur.x);
+            double e2 = sqrt((di * di) + (dq * dq));
+            bool valid = have && (e2 > 100.0);
+            unsigned long long vm = __ballot(valid);
+            if (valid) {
+                int rank = __popcll(vm & ((1ull << lane) - 1ull));
+                int pos = nbits + rank;
+                if (pos < a.max_bits) blog[HIST_BITS + pos] = (di < 0.0) ? (signed char)1 : (signed char)-1;
+            }
+            nbits += __popcll(vm);
+            // the last decision of the chunk defines dmLastIQ / energy2 for what follows
+            int lastd = nd - 1 - d0;
+            if (lastd >= 0 && lastd < 64) {
+                energy2 = __shfl(e2, lastd, 64);
+                lastI = __shfl(cur.x, lastd, 64);
+                lastQ = __shfl(cur.y, lastd, 64);
+            }
+        }
+        // energy1 = that of the last sample processed (:534)
+        {
+            long long glast = 8 * (MB + nper - 1) + 7;
+            if (glast >= g_end) glast = g_end - 1;
+            long long pl = (glast >> 3) - MB;
+            energy1 = enL[pl][glast & 7];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    // ---------------- write back
+    double e8 = __shfl(e, 8, 64);
+    if (lane < 8) a.st[s].dmEnergy[lane] = e;
+    if (lane == 0) {
+        TailState *o = &a.st[s];
+        o->dmEnergyOut = e8;
+        o->lastI = lastI;
+        o->lastQ = lastQ;
+        o->energy1 = energy1;
+        o->energy2 = energy2;
+        o->peakPos = peakPos;
+        o->newPeak = newPeak;
+        int nb = nbits < a.max_bits ? nbits : a.max_bits;
+        o->cntBit = st.cntBit + nb;
+        o->nbits_prev = nb;
+        if (nbits > a.max_bits) o->overflow = 1;
+        a.nbits[s] = nb;
+    }
+}
+
+// ------------------------------------------------------------------------------------------- k_sync
+// sync-vector correlation for every new bit (:556-559): window = the 5200 most recent bits, 65 taps at
+// stride 80.  corr[b] kept (int8) for the dmMaxCorr bookkeeping; hits (>=45, :560) go to a per-stream list.
+struct SyncArgs {
+    const signed char *bitlog;
+    long long bitlog_stride;
+    const int *nbits;
+    signed char *corr;      // [S][max_bits]
+    int max_bits;
+    int *trig_count;        // [S], zeroed before launch
+    int *trig_bits;         // [S][MAX_TRIG]
+};
+__global__ void k_sync(SyncArgs a)
+{
+    const int s = blockIdx.y;
+    const int nb = a.nbits[s];
+    const signed char *bl = a.bitlog + (long long)s * a.bitlog_stride;
+    for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < nb; b += gridDim.x * blockDim.x) {
+        const signed char *w = bl + b + 1;  // dmFECCorr after shifting bit b in
+        int c = 0;
+#pragma unroll 5
+        for (int n = 0; n < SYNC_N; n++) c += (int)w[n * 80] * (int)c_bpsk.sync[n];
+        a.corr[(long long)s * a.max_bits + b] = (signed char)c;
+        if (c >= 45) {
+            int slot = atomicAdd(&a.trig_count[s], 1);
+            if (slot < MAX_TRIG) a.trig_bits[s * MAX_TRIG + slot] = b;
+        }
+    }
+}
+
+// order the hits, then dmCorr / dmMaxCorr exactly as the serial loop leaves them (:556-572):
+// after a hit dmMaxCorr restarts from 0 (:567) and immediately takes that bit's correlation (:571-572)
+__global__ __launch_bounds__(64) void k_sync_fin(const int *nbits, const signed char *corr, int max_bits, int *trig_count,
+                                                 int *trig_bits, TailState *st, int nstreams)
+{
+    const int s = blockIdx.x, lane = threadIdx.x;
+    if (s >= nstreams) return;
+    int nb = nbits[s];
+    int nt = trig_count[s];
+    if (nt > MAX_TRIG) {
+        if (lane == 0) st[s].overflow = 1;
+        nt = MAX_TRIG;
+    }
+    if (lane == 0 && nt > 1) {  // insertion sort of a handful of indices
+        int *t = trig_bits + s * MAX_TRIG;
+        for (int i = 1; i < nt; i++) {
+            int v = t[i], j = i - 1;
+            while (j >= 0 && t[j] > v) {
+                t[j + 1] = t[j];
+                j--;
+            }
+            t[j + 1] = v;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    int from = 0, best = st[s].dmMaxCorr;
+    if (nt > 0) {
+        from = trig_bits[s * MAX_TRIG + nt - 1];
+        best = 0;
+    }
+    const signed char *c = corr + (long long)s * max_bits;
+    for (int b = from + lane; b < nb; b += 64) best = best > (int)c[b] ? best : (int)c[b];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        int o = __shfl_xor(best, off, 64);
+        best = best > o ? best : o;
+    }
+    if (lane == 0) {
+        if (nb > 0) st[s].dmCorr = c[nb - 1];
+        st[s].dmMaxCorr = best;
+        st[s].cntFEC += nt;
+        if (lane == 0) trig_count[s] = nt;
+    }
+}
+
+}  // namespace jsdr
+
+using namespace jsdr;
+
+// =============================================================================================== host
+struct jsdr_bpsk {
+    int rate = 0, nsf = 0, tuning = 0, do_fft = 0, do_up = 0, nstreams = 0, decim = 0;
+    long long max_batch = 0, max_ds = 0;
+    int max_bits = 0;
+    // input-independent scheduler state, exact doubles (FUNcubeBPSKDemod.java:381,:494,:501,:468)
+    double tuPhase = 0.0, tuPhaseInc = 0.0, vcoPhase = 0.0;
+    int dsCnt = 0;
+    long long n_in = 0, n_ds = 0;  // samples consumed / demodulated since creation (cntRaw, cntDS)
+    // one-entry schedule cache
+    bool cache_valid = false;
+    double c_tu0 = 0, c_vco0 = 0, c_tu1 = 0, c_vco1 = 0;
+    int c_ds0 = 0, c_ds1 = 0;
+    long long c_L = -1, c_nds = 0;
+    std::vector<short> h_ktu;
+    std::vector<unsigned char> h_kvco;
+    // device
+    DevBuf<double> sincos;
+    DevBuf<short> ktu;
+    DevBuf<unsigned char> kvco;
+    DevBuf<double2> hist_in[2];
+    int hist_cur = 0;
+    DevBuf<double2> dm, y;
+    long long dm_stride = 0, y_stride = 0;
+    DevBuf<TailState> tail;
+    DevBuf<signed char> bitlog[2];
+    int bitlog_cur = 0;
+    long long bitlog_stride = 0;
+    DevBuf<int> nbits, trig_count, trig_bits, fec_rc, fec_last, cnt_dec;
+    DevBuf<signed char> corr;
+    DevBuf<unsigned char> fec_data, decoded;
+    DevBuf<int> stage_raw;  // one frame for receive_*()
+    long long last_nds = 0;
+    hipStream_t last_stream = 0;
+    // optional per-kernel HIP-event timing (bench.py's roofline leg)
+    bool prof_on = false;
+    struct ProfRec {
+        int kernel;
+        hipEvent_t a, b;
+    };
+    std::vector<ProfRec> prof_recs;
+    std::vector<hipEvent_t> prof_pool;
+};
+
+enum { PK_FRONT = 0, PK_HIST, PK_MATCHED, PK_DMHIST, PK_TAIL, PK_SYNC, PK_SYNCFIN, PK_FEC, PK_COUNT };
+static const char *const kProfNames[PK_COUNT] = {"k_front", "k_hist_in", "k_matched", "k_dm_history",
+                                                 "k_tail", "k_sync", "k_sync_fin", "k_fec_bpsk"};
+
+static hipEvent_t prof_event(jsdr_bpsk *h)
+{
+    if (!h->prof_pool.empty()) {
+        hipEvent_t e = h->prof_pool.back();
+        h->prof_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+struct ProfScope {
+    jsdr_bpsk *h;
+    hipStream_t st;
+    hipEvent_t a = nullptr, b = nullptr;
+    int k;
+    ProfScope(jsdr_bpsk *h_, int k_, hipStream_t st_) : h(h_), st(st_), k(k_)
+    {
+        if (h->prof_on) {
+            a = prof_event(h);
+            b = prof_event(h);
+            (void)hipEventRecord(a, st);
+        }
+    }
+    ~ProfScope()
+    {
+        if (h->prof_on && a && b) {
+            (void)hipEventRecord(b, st);
+            h->prof_recs.push_back({k, a, b});
+        }
+    }
+};
+
+static const double JPI = 3.14159265358979323846;
+
+// FUNcubeBPSKDemod.java:384-390 / :511-516 -- advance the phase accumulators exactly as the reference
+// does and record the table index each sample will use.  Returns the number of decimated outputs.
+static long long build_schedule(jsdr_bpsk *h, long long L)
+{
+    if (h->cache_valid && h->c_L == L && h->c_tu0 == h->tuPhase && h->c_vco0 == h->vcoPhase && h->c_ds0 == h->dsCnt) {
+        h->tuPhase = h->c_tu1;
+        h->vcoPhase = h->c_vco1;
+        h->dsCnt = h->c_ds1;
+        return h->c_nds;
+    }
+    const double two_pi = 2.0 * JPI;
+    const double vinc = 2.0 * JPI * 1200.0 / (double)9600;  // VCO_PHASE_INC (:88)
+    h->c_tu0 = h->tuPhase;
+    h->c_vco0 = h->vcoPhase;
+    h->c_ds0 = h->dsCnt;
+    h->h_ktu.resize((size_t)L);
+    h->h_kvco.clear();
+    double tu = h->tuPhase, vco = h->vcoPhase;
+    int cnt = h->dsCnt;
+    for (long long n = 0; n < L; n++) {
+        tu += h->tuPhaseInc;
+        if (tu > two_pi) tu -= two_pi;
+        if (tu > 0.0)
+            h->h_ktu[(size_t)n] = (short)((int)(tu * (double)256 / two_pi) % 256);
+        else
+            h->h_ktu[(size_t)n] = -1;
+        if (++cnt >= h->decim) {
+            cnt = 0;
+            vco += vinc;
+            if (vco > two_pi) vco -= two_pi;
+            h->h_kvco.push_back((unsigned char)((int)(vco * (double)256 / two_pi) % 256));
+        }
+    }
+    h->tuPhase = tu;
+    h->vcoPhase = vco;
+    h->dsCnt = cnt;
+    h->c_tu1 = tu;
+    h->c_vco1 = vco;
+    h->c_ds1 = cnt;
+    h->c_L = L;
+    h->c_nds = (long long)h->h_kvco.size();
+    h->cache_valid = false;  // device copy refreshed by the caller
+    return h->c_nds;
+}
+
+// the bit clock (:581-584) must be the regular one the tail kernel assumes
+static bool bit_clock_is_regular()
+{
+    const double inc = 1.0 / (double)9600, bt = 1.0 / (double)1200;
+    double ph = 0.0;
+    int pos = 0;
+    for (int t = 0; t < 8 * 64; t++) {
+        int expect = t & 7;
+        if (pos != expect) return false;
+        pos = (pos + 1) % 8;
+        ph += inc;
+        bool roll = false;
+        if (ph >= bt) {
+            ph -= bt;
+            pos = 0;
+            roll = true;
+        }
+        if (roll != (expect == 7)) return false;
+        if (roll && ph != 0.0) return false;
+    }
+    return true;
+}
+
+template <int D>
+static void launch_front(const FrontArgs &fa, int nstreams, long long nds, hipStream_t st)
+{
+    using G = FrontGeom<D>;
+    size_t lds = 512 * sizeof(double) + 4 * (size_t)G::NLDS * sizeof(double2);
+    long long nchunks = (nds + 63) / 64;
+    long long gx = (nchunks + 3) / 4;
+    if (gx > 4096) gx = 4096;
+    if (gx < 1) gx = 1;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_front<D>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(k_front<D>, dim3((unsigned)gx, (unsigned)nstreams), dim3(256), lds, st, fa);
+}
+
+static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev, long long stride_i16, long long L,
+                    int ic, int qc, hipStream_t st)
+{
+    JSDR_REQUIRE(h, "bpsk: null handle");
+    JSDR_REQUIRE(raw_dev || rawf_dev, "bpsk: null input");
+    JSDR_REQUIRE(L > 0 && L <= h->max_batch, "bpsk: nsamples=%lld outside (0, max_batch_samples=%lld]", L, h->max_batch);
+    JSDR_REQUIRE((stride_i16 & 1) == 0 && (h->nstreams == 1 || stride_i16 >= 2 * L),
+                 "bpsk: stream stride %lld too small for %lld samples", stride_i16, L);
+    JSDR_REQUIRE(!h->do_fft, "bpsk: FFT-acquire mode is handled by bpsk_fft (not linked in this build)");
+    const int first_out = h->decim - 1 - h->dsCnt;
+    const long long g_first = h->n_ds;
+    const long long nds = build_schedule(h, L);
+    JSDR_REQUIRE(nds <= h->max_ds, "bpsk: internal: %lld decimated samples exceed capacity %lld", nds, h->max_ds);
+    if (!h->cache_valid) {
+        JSDR_HIP_TRY(hipMemcpyAsync(h->ktu.p, h->h_ktu.data(), sizeof(short) * (size_t)L, hipMemcpyHostToDevice, st));
+        if (nds > 0)
+            JSDR_HIP_TRY(hipMemcpyAsync(h->kvco.p, h->h_kvco.data(), (size_t)nds, hipMemcpyHostToDevice, st));
+        // the host vectors must stay untouched until the copies ran; pageable memcpyAsync stages
+        // synchronously, so they are safe to reuse on return
+        h->cache_valid = true;
+    }
+    const int S = h->nstreams;
+    FrontArgs fa;
+    fa.raw = reinterpret_cast<const int *>(raw_dev);
+    fa.rawf = reinterpret_cast<const float2 *>(rawf_dev);
+    fa.stride_pairs = stride_i16 / 2;
+    fa.nsamples = L;
+    fa.ic = ic;
+    fa.qc = qc;
+    fa.ktu = h->ktu.p;
+    fa.kvco = h->kvco.p;
+    fa.sincos = h->sincos.p;
+    fa.hist_in = h->hist_in[h->hist_cur].p;
+    fa.dm = h->dm.p;
+    fa.dm_stride = h->dm_stride;
+    fa.ds_dbg = nullptr;
+    fa.nds = nds;
+    fa.first_out = first_out;
+    if (nds > 0) {
+        ProfScope ps(h, PK_FRONT, st);
+        switch (h->decim) {
+            case 4: launch_front<4>(fa, S, nds, st); break;
+            case 5: launch_front<5>(fa, S, nds, st); break;
+            case 10: launch_front<10>(fa, S, nds, st); break;
+            case 20: launch_front<20>(fa, S, nds, st); break;
+            default: JSDR_REQUIRE(false, "bpsk: unsupported decimation %d", h->decim);
+        }
+        JSDR_LAUNCH_CHECK();
+    }
+    {
+        HistArgs ha;
+        ha.raw = fa.raw;
+        ha.rawf = fa.rawf;
+        ha.stride_pairs = fa.stride_pairs;
+        ha.nsamples = L;
+        ha.ic = ic;
+        ha.qc = qc;
+        ha.ktu = h->ktu.p;
+        ha.sincos = h->sincos.p;
+        ha.hist_old = h->hist_in[h->hist_cur].p;
+        ha.hist_new = h->hist_in[h->hist_cur ^ 1].p;
+        ha.nstreams = S;
+        ProfScope ps(h, PK_HIST, st);
+        hipLaunchKernelGGL(k_hist_in, dim3((unsigned)((S * 32 + 255) / 256)), dim3(256), 0, st, ha);
+        JSDR_LAUNCH_CHECK();
+        h->hist_cur ^= 1;
+    }
+    if (nds > 0) {
+        MatchedArgs ma;
+        ma.dm = h->dm.p;
+        ma.dm_stride = h->dm_stride;
+        ma.y = h->y.p;
+        ma.y_stride = h->y_stride;
+        ma.nds = nds;
+        ma.g_first = g_first;
+        // first block boundary (slot 0 <=> g == 64 mod 65) at or before g_first; may be "negative" for g < 64
+        long long b0 = g_first - (((g_first - 64) % 65 + 65) % 65);
+        ma.tile0 = b0;
+        long long ntiles = (g_first + nds - b0 + 4159) / 4160;
+        const size_t lds = (64 + 4160) * sizeof(double2);
+        static bool attr_done = false;
+        if (!attr_done) {
+            JSDR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_matched),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_done = true;
+        }
+        {
+            ProfScope ps(h, PK_MATCHED, st);
+            hipLaunchKernelGGL(k_matched, dim3((unsigned)ntiles, (unsigned)S), dim3(512), lds, st, ma);
+        }
+        JSDR_LAUNCH_CHECK();
+        ProfScope ps2(h, PK_DMHIST, st);
+        hipLaunchKernelGGL(k_dm_history, dim3((unsigned)S), dim3(64), 0, st, h->dm.p, h->dm_stride, nds, S);
+        JSDR_LAUNCH_CHECK();
+    }
+    {
+        TailArgs ta;
+        ta.y = h->y.p;
+        ta.y_stride = h->y_stride;
+        ta.nds = nds;
+        ta.g_first = g_first;
+        ta.st = h->tail.p;
+        ta.bitlog_new = h->bitlog[h->bitlog_cur ^ 1].p;
+        ta.bitlog_old = h->bitlog[h->bitlog_cur].p;
+        ta.bitlog_stride = h->bitlog_stride;
+        ta.nbits = h->nbits.p;
+        ta.max_bits = h->max_bits;
+        ta.nstreams = S;
+        ProfScope ps(h, PK_TAIL, st);
+        hipLaunchKernelGGL(k_tail, dim3((unsigned)S), dim3(64), 0, st, ta);
+        JSDR_LAUNCH_CHECK();
+        h->bitlog_cur ^= 1;
+    }
+    {
+        JSDR_HIP_TRY(hipMemsetAsync(h->trig_count.p, 0, sizeof(int) * (size_t)S, st));
+        SyncArgs sa;
+        sa.bitlog = h->bitlog[h->bitlog_cur].p;
+        sa.bitlog_stride = h->bitlog_stride;
+        sa.nbits = h->nbits.p;
+        sa.corr = h->corr.p;
+        sa.max_bits = h->max_bits;
+        sa.trig_count = h->trig_count.p;
+        sa.trig_bits = h->trig_bits.p;
+        int gx = (h->max_bits + 255) / 256;
+        long long maxnew = nds / 4 + 8;
+        if ((long long)gx * 256 > maxnew + 255) gx = (int)((maxnew + 255) / 256);
+        if (gx < 1) gx = 1;
+        {
+            ProfScope ps(h, PK_SYNC, st);
+            hipLaunchKernelGGL(k_sync, dim3((unsigned)gx, (unsigned)S), dim3(256), 0, st, sa);
+        }
+        JSDR_LAUNCH_CHECK();
+        {
+            ProfScope ps(h, PK_SYNCFIN, st);
+            hipLaunchKernelGGL(k_sync_fin, dim3((unsigned)S), dim3(64), 0, st, h->nbits.p, h->corr.p, h->max_bits,
+                               h->trig_count.p, h->trig_bits.p, h->tail.p, S);
+        }
+        JSDR_LAUNCH_CHECK();
+        BpskFecArgs fa2;
+        fa2.bitlog = h->bitlog[h->bitlog_cur].p;
+        fa2.bitlog_stride = h->bitlog_stride;
+        fa2.trig_count = h->trig_count.p;
+        fa2.trig_bits = h->trig_bits.p;
+        fa2.max_trig = MAX_TRIG;
+        fa2.decoded = h->decoded.p;
+        fa2.fec_rc = h->fec_rc.p;
+        fa2.fec_data = h->fec_data.p;
+        fa2.last = h->fec_last.p;
+        fa2.cnt_dec = h->cnt_dec.p;
+        fa2.nstreams = S;
+        ProfScope ps(h, PK_FEC, st);
+        if (launch_fec_bpsk(fa2, st) != JSDR_OK) return JSDR_ERR;
+    }
+    h->n_in += L;
+    h->n_ds += nds;
+    h->last_nds = nds;
+    h->last_stream = st;
+    return JSDR_OK;
+}
+
+extern "C" {
+
+int jsdr_bpsk_create(jsdr_bpsk **out, int rate, int nsamples_per_frame, int tuning_hz, int do_fft, int do_up,
+                     int nstreams, int64_t max_batch_samples)
+{
+    JSDR_REQUIRE(out, "jsdr_bpsk_create: null handle pointer");
+    *out = nullptr;
+    JSDR_REQUIRE(rate >= 9600, "jsdr_bpsk_create: rate %d below the 9600 Hz demodulator rate", rate);
+    const int decim = rate / 9600;  // adsc.rate/DOWN_SAMPLE_RATE (:476), int division
+    JSDR_REQUIRE(decim == 4 || decim == 5 || decim == 10 || decim == 20,
+                 "jsdr_bpsk_create: rate %d gives decimation %d; built for 4, 5, 10, 20 (44.1k, 48k, 96k, 192k)", rate,
+                 decim);
+    JSDR_REQUIRE(nsamples_per_frame > 0 && nstreams > 0 && nstreams <= 65535, "jsdr_bpsk_create: bad geometry");
+    if (max_batch_samples < nsamples_per_frame) max_batch_samples = nsamples_per_frame;
+    JSDR_REQUIRE(!do_fft, "jsdr_bpsk_create: FFT-acquire mode (bpsk-dofft=1) is not in this build yet");
+    JSDR_REQUIRE(bit_clock_is_regular(), "jsdr_bpsk_create: bit clock schedule is not the regular 8-cycle");
+    if (fec_prepare() != JSDR_OK) return JSDR_ERR;
+    jsdr_bpsk *h = new jsdr_bpsk();
+    h->rate = rate;
+    h->nsf = nsamples_per_frame;
+    h->tuning = tuning_hz;
+    h->do_fft = do_fft;
+    h->do_up = do_up;
+    h->nstreams = nstreams;
+    h->decim = decim;
+    h->max_batch = max_batch_samples;
+    h->max_ds = max_batch_samples / decim + 2;
+    h->max_bits = (int)(h->max_ds / 4 + 16);
+    h->tuPhaseInc = 2.0 * JPI * (double)tuning_hz / (double)rate;  // :196
+    const size_t S = (size_t)nstreams;
+    h->dm_stride = 64 + h->max_ds + 64;
+    h->y_stride = h->max_ds;
+    h->bitlog_stride = HIST_BITS + h->max_bits + 64;
+    bool ok = h->sincos.alloc(512) == JSDR_OK && h->ktu.alloc((size_t)h->max_batch) == JSDR_OK &&
+              h->kvco.alloc((size_t)h->max_ds) == JSDR_OK && h->hist_in[0].alloc(S * 32) == JSDR_OK &&
+              h->hist_in[1].alloc(S * 32) == JSDR_OK && h->dm.alloc(S * (size_t)h->dm_stride) == JSDR_OK &&
+              h->y.alloc(S * (size_t)h->y_stride) == JSDR_OK && h->tail.alloc(S) == JSDR_OK &&
+              h->bitlog[0].alloc(S * (size_t)h->bitlog_stride) == JSDR_OK &&
+              h->bitlog[1].alloc(S * (size_t)h->bitlog_stride) == JSDR_OK && h->nbits.alloc(S) == JSDR_OK &&
+              h->trig_count.alloc(S) == JSDR_OK && h->trig_bits.alloc(S * MAX_TRIG) == JSDR_OK &&
+              h->fec_rc.alloc(S * MAX_TRIG) == JSDR_OK && h->fec_last.alloc(S * 2) == JSDR_OK &&
+              h->cnt_dec.alloc(S) == JSDR_OK && h->corr.alloc(S * (size_t)h->max_bits) == JSDR_OK &&
+              h->fec_data.alloc(S * MAX_TRIG * 256) == JSDR_OK && h->decoded.alloc(S * 256) == JSDR_OK &&
+              h->stage_raw.alloc((size_t)nsamples_per_frame * 2) == JSDR_OK;
+    if (!ok) {
+        jsdr_bpsk_destroy(h);
+        return JSDR_ERR;
+    }
+    // tables (:159-162): Math.sin/cos are allowed 1 ulp; the host libm stands in (DESIGN.md "tables")
+    std::vector<double> sc(512);
+    for (int n = 0; n < 256; n++) {
+        sc[n] = cos(n * 2.0 * JPI / 256);
+        sc[256 + n] = sin(n * 2.0 * JPI / 256);
+    }
+    BpskConst bc;
+    memset(&bc, 0, sizeof(bc));
+    for (int i = 0; i < 14; i++) {
+        bc.ds_taps[i] = (double)h_ds_half[i];
+        bc.ds_taps[26 - i] = (double)h_ds_half[i];
+    }
+    for (int i = 0; i < 33; i++) {
+        bc.dm_taps[i] = (double)h_dm_half[i];
+        bc.dm_taps[64 - i] = (double)h_dm_half[i];
+    }
+    int sr = 0x7f;  // sync LFSR == SYNC_VECTOR (:79-81; FECDecoder.java:600-605)
+    for (int i = 0; i < SYNC_N; i++) {
+        bc.sync[i] = (sr & 64) ? 1 : -1;
+        int v = sr & 0x48;
+        v ^= v >> 4;
+        v ^= v >> 2;
+        v ^= v >> 1;
+        sr = ((sr << 1) | (v & 1)) & 0xffff;
+    }
+    std::vector<TailState> ts(S);
+    memset(ts.data(), 0, sizeof(TailState) * S);
+    for (size_t i = 0; i < S; i++) ts[i].dmEnergyOut = 1.0;  // :499
+    bool up = hipMemcpy(h->sincos.p, sc.data(), sizeof(double) * 512, hipMemcpyHostToDevice) == hipSuccess &&
+              hipMemcpyToSymbol(HIP_SYMBOL(c_bpsk), &bc, sizeof(bc)) == hipSuccess &&
+              hipMemcpy(h->tail.p, ts.data(), sizeof(TailState) * S, hipMemcpyHostToDevice) == hipSuccess &&
+              h->hist_in[0].zero() == JSDR_OK && h->hist_in[1].zero() == JSDR_OK && h->dm.zero() == JSDR_OK &&
+              h->bitlog[0].zero() == JSDR_OK && h->bitlog[1].zero() == JSDR_OK && h->decoded.zero() == JSDR_OK &&
+              h->nbits.zero() == JSDR_OK && h->trig_count.zero() == JSDR_OK && h->fec_last.zero() == JSDR_OK &&
+              h->cnt_dec.zero() == JSDR_OK && h->y.zero() == JSDR_OK;
+    if (!up || hipDeviceSynchronize() != hipSuccess) {
+        set_error("jsdr_bpsk_create: device initialisation failed");
+        jsdr_bpsk_destroy(h);
+        return JSDR_ERR;
+    }
+    *out = h;
+    return JSDR_OK;
+}
+
+int jsdr_bpsk_destroy(jsdr_bpsk *h)
+{
+    if (!h) return JSDR_OK;
+    h->sincos.release();
+    h->ktu.release();
+    h->kvco.release();
+    h->hist_in[0].release();
+    h->hist_in[1].release();
+    h->dm.release();
+    h->y.release();
+    h->tail.release();
+    h->bitlog[0].release();
+    h->bitlog[1].release();
+    h->nbits.release();
+    h->trig_count.release();
+    h->trig_bits.release();
+    h->fec_rc.release();
+    h->fec_last.release();
+    h->cnt_dec.release();
+    h->corr.release();
+    h->fec_data.release();
+    h->decoded.release();
+    h->stage_raw.release();
+    for (auto &r : h->prof_recs) {
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    for (auto e : h->prof_pool) (void)hipEventDestroy(e);
+    delete h;
+    return JSDR_OK;
+}
+
+int jsdr_bpsk_batch_i16(jsdr_bpsk *h, const int16_t *raw_dev, int64_t stream_stride_i16, int64_t nsamples, int ic,
+                        int qc, void *stream)
+{
+    return bpsk_run(h, raw_dev, nullptr, stream_stride_i16, nsamples, ic, qc, as_stream(stream));
+}
+
+int jsdr_bpsk_receive_i16(jsdr_bpsk *h, const int16_t *raw_host, int ic, int qc)
+{
+    JSDR_REQUIRE(h && raw_host, "jsdr_bpsk_receive_i16: null argument");
+    JSDR_REQUIRE(h->nstreams == 1, "jsdr_bpsk_receive_i16: handle has %d streams; receive() is the 1-stream form",
+                 h->nstreams);
+    JSDR_HIP_TRY(hipMemcpy(h->stage_raw.p, raw_host, sizeof(int16_t) * 2 * (size_t)h->nsf, hipMemcpyHostToDevice));
+    if (bpsk_run(h, reinterpret_cast<const int16_t *>(h->stage_raw.p), nullptr, 2LL * h->nsf, h->nsf, ic, qc, 0) != JSDR_OK)
+        return JSDR_ERR;
+    JSDR_HIP_TRY(hipStreamSynchronize(0));
+    return JSDR_OK;
+}
+
+int jsdr_bpsk_receive_f32(jsdr_bpsk *h, const float *iq_host)
+{
+    JSDR_REQUIRE(h && iq_host, "jsdr_bpsk_receive_f32: null argument");
+    JSDR_REQUIRE(h->nstreams == 1, "jsdr_bpsk_receive_f32: handle has %d streams; receive() is the 1-stream form",
+                 h->nstreams);
+    JSDR_HIP_TRY(hipMemcpy(h->stage_raw.p, iq_host, sizeof(float) * 2 * (size_t)h->nsf, hipMemcpyHostToDevice));
+    if (bpsk_run(h, nullptr, reinterpret_cast<const float *>(h->stage_raw.p), 2LL * h->nsf, h->nsf, 0, 0, 0) != JSDR_OK)
+        return JSDR_ERR;
+    JSDR_HIP_TRY(hipStreamSynchronize(0));
+    return JSDR_OK;
+}
+
+static int sync_last(jsdr_bpsk *h)
+{
+    JSDR_HIP_TRY(hipStreamSynchronize(h->last_stream));
+    return JSDR_OK;
+}
+
+int jsdr_bpsk_get_counters(jsdr_bpsk *h, int stream, int32_t out[JSDR_BPSK_NCOUNTERS])
+{
+    JSDR_REQUIRE(h && out, "jsdr_bpsk_get_counters: null argument");
+    JSDR_REQUIRE(stream >= 0 && stream < h->nstreams, "jsdr_bpsk_get_counters: stream %d out of range", stream);
+    if (sync_last(h) != JSDR_OK) return JSDR_ERR;
+    TailState t;
+    int last[2], cdec;
+    JSDR_HIP_TRY(hipMemcpy(&t, h->tail.p + stream, sizeof(t), hipMemcpyDeviceToHost));
+    JSDR_HIP_TRY(hipMemcpy(last, h->fec_last.p + 2 * stream, sizeof(last), hipMemcpyDeviceToHost));
+    JSDR_HIP_TRY(hipMemcpy(&cdec, h->cnt_dec.p + stream, sizeof(int), hipMemcpyDeviceToHost));
+    JSDR_REQUIRE(!t.overflow, "jsdr_bpsk_get_counters: stream %d overflowed its per-call bit/FEC capacity", stream);
+    out[0] = (int32_t)h->n_in;
+    out[1] = (int32_t)h->n_ds;
+    out[2] = t.cntBit;
+    out[3] = t.cntFEC;
+    out[4] = cdec;
+    out[5] = last[0];
+    out[6] = t.dmCorr;
+    out[7] = t.dmMaxCorr;
+    out[8] = last[1];
+    out[9] = 0;
+    return JSDR_OK;
+}
+
+int jsdr_bpsk_get_bits(jsdr_bpsk *h, int stream, int8_t *bits_host, int cap, int *nbits)
+{
+    JSDR_REQUIRE(h && nbits, "jsdr_bpsk_get_bits: null argument");
+    JSDR_REQUIRE(stream >= 0 && stream < h->nstreams, "jsdr_bpsk_get_bits: stream %d out of range", stream);
+    if (sync_last(h) != JSDR_OK) return JSDR_ERR;
+    int nb = 0;
+    JSDR_HIP_TRY(hipMemcpy(&nb, h->nbits.p + stream, sizeof(int), hipMemcpyDeviceToHost));
+    *nbits = nb;
+    int n = nb < cap ? nb : cap;
+    if (n > 0 && bits_host)
+        JSDR_HIP_TRY(hipMemcpy(bits_host, h->bitlog[h->bitlog_cur].p + (size_t)stream * h->bitlog_stride + HIST_BITS,
+                               (size_t)n, hipMemcpyDeviceToHost));
+    return JSDR_OK;
+}
+
+int jsdr_bpsk_get_fec_count(jsdr_bpsk *h, int stream, int *count)
+{
+    JSDR_REQUIRE(h && count, "jsdr_bpsk_get_fec_count: null argument");
+    JSDR_REQUIRE(stream >= 0 && stream < h->nstreams, "jsdr_bpsk_get_fec_count: stream %d out of range", stream);
+    if (sync_last(h) != JSDR_OK) return JSDR_ERR;
+    JSDR_HIP_TRY(hipMemcpy(count, h->trig_count.p + stream, sizeof(int), hipMemcpyDeviceToHost));
+    return JSDR_OK;
+}
+
+int jsdr_bpsk_get_fec(jsdr_bpsk *h, int stream, int idx, int32_t *rc, int32_t *bit_index, uint8_t out_host[256])
+{
+    JSDR_REQUIRE(h && rc && bit_index && out_host, "jsdr_bpsk_get_fec: null argument");
+    JSDR_REQUIRE(stream >= 0 && stream < h->nstreams, "jsdr_bpsk_get_fec: stream %d out of range", stream);
+    int cnt = 0;
+    if (jsdr_bpsk_get_fec_count(h, stream, &cnt) != JSDR_OK) return JSDR_ERR;
+    JSDR_REQUIRE(idx >= 0 && idx < cnt, "jsdr_bpsk_get_fec: index %d outside the %d calls of the last batch", idx, cnt);
+    int b = 0;
+    JSDR_HIP_TRY(hipMemcpy(rc, h->fec_rc.p + stream * MAX_TRIG + idx, sizeof(int), hipMemcpyDeviceToHost));
+    JSDR_HIP_TRY(hipMemcpy(&b, h->trig_bits.p + stream * MAX_TRIG + idx, sizeof(int), hipMemcpyDeviceToHost));
+    *bit_index = b + 1;
+    JSDR_HIP_TRY(hipMemcpy(out_host, h->fec_data.p + ((size_t)stream * MAX_TRIG + idx) * 256, 256, hipMemcpyDeviceToHost));
+    return JSDR_OK;
+}
+
+int jsdr_bpsk_get_decoded(jsdr_bpsk *h, int stream, uint8_t out_host[256])
+{
+    JSDR_REQUIRE(h && out_host, "jsdr_bpsk_get_decoded: null argument");
+    JSDR_REQUIRE(stream >= 0 && stream < h->nstreams, "jsdr_bpsk_get_decoded: stream %d out of range", stream);
+    if (sync_last(h) != JSDR_OK) return JSDR_ERR;
+    JSDR_HIP_TRY(hipMemcpy(out_host, h->decoded.p + (size_t)stream * 256, 256, hipMemcpyDeviceToHost));
+    return JSDR_OK;
+}
+
+int jsdr_bpsk_get_trace(jsdr_bpsk *h, int stream, double *out_host, int64_t cap_pairs, int64_t *npairs)
+{
+    JSDR_REQUIRE(h && npairs, "jsdr_bpsk_get_trace: null argument");
+    JSDR_REQUIRE(stream >= 0 && stream < h->nstreams, "jsdr_bpsk_get_trace: stream %d out of range", stream);
+    if (sync_last(h) != JSDR_OK) return JSDR_ERR;
+    *npairs = h->last_nds;
+    long long n = h->last_nds < cap_pairs ? h->last_nds : cap_pairs;
+    if (n > 0 && out_host)
+        JSDR_HIP_TRY(hipMemcpy(out_host, h->y.p + (size_t)stream * h->y_stride, sizeof(double2) * (size_t)n,
+                               hipMemcpyDeviceToHost));
+    return JSDR_OK;
+}
+
+int jsdr_bpsk_get_state(jsdr_bpsk *h, int stream, double out[18])
+{
+    JSDR_REQUIRE(h && out, "jsdr_bpsk_get_state: null argument");
+    JSDR_REQUIRE(stream >= 0 && stream < h->nstreams, "jsdr_bpsk_get_state: stream %d out of range", stream);
+    if (sync_last(h) != JSDR_OK) return JSDR_ERR;
+    TailState t;
+    JSDR_HIP_TRY(hipMemcpy(&t, h->tail.p + stream, sizeof(t), hipMemcpyDeviceToHost));
+    out[0] = h->tuPhase;
+    out[1] = h->vcoPhase;
+    // dmBitPhase (:501,:581-584): k steps of +1/9600 from 0.0 within the current bit, replayed exactly
+    double ph = 0.0;
+    for (int i = 0; i < (int)(h->n_ds & 7); i++) ph += 1.0 / (double)9600;
+    out[2] = ph;
+    out[3] = t.dmEnergyOut;
+    out[4] = t.energy1;
+    out[5] = t.energy2;
+    out[6] = 0.0;
+    out[7] = 0.0;
+    for (int i = 0; i < 8; i++) out[8 + i] = t.dmEnergy[i];
+    out[16] = t.lastI;
+    out[17] = t.lastQ;
+    return JSDR_OK;
+}
+
+int jsdr_bpsk_profile_enable(jsdr_bpsk *h, int on)
+{
+    JSDR_REQUIRE(h, "jsdr_bpsk_profile_enable: null handle");
+    h->prof_on = on != 0;
+    return JSDR_OK;
+}
+
+int jsdr_bpsk_profile_count(void) { return PK_COUNT; }
+
+const char *jsdr_bpsk_profile_name(int k) { return (k >= 0 && k < PK_COUNT) ? kProfNames[k] : ""; }
+
+int jsdr_bpsk_profile_read(jsdr_bpsk *h, double *ms_total, int *launches)
+{
+    JSDR_REQUIRE(h && ms_total && launches, "jsdr_bpsk_profile_read: null argument");
+    for (int k = 0; k < PK_COUNT; k++) {
+        ms_total[k] = 0.0;
+        launches[k] = 0;
+    }
+    for (auto &r : h->prof_recs) {
+        float ms = 0.f;
+        JSDR_HIP_TRY(hipEventSynchronize(r.b));
+        JSDR_HIP_TRY(hipEventElapsedTime(&ms, r.a, r.b));
+        ms_total[r.kernel] += (double)ms;
+        launches[r.kernel] += 1;
+        h->prof_pool.push_back(r.a);
+        h->prof_pool.push_back(r.b);
+    }
+    h->prof_recs.clear();
+    return JSDR_OK;
+}
+
+int jsdr_bpsk_slot_info(jsdr_bpsk *h, int64_t *slot_bytes, int64_t *bits_offset, int64_t *fec_offset, int *slot_bits,
+                        int *nfec_max)
+{
+    JSDR_REQUIRE(h, "jsdr_bpsk_slot_info: null handle");
+    int64_t bits = (h->max_bits + 15) & ~15;
+    if (bits_offset) *bits_offset = 64;
+    if (fec_offset) *fec_offset = 64 + bits;
+    if (slot_bits) *slot_bits = (int)bits;
+    if (nfec_max) *nfec_max = MAX_TRIG;
+    if (slot_bytes) *slot_bytes = 64 + bits + (int64_t)MAX_TRIG * 264;
+    return JSDR_OK;
+}
+
+}  // extern "C"
+
+namespace jsdr {
+// slot = int32 header[16] | int8 bits[slot_bits] | MAX_TRIG x {int32 rc, int32 bit_index, uint8 data[256]}
+__global__ void k_pack_slots(unsigned char *slots, long long slot_bytes, int slot_bits, const TailState *st,
+                             const int *nbits, const signed char *bitlog, long long bitlog_stride, const int *trig_count,
+                             const int *trig_bits, const int *fec_rc, const unsigned char *fec_data, const int *fec_last,
+                             const int *cnt_dec, int n_in, int n_ds)
+{
+    const int s = blockIdx.x;
+    unsigned char *slot = slots + (long long)s * slot_bytes;
+    int *hdr = reinterpret_cast<int *>(slot);
+    const int nb = nbits[s], nt = trig_count[s];
+    if (threadIdx.x < 16) {
+        int v = 0;
+        switch (threadIdx.x) {
+            case 0: v = nb; break;
+            case 1: v = nt; break;
+            case 2: v = n_in; break;
+            case 3: v = n_ds; break;
+            case 4: v = st[s].cntBit; break;
+            case 5: v = st[s].cntFEC; break;
+            case 6: v = cnt_dec[s]; break;
+            case 7: v = fec_last[2 * s]; break;
+            case 8: v = st[s].dmCorr; break;
+            case 9: v = st[s].dmMaxCorr; break;
+            case 10: v = fec_last[2 * s + 1]; break;
+            default: v = 0;
+        }
+        hdr[threadIdx.x] = v;
+    }
+    const signed char *bl = bitlog + (long long)s * bitlog_stride + HIST_BITS;
+    for (int i = threadIdx.x; i < slot_bits; i += blockDim.x) slot[64 + i] = (i < nb) ? (unsigned char)bl[i] : 0;
+    unsigned char *f = slot + 64 + slot_bits;
+    for (int t = 0; t < MAX_TRIG; t++) {
+        int *fh = reinterpret_cast<int *>(f + t * 264);
+        if (threadIdx.x == 0) {
+            fh[0] = (t < nt) ? fec_rc[s * MAX_TRIG + t] : 0;
+            fh[1] = (t < nt) ? trig_bits[s * MAX_TRIG + t] + 1 : 0;
+        }
+        for (int i = threadIdx.x; i < 256; i += blockDim.x)
+            f[t * 264 + 8 + i] = (t < nt) ? fec_data[((long long)s * MAX_TRIG + t) * 256 + i] : 0;
+    }
+}
+}  // namespace jsdr
+
+extern "C" int jsdr_bpsk_pack_slots(jsdr_bpsk *h, uint8_t *slots_dev, void *stream)
+{
+    JSDR_REQUIRE(h && slots_dev, "jsdr_bpsk_pack_slots: null argument");
+    int64_t slot_bytes = 0;
+    int slot_bits = 0;
+    jsdr_bpsk_slot_info(h, &slot_bytes, nullptr, nullptr, &slot_bits, nullptr);
+    hipLaunchKernelGGL(k_pack_slots, dim3((unsigned)h->nstreams), dim3(256), 0, as_stream(stream), slots_dev,
+                       (long long)slot_bytes, slot_bits, h->tail.p, h->nbits.p, h->bitlog[h->bitlog_cur].p,
+                       h->bitlog_stride, h->trig_count.p, h->trig_bits.p, h->fec_rc.p, h->fec_data.p, h->fec_last.p,
+                       h->cnt_dec.p, (int)h->n_in, (int)h->n_ds);
+    JSDR_LAUNCH_CHECK();
+    return JSDR_OK;
+}

@@ -1,0 +1,27 @@
+// bpsk_fec.h -- the hook between the demodulator (bpsk.hip) and the FEC decoder (fec.hip).
+#pragma once
+#include "common.h"
+
+namespace jsdr {
+
+// One wave per stream that has sync hits in this call.  For each hit (in bit order) build the soft block
+// from the +1/-1/0 bit history (FUNcubeBPSKDemod.java:562-564), decode, keep the stream's decoded[] on
+// success, log {rc, decoded[]} per call.
+struct BpskFecArgs {
+    const signed char *bitlog;  // [nstreams][bitlog_stride]; the window of bit b (0-based in this call) starts at b+1
+    long long bitlog_stride;
+    const int *trig_count;      // [nstreams]
+    const int *trig_bits;       // [nstreams][max_trig], ascending
+    int max_trig;
+    unsigned char *decoded;     // [nstreams][256], persistent decoded[] (FUNcubeBPSKDemod.java:111)
+    int *fec_rc;                // [nstreams][max_trig]
+    unsigned char *fec_data;    // [nstreams][max_trig][256]
+    int *last;                  // [nstreams][2]: dmErrBits, decodeOK (:565-568)
+    int *cnt_dec;               // [nstreams] cntDec (:569)
+    int nstreams;
+};
+
+int launch_fec_bpsk(const BpskFecArgs &a, hipStream_t st);
+int fec_prepare();
+
+}  // namespace jsdr

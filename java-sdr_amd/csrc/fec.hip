@@ -1,0 +1,582 @@
+// fec.hip -- AO-40 FEC on the GPU: FECDecoder.FECDecode (FECDecoder.java:703-852) and the re-encoder
+// encode_FEC40 (:538-688).  Integer only, bit-exact by construction.
+//
+// MI355X mapping: ONE WAVEFRONT PER 5200-SYMBOL BLOCK.
+//   * Viterbi K=7 r=1/2 has 64 states = the 64 lanes of a wave.  Lane s keeps the path metric of state s
+//     in a VGPR; the two predecessors (s>>1, (s>>1)+32) arrive by cross-lane reads; the 64 decisions of a
+//     step are one __ballot -- the same 64 bits the reference packs into its two `long pp[]` words per step
+//     (FECDecoder.java:229-255) -- kept in LDS for the chain-back.
+//   * RS(255,223) x2: the 2 x 32 syndromes are the 64 lanes (Horner over the 160 non-padding columns);
+//     Berlekamp-Massey / Chien / Forney only run when a syndrome is non-zero, one lane per codeword,
+//     restating :387-511 verbatim.
+//   * re-encode: the two RS parity LFSRs run on the two half-waves (lane = register position), the
+//     convolutional encoder + interleaver is parallel over the 2566 bits.
+#include "bpsk_fec.h"
+#include <vector>
+
+namespace jsdr {
+
+enum {
+    NN = 255, KK = 223, NROOTS = 32, FCR = 112, PRIM = 11, IPRIM = 116, A0 = 255,
+    RSPAD = 95, NBITS = 2566, ROWS = 80, COLUMNS = 65, SYMPBLOCK = 5200
+};
+
+struct FecTables {
+    unsigned char alpha_to[256];
+    unsigned char index_of[256];
+    unsigned char scrambler[320];
+    unsigned char rs_coef[32];  // index-form generator coefficient applied to register position q (q=1..31), [0] unused
+    unsigned char sync[65];     // sync vector bits (1/0), FECDecoder.java:600-605
+    short mettab[2][256];
+};
+
+__constant__ FecTables c_fec;
+
+// FECDecoder.java:67-83 mettab[0] (sent symbol 0); row [1] is its mirror except two entries (:84).
+static const short h_mettab0[256] = {
+    20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20,
+    20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20,
+    20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20, 20,
+    19, 19, 19, 19, 19, 19, 19, 19, 19, 19, 19, 18, 18, 18, 18, 18, 18, 17, 17, 17, 16, 16, 16, 15, 15, 14, 14, 13, 13,
+    12, 11, 10, 10, 9, 8, 7, 6, 5, 3, 2, 1, -1, -2, -4, -5, -7, -9, -11, -13, -15, -17, -19, -21, -23, -25, -28, -30,
+    -32, -35, -37, -40, -42, -45, -47, -50, -52, -55, -58, -60, -63, -66, -68, -71, -74, -77, -79, -82, -85, -88, -90,
+    -93, -96, -99, -102, -104, -107, -110, -113, -116, -119, -121, -124, -127, -130, -133, -136, -138, -141, -144, -147,
+    -150, -153, -155, -158, -161, -164, -167, -170, -172, -175, -178, -181, -184, -187, -190, -192, -195, -198, -201,
+    -204, -207, -210, -212, -215, -218, -221, -224, -227, -229, -232, -235, -238, -241, -244, -247, -249, -252, -255,
+    -258, -261, -264, -267, -269, -272, -275, -278, -281, -284, -286, -289, -292, -295, -298, -301, -304, -306, -309,
+    -312, -315, -318, -320, -324, -326, -329, -332, -335, -337, -341, -372};
+
+static bool g_tables_ready[64] = {false};
+
+static int upload_tables()
+{
+    int dev = 0;
+    JSDR_HIP_TRY(hipGetDevice(&dev));
+    if (dev >= 0 && dev < 64 && g_tables_ready[dev]) return JSDR_OK;
+    FecTables t;
+    memset(&t, 0, sizeof(t));
+    // GF(256), field polynomial 0x187 (FECDecoder.java:145-181)
+    int x = 1;
+    for (int i = 0; i < 255; i++) {
+        t.alpha_to[i] = (unsigned char)x;
+        t.index_of[x] = (unsigned char)i;
+        x <<= 1;
+        if (x & 0x100) x ^= 0x187;
+    }
+    t.alpha_to[255] = 0;
+    t.index_of[0] = A0;
+    // CCSDS randomiser x^8+x^7+x^5+x^3+1, all-ones start (:118-139)
+    unsigned sr = 0xff;
+    for (int i = 0; i < 320; i++) {
+        int byte = 0;
+        for (int b = 0; b < 8; b++) {
+            byte = (byte << 1) | (int)(sr & 1u);
+            unsigned fb = (sr ^ (sr >> 3) ^ (sr >> 5) ^ (sr >> 7)) & 1u;
+            sr = (sr >> 1) | (fb << 7);
+        }
+        t.scrambler[i] = (unsigned char)byte;
+    }
+    // RS generator prod_{i<32}(x - alpha^{PRIM(FCR+i)}), index form; palindromic (:544-546, :634-640)
+    int g[NROOTS + 1];
+    memset(g, 0, sizeof(g));
+    g[0] = 1;
+    for (int i = 0; i < NROOTS; i++) {
+        int root = ((FCR + i) * PRIM) % 255;
+        g[i + 1] = 1;
+        for (int j = i; j > 0; j--) {
+            if (g[j] != 0)
+                g[j] = g[j - 1] ^ t.alpha_to[(t.index_of[g[j]] + root) % 255];
+            else
+                g[j] = g[j - 1];
+        }
+        g[0] = t.alpha_to[(t.index_of[g[0]] + root) % 255];
+    }
+    for (int q = 1; q < 32; q++) t.rs_coef[q] = t.index_of[g[q]];
+    // sync LFSR (:600-605)
+    int s7 = 0x7f;
+    for (int i = 0; i < 65; i++) {
+        t.sync[i] = (s7 & 64) ? 1 : 0;
+        int v = s7 & 0x48;
+        v ^= v >> 4;
+        v ^= v >> 2;
+        v ^= v >> 1;
+        s7 = ((s7 << 1) | (v & 1)) & 0xffff;
+    }
+    for (int i = 0; i < 256; i++) {
+        t.mettab[0][i] = h_mettab0[i];
+        t.mettab[1][i] = h_mettab0[255 - i];
+    }
+    t.mettab[1][2] = -338;
+    t.mettab[1][8] = -321;
+    JSDR_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_fec), &t, sizeof(t)));
+    if (dev >= 0 && dev < 64) g_tables_ready[dev] = true;
+    return JSDR_OK;
+}
+
+int fec_prepare() { return upload_tables(); }
+
+// ----------------------------------------------------------------------------------------------
+// LDS work area of one wave
+struct FecLds {
+    unsigned char raw[SYMPBLOCK];       // soft symbols in, or re-encoded symbols
+    unsigned char enc[SYMPBLOCK];       // encoder output
+    unsigned long long dec[NBITS + 2];  // decisions per step (== the reference's pp[2k], pp[2k+1])
+    short mets[NBITS][4];               // branch metrics per step
+    unsigned char alpha_to[256];
+    unsigned char index_of[256];
+    unsigned char vit[320];             // Viterbi output / scrambled byte stream
+    unsigned char rs[2][256];           // RS code words (255 used)
+    unsigned char data[256];            // decoded payload
+    int misc[8];
+};
+
+__device__ __forceinline__ int parity7(int v)
+{
+    return __popc(v) & 1;
+}
+
+__device__ __forceinline__ int gf_mod255(int x) { return x % 255; }
+
+// encode_FEC40 (:677-688): data[256] (LDS) -> L.enc[5200]; 64 lanes cooperate.
+__device__ void fec_encode_wave(FecLds &L, const unsigned char *data, int lane)
+{
+    // ---- RS parity, two interleaved code words: lanes 0..31 block 0 (even bytes), 32..63 block 1 (odd)
+    const int blk = lane >> 5, q = lane & 31;
+    int reg = 0;
+    const int coef = (q < 31) ? (int)c_fec.rs_coef[q + 1] : 0;  // generator coefficient feeding position q after the shift
+    for (int n = 0; n < 128; n++) {
+        int c = data[2 * n + blk];
+        int r0 = __shfl(reg, blk * 32, 64);
+        int fb = L.index_of[c ^ r0];           // :623
+        int up = __shfl_down(reg, 1, 64);      // old RS_block[q+1]
+        int nv;
+        if (q < 31) {
+            nv = up;
+            if (fb != A0) nv ^= L.alpha_to[gf_mod255(fb + coef)];   // :634-645
+        } else {
+            nv = (fb != A0) ? (int)L.alpha_to[fb] : 0;              // :648-652
+        }
+        reg = nv;
+    }
+    // byte stream: 256 data + 64 parity (parity byte 256+2q+b = RS_block[b][q], :665), scrambled (:570)
+    for (int i = lane; i < 256; i += 64) L.vit[i] = data[i] ^ c_fec.scrambler[i];
+    L.vit[256 + 2 * q + blk] = (unsigned char)(reg ^ c_fec.scrambler[256 + 2 * q + blk]);
+    for (int i = lane; i < SYMPBLOCK; i += 64) L.enc[i] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // sync vector in interleaver column 0 (:600-605)
+    for (int i = lane; i < 65; i += 64)
+        if (c_fec.sync[i]) L.enc[ROWS * i] = 1;
+    // convolutional encoder + interleaver, parallel over the 2566 bits (:559-566, :549-556)
+    for (int k = lane; k < NBITS; k += 64) {
+        int sr = 0;
+#pragma unroll
+        for (int d = 6; d >= 0; d--) {
+            int kk = k - d;
+            int bit = 0;
+            if (kk >= 0 && kk < 2560) bit = (L.vit[kk >> 3] >> (7 - (kk & 7))) & 1;
+            sr = (sr << 1) | bit;
+        }
+        int a = parity7(sr & 0x4f);
+        int b = 1 - parity7(sr & 0x6d);
+        int bi = COLUMNS + 2 * k;
+        if (a) L.enc[(bi % COLUMNS) * ROWS + bi / COLUMNS] = 1;
+        bi++;
+        if (b) L.enc[(bi % COLUMNS) * ROWS + bi / COLUMNS] = 1;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// decode_rs_8 (:325-519) after the syndromes: one lane per code word, verbatim control flow.
+// s[] in index form.  Returns the number of corrected symbols or -1.
+__device__ __noinline__ int rs_correct_lane(unsigned char *data, const int *s_in, const unsigned char *alpha_to,
+                                            const unsigned char *index_of)
+{
+    int lambda[NROOTS + 1], s[NROOTS], b[NROOTS + 1], t[NROOTS + 1], omega[NROOTS + 1];
+    int root[NROOTS], reg[NROOTS + 1], loc[NROOTS];
+    int deg_lambda, el, deg_omega, i, j, r, k, q, tmp, num1, num2, den, discr_r, count;
+    for (i = 0; i < NROOTS; i++) s[i] = s_in[i];
+    for (i = 0; i <= NROOTS; i++) {
+        lambda[i] = 0;
+        t[i] = 0;
+        omega[i] = 0;
+        reg[i] = 0;
+    }
+    lambda[0] = 1;
+    for (i = 0; i < NROOTS + 1; i++) b[i] = index_of[lambda[i]];
+    r = 0;
+    el = 0;
+    while (++r <= NROOTS) {
+        discr_r = 0;
+        for (i = 0; i < r; i++) {
+            if ((lambda[i] != 0) && (s[r - i - 1] != A0))
+                discr_r ^= alpha_to[gf_mod255(index_of[lambda[i]] + s[r - i - 1])];
+        }
+        discr_r = index_of[discr_r];
+        if (discr_r == A0) {
+            for (i = NROOTS; i > 0; i--) b[i] = b[i - 1];
+            b[0] = A0;
+        } else {
+            t[0] = lambda[0];
+            for (i = 0; i < NROOTS; i++) {
+                if (b[i] != A0)
+                    t[i + 1] = lambda[i + 1] ^ alpha_to[gf_mod255(discr_r + b[i])];
+                else
+                    t[i + 1] = lambda[i + 1];
+            }
+            if (2 * el <= r - 1) {
+                el = r - el;
+                for (i = 0; i <= NROOTS; i++)
+                    b[i] = (lambda[i] == 0) ? A0 : gf_mod255(index_of[lambda[i]] - discr_r + NN);
+            } else {
+                for (i = NROOTS; i > 0; i--) b[i] = b[i - 1];
+                b[0] = A0;
+            }
+            for (i = 0; i <= NROOTS; i++) lambda[i] = t[i];
+        }
+    }
+    deg_lambda = 0;
+    for (i = 0; i < NROOTS + 1; i++) {
+        lambda[i] = index_of[lambda[i]];
+        if (lambda[i] != A0) deg_lambda = i;
+    }
+    for (i = 1; i <= NROOTS; i++) reg[i] = lambda[i];
+    count = 0;
+    for (i = 1, k = IPRIM - 1; i <= NN; i++, k = gf_mod255(k + IPRIM)) {
+        q = 1;
+        for (j = deg_lambda; j > 0; j--) {
+            if (reg[j] != A0) {
+                reg[j] = gf_mod255(reg[j] + j);
+                q ^= alpha_to[reg[j]];
+            }
+        }
+        if (q != 0) continue;
+        root[count] = i;
+        loc[count] = k;
+        if (++count == deg_lambda) break;
+    }
+    if (deg_lambda != count) return -1;
+    deg_omega = 0;
+    for (i = 0; i < NROOTS; i++) {
+        tmp = 0;
+        j = (deg_lambda < i) ? deg_lambda : i;
+        for (; j >= 0; j--) {
+            if ((s[i - j] != A0) && (lambda[j] != A0)) tmp ^= alpha_to[gf_mod255(s[i - j] + lambda[j])];
+        }
+        if (tmp != 0) deg_omega = i;
+        omega[i] = index_of[tmp];
+    }
+    omega[NROOTS] = A0;
+    for (j = count - 1; j >= 0; j--) {
+        num1 = 0;
+        for (i = deg_omega; i >= 0; i--) {
+            if (omega[i] != A0) num1 ^= alpha_to[gf_mod255(omega[i] + i * root[j])];
+        }
+        num2 = alpha_to[gf_mod255(root[j] * (FCR - 1) + NN)];
+        den = 0;
+        int top = deg_lambda < NROOTS - 1 ? deg_lambda : NROOTS - 1;
+        for (i = top & ~1; i >= 0; i -= 2) {
+            if (lambda[i + 1] != A0) den ^= alpha_to[gf_mod255(lambda[i + 1] + i * root[j])];
+        }
+        if (den == 0) return -1;
+        if (num1 != 0)
+            data[loc[j]] ^= alpha_to[gf_mod255(index_of[num1] + index_of[num2] + NN - index_of[den])];
+    }
+    return count;
+}
+
+// FECDecode (:703-852) on L.raw; payload to L.data only on success (as the reference leaves
+// RSdecdata untouched on failure).  Returns -1 or the channel error count (wave-uniform).
+__device__ int fec_decode_wave(FecLds &L, int lane)
+{
+    // ---- step 1+2a: de-interleave (:715-722) fused with the branch metrics (:220-225)
+    for (int k = lane; k < NBITS; k += 64) {
+        int j0 = 2 * k, j1 = 2 * k + 1;
+        int y0 = L.raw[(j0 % COLUMNS) * ROWS + (j0 / COLUMNS + 1)];
+        int y1 = L.raw[(j1 % COLUMNS) * ROWS + (j1 / COLUMNS + 1)];
+#pragma unroll
+        for (int i = 0; i < 4; i++) L.mets[k][i] = (short)(c_fec.mettab[(i >> 1) & 1][y0] + c_fec.mettab[i & 1][y1]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ---- step 2b: add-compare-select, lane = state (:229-253).  Metrics fit int32 (|m| < 3e6).
+    {
+        // Syms[i] = (Partab[i&0x4f]<<1) | (1-Partab[i&0x6d])   (:105-114)
+        const int ia = (parity7(lane & 0x4f) << 1) | (1 - parity7(lane & 0x6d));
+        const int ib = (parity7((lane ^ 1) & 0x4f) << 1) | (1 - parity7((lane ^ 1) & 0x6d));
+        int metric = (lane == 0) ? 0 : -999999;
+        const int src_lo = lane >> 1, src_hi = (lane >> 1) + 32;
+        for (int k = 0; k < NBITS; k++) {
+            const short *m = L.mets[k];
+            int lo = __shfl(metric, src_lo, 64);
+            int hi = __shfl(metric, src_hi, 64);
+            int m0 = lo + (int)m[ia];
+            int m1 = hi + (int)m[ib];
+            bool d = m1 > m0;
+            metric = d ? m1 : m0;
+            unsigned long long mask = __ballot(d);
+            if (lane == 0) L.dec[k] = mask;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ---- step 2c: chain back from state 0 (:264-276); decision words fetched 64 steps at a time
+    {
+        for (int i = lane; i < 320; i += 64) L.vit[i] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        int beststate = 0;
+        int cur = 0;  // byte being assembled (bits of 8 consecutive i)
+        for (int hi_i = NBITS - 7; hi_i >= 0; hi_i -= 64) {
+            // this chunk covers i = hi_i .. max(hi_i-63,0); step index k = i + 6
+            int my_i = hi_i - lane;
+            unsigned long long w = (my_i >= 0) ? L.dec[my_i + 6] : 0ull;
+            unsigned wl = (unsigned)w, wh = (unsigned)(w >> 32);
+            int nsteps = hi_i + 1 < 64 ? hi_i + 1 : 64;
+            for (int t = 0; t < nsteps; t++) {
+                int i = hi_i - t;
+                unsigned l32 = __builtin_amdgcn_readlane(wl, t);
+                unsigned h32 = __builtin_amdgcn_readlane(wh, t);
+                unsigned word = (beststate >> 5) ? h32 : l32;
+                if ((word >> (beststate & 31)) & 1u) {
+                    beststate |= 64;
+                    cur |= 0x80 >> (i & 7);
+                }
+                beststate >>= 1;
+                if ((i & 7) == 0) {
+                    if (lane == 0) L.vit[i >> 3] = (unsigned char)cur;
+                    cur = 0;
+                }
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ---- step 3: de-scramble into the two RS code words (:765-771), syndromes (:336-347)
+    const int blk = lane >> 5, ri = lane & 31;
+    for (int i = lane; i < 2 * 256; i += 64) (&L.rs[0][0])[i] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int i = lane; i < 320; i += 64) L.rs[i & 1][RSPAD + (i >> 1)] = L.vit[i] ^ c_fec.scrambler[i];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    int syn = 0;
+    {
+        const int step = (FCR + ri) * PRIM;
+        const unsigned char *dw = L.rs[blk];
+        for (int j = RSPAD; j < NN; j++) {  // columns < RSPAD are zero padding: s stays 0 through them
+            int dj = dw[j];
+            syn = (syn == 0) ? dj : (dj ^ (int)L.alpha_to[gf_mod255((int)L.index_of[syn] + step)]);
+        }
+    }
+    unsigned long long nz = __ballot(syn != 0);
+    int *sidx = reinterpret_cast<int *>(&L.mets[0][0]);  // branch metrics are dead: reuse as int s[2][32]
+    sidx[lane] = L.index_of[syn];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    int rserr = 0;
+    bool need0 = (nz & 0xffffffffull) != 0, need1 = (nz >> 32) != 0;
+    if ((lane == 0 && need0) || (lane == 32 && need1))
+        rserr = rs_correct_lane(L.rs[blk], sidx + blk * 32, L.alpha_to, L.index_of);
+    int e0 = __shfl(rserr, 0, 64), e1 = __shfl(rserr, 32, 64);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (e0 == -1 || e1 == -1) return -1;  // :821-824
+    for (int j = lane; j < 256; j += 64) L.data[j] = L.rs[j & 1][RSPAD + (j >> 1)];  // :783-787
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ---- step 4: re-encode and count channel errors (:831-847)
+    fec_encode_wave(L, L.data, lane);
+    int errs = 0;
+    for (int i = lane; i < SYMPBLOCK; i += 64) errs += (L.enc[i] != (L.raw[i] >> 7)) ? 1 : 0;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) errs += __shfl_xor(errs, off, 64);
+    return errs;
+}
+
+__device__ __forceinline__ void fec_lds_init(FecLds &L, int lane)
+{
+    for (int i = lane; i < 256; i += 64) {
+        L.alpha_to[i] = c_fec.alpha_to[i];
+        L.index_of[i] = c_fec.index_of[i];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__global__ __launch_bounds__(64) void k_fec_decode(const unsigned char *__restrict__ raw, long long nblocks,
+                                                   unsigned char *__restrict__ out, int *__restrict__ rc)
+{
+    __shared__ FecLds L;
+    const int lane = threadIdx.x;
+    fec_lds_init(L, lane);
+    for (long long blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+        const unsigned *src = reinterpret_cast<const unsigned *>(raw + blk * SYMPBLOCK);
+        for (int i = lane; i < SYMPBLOCK / 4; i += 64) reinterpret_cast<unsigned *>(L.raw)[i] = src[i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        int r = fec_decode_wave(L, lane);
+        if (r >= 0)
+            for (int i = lane; i < 256; i += 64) out[blk * 256 + i] = L.data[i];
+        if (lane == 0) rc[blk] = r;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+__global__ __launch_bounds__(64) void k_fec_encode(const unsigned char *__restrict__ data, long long nblocks,
+                                                   unsigned char *__restrict__ sym)
+{
+    __shared__ FecLds L;
+    const int lane = threadIdx.x;
+    fec_lds_init(L, lane);
+    for (long long blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+        for (int i = lane; i < 256; i += 64) L.data[i] = data[blk * 256 + i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        fec_encode_wave(L, L.data, lane);
+        unsigned *dst = reinterpret_cast<unsigned *>(sym + blk * SYMPBLOCK);
+        for (int i = lane; i < SYMPBLOCK / 4; i += 64) dst[i] = reinterpret_cast<unsigned *>(L.enc)[i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+__global__ __launch_bounds__(64) void k_fec_bpsk(BpskFecArgs a)
+{
+    __shared__ FecLds L;
+    const int lane = threadIdx.x;
+    bool inited = false;
+    for (int s = blockIdx.x; s < a.nstreams; s += gridDim.x) {
+        int nt = a.trig_count[s];
+        if (nt > a.max_trig) nt = a.max_trig;
+        if (nt <= 0) continue;
+        if (!inited) {
+            fec_lds_init(L, lane);
+            inited = true;
+        }
+        int ndec = 0, lastrc = 0;
+        for (int t = 0; t < nt; t++) {
+            const signed char *win = a.bitlog + (long long)s * a.bitlog_stride + (a.trig_bits[s * a.max_trig + t] + 1);
+            for (int i = lane; i < SYMPBLOCK; i += 64) L.raw[i] = (win[i] == 1) ? 0xc0 : 0x40;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            int r = fec_decode_wave(L, lane);
+            unsigned char *dst = a.decoded + (long long)s * 256;
+            if (r >= 0) {
+                for (int i = lane; i < 256; i += 64) dst[i] = L.data[i];
+                ndec++;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            unsigned char *logd = a.fec_data + ((long long)s * a.max_trig + t) * 256;
+            for (int i = lane; i < 256; i += 64) logd[i] = (r >= 0) ? L.data[i] : dst[i];
+            if (lane == 0) a.fec_rc[s * a.max_trig + t] = r;
+            lastrc = r;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (lane == 0) {
+            a.last[2 * s] = lastrc;
+            a.last[2 * s + 1] = lastrc < 0 ? 0 : 1;
+            a.cnt_dec[s] += ndec;
+        }
+    }
+}
+
+int launch_fec_bpsk(const BpskFecArgs &a, hipStream_t st)
+{
+    if (upload_tables() != JSDR_OK) return JSDR_ERR;
+    int grid = a.nstreams < 2048 ? a.nstreams : 2048;
+    hipLaunchKernelGGL(k_fec_bpsk, dim3(grid), dim3(64), 0, st, a);
+    JSDR_LAUNCH_CHECK();
+    return JSDR_OK;
+}
+
+}  // namespace jsdr
+
+using namespace jsdr;
+
+extern "C" {
+
+int jsdr_fec_decode_batch(const uint8_t *raw_dev, int64_t nblocks, uint8_t *out_dev, int32_t *rc_dev, void *stream)
+{
+    JSDR_REQUIRE(raw_dev && out_dev && rc_dev, "jsdr_fec_decode_batch: null buffer");
+    JSDR_REQUIRE(nblocks >= 0, "jsdr_fec_decode_batch: negative block count");
+    if (nblocks == 0) return JSDR_OK;
+    if (upload_tables() != JSDR_OK) return JSDR_ERR;
+    int grid = (int)(nblocks < 4096 ? nblocks : 4096);
+    hipLaunchKernelGGL(k_fec_decode, dim3(grid), dim3(64), 0, as_stream(stream), raw_dev, (long long)nblocks, out_dev,
+                       rc_dev);
+    JSDR_LAUNCH_CHECK();
+    return JSDR_OK;
+}
+
+int jsdr_fec_encode_batch(const uint8_t *data_dev, int64_t nblocks, uint8_t *sym_dev, void *stream)
+{
+    JSDR_REQUIRE(data_dev && sym_dev, "jsdr_fec_encode_batch: null buffer");
+    JSDR_REQUIRE(nblocks >= 0, "jsdr_fec_encode_batch: negative block count");
+    if (nblocks == 0) return JSDR_OK;
+    if (upload_tables() != JSDR_OK) return JSDR_ERR;
+    int grid = (int)(nblocks < 4096 ? nblocks : 4096);
+    hipLaunchKernelGGL(k_fec_encode, dim3(grid), dim3(64), 0, as_stream(stream), data_dev, (long long)nblocks, sym_dev);
+    JSDR_LAUNCH_CHECK();
+    return JSDR_OK;
+}
+
+int jsdr_fec_decode(const uint8_t raw_host[5200], uint8_t out_host[256], int *rc)
+{
+    JSDR_REQUIRE(raw_host && out_host && rc, "jsdr_fec_decode: null argument");
+    DevBuf<unsigned char> raw, out;
+    DevBuf<int> drc;
+    int ret = JSDR_ERR;
+    if (raw.alloc(SYMPBLOCK) == JSDR_OK && out.alloc(256) == JSDR_OK && drc.alloc(1) == JSDR_OK) {
+        // the reference leaves RSdecdata untouched when RS fails: seed the device copy with the caller's bytes
+        if (hipMemcpy(raw.p, raw_host, SYMPBLOCK, hipMemcpyHostToDevice) == hipSuccess &&
+            hipMemcpy(out.p, out_host, 256, hipMemcpyHostToDevice) == hipSuccess &&
+            jsdr_fec_decode_batch(raw.p, 1, out.p, drc.p, 0) == JSDR_OK &&
+            hipMemcpy(out_host, out.p, 256, hipMemcpyDeviceToHost) == hipSuccess &&
+            hipMemcpy(rc, drc.p, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess)
+            ret = JSDR_OK;
+        else if (jsdr_last_error()[0] == 0)
+            set_error("jsdr_fec_decode: transfer failed");
+    }
+    raw.release();
+    out.release();
+    drc.release();
+    return ret;
+}
+
+int jsdr_fec_encode(const uint8_t data_host[256], uint8_t sym_host[5200])
+{
+    JSDR_REQUIRE(data_host && sym_host, "jsdr_fec_encode: null argument");
+    DevBuf<unsigned char> data, sym;
+    int ret = JSDR_ERR;
+    if (data.alloc(256) == JSDR_OK && sym.alloc(SYMPBLOCK) == JSDR_OK) {
+        if (hipMemcpy(data.p, data_host, 256, hipMemcpyHostToDevice) == hipSuccess &&
+            jsdr_fec_encode_batch(data.p, 1, sym.p, 0) == JSDR_OK &&
+            hipMemcpy(sym_host, sym.p, SYMPBLOCK, hipMemcpyDeviceToHost) == hipSuccess)
+            ret = JSDR_OK;
+        else if (jsdr_last_error()[0] == 0)
+            set_error("jsdr_fec_encode: transfer failed");
+    }
+    data.release();
+    sym.release();
+    return ret;
+}
+
+}  // extern "C"

@@ -1,0 +1,541 @@
+// fft_psd.hip -- batched complex forward FFT + PSD + argmax: the fft.java waterfall path.
+//
+// Replaces fft.receive (fft.java:190-228) and the JTransforms FloatFFT_1D.complexForward call inside
+// it (fft.java:194-195), with the int16 -> float rule of JavaAudio.java:276-293 fused into the load.
+//
+// MI355X mapping (DESIGN.md "fft kernel"): one frame = T threads of a 256/512-thread workgroup; the
+// frame is transformed by a 2..4 pass Stockham autosort FFT with radix-16/8/4 butterflies held in
+// registers; passes exchange through one padded LDS image per frame (pad 1 float2 per 16 so that the
+// stride-16 stores of pass 1 and the stride-N/R loads of the next pass are bank-conflict free).
+// Global loads are one dword (I,Q int16 pair) per lane, 256 contiguous bytes per wave instruction;
+// PSD stores likewise.  HBM traffic = 4 B in + 4 B out per sample: the kernel is HBM bound.
+// Float arithmetic may contract to FMA here: parity for this path is the 1e-5 (peak-normalised)
+// tolerance of BASELINE.json, JTransforms' own rounding being unknowable (source absent).
+#include "common.h"
+#include <math.h>
+#include <utility>
+#include <vector>
+
+namespace jsdr {
+
+// ------------------------------------------------------------------ compile-time twiddles
+constexpr double cx_pi = 3.14159265358979323846264338327950288;
+
+constexpr double cx_sin_small(double x)  // |x| <= pi/4
+{
+    double x2 = x * x, term = x, sum = x;
+    for (int i = 1; i < 12; i++) {
+        term *= -x2 / ((2 * i) * (2 * i + 1));
+        sum += term;
+    }
+    return sum;
+}
+constexpr double cx_cos_small(double x)
+{
+    double x2 = x * x, term = 1.0, sum = 1.0;
+    for (int i = 1; i < 12; i++) {
+        term *= -x2 / ((2 * i - 1) * (2 * i));
+        sum += term;
+    }
+    return sum;
+}
+// cos/sin of 2*pi*j/len for 0 <= j < len, exact symmetries first
+constexpr double cx_cos_turn(int j, int len)
+{
+    j %= len;
+    if (8 * j <= len) return cx_cos_small(2 * cx_pi * j / len);
+    if (8 * j <= 3 * len) return -cx_sin_small(2 * cx_pi * (j - 0.25 * len) / len);
+    if (8 * j <= 5 * len) return -cx_cos_small(2 * cx_pi * (j - 0.5 * len) / len);
+    if (8 * j <= 7 * len) return cx_sin_small(2 * cx_pi * (j - 0.75 * len) / len);
+    return cx_cos_small(2 * cx_pi * (j - len) / len);
+}
+constexpr double cx_sin_turn(int j, int len) { return cx_cos_turn(4 * j + 3 * len, 4 * len); }
+
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cmul(float2 a, float2 w)
+{
+    return make_float2(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x);
+}
+
+// d * exp(-2 pi i J/LEN) with the trivial cases folded
+template <int LEN, int J>
+__device__ __forceinline__ float2 mul_w(float2 d)
+{
+    if constexpr (J == 0) {
+        return d;
+    } else if constexpr (4 * J == LEN) {
+        return make_float2(d.y, -d.x);
+    } else if constexpr (8 * J == LEN) {
+        constexpr float c = (float)0.70710678118654752440;
+        return make_float2((d.x + d.y) * c, (d.y - d.x) * c);
+    } else if constexpr (8 * J == 3 * LEN) {
+        constexpr float c = (float)0.70710678118654752440;
+        return make_float2((d.y - d.x) * c, -(d.x + d.y) * c);
+    } else {
+        constexpr float c = (float)cx_cos_turn(J, LEN);
+        constexpr float s = (float)cx_sin_turn(J, LEN);
+        return make_float2(d.x * c + d.y * s, d.y * c - d.x * s);
+    }
+}
+
+template <int LEN, int BASE, int J>
+__device__ __forceinline__ void bfly(float2 *x)
+{
+    constexpr int H = LEN / 2;
+    float2 a = x[BASE + J], b = x[BASE + J + H];
+    x[BASE + J] = cadd(a, b);
+    x[BASE + J + H] = mul_w<LEN, J>(csub(a, b));
+}
+template <int LEN, int BASE, int... Js>
+__device__ __forceinline__ void bfly_group(float2 *x, std::integer_sequence<int, Js...>)
+{
+    (bfly<LEN, BASE, Js>(x), ...);
+}
+template <int R, int LEN, int... Bs>
+__device__ __forceinline__ void bfly_stage(float2 *x, std::integer_sequence<int, Bs...>)
+{
+    (bfly_group<LEN, Bs * LEN>(x, std::make_integer_sequence<int, LEN / 2>{}), ...);
+}
+// in-register radix-R DFT, decimation in frequency: natural order in, BIT-REVERSED order out
+template <int R, int LEN = R>
+__device__ __forceinline__ void dft_reg(float2 *x)
+{
+    if constexpr (LEN >= 2) {
+        bfly_stage<R, LEN>(x, std::make_integer_sequence<int, R / LEN>{});
+        dft_reg<R, LEN / 2>(x);
+    }
+}
+constexpr int cx_bitrev(int v, int r)
+{
+    int o = 0;
+    for (int b = 1; b < r; b <<= 1) {
+        o = (o << 1) | (v & 1);
+        v >>= 1;
+    }
+    return o;
+}
+
+__device__ __forceinline__ int lds_pad(int idx) { return idx + (idx >> 4); }
+constexpr int lds_frame_elems(int n) { return n + (n >> 4) + 1; }
+
+// ------------------------------------------------------------------ kernel
+enum { IN_I16 = 0, IN_F32 = 1 };
+enum { OUT_PSD = 0, OUT_SPEC = 1 };
+
+struct FftArgs {
+    const void *in;      // int16 pairs or float pairs, [nframes][n]
+    float *out;          // psd [nframes][n+2] or spectrum [nframes][2n]
+    const float2 *tw;    // per-pass twiddle tables, concatenated (see tw_layout)
+    long long nframes;
+    int rate;
+    int ic, qc;
+};
+
+// Twiddle tables of pass with radix R and P = product of earlier radices (P > 1):
+//   P*R <= 512 : "direct"  D[r*P + k] = exp(-2 pi i k r/(P R)), r < R, k < P   (k fastest: conflict-free)
+//   else       : "base"    B[k]       = exp(-2 pi i k  /(P R)), k < P; powers r=2.. by repeated products
+constexpr bool tw_direct(int P, int R) { return P * R <= 512; }
+constexpr int tw_size(int P, int R) { return P <= 1 ? 0 : (tw_direct(P, R) ? P * R : P); }
+constexpr int tw_total(int R0, int R1, int R2, int R3)
+{
+    return tw_size(R0, R1) + (R2 > 1 ? tw_size(R0 * R1, R2) : 0) + (R3 > 1 ? tw_size(R0 * R1 * R2, R3) : 0);
+}
+
+template <int R, int P>
+__device__ __forceinline__ void apply_twiddles(float2 *v, int k, const float2 *tab)
+{
+    if constexpr (P > 1) {
+        if constexpr (tw_direct(P, R)) {
+#pragma unroll
+            for (int r = 1; r < R; r++) v[r] = cmul(v[r], tab[r * P + k]);
+        } else {
+            float2 w1 = tab[k];
+            float2 w[R];
+            w[1] = w1;
+#pragma unroll
+            for (int r = 2; r < R; r++) w[r] = (r & 1) ? cmul(w[r - 1], w1) : cmul(w[r / 2], w[r / 2]);
+#pragma unroll
+            for (int r = 1; r < R; r++) v[r] = cmul(v[r], w[r]);
+        }
+    }
+}
+
+template <int R, int... Rs>
+__device__ __forceinline__ void store_lds(float2 *dst, const float2 *v, int j0, int p, std::integer_sequence<int, Rs...>)
+{
+    ((dst[lds_pad(j0 + Rs * p)] = v[cx_bitrev(Rs, R)]), ...);
+}
+
+struct Best {
+    float v;
+    int k;
+};
+
+// One Stockham pass of one frame by T threads.  Each thread owns ITERS = (N/R)/T butterflies, loads
+// them all (global for the first pass, LDS otherwise), transforms in registers, and only after a
+// barrier (every load of the in-place image has landed) writes its outputs.
+template <int N, int T, int IN, int OUT, int R, int P, bool FIRST, bool LAST>
+__device__ __forceinline__ void fft_pass(const FftArgs &a, long long frame, bool active, int tid, float2 *buf,
+                                         const float2 *tab, Best &best)
+{
+    constexpr int NB = N / R;
+    static_assert(NB % T == 0, "butterflies per pass must be a multiple of the threads per frame");
+    constexpr int ITERS = NB / T;
+    float2 v[ITERS][R];
+#pragma unroll
+    for (int it = 0; it < ITERS; it++) {
+        const int b = it * T + tid;
+        if constexpr (FIRST) {
+            if (active) {
+                if constexpr (IN == IN_I16) {
+                    const int *src = reinterpret_cast<const int *>(a.in) + frame * N;
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        int w = src[b + r * NB];
+                        int si = java_short_add((int)(short)(w & 0xffff), a.ic);
+                        int sq = java_short_add(w >> 16, a.qc);
+                        v[it][r] = make_float2(i16_to_float_java(si), i16_to_float_java(sq));
+                    }
+                } else {
+                    const float2 *src = reinterpret_cast<const float2 *>(a.in) + frame * N;
+#pragma unroll
+                    for (int r = 0; r < R; r++) v[it][r] = src[b + r * NB];
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < R; r++) v[it][r] = make_float2(0.f, 0.f);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; r++) v[it][r] = buf[lds_pad(b + r * NB)];
+        }
+        apply_twiddles<R, P>(v[it], b & (P - 1), tab);
+        dft_reg<R>(v[it]);
+    }
+    if constexpr (!FIRST && !LAST) __syncthreads();
+#pragma unroll
+    for (int it = 0; it < ITERS; it++) {
+        const int b = it * T + tid;
+        const int k = b & (P - 1);
+        const int j0 = (b - k) * R + k;
+        if constexpr (!LAST) {
+            store_lds<R>(buf, v[it], j0, P, std::make_integer_sequence<int, R>{});
+        } else if (active) {
+            if constexpr (OUT == OUT_SPEC) {
+                float2 *dst = reinterpret_cast<float2 *>(a.out) + frame * N;
+#pragma unroll
+                for (int r = 0; r < R; r++) dst[j0 + r * P] = v[it][cx_bitrev(r, R)];
+            } else {
+                const float cf = (2.0f / (float)N) * (2.0f / (float)N);
+                float *dst = a.out + frame * (N + 2);
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    float2 x = v[it][cx_bitrev(r, R)];
+                    float pw = (x.x * x.x + x.y * x.y) * cf;
+                    // 10*log10(pw) = 10*log10(2) * log2(pw)   (fft.java:207)
+                    float db = 3.0102999566398120f * __log2f(pw);
+                    int bin = j0 + r * P;
+                    dst[bin] = db;
+                    if (db > best.v || (db == best.v && bin < best.k)) {
+                        best.v = db;
+                        best.k = bin;
+                    }
+                }
+            }
+        }
+    }
+    if constexpr (!LAST) __syncthreads();
+}
+
+// One frame, executed by T threads (tid in [0,T)).  `active` false => keep barriers, skip memory.
+template <int N, int T, int IN, int OUT, int R0, int R1, int R2, int R3>
+__device__ __forceinline__ void fft_frame(const FftArgs &a, long long frame, bool active, int tid, float2 *buf,
+                                          const float2 *tw_lds, float *red_val, int *red_idx, int frame_in_block)
+{
+    constexpr int NPASS = (R1 == 1) ? 1 : (R2 == 1) ? 2 : (R3 == 1) ? 3 : 4;
+    static_assert(R0 * R1 * R2 * R3 == N, "radix plan must multiply to N");
+    Best best;
+    best.v = -3.402823466e+38f;
+    best.k = 0x7fffffff;
+    constexpr int O1 = 0, O2 = tw_size(R0, R1), O3 = O2 + tw_size(R0 * R1, R2);
+    fft_pass<N, T, IN, OUT, R0, 1, true, NPASS == 1>(a, frame, active, tid, buf, tw_lds, best);
+    if constexpr (NPASS >= 2)
+        fft_pass<N, T, IN, OUT, R1, R0, false, NPASS == 2>(a, frame, active, tid, buf, tw_lds + O1, best);
+    if constexpr (NPASS >= 3)
+        fft_pass<N, T, IN, OUT, R2, R0 * R1, false, NPASS == 3>(a, frame, active, tid, buf, tw_lds + O2, best);
+    if constexpr (NPASS >= 4)
+        fft_pass<N, T, IN, OUT, R3, R0 * R1 * R2, false, NPASS == 4>(a, frame, active, tid, buf, tw_lds + O3, best);
+
+    if constexpr (OUT == OUT_PSD) {
+        // first strict maximum (fft.java:208-211): highest value, lowest bin on ties; none if all -inf
+        float bestv = best.v;
+        int bestk = best.k;
+        constexpr int W = (T < 64) ? T : 64;
+#pragma unroll
+        for (int off = W / 2; off >= 1; off >>= 1) {
+            float ov = __shfl_xor(bestv, off, W);
+            int ok = __shfl_xor(bestk, off, W);
+            if (ov > bestv || (ov == bestv && ok < bestk)) {
+                bestv = ov;
+                bestk = ok;
+            }
+        }
+        if constexpr (T > 64) {
+            constexpr int NW = T / 64;
+            if ((tid & 63) == 0) {
+                red_val[frame_in_block * NW + (tid >> 6)] = bestv;
+                red_idx[frame_in_block * NW + (tid >> 6)] = bestk;
+            }
+            __syncthreads();
+            if (tid == 0) {
+                for (int w = 1; w < NW; w++) {
+                    float ov = red_val[frame_in_block * NW + w];
+                    int ok = red_idx[frame_in_block * NW + w];
+                    if (ov > bestv || (ov == bestv && ok < bestk)) {
+                        bestv = ov;
+                        bestk = ok;
+                    }
+                }
+            }
+        }
+        if (tid == 0 && active) {
+            // fft.java:201-224: m starts at -Float.MAX_VALUE, p at -1; Hz in wrapping int arithmetic
+            int p = (bestv > -3.402823466e+38f) ? 2 * bestk : -1;
+            float m = (p >= 0) ? bestv : -3.402823466e+38f;
+            const int datlen = 2 * N;
+            if (p >= datlen / 2) p -= datlen;
+            int hz = (int)((unsigned)p * (unsigned)a.rate) / datlen;
+            float *dst = a.out + frame * (N + 2);
+            dst[N] = (float)hz;
+            dst[N + 1] = m;
+        }
+    }
+}
+
+template <int N, int T, int FPB, int IN, int OUT, int R0, int R1, int R2, int R3>
+__global__ __launch_bounds__(T *FPB) void k_fft(FftArgs a)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    constexpr int FE = lds_frame_elems(N);
+    constexpr int TWN = tw_total(R0, R1, R2, R3);
+    float2 *tw_lds = reinterpret_cast<float2 *>(smem);                   // [TWN]
+    float2 *bufs = tw_lds + TWN;                                          // [FPB][FE]
+    float *red_val = reinterpret_cast<float *>(bufs + (size_t)FPB * FE);  // [FPB*NW]
+    int *red_idx = reinterpret_cast<int *>(red_val + FPB * ((T + 63) / 64));
+
+    const int tid_b = threadIdx.x;
+    for (int i = tid_b; i < TWN; i += T * FPB) tw_lds[i] = a.tw[i];
+    __syncthreads();
+
+    const int fib = tid_b / T;
+    const int tid = tid_b - fib * T;
+    float2 *buf = bufs + (size_t)fib * FE;
+    const long long ngroups = (a.nframes + FPB - 1) / FPB;
+    for (long long g = blockIdx.x; g < ngroups; g += gridDim.x) {
+        long long frame = g * FPB + fib;
+        bool active = frame < a.nframes;
+        fft_frame<N, T, IN, OUT, R0, R1, R2, R3>(a, frame, active, tid, buf, tw_lds, red_val, red_idx, fib);
+        __syncthreads();
+    }
+}
+
+template <int N, int FPB, int T, int R0, int R1, int R2, int R3>
+constexpr size_t fft_lds_bytes()
+{
+    return sizeof(float2) * ((size_t)tw_total(R0, R1, R2, R3) + (size_t)FPB * lds_frame_elems(N)) +
+           (sizeof(float) + sizeof(int)) * FPB * ((T + 63) / 64);
+}
+
+struct Launcher {
+    void (*launch)(const FftArgs &, int grid, hipStream_t) = nullptr;
+    int frames_per_block = 0;
+    size_t lds_bytes = 0;
+    int block = 0;
+    int radix[4] = {1, 1, 1, 1};
+};
+
+template <int N, int T, int FPB, int IN, int OUT, int R0, int R1, int R2, int R3>
+static void launch_impl(const FftArgs &a, int grid, hipStream_t s)
+{
+    constexpr size_t lds = fft_lds_bytes<N, FPB, T, R0, R1, R2, R3>();
+    hipLaunchKernelGGL((k_fft<N, T, FPB, IN, OUT, R0, R1, R2, R3>), dim3(grid), dim3(T * FPB), lds, s, a);
+}
+
+template <int N, int T, int FPB, int R0, int R1, int R2, int R3>
+static Launcher make_launcher(int in, int out)
+{
+    Launcher l;
+    l.frames_per_block = FPB;
+    l.block = T * FPB;
+    l.lds_bytes = fft_lds_bytes<N, FPB, T, R0, R1, R2, R3>();
+    l.radix[0] = R0;
+    l.radix[1] = R1;
+    l.radix[2] = R2;
+    l.radix[3] = R3;
+    if (in == IN_I16 && out == OUT_PSD) l.launch = launch_impl<N, T, FPB, IN_I16, OUT_PSD, R0, R1, R2, R3>;
+    if (in == IN_F32 && out == OUT_PSD) l.launch = launch_impl<N, T, FPB, IN_F32, OUT_PSD, R0, R1, R2, R3>;
+    if (in == IN_F32 && out == OUT_SPEC) l.launch = launch_impl<N, T, FPB, IN_F32, OUT_SPEC, R0, R1, R2, R3>;
+    return l;
+}
+
+static Launcher pick_launcher(int n, int in, int out)
+{
+    switch (n) {
+        case 64: return make_launcher<64, 8, 32, 8, 8, 1, 1>(in, out);
+        case 128: return make_launcher<128, 8, 32, 16, 8, 1, 1>(in, out);
+        case 256: return make_launcher<256, 16, 16, 16, 16, 1, 1>(in, out);
+        case 512: return make_launcher<512, 64, 4, 8, 8, 8, 1>(in, out);
+        case 1024: return make_launcher<1024, 64, 4, 16, 8, 8, 1>(in, out);
+        case 2048: return make_launcher<2048, 128, 2, 16, 16, 8, 1>(in, out);
+        case 4096: return make_launcher<4096, 256, 1, 16, 16, 16, 1>(in, out);
+        case 8192: return make_launcher<8192, 512, 1, 16, 16, 8, 4>(in, out);
+        default: return Launcher();
+    }
+}
+
+}  // namespace jsdr
+
+using namespace jsdr;
+
+struct jsdr_fft {
+    int n = 0;
+    int rate = 0;
+    DevBuf<float2> tw;
+    DevBuf<unsigned char> in_stage;  // one frame, for the host-buffer receive() forms
+    DevBuf<float> out_stage;
+    int num_cu = 256;
+};
+
+static int fft_run(jsdr_fft *h, const void *in_dev, int in_kind, int out_kind, long long nframes, int ic, int qc,
+                   float *out_dev, hipStream_t s)
+{
+    JSDR_REQUIRE(h, "fft: null handle");
+    JSDR_REQUIRE(in_dev && out_dev, "fft: null buffer");
+    JSDR_REQUIRE(nframes >= 0, "fft: negative frame count");
+    if (nframes == 0) return JSDR_OK;
+    Launcher l = pick_launcher(h->n, in_kind, out_kind);
+    JSDR_REQUIRE(l.launch, "fft: no kernel for n=%d in=%d out=%d", h->n, in_kind, out_kind);
+    FftArgs a;
+    a.in = in_dev;
+    a.out = out_dev;
+    a.tw = h->tw.p;
+    a.nframes = nframes;
+    a.rate = h->rate;
+    a.ic = ic;
+    a.qc = qc;
+    long long groups = (nframes + l.frames_per_block - 1) / l.frames_per_block;
+    // enough workgroups to fill every CU at the LDS-limited occupancy, grid-stride over the rest
+    long long per_cu = (long long)(160 * 1024 / l.lds_bytes);
+    if (per_cu < 1) per_cu = 1;
+    if (per_cu * l.block > 2048) per_cu = 2048 / l.block;
+    long long cap = (long long)h->num_cu * per_cu * 4;
+    int grid = (int)(groups < cap ? groups : cap);
+    l.launch(a, grid, s);
+    JSDR_LAUNCH_CHECK();
+    return JSDR_OK;
+}
+
+extern "C" {
+
+int jsdr_fft_create(jsdr_fft **out, int n, int rate)
+{
+    JSDR_REQUIRE(out, "jsdr_fft_create: null handle pointer");
+    *out = nullptr;
+    JSDR_REQUIRE(n >= 64 && n <= 8192 && (n & (n - 1)) == 0,
+                 "jsdr_fft_create: n=%d unsupported (powers of two 64..8192; the reference's default "
+                 "9600-sample frame needs the mixed-radix path, SURVEY.md 8f next-2)", n);
+    JSDR_REQUIRE(rate > 0, "jsdr_fft_create: rate must be positive");
+    int dev = 0;
+    JSDR_HIP_TRY(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    JSDR_HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    jsdr_fft *h = new jsdr_fft();
+    h->n = n;
+    h->rate = rate;
+    h->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    // per-pass twiddle tables in the layout fft_pass expects (tw_direct / tw_size above)
+    Launcher l = pick_launcher(n, IN_I16, OUT_PSD);
+    std::vector<float2> tw;
+    int P = l.radix[0];
+    for (int pass = 1; pass < 4 && l.radix[pass] > 1; pass++) {
+        const int R = l.radix[pass];
+        const double base = -2.0 * 3.14159265358979323846 / ((double)P * (double)R);
+        if (tw_direct(P, R)) {
+            for (int r = 0; r < R; r++)
+                for (int k = 0; k < P; k++) {
+                    double ang = base * (double)k * (double)r;
+                    tw.push_back(make_float2((float)cos(ang), (float)sin(ang)));
+                }
+        } else {
+            for (int k = 0; k < P; k++) {
+                double ang = base * (double)k;
+                tw.push_back(make_float2((float)cos(ang), (float)sin(ang)));
+            }
+        }
+        P *= R;
+    }
+    if ((int)tw.size() != tw_total(l.radix[0], l.radix[1], l.radix[2], l.radix[3])) {
+        set_error("jsdr_fft_create: internal twiddle layout mismatch (%d)", (int)tw.size());
+        delete h;
+        return JSDR_ERR;
+    }
+    if (h->tw.alloc(tw.size()) != JSDR_OK || h->in_stage.alloc((size_t)n * 8) != JSDR_OK ||
+        h->out_stage.alloc((size_t)n + 2) != JSDR_OK) {
+        jsdr_fft_destroy(h);
+        return JSDR_ERR;
+    }
+    if (hipMemcpy(h->tw.p, tw.data(), sizeof(float2) * tw.size(), hipMemcpyHostToDevice) != hipSuccess) {
+        set_error("jsdr_fft_create: twiddle upload failed");
+        jsdr_fft_destroy(h);
+        return JSDR_ERR;
+    }
+    *out = h;
+    return JSDR_OK;
+}
+
+int jsdr_fft_destroy(jsdr_fft *h)
+{
+    if (!h) return JSDR_OK;
+    h->tw.release();
+    h->in_stage.release();
+    h->out_stage.release();
+    delete h;
+    return JSDR_OK;
+}
+
+int jsdr_fft_batch_f32(jsdr_fft *h, const float *iq_dev, int64_t nframes, float *psd_dev, void *stream)
+{
+    return fft_run(h, iq_dev, IN_F32, OUT_PSD, nframes, 0, 0, psd_dev, as_stream(stream));
+}
+
+int jsdr_fft_batch_i16(jsdr_fft *h, const int16_t *raw_dev, int64_t nframes, int ic, int qc, float *psd_dev,
+                       void *stream)
+{
+    return fft_run(h, raw_dev, IN_I16, OUT_PSD, nframes, ic, qc, psd_dev, as_stream(stream));
+}
+
+int jsdr_fft_spectrum_f32(jsdr_fft *h, const float *iq_dev, int64_t nframes, float *spec_dev, void *stream)
+{
+    return fft_run(h, iq_dev, IN_F32, OUT_SPEC, nframes, 0, 0, spec_dev, as_stream(stream));
+}
+
+int jsdr_fft_receive_f32(jsdr_fft *h, const float *iq_host, float *psd_host)
+{
+    JSDR_REQUIRE(h && iq_host && psd_host, "jsdr_fft_receive_f32: null argument");
+    JSDR_HIP_TRY(hipMemcpy(h->in_stage.p, iq_host, sizeof(float) * 2 * (size_t)h->n, hipMemcpyHostToDevice));
+    if (fft_run(h, h->in_stage.p, IN_F32, OUT_PSD, 1, 0, 0, h->out_stage.p, 0) != JSDR_OK) return JSDR_ERR;
+    JSDR_HIP_TRY(hipMemcpy(psd_host, h->out_stage.p, sizeof(float) * ((size_t)h->n + 2), hipMemcpyDeviceToHost));
+    return JSDR_OK;
+}
+
+int jsdr_fft_receive_i16(jsdr_fft *h, const int16_t *raw_host, int ic, int qc, float *psd_host)
+{
+    JSDR_REQUIRE(h && raw_host && psd_host, "jsdr_fft_receive_i16: null argument");
+    JSDR_HIP_TRY(hipMemcpy(h->in_stage.p, raw_host, sizeof(int16_t) * 2 * (size_t)h->n, hipMemcpyHostToDevice));
+    if (fft_run(h, h->in_stage.p, IN_I16, OUT_PSD, 1, ic, qc, h->out_stage.p, 0) != JSDR_OK) return JSDR_ERR;
+    JSDR_HIP_TRY(hipMemcpy(psd_host, h->out_stage.p, sizeof(float) * ((size_t)h->n + 2), hipMemcpyDeviceToHost));
+    return JSDR_OK;
+}
+
+}  // extern "C"

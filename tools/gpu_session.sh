@@ -1,0 +1,41 @@
+#!/bin/bash
+# tools/gpu_session.sh -- what one gpurun call runs on the MI355X box.  Every step writes under
+# gpurun_out/; a step that TIMES OUT (124/137) ends the session (no further GPU work after a kill),
+# an ordinary failure (assert, non-zero exit) is logged and the session goes on.
+#   usage: tools/gpu_session.sh step [step ...]   steps: tests micro bench_small bench bench_fft bench_bpsk prof pmc
+set -u
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+R=${ROUND:-r01}
+run() { # name timeout cmd...
+  local name=$1 to=$2; shift 2
+  echo "=== $name: $*" | tee -a gpurun_out/session.log
+  local t0=$(date +%s)
+  timeout -k 10 "$to" "$@" > "gpurun_out/$name.log" 2>&1
+  local rc=$?
+  echo "=== $name rc=$rc ($(( $(date +%s) - t0 )) s)" | tee -a gpurun_out/session.log
+  tail -n 15 "gpurun_out/$name.log"
+  if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "TIMEOUT in $name: stopping session" | tee -a gpurun_out/session.log; exit 99; fi
+  return 0
+}
+for step in "$@"; do
+  case $step in
+    tests)       run tests 900 python -m pytest tests -m gpu -q --maxfail=30 -p no:cacheprovider --timeout 600 ;;
+    tests_x)     run tests 900 python -m pytest tests -m gpu -x -q -p no:cacheprovider --timeout 600 ;;
+    smoke)       run smoke 300 python -c "import __graft_entry__ as g; g.smoke()" ;;
+    micro)       run micro_build 120 hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -o /tmp/mb_fp64 tools/microbench_fp64.hip
+                 run micro 120 /tmp/mb_fp64 ;;
+    bench_small) run bench_small 300 python bench.py --steps 3 --warmup 1 --streams 128 --samples 1048576 --cpu-seconds 3 ;;
+    bench)       run bench 600 python bench.py ;;
+    bench_fft)   run bench_fft 300 python bench.py --workload fft --no-cpu-baseline ;;
+    bench_bpsk)  run bench_bpsk 400 python bench.py --workload bpsk --no-cpu-baseline ;;
+    prof)        rm -rf gpurun_out/prof_$R
+                 run prof 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$R -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline ;;
+    pmc_rd)      rm -rf gpurun_out/pmc_rd_$R
+                 run pmc_rd 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_rd_$R -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-validate ;;
+    pmc_wr)      rm -rf gpurun_out/pmc_wr_$R
+                 run pmc_wr 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_wr_$R -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-validate ;;
+    *) echo "unknown step $step" ;;
+  esac
+done
+echo "session done" | tee -a gpurun_out/session.log
