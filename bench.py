@@ -59,8 +59,7 @@ def make_inputs(J, O, S, L, stream0):
     nfr = -(-L // (5200 * sps)) + 1
     pay = J.synth_payloads(SEED, stream0, S, nfr)
     d_sym = J.DeviceBuffer(S * nfr * 5200)
-    if J.lib().jsdr_fec_encode_batch(pay.ptr, S * nfr, d_sym.ptr, None) != 0:
-        raise RuntimeError(J.lib().jsdr_last_error())
+    J.fec_encode_dev(pay, S * nfr, d_sym)
     d_ds = J.DeviceBuffer(S * nfr * 5200)
     J.synth_diffsign(d_sym, nfr * 5200, S, d_ds)
     ct, st = O.synth_tables(3000)
@@ -73,10 +72,31 @@ def make_inputs(J, O, S, L, stream0):
     return d_iq, pay, nfr
 
 
+def usable_cores():
+    """threads this process may really run at once: affinity mask, capped by the cgroup CPU quota (a GPU box
+    shows all host cores but grants a share of them)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+            break
+        except Exception:
+            continue
+    return max(1, min(n, int(os.environ.get("JSDR_CPU_THREADS", "64"))))
+
+
 def cpu_baseline(O, workload, L, seconds):
     """the oracle on the host cores: one stream per thread (ctypes releases the GIL), repeated until
     ~`seconds` of wall time; same signal family, same frame size."""
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     Lc = min(L, 1048576)
     streams = [O.make_dbpsk_stream(SEED, s, Lc)[0] for s in range(cores)]
     nframes = Lc // N_FFT
@@ -93,8 +113,16 @@ def cpu_baseline(O, workload, L, seconds):
     t0 = time.perf_counter()
     one_pass(0, dem0)
     t1 = time.perf_counter() - t0
-    reps = max(1, int(seconds / max(t1, 1e-3)))
     dems = [O.Bpsk() for _ in range(cores)]
+    # one parallel round to see what a pass costs with every thread busy (shared caches, CPU quota)
+    th = [threading.Thread(target=one_pass, args=(s, dems[s])) for s in range(cores)]
+    t0 = time.perf_counter()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    tpar = time.perf_counter() - t0
+    reps = max(1, min(int(seconds / max(tpar, 1e-3)), 400))
 
     def worker(s):
         for _ in range(reps):

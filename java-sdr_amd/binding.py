@@ -309,6 +309,17 @@ def fec_encode_batch(datas):
     return d_out.to_host(np.uint8).reshape(nb, 5200)
 
 
+def fec_encode_dev(data_dev, nblocks, sym_dev, stream=None):
+    """device-resident form: data_dev[nblocks][256] -> sym_dev[nblocks][5200]"""
+    _check(lib().jsdr_fec_encode_batch(_addr(data_dev), C.c_int64(nblocks), _addr(sym_dev), C.c_void_p(stream)),
+           "jsdr_fec_encode_batch")
+
+
+def fec_decode_dev(raw_dev, nblocks, out_dev, rc_dev, stream=None):
+    _check(lib().jsdr_fec_decode_batch(_addr(raw_dev), C.c_int64(nblocks), _addr(out_dev), _addr(rc_dev),
+                                       C.c_void_p(stream)), "jsdr_fec_decode_batch")
+
+
 # ------------------------------------------------------------------ FUNcubeBPSKDemod.java
 COUNTER_NAMES = ["cntRaw", "cntDS", "cntBit", "cntFEC", "cntDec", "dmErrBits", "dmCorr", "dmMaxCorr", "decodeOK",
                  "centreBin"]

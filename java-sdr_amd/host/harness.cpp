@@ -1,0 +1,104 @@
+// harness.cpp -- headless stand-in for JavaAudio.run (JavaAudio.java:195-329) that drives the C++ plugin
+// mirror exactly as the reference's audio thread drives its handlers: read blen bytes, hand them to the
+// raw handlers, convert int16 -> float with the I/Q corrections (:276-293), hand the float frame to every
+// IAudioHandler in registration order.   usage: jsdr_harness <file.raw> [rate=96000] [blen=8192] [ic] [qc]
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include "jsdr_plugins.hpp"
+
+using namespace java_sdr;
+
+struct Bus : IPublish {
+    std::map<std::string, PublishValue> vals;
+    std::vector<IPublishListener *> ls;
+    void setPublish(const std::string &k, const PublishValue &v) override
+    {
+        vals[k] = v;
+        for (auto *l : ls) l->notify(k, v);
+    }
+    void listen(IPublishListener *l) override { ls.push_back(l); }
+    void unlisten(IPublishListener *l) override { ls.erase(std::remove(ls.begin(), ls.end(), l), ls.end()); }
+};
+
+struct Cfg : IConfig {
+    std::map<std::string, int> m;
+    int getIntConfig(const std::string &k, int d) override
+    {
+        auto it = m.find(k);
+        if (it == m.end()) {
+            m[k] = d;  // jsdr.getIntConfig writes the default back (jsdr.java:87-95)
+            return d;
+        }
+        return it->second;
+    }
+    void setIntConfig(const std::string &k, int v) override { m[k] = v; }
+};
+
+struct FileAudio : IAudio {
+    AudioDescriptor ad;
+    int ic, qc;
+    std::vector<IAudioHandler *> hands;
+    std::vector<IRawHandler *> raws;
+    FileAudio(int rate, int blen, int ic_, int qc_) : ad(rate, 16, 2, 4, blen), ic(ic_), qc(qc_) {}
+    AudioDescriptor getAudioDescriptor() override { return ad; }
+    int getICorrection() override { return ic; }
+    int getQCorrection() override { return qc; }
+    void addHandler(IAudioHandler *h) override { hands.push_back(h); }
+    void remHandler(IAudioHandler *h) override { hands.erase(std::remove(hands.begin(), hands.end(), h), hands.end()); }
+    void addRawHandler(IRawHandler *h) override { raws.push_back(h); }
+    void remRawHandler(IRawHandler *h) override { raws.erase(std::remove(raws.begin(), raws.end(), h), raws.end()); }
+};
+
+int main(int argc, char **argv)
+{
+    if (argc < 2) {
+        fprintf(stderr, "usage: %s file.raw [rate] [blen] [ic] [qc]\n", argv[0]);
+        return 2;
+    }
+    const int rate = argc > 2 ? atoi(argv[2]) : 96000, blen = argc > 3 ? atoi(argv[3]) : 8192;
+    const int ic = argc > 4 ? atoi(argv[4]) : 0, qc = argc > 5 ? atoi(argv[5]) : 0;
+    FILE *fp = fopen(argv[1], "rb");
+    if (!fp) {
+        perror(argv[1]);
+        return 2;
+    }
+    try {
+        Bus bus;
+        Cfg cfg;
+        FileAudio audio(rate, blen, ic, qc);
+        phase ph(&cfg, &bus, &audio);
+        fft ff(&cfg, &bus, &audio);
+        FUNcubeBPSKDemod dem(0, &cfg, &bus, &audio);
+        std::vector<uint8_t> raw((size_t)blen);
+        std::vector<float> buf((size_t)2 * blen / 4);
+        int frame = 0;
+        while (fread(raw.data(), 1, raw.size(), fp) == raw.size()) {
+            for (auto *r : audio.raws) r->receive(raw.data(), raw.size());
+            const int16_t *s16 = reinterpret_cast<const int16_t *>(raw.data());
+            for (size_t sn = 0; sn < buf.size(); sn += 2) {  // JavaAudio.java:279-293
+                short s = s16[sn];
+                s = (short)(s + (short)ic);
+                buf[sn] = (float)s / (float)32767;
+                s = s16[sn + 1];
+                s = (short)(s + (short)qc);
+                buf[sn + 1] = (float)s / (float)32767;
+            }
+            for (auto *h : audio.hands) h->receive(buf.data(), buf.size());
+            const auto &psd = bus.vals["fft-psd"].f;
+            int32_t c[JSDR_BPSK_NCOUNTERS];
+            dem.counters(c);
+            printf("frame %d fft-psd max %.4f dB @ %.1f Hz phase-max %.6f bpsk raw=%d ds=%d bit=%d fec=%d dec=%d tune=%d\n",
+                   frame, psd[psd.size() - 1], psd[psd.size() - 2], ph.maxAbs(), c[0], c[1], c[2], c[3], c[4],
+                   bus.vals["FUNcube0-bpsk-tune"].i);
+            frame++;
+        }
+    } catch (const std::exception &e) {
+        // JavaAudio.java:321-323: an exception escaping a handler ends the audio thread with a status message
+        fprintf(stderr, "Audio oops: %s\n", e.what());
+        fclose(fp);
+        return 1;
+    }
+    fclose(fp);
+    return 0;
+}

@@ -164,7 +164,7 @@ def test_bpsk_roundtrip_property_at_baseline_batch_shape():
     seed = 20020109
     pay = J.synth_payloads(seed, 0, S, nfr)
     d_sym = J.DeviceBuffer(S * nfr * 5200)
-    assert J.lib().jsdr_fec_encode_batch(pay.ptr, S * nfr, d_sym.ptr, None) == 0
+    J.fec_encode_dev(pay, S * nfr, d_sym)
     d_ds = J.DeviceBuffer(S * nfr * 5200)
     J.synth_diffsign(d_sym, nfr * 5200, S, d_ds)
     ct, st = O.synth_tables(3000)

@@ -16,6 +16,7 @@ run() { # name timeout cmd...
   echo "=== $name rc=$rc ($(( $(date +%s) - t0 )) s)" | tee -a gpurun_out/session.log
   tail -n 15 "gpurun_out/$name.log"
   if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "TIMEOUT in $name: stopping session" | tee -a gpurun_out/session.log; exit 99; fi
+  if grep -q "Memory access fault" "gpurun_out/$name.log"; then echo "GPU FAULT in $name: stopping session" | tee -a gpurun_out/session.log; exit 98; fi
   return 0
 }
 for step in "$@"; do
