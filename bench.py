@@ -195,6 +195,8 @@ def main():
                 dist.all_gather_into_tensor(gathered, slots)
 
     def sync():
+        if dem is not None:
+            dem.sync()  # the tail / FEC of the last step run on the handle's side stream
         if N > 1:
             torch.cuda.synchronize()
             dist.barrier()

@@ -115,7 +115,10 @@ int jsdr_bpsk_receive_i16(jsdr_bpsk *h, const int16_t *raw_host, int ic, int qc)
  * multiple of nsamples_per_frame in FFT mode; asynchronous on `stream`.                        */
 int jsdr_bpsk_batch_i16(jsdr_bpsk *h, const int16_t *raw_dev, int64_t stream_stride_i16,
                         int64_t nsamples, int ic, int qc, void *stream);
-/* results (synchronise the handle's stream first) */
+/* wait until every kernel of the calls made so far has finished (the 9600 Hz tail and the FEC decoder run on
+ * an internal side stream so that they overlap the next call's front end; the getters below call this). */
+int jsdr_bpsk_sync(jsdr_bpsk *h);
+/* results */
 enum { JSDR_BPSK_NCOUNTERS = 10 };
 /* cntRaw,cntDS,cntBit,cntFEC,cntDec,dmErrBits,dmCorr,dmMaxCorr,decodeOK,centreBin (:110-115,:405,:498) */
 int jsdr_bpsk_get_counters(jsdr_bpsk *h, int stream, int32_t out[JSDR_BPSK_NCOUNTERS]);

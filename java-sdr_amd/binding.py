@@ -351,6 +351,9 @@ class Bpsk:
         _check(lib().jsdr_bpsk_batch_i16(self.h, _addr(raw_dev), C.c_int64(stride_i16), C.c_int64(nsamples), ic, qc,
                                          C.c_void_p(stream)), "jsdr_bpsk_batch_i16")
 
+    def sync(self):
+        _check(lib().jsdr_bpsk_sync(self.h), "jsdr_bpsk_sync")
+
     def counters(self, stream=0):
         out = np.empty(10, np.int32)
         _check(lib().jsdr_bpsk_get_counters(self.h, stream, _addr(out)), "jsdr_bpsk_get_counters")

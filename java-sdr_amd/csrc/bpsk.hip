@@ -19,6 +19,7 @@
 // DESIGN.md has the lane/LDS mapping of each kernel and its roofline.
 #include "bpsk_fec.h"
 #include <math.h>
+#include <stdlib.h>
 #include <vector>
 
 namespace jsdr {
@@ -39,12 +40,28 @@ static const float h_dm_half[33] = {
     -0.1244834076F, -0.1568500423F, -0.1553748911F, -0.1061032953F, -0.0015013786F, +0.1568500423F, +0.3572048240F,
     +0.5786381191F, +0.7940228249F, +0.9744923010F, +1.0945250059F, +1.1366117829F};
 
+// device-side copy with a static initialiser: indexed with compile-time constants in k_front, so the taps
+// fold into the instruction stream (14 distinct values) instead of occupying 54 SGPRs
+__constant__ const float kDsHalf[14] = {-6.103515625000e-004F, -1.220703125000e-004F, +2.380371093750e-003F,
+                                        +6.164550781250e-003F, +7.324218750000e-003F, +7.629394531250e-004F,
+                                        -1.464843750000e-002F, -3.112792968750e-002F, -3.225708007813e-002F,
+                                        -1.617431640625e-003F, +6.463623046875e-002F, +1.502380371094e-001F,
+                                        +2.231445312500e-001F, +2.518310546875e-001F};
+__device__ __forceinline__ double ds_tap(int n) { return (double)kDsHalf[n < 14 ? n : 26 - n]; }
+
 struct BpskConst {
     double ds_taps[32];   // [27] used
     double dm_taps[96];   // [65] used, zero beyond (edge steps of the register-blocked loops read past 64)
     signed char sync[72]; // [65] used, +1/-1
 };
 __constant__ BpskConst c_bpsk;
+
+#define JSDR_WAVE_SYNC()                                      \
+    do {                                                      \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();                      \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+    } while (0)
 
 // per-stream demodulator state that depends on the data (FUNcubeBPSKDemod.java:497-503)
 struct TailState {
@@ -61,15 +78,31 @@ struct TailState {
 };
 
 // ------------------------------------------------------------------------------------------- k_front
-// One wave = one chunk of 64 decimated outputs of one stream.  The wave converts and tuner-mixes the
-// 26 + 64*D input samples its outputs need, parks them as double2 in LDS, then every lane runs the 27-tap
-// filter for its own output.  LDS element e sits at e + PADK*(e/D): the lane stride of the FIR reads is
-// then D+PADK, an odd number of 16-byte slots -> ds_read_b128 conflict-free.
-template <int D>
+// int16 -> float -> double, tuner mix, 27-tap low-pass at the decimated instants, x HOWARD, VCO mix.
+//
+// One wave = one tile of 64*R consecutive outputs of one stream (R = RD/D outputs per lane).
+//   stage : the wave copies the tile's raw IQ dwords (4 B/sample, fully coalesced, loads issued in batches
+//           of 8) and tuner indices (1 B/sample) into LDS -- 5 B per sample instead of the 16 B of a mixed
+//           double2.  Lane l's span starts at sample RD*l; one pad dword (four pad bytes for the indices)
+//           per span makes the lane stride odd in dwords: the per-lane reads below are conflict-free.
+//   walk  : every lane walks ITS OWN samples from newest to oldest in blocks of D (one output period).
+//           A sample at offset t of block b belongs to the windows of outputs b, b-1, .. with ages
+//           26-t, 26-t-D, .. (compile-time constants), so the 27-tap sums of NACC = 26/D+1 outputs are in
+//           flight at once in rotating register accumulators.  Walking backwards in time makes every
+//           output accumulate ages 0,1,..,26: the reference's newest-first order (:479-483).  Each sample
+//           is converted and mixed once per lane, in registers; no LDS traffic per multiply-add.
+// Samples before the start of the call come from the raw history kept by k_hist_in.
+template <int D, int RD>
 struct FrontGeom {
-    static constexpr int PADK = (D & 1) ? 2 : 1;
-    static constexpr int NIN = 26 + 63 * D + 1;             // samples per chunk
-    static constexpr int NLDS = NIN + PADK * (NIN / D + 1);  // padded elements per wave
+    static_assert(RD % D == 0, "a lane span must hold whole outputs");
+    static constexpr int R = RD / D;                 // outputs per lane
+    static constexpr int NACC = 26 / D + 1;          // outputs whose windows contain one sample
+    static_assert(R >= NACC, "span too short for the rotating accumulators");
+    static constexpr int NT = 64 * RD - D + 27;      // samples per wave tile
+    static constexpr int RSTR = RD + 1;              // elements between lane spans (raw)
+    static constexpr int KSTR = RD + 4;              // bytes between lane spans (tuner indices)
+    static constexpr int RAW_EL = 64 * RSTR + 32;    // raw elements per wave
+    static constexpr int K_BYTES = 64 * KSTR + 64;
 };
 
 struct FrontArgs {
@@ -78,10 +111,11 @@ struct FrontArgs {
     long long stride_pairs;
     long long nsamples;        // L
     int ic, qc;
-    const short *ktu;          // [L] tuner table index or -1 (no mix: tuPhase <= 0, :388)
+    int mix;                   // 0: tuPhase never exceeds 0 (tuning <= 0): samples pass unmixed (:388,:395)
+    const unsigned char *ktu;  // [26 + L] tuner table index per sample, 26 history entries first
     const unsigned char *kvco; // [nds]
     const double *sincos;      // cos[256], sin[256]
-    const double2 *hist_in;    // [S][32]: the 26 samples fed to RxDownSample before this call (time order)
+    const int2 *hist;          // [S][32]: the 26 inputs before this call: DC-corrected int16 pair (.x) or float2 bits
     double2 *dm;               // [S][dm_stride]: 64 history + nds VCO-mixed samples
     long long dm_stride;
     double2 *ds_dbg;           // optional [S][nds] down-sampler outputs (after HOWARD), may be null
@@ -89,97 +123,192 @@ struct FrontArgs {
     int first_out;             // input index whose arrival completes output 0 (= D-1-dsCnt0)
 };
 
-template <int D>
-__global__ __launch_bounds__(256) void k_front(FrontArgs a)
+template <bool F32IN>
+struct FrontElem {
+    using type = int;
+};
+template <>
+struct FrontElem<true> {
+    using type = float2;
+};
+
+// one block of D samples (newest first): outputs b-JLO .. b-JHI take part
+template <int D, int RD, bool F32IN, int JLO, int JHI, int NACC>
+__device__ __forceinline__ void front_block(int b, const typename FrontElem<F32IN>::type *xl, const unsigned char *kl,
+                                            const double *sc, int mix, double (&ai)[NACC], double (&aq)[NACC])
 {
-    using G = FrontGeom<D>;
-    extern __shared__ __align__(16) unsigned char smem[];
-    double *sc = reinterpret_cast<double *>(smem);                            // [512]
-    double2 *lds_all = reinterpret_cast<double2 *>(smem + 512 * sizeof(double));
-    for (int i = threadIdx.x; i < 512; i += 256) sc[i] = a.sincos[i];
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    double2 *x = lds_all + wave * G::NLDS;
-    const int s = blockIdx.y;
-    const long long nchunks = (a.nds + 63) / 64;
-    const double HOWARD = 0.9 * 32768.0;  // :469
-    for (long long chunk = (long long)blockIdx.x * 4 + wave; chunk < nchunks; chunk += (long long)gridDim.x * 4) {
-        const long long j0 = chunk * 64;
-        const long long lo = (long long)a.first_out + (long long)D * j0 - 26;  // first input index needed
-        const int *raw = a.raw + (long long)s * a.stride_pairs;
-        // ---- stage the mixed samples
 #pragma unroll
-        for (int it = 0; it < (G::NIN + 63) / 64; it++) {
-            int e = it * 64 + lane;
-            if (e < G::NIN) {
-                long long n = lo + e;
-                double2 v;
-                if (n < 0) {
-                    v = a.hist_in[(long long)s * 32 + (26 + n)];
-                } else if (n < a.nsamples) {
-                    double di, dq;
-                    if (a.rawf) {
-                        float2 f = a.rawf[(long long)s * a.stride_pairs + n];
-                        di = (double)f.x;  // (double)buf[n*2]   :372
-                        dq = (double)f.y;
-                    } else {
-                        int w = raw[n];
-                        int si = java_short_add((int)(short)(w & 0xffff), a.ic);
-                        int sq = java_short_add(w >> 16, a.qc);
-                        di = (double)i16_to_float_java(si);
-                        dq = (double)i16_to_float_java(sq);
-                    }
-                    int k = a.ktu[n];
-                    if (k >= 0) {  // :388-390 component-wise, not a complex multiply
-                        di = di * sc[k];
-                        dq = dq * sc[256 + k];
-                    }
-                    v = make_double2(di, dq);
-                } else {
-                    v = make_double2(0.0, 0.0);
+    for (int t = D - 1; t >= 0; t--) {
+        if (26 - t - D * JLO >= 0) {  // the sample lies in at least one participating window (compile time)
+            const int m = D * b + t;
+            const int wrap = (m >= RD) ? 1 : 0;
+            double di, dq;
+            if constexpr (F32IN) {
+                const float2 f = xl[m + wrap];
+                di = (double)f.x;  // (double)buf[n*2]  :372
+                dq = (double)f.y;
+            } else {
+                const int w = xl[m + wrap];
+                di = (double)i16_to_float_java((int)(short)(w & 0xffff));
+                dq = (double)i16_to_float_java(w >> 16);
+            }
+            if (mix) {  // :388-390 component-wise, not a complex multiply
+                const int k = kl[m + 4 * wrap];
+                di = di * sc[k];
+                dq = dq * sc[256 + k];
+            }
+#pragma unroll
+            for (int j = JLO; j <= JHI; j++) {
+                if (26 - t - D * j >= 0) {  // age of this sample in the window of output b-j
+                    const double tp = ds_tap(26 - t - D * j);
+                    ai[j] += di * tp;
+                    aq[j] += dq * tp;
                 }
-                x[e + G::PADK * (e / D)] = v;
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // ---- 27-tap low-pass for output j0+lane: newest sample first (:479-483)
-        const long long j = j0 + lane;
-        double fi = 0.0, fq = 0.0;
-        const double2 *xl = x + (D + G::PADK) * lane;
-#pragma unroll
-        for (int n = 0; n < DS_N; n++) {
-            constexpr int dummy = 0;
-            (void)dummy;
-            const int d = 26 - n;                       // element offset of the sample of age n
-            const int dp = d + G::PADK * (d / D);       // folded at compile time after unrolling
-            double2 v = xl[dp];
-            double t = c_bpsk.ds_taps[n];
-            fi += v.x * t;
-            fq += v.y * t;
-        }
-        if (j < a.nds) {
-            double oi = fi * HOWARD, oq = fq * HOWARD;  // :486
-            if (a.ds_dbg) a.ds_dbg[(long long)s * a.nds + j] = make_double2(oi, oq);
-            int kv = a.kvco[j];
-            a.dm[(long long)s * a.dm_stride + 64 + j] = make_double2(oi * sc[kv], oq * sc[256 + kv]);  // :515-516
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
     }
 }
 
-// the 26 most recent samples fed to RxDownSample, for the next call (new history), one lane each
+template <int D, int RD, bool F32IN>
+__global__ __launch_bounds__(128, 4) void k_front(FrontArgs a)
+{
+    using G = FrontGeom<D, RD>;
+    using Elem = typename FrontElem<F32IN>::type;
+    constexpr int R = G::R, NACC = G::NACC;
+    extern __shared__ __align__(16) unsigned char smem[];
+    double *sc = reinterpret_cast<double *>(smem);  // [512]
+    for (int i = threadIdx.x; i < 512; i += blockDim.x) sc[i] = a.sincos[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+    constexpr size_t WAVE_BYTES = (size_t)G::RAW_EL * sizeof(Elem) + G::K_BYTES;
+    unsigned char *wbase = smem + 512 * sizeof(double) + wave * WAVE_BYTES;
+    Elem *rawL = reinterpret_cast<Elem *>(wbase);
+    unsigned char *kL = wbase + (size_t)G::RAW_EL * sizeof(Elem);
+    const int s = blockIdx.y;
+    const long long ntiles = (a.nds + 64 * R - 1) / (64 * R);
+    const double HOWARD = 0.9 * 32768.0;  // :469
+    const int *raw = a.raw + (long long)s * a.stride_pairs;
+    const float2 *rawf = a.rawf + (long long)s * a.stride_pairs;
+    const int2 *hist = a.hist + (long long)s * 32;
+    const long long L = a.nsamples;
+    for (long long tile = (long long)blockIdx.x * nwave + wave; tile < ntiles; tile += (long long)gridDim.x * nwave) {
+        const long long j0 = tile * 64 * R;
+        const long long lo = (long long)a.first_out + (long long)D * j0 - 26;  // input index of tile sample 0
+        // ---- stage raw samples + tuner indices: 8 independent loads in flight per lane
+        constexpr int NIT = (G::NT + 63) / 64;
+#pragma unroll 1
+        for (int it0 = 0; it0 < NIT; it0 += 8) {
+            Elem w[8];
+            unsigned char kk[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int e = (it0 + u) * 64 + lane;
+                const long long n = lo + e;
+                const bool inr = (n >= 0) && (n < L);
+                const long long idx = inr ? n : 0;
+                if constexpr (F32IN) w[u] = rawf[idx]; else w[u] = raw[idx];
+                kk[u] = a.ktu[26 + idx];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int e = (it0 + u) * 64 + lane;
+                const long long n = lo + e;
+                const bool inr = (n >= 0) && (n < L);
+                if (e < G::NT) {
+                    Elem v = w[u];
+                    if constexpr (F32IN) {
+                        if (!inr) v = make_float2(0.f, 0.f);
+                    } else {
+                        int si = java_short_add((int)(short)(v & 0xffff), a.ic);
+                        int sq = java_short_add(v >> 16, a.qc);
+                        v = inr ? ((si & 0xffff) | (sq << 16)) : 0;
+                    }
+                    const int span = e / RD;
+                    rawL[e + span] = v;
+                    kL[e + 4 * span] = inr ? kk[u] : (unsigned char)0;
+                }
+            }
+        }
+        if (lo < 0) {  // first tile of the call: the 26 inputs before it come from the history
+            const int e = lane;
+            const long long n = lo + e;
+            if (n < 0) {
+                const int2 h = hist[26 + n];
+                const int span = e / RD;
+                if constexpr (F32IN) rawL[e + span] = make_float2(__int_as_float(h.x), __int_as_float(h.y));
+                else rawL[e + span] = h.x;
+                kL[e + 4 * span] = a.ktu[26 + n];
+            }
+        }
+        JSDR_WAVE_SYNC();
+        // ---- walk this lane's span from newest to oldest, one output period per block
+        const Elem *xl = rawL + G::RSTR * lane;
+        const unsigned char *kl = kL + G::KSTR * lane;
+        double ai[NACC], aq[NACC];
+#pragma unroll
+        for (int j = 0; j < NACC; j++) {
+            ai[j] = 0.0;
+            aq[j] = 0.0;
+        }
+        const long long jl = j0 + (long long)R * lane;
+        auto finish = [&](int b) {  // output b is complete: x HOWARD (:486), VCO mix (:515-516), rotate
+            const long long j = jl + b;
+            if (j < a.nds) {
+                const double oi = ai[0] * HOWARD, oq = aq[0] * HOWARD;
+                if (a.ds_dbg) a.ds_dbg[(long long)s * a.nds + j] = make_double2(oi, oq);
+                const int kv = a.kvco[j];
+                a.dm[(long long)s * a.dm_stride + 64 + j] = make_double2(oi * sc[kv], oq * sc[256 + kv]);
+            }
+#pragma unroll
+            for (int j2 = 0; j2 + 1 < NACC; j2++) {
+                ai[j2] = ai[j2 + 1];
+                aq[j2] = aq[j2 + 1];
+            }
+            ai[NACC - 1] = 0.0;
+            aq[NACC - 1] = 0.0;
+        };
+        auto rotate_only = [&]() {
+#pragma unroll
+            for (int j2 = 0; j2 + 1 < NACC; j2++) {
+                ai[j2] = ai[j2 + 1];
+                aq[j2] = aq[j2 + 1];
+            }
+            ai[NACC - 1] = 0.0;
+            aq[NACC - 1] = 0.0;
+        };
+        // top blocks b = R-1+k (k = NACC-1 .. 1): only outputs <= R-1 exist, i.e. j >= k
+        if constexpr (NACC >= 7) { front_block<D, RD, F32IN, 6, NACC - 1, NACC>(R + 5, xl, kl, sc, a.mix, ai, aq); rotate_only(); }
+        if constexpr (NACC >= 6) { front_block<D, RD, F32IN, 5, NACC - 1, NACC>(R + 4, xl, kl, sc, a.mix, ai, aq); rotate_only(); }
+        if constexpr (NACC >= 5) { front_block<D, RD, F32IN, 4, NACC - 1, NACC>(R + 3, xl, kl, sc, a.mix, ai, aq); rotate_only(); }
+        if constexpr (NACC >= 4) { front_block<D, RD, F32IN, 3, NACC - 1, NACC>(R + 2, xl, kl, sc, a.mix, ai, aq); rotate_only(); }
+        if constexpr (NACC >= 3) { front_block<D, RD, F32IN, 2, NACC - 1, NACC>(R + 1, xl, kl, sc, a.mix, ai, aq); rotate_only(); }
+        if constexpr (NACC >= 2) { front_block<D, RD, F32IN, 1, NACC - 1, NACC>(R + 0, xl, kl, sc, a.mix, ai, aq); rotate_only(); }
+        // main blocks: every window exists
+#pragma unroll 1
+        for (int b = R - 1; b >= NACC - 1; b--) {
+            front_block<D, RD, F32IN, 0, NACC - 1, NACC>(b, xl, kl, sc, a.mix, ai, aq);
+            finish(b);
+        }
+        // bottom blocks b = NACC-2 .. 0: outputs below 0 belong to the previous lane
+        if constexpr (NACC >= 7) { front_block<D, RD, F32IN, 0, 5, NACC>(5, xl, kl, sc, a.mix, ai, aq); finish(5); }
+        if constexpr (NACC >= 6) { front_block<D, RD, F32IN, 0, 4, NACC>(4, xl, kl, sc, a.mix, ai, aq); finish(4); }
+        if constexpr (NACC >= 5) { front_block<D, RD, F32IN, 0, 3, NACC>(3, xl, kl, sc, a.mix, ai, aq); finish(3); }
+        if constexpr (NACC >= 4) { front_block<D, RD, F32IN, 0, 2, NACC>(2, xl, kl, sc, a.mix, ai, aq); finish(2); }
+        if constexpr (NACC >= 3) { front_block<D, RD, F32IN, 0, 1, NACC>(1, xl, kl, sc, a.mix, ai, aq); finish(1); }
+        if constexpr (NACC >= 2) { front_block<D, RD, F32IN, 0, 0, NACC>(0, xl, kl, sc, a.mix, ai, aq); finish(0); }
+        if constexpr (NACC == 1) { /* D >= 27: every block is a main block */ }
+        JSDR_WAVE_SYNC();
+    }
+}
+
+// keep the 26 most recent inputs (DC-corrected int16 pair, or the float pair) for the next call
 struct HistArgs {
     const int *raw;
     const float2 *rawf;
     long long stride_pairs, nsamples;
     int ic, qc;
-    const short *ktu;
-    const double *sincos;
-    const double2 *hist_old;
-    double2 *hist_new;
+    const int2 *hist_old;
+    int2 *hist_new;
     int nstreams;
 };
 __global__ void k_hist_in(HistArgs a)
@@ -188,26 +317,17 @@ __global__ void k_hist_in(HistArgs a)
     int s = t >> 5, i = t & 31;
     if (s >= a.nstreams || i >= 26) return;
     long long n = a.nsamples - 26 + i;
-    double2 v;
+    int2 v;
     if (n < 0) {
         v = a.hist_old[(long long)s * 32 + (26 + n)];
+    } else if (a.rawf) {
+        float2 f = a.rawf[(long long)s * a.stride_pairs + n];
+        v = make_int2(__float_as_int(f.x), __float_as_int(f.y));
     } else {
-        double di, dq;
-        if (a.rawf) {
-            float2 f = a.rawf[(long long)s * a.stride_pairs + n];
-            di = (double)f.x;
-            dq = (double)f.y;
-        } else {
-            int w = a.raw[(long long)s * a.stride_pairs + n];
-            di = (double)i16_to_float_java(java_short_add((int)(short)(w & 0xffff), a.ic));
-            dq = (double)i16_to_float_java(java_short_add(w >> 16, a.qc));
-        }
-        int k = a.ktu[n];
-        if (k >= 0) {
-            di = di * a.sincos[k];
-            dq = dq * a.sincos[256 + k];
-        }
-        v = make_double2(di, dq);
+        int w = a.raw[(long long)s * a.stride_pairs + n];
+        int si = java_short_add((int)(short)(w & 0xffff), a.ic);
+        int sq = java_short_add(w >> 16, a.qc);
+        v = make_int2((si & 0xffff) | (sq << 16), 0);
     }
     a.hist_new[(long long)s * 32 + i] = v;
 }
@@ -342,12 +462,17 @@ __global__ __launch_bounds__(64) void k_dm_history(double2 *dm, long long dm_str
 // ------------------------------------------------------------------------------------------- k_tail
 // One wave per stream, the 9600 Hz tail (:534-593) in chunks of 64 bit periods (512 samples).
 // The bit clock is input independent and exactly periodic (bitPos == g mod 8, a new peak is measured
-// after every g == 7 mod 8; verified on the host at create time).  Per chunk:
-//   parallel : lane = bit period: load its 8 (fi,fq), energy1 = fi*fi+fq*fq                  (:534)
-//   serial   : per period -- scalar peak logic (:537,:577-579), then ONE vector update in which lanes 0..7
-//              advance the eight dmEnergy IIRs (:535) and lane 8 advances dmEnergyOut (:538), then an
-//              8-lane argmax with first-maximum-wins (:586-592)
-//   parallel : lane = decision: differential detector, sqrt, threshold, bit (:539-545), compaction
+// after every g == 7 mod 8; verified on the host at create time).  The only truly serial arithmetic is
+// the nine first-order IIRs (eight dmEnergy channels :535, dmEnergyOut :538); everything else is taken
+// out of their loop:
+//   parallel : coalesced load of the chunk (prefetched one chunk ahead), energy1 = fi*fi+fq*fq     (:534)
+//   serial   : 64 steps; lanes 0..7 advance dmEnergy[lane], lane 8 advances dmEnergyOut SPECULATING that
+//              the peak position stays where it is (decision point = bitPos v in every period)
+//   parallel : lane = period: first-maximum argmax of the eight energies after that period (:586-592)
+//   check    : if every new peak equals v the speculation held (the steady state of a locked demodulator):
+//              decision points are (period, v).  Otherwise (rare: acquisition, fades) the chunk is replayed
+//              by the scalar state machine of :537,:577-579 and dmEnergyOut is recomputed from its saved value
+//   parallel : lane = decision: differential detector, sqrt, threshold, bit (:539-545), ordered compaction
 struct TailArgs {
     const double2 *y;
     long long y_stride;
@@ -364,108 +489,144 @@ struct TailArgs {
 
 __global__ __launch_bounds__(64) void k_tail(TailArgs a)
 {
-    __shared__ double2 yL[64][8];
-    __shared__ double enL[64][8];
+    __shared__ double2 yL[512];        // [period*8 + bitPos]
+    __shared__ double enL[512];
+    __shared__ double eL[64][9];       // dmEnergy[c] after each period (row padded: conflict-free column walk)
     __shared__ unsigned char maskL[64];
+    __shared__ signed char npL[64];
     __shared__ short declist[136];
     const int lane = threadIdx.x;
     const int s = blockIdx.x;
     if (s >= a.nstreams) return;
-    TailState st = a.st[s];
+    TailState *sp = &a.st[s];
     const double2 *y = a.y + (long long)s * a.y_stride;
     signed char *blog = a.bitlog_new + (long long)s * a.bitlog_stride;
+    const int nbits_prev = sp->nbits_prev;
+    const int cntBit0 = sp->cntBit;
     // carry the 5200-bit shift register (dmFECCorr, :503) over from the previous call's log
     {
-        const signed char *old = a.bitlog_old + (long long)s * a.bitlog_stride + st.nbits_prev;
+        const signed char *old = a.bitlog_old + (long long)s * a.bitlog_stride + nbits_prev;
+#pragma unroll 4
         for (int i = lane; i < HIST_BITS; i += 64) blog[i] = old[i];
     }
     const double K1 = 1.0 - 1.0 / 200.0, S1 = 1.0 / 200.0;  // BIT_SMOOTH1 (:89)
     const double K2 = 1.0 - 1.0 / 800.0, S2 = 1.0 / 800.0;  // BIT_SMOOTH2 (:90)
     // lanes 0..7 carry dmEnergy[lane], lane 8 carries dmEnergyOut
-    double e = (lane < 8) ? st.dmEnergy[lane] : st.dmEnergyOut;
+    double e = (lane < 8) ? sp->dmEnergy[lane] : sp->dmEnergyOut;
     const double Kc = (lane < 8) ? K1 : K2, Sc = (lane < 8) ? S1 : S2;
-    int peakPos = st.peakPos, newPeak = st.newPeak;
-    double lastI = st.lastI, lastQ = st.lastQ, energy1 = st.energy1, energy2 = st.energy2;
+    int peakPos = __builtin_amdgcn_readfirstlane(sp->peakPos);
+    int newPeak = __builtin_amdgcn_readfirstlane(sp->newPeak);
+    double lastI = sp->lastI, lastQ = sp->lastQ, energy1 = sp->energy1, energy2 = sp->energy2;
     int nbits = 0;
-    const long long g_end = a.g_first + a.nds;
-    const long long M_first = a.g_first >> 3, M_last = (g_end - 1) >> 3;
-    for (long long MB = M_first; MB <= M_last && a.nds > 0; MB += 64) {
-        // ---------------- parallel: load + energy
-        {
-            const long long M = MB + lane;
+    const long long g_first = a.g_first, g_end = a.g_first + a.nds;
+    const long long M_first = g_first >> 3, M_last = (g_end - 1) >> 3;
+
+    double2 pre[8];
+    auto fetch = [&](long long MB) {
 #pragma unroll
-            for (int c = 0; c < 8; c++) {
-                long long g = 8 * M + c;
-                double2 v = make_double2(0.0, 0.0);
-                if (g >= a.g_first && g < g_end) v = y[g - a.g_first];
-                yL[lane][c] = v;
-                enL[lane][c] = v.x * v.x + v.y * v.y;
+        for (int k = 0; k < 8; k++) {
+            long long g = 8 * MB + k * 64 + lane;
+            pre[k] = (g >= g_first && g < g_end) ? y[g - g_first] : make_double2(0.0, 0.0);
+        }
+    };
+    if (a.nds > 0) fetch(M_first);
+
+    for (long long MB = M_first; MB <= M_last && a.nds > 0; MB += 64) {
+        // ---------------- stage the prefetched chunk, start fetching the next one
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            yL[k * 64 + lane] = pre[k];
+            enL[k * 64 + lane] = pre[k].x * pre[k].x + pre[k].y * pre[k].y;  // :534
+        }
+        JSDR_WAVE_SYNC();
+        if (MB + 64 <= M_last) fetch(MB + 64);
+        const int nper = (int)((M_last - MB + 1) < 64 ? (M_last - MB + 1) : 64);
+        // ---------------- serial IIRs, speculating that the peak position stays at v
+        const int v = peakPos;
+        const bool spec = (newPeak == peakPos);
+        const double e_in = e;
+        {
+            const int idx = (lane < 8) ? lane : v;
+            const long long glane = 8 * MB + idx;
+            const bool lane_iir = lane < 8, lane_out = (lane == 8) && spec;
+#pragma unroll 4
+            for (int p = 0; p < nper; p++) {
+                const long long g = glane + 8 * p;
+                const bool ok = (g >= g_first) && (g < g_end) && (lane_iir || lane_out);
+                const double xv = enL[p * 8 + idx];
+                const double ne = (e * Kc) + (xv * Sc);  // :535 / :538
+                if (ok) e = ne;
+                if (lane_iir) eL[p][lane] = e;
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // ---------------- serial over the periods of this chunk
-        int nper = (int)((M_last - MB + 1) < 64 ? (M_last - MB + 1) : 64);
-        for (int p = 0; p < nper; p++) {
-            const long long gbase = 8 * (MB + p);
-            // sample validity of this period (only the first / last period of a call can be partial)
-            int cfirst = (gbase < a.g_first) ? (int)(a.g_first - gbase) : 0;
-            int clast = (gbase + 7 >= g_end) ? (int)(g_end - 1 - gbase) : 7;
-            // scalar peak logic: which samples are decision points (:537), half-bit hand-over (:577-578)
-            int mask = 0, c1 = -1, c2 = -1;
-            for (int c = cfirst; c <= clast; c++) {
-                if (c == peakPos) {
-                    mask |= 1 << c;
-                    if (c1 < 0) c1 = c; else c2 = c;
-                }
-                if (c == ((peakPos + 4) & 7)) peakPos = newPeak;  // dmHalfTable = {4,5,6,7,0,1,2,3} (:500)
-            }
-            // vector update: lanes 0..7 their IIR, lane 8 dmEnergyOut at the (first) decision point
-            {
-                int idx = (lane < 8) ? lane : (c1 < 0 ? 0 : c1);
-                bool on = (lane < 8) ? (lane >= cfirst && lane <= clast) : (lane == 8 && c1 >= 0);
-                double xv = enL[p][idx & 7];
-                double ne = (e * Kc) + (xv * Sc);
-                if (on) e = ne;
-                if (c2 >= 0) {  // two decision points in one period (peak moved forward): rare
-                    double xv2 = enL[p][c2];
-                    double ne2 = (e * Kc) + (xv2 * Sc);
-                    if (lane == 8) e = ne2;
-                }
-            }
-            if (lane == 0) maskL[p] = (unsigned char)mask;
-            // new peak measurement after the sample with bitPos 7 (:582-593): first maximum wins
-            if (clast == 7) {
-                double bv = e;
-                int bi = lane;
+        JSDR_WAVE_SYNC();
+        // ---------------- new peak after every period whose last sample (bitPos 7) is in range (:582-593)
+        int np = -1;
+        if (lane < nper) {
+            const long long g7 = 8 * (MB + lane) + 7;
+            if (g7 >= g_first && g7 < g_end) {
+                double bv = eL[lane][0];
+                np = 0;
 #pragma unroll
-                for (int off = 1; off < 8; off <<= 1) {
-                    double ov = __shfl_xor(bv, off, 8);
-                    int oi = __shfl_xor(bi, off, 8);
-                    if (ov > bv || (ov == bv && oi < bi)) {
+                for (int c = 1; c < 8; c++) {
+                    double ov = eL[lane][c];
+                    if (ov > bv) {  // strict: the first maximum wins
                         bv = ov;
-                        bi = oi;
+                        np = c;
                     }
                 }
-                newPeak = __builtin_amdgcn_readfirstlane(bi);
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const bool bad = (np >= 0) && (np != v);
+        const bool held = spec && (__ballot(bad) == 0ull);
+        if (held) {
+            if (lane < nper) {
+                const long long g = 8 * (MB + lane) + v;
+                maskL[lane] = (g >= g_first && g < g_end) ? (unsigned char)(1 << v) : (unsigned char)0;
+            }
+            // peakPos stays v; every measured peak was v, so newPeak stays v as well
+        } else {
+            // replay the chunk with the reference's state machine; dmEnergyOut restarts from its saved value
+            if (lane < 64) npL[lane] = (signed char)np;
+            if (lane == 8) e = e_in;
+            JSDR_WAVE_SYNC();
+            for (int p = 0; p < nper; p++) {
+                const long long gbase = 8 * (MB + p);
+                const int cfirst = (gbase < g_first) ? (int)(g_first - gbase) : 0;
+                const int clast = (gbase + 7 >= g_end) ? (int)(g_end - 1 - gbase) : 7;
+                int mask = 0, c1 = -1, c2 = -1;
+                for (int c = cfirst; c <= clast; c++) {
+                    if (c == peakPos) {  // decision point (:537)
+                        mask |= 1 << c;
+                        if (c1 < 0) c1 = c; else c2 = c;
+                    }
+                    if (c == ((peakPos + 4) & 7)) peakPos = newPeak;  // dmHalfTable (:500,:577-578)
+                }
+                if (c1 >= 0) {
+                    const double ne = (e * Kc) + (enL[p * 8 + c1] * Sc);
+                    if (lane == 8) e = ne;
+                }
+                if (c2 >= 0) {  // two decision points in one period: the peak moved forward
+                    const double ne = (e * Kc) + (enL[p * 8 + c2] * Sc);
+                    if (lane == 8) e = ne;
+                }
+                if (lane == 0) maskL[p] = (unsigned char)mask;
+                if (clast == 7) newPeak = __builtin_amdgcn_readfirstlane((int)npL[p]);
+            }
+        }
+        JSDR_WAVE_SYNC();
         // ---------------- decision list of the chunk, in time order
-        int mymask = (lane < nper) ? (int)maskL[lane] : 0;
-        int mycnt = __popc(mymask);
-        int pre = mycnt;  // inclusive prefix sum over lanes
+        const int mymask = (lane < nper) ? (int)maskL[lane] : 0;
+        const int mycnt = __popc(mymask);
+        int pre_sum = mycnt;  // inclusive prefix sum over lanes
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
-            int o = __shfl_up(pre, off, 64);
-            if (lane >= off) pre += o;
+            int o = __shfl_up(pre_sum, off, 64);
+            if (lane >= off) pre_sum += o;
         }
-        int nd = __shfl(pre, 63, 64);
+        const int nd = __shfl(pre_sum, 63, 64);
         {
-            int pos = pre - mycnt;
+            int pos = pre_sum - mycnt;
             int m = mymask;
             while (m) {
                 int c = __ffs(m) - 1;
@@ -473,27 +634,21 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs a)
                 declist[pos++] = (short)(lane * 8 + c);
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        JSDR_WAVE_SYNC();
         // ---------------- parallel: differential detector per decision (:539-545)
         for (int d0 = 0; d0 < nd; d0 += 64) {
-            int d = d0 + lane;
-            bool have = d < nd;
+            const int d = d0 + lane;
+            const bool have = d < nd;
             double2 cur = make_double2(0.0, 0.0), prv = make_double2(lastI, lastQ);
             if (have) {
-                int pc = declist[d];
-                cur = yL[pc >> 3][pc & 7];
-                if (d > 0) {
-                    int pp = declist[d - 1];
-                    prv = yL[pp >> 3][pp & 7];
-                }
+                cur = yL[declist[d]];
+                if (d > 0) prv = yL[declist[d - 1]];
             }
-            double di = -((prv.x * cur.x) + (prv.y * cur.y));
-            double dq = (prv.x * cur.y) - (prv.y * cur.x);
-            double e2 = sqrt((di * di) + (dq * dq));
-            bool valid = have && (e2 > 100.0);
-            unsigned long long vm = __ballot(valid);
+            const double di = -((prv.x * cur.x) + (prv.y * cur.y));
+            const double dq = (prv.x * cur.y) - (prv.y * cur.x);
+            const double e2 = sqrt((di * di) + (dq * dq));
+            const bool valid = have && (e2 > 100.0);
+            const unsigned long long vm = __ballot(valid);
             if (valid) {
                 int rank = __popcll(vm & ((1ull << lane) - 1ull));
                 int pos = nbits + rank;
@@ -501,7 +656,7 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs a)
             }
             nbits += __popcll(vm);
             // the last decision of the chunk defines dmLastIQ / energy2 for what follows
-            int lastd = nd - 1 - d0;
+            const int lastd = nd - 1 - d0;
             if (lastd >= 0 && lastd < 64) {
                 energy2 = __shfl(e2, lastd, 64);
                 lastI = __shfl(cur.x, lastd, 64);
@@ -512,28 +667,25 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs a)
         {
             long long glast = 8 * (MB + nper - 1) + 7;
             if (glast >= g_end) glast = g_end - 1;
-            long long pl = (glast >> 3) - MB;
-            energy1 = enL[pl][glast & 7];
+            energy1 = enL[(int)(glast - 8 * MB)];
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        JSDR_WAVE_SYNC();
     }
     // ---------------- write back
-    double e8 = __shfl(e, 8, 64);
-    if (lane < 8) a.st[s].dmEnergy[lane] = e;
+    const double e8 = __shfl(e, 8, 64);
+    if (lane < 8) sp->dmEnergy[lane] = e;
     if (lane == 0) {
-        TailState *o = &a.st[s];
-        o->dmEnergyOut = e8;
-        o->lastI = lastI;
-        o->lastQ = lastQ;
-        o->energy1 = energy1;
-        o->energy2 = energy2;
-        o->peakPos = peakPos;
-        o->newPeak = newPeak;
-        int nb = nbits < a.max_bits ? nbits : a.max_bits;
-        o->cntBit = st.cntBit + nb;
-        o->nbits_prev = nb;
-        if (nbits > a.max_bits) o->overflow = 1;
+        sp->dmEnergyOut = e8;
+        sp->lastI = lastI;
+        sp->lastQ = lastQ;
+        sp->energy1 = energy1;
+        sp->energy2 = energy2;
+        sp->peakPos = peakPos;
+        sp->newPeak = newPeak;
+        const int nb = nbits < a.max_bits ? nbits : a.max_bits;
+        sp->cntBit = cntBit0 + nb;
+        sp->nbits_prev = nb;
+        if (nbits > a.max_bits) sp->overflow = 1;
         a.nbits[s] = nb;
     }
 }
@@ -633,15 +785,24 @@ struct jsdr_bpsk {
     double c_tu0 = 0, c_vco0 = 0, c_tu1 = 0, c_vco1 = 0;
     int c_ds0 = 0, c_ds1 = 0;
     long long c_L = -1, c_nds = 0;
-    std::vector<short> h_ktu;
+    std::vector<unsigned char> h_ktu;  // [26 history + L]
+    unsigned char h_khist[26] = {0};   // tuner indices of the 26 samples before the next call
+    unsigned char c_khist[26] = {0};
+    int mix = 1, c_mix = 1;
     std::vector<unsigned char> h_kvco;
     // device
     DevBuf<double> sincos;
-    DevBuf<short> ktu;
+    DevBuf<unsigned char> ktu;
     DevBuf<unsigned char> kvco;
-    DevBuf<double2> hist_in[2];
+    DevBuf<int2> hist_in[2];
     int hist_cur = 0;
-    DevBuf<double2> dm, y;
+    DevBuf<double2> dm, y[2];  // y is double-buffered: the tail of call k overlaps the front end of call k+1
+    int y_cur = 0;
+    hipStream_t tail_stream = nullptr;   // non-blocking side stream for the latency-bound 9600 Hz tail + FEC
+    hipEvent_t ev_matched = nullptr;     // caller stream -> tail stream: (fi,fq) of this call are complete
+    hipEvent_t ev_tail_done[2] = {nullptr, nullptr};  // tail stream -> caller stream: y[i] may be overwritten
+    bool tail_pending[2] = {false, false};
+    bool overlap = true;
     long long dm_stride = 0, y_stride = 0;
     DevBuf<TailState> tail;
     DevBuf<signed char> bitlog[2];
@@ -652,7 +813,9 @@ struct jsdr_bpsk {
     DevBuf<unsigned char> fec_data, decoded;
     DevBuf<int> stage_raw;  // one frame for receive_*()
     long long last_nds = 0;
+    int last_y = 0;
     hipStream_t last_stream = 0;
+    int front_rd = 40;  // samples per lane span in k_front at 96 kHz (JSDR_FRONT_RD=80 selects the wide variant)
     // optional per-kernel HIP-event timing (bench.py's roofline leg)
     bool prof_on = false;
     struct ProfRec {
@@ -706,10 +869,13 @@ static const double JPI = 3.14159265358979323846;
 // does and record the table index each sample will use.  Returns the number of decimated outputs.
 static long long build_schedule(jsdr_bpsk *h, long long L)
 {
-    if (h->cache_valid && h->c_L == L && h->c_tu0 == h->tuPhase && h->c_vco0 == h->vcoPhase && h->c_ds0 == h->dsCnt) {
+    if (h->cache_valid && h->c_L == L && h->c_tu0 == h->tuPhase && h->c_vco0 == h->vcoPhase && h->c_ds0 == h->dsCnt &&
+        memcmp(h->c_khist, h->h_khist, 26) == 0) {
         h->tuPhase = h->c_tu1;
         h->vcoPhase = h->c_vco1;
         h->dsCnt = h->c_ds1;
+        h->mix = h->c_mix;
+        memcpy(h->h_khist, h->h_ktu.data() + L, 26);
         return h->c_nds;
     }
     const double two_pi = 2.0 * JPI;
@@ -717,17 +883,22 @@ static long long build_schedule(jsdr_bpsk *h, long long L)
     h->c_tu0 = h->tuPhase;
     h->c_vco0 = h->vcoPhase;
     h->c_ds0 = h->dsCnt;
-    h->h_ktu.resize((size_t)L);
+    memcpy(h->c_khist, h->h_khist, 26);
+    h->h_ktu.resize((size_t)L + 26);
+    memcpy(h->h_ktu.data(), h->h_khist, 26);
     h->h_kvco.clear();
     double tu = h->tuPhase, vco = h->vcoPhase;
     int cnt = h->dsCnt;
+    long long nmix = 0;
     for (long long n = 0; n < L; n++) {
         tu += h->tuPhaseInc;
         if (tu > two_pi) tu -= two_pi;
-        if (tu > 0.0)
-            h->h_ktu[(size_t)n] = (short)((int)(tu * (double)256 / two_pi) % 256);
-        else
-            h->h_ktu[(size_t)n] = -1;
+        int k = 0;
+        if (tu > 0.0) {  // :388
+            k = (int)(tu * (double)256 / two_pi) % 256;
+            nmix++;
+        }
+        h->h_ktu[(size_t)n + 26] = (unsigned char)k;
         if (++cnt >= h->decim) {
             cnt = 0;
             vco += vinc;
@@ -735,6 +906,8 @@ static long long build_schedule(jsdr_bpsk *h, long long L)
             h->h_kvco.push_back((unsigned char)((int)(vco * (double)256 / two_pi) % 256));
         }
     }
+    // tuPhase > 0 holds for every sample (tuning > 0) or for none (tuning <= 0): one flag per handle
+    h->mix = (nmix == L) ? 1 : (nmix == 0 ? 0 : -1);
     h->tuPhase = tu;
     h->vcoPhase = vco;
     h->dsCnt = cnt;
@@ -742,7 +915,9 @@ static long long build_schedule(jsdr_bpsk *h, long long L)
     h->c_vco1 = vco;
     h->c_ds1 = cnt;
     h->c_L = L;
+    h->c_mix = h->mix;
     h->c_nds = (long long)h->h_kvco.size();
+    memcpy(h->h_khist, h->h_ktu.data() + L, 26);
     h->cache_valid = false;  // device copy refreshed by the caller
     return h->c_nds;
 }
@@ -770,23 +945,36 @@ static bool bit_clock_is_regular()
     return true;
 }
 
-template <int D>
-static void launch_front(const FrontArgs &fa, int nstreams, long long nds, hipStream_t st)
+template <int D, int RD, bool F32IN>
+static void launch_front_t(const FrontArgs &fa, int nstreams, long long nds, hipStream_t st)
 {
-    using G = FrontGeom<D>;
-    size_t lds = 512 * sizeof(double) + 4 * (size_t)G::NLDS * sizeof(double2);
-    long long nchunks = (nds + 63) / 64;
-    long long gx = (nchunks + 3) / 4;
-    if (gx > 4096) gx = 4096;
+    using G = FrontGeom<D, RD>;
+    constexpr int WAVES = 2;
+    constexpr size_t elem = F32IN ? sizeof(float2) : sizeof(int);
+    const size_t lds = 512 * sizeof(double) + WAVES * ((size_t)G::RAW_EL * elem + G::K_BYTES);
+    long long ntiles = (nds + 64 * G::R - 1) / (64 * G::R);
+    long long gx = (ntiles + WAVES - 1) / WAVES;
+    if (gx > 2048) gx = 2048;
     if (gx < 1) gx = 1;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_front<D>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_front<D, RD, F32IN>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-    hipLaunchKernelGGL(k_front<D>, dim3((unsigned)gx, (unsigned)nstreams), dim3(256), lds, st, fa);
+    hipLaunchKernelGGL((k_front<D, RD, F32IN>), dim3((unsigned)gx, (unsigned)nstreams), dim3(64 * WAVES), lds, st, fa);
 }
+
+template <int D, int RD>
+static void launch_front(const FrontArgs &fa, int nstreams, long long nds, hipStream_t st)
+{
+    if (fa.rawf)
+        launch_front_t<D, RD, true>(fa, nstreams, nds, st);
+    else
+        launch_front_t<D, RD, false>(fa, nstreams, nds, st);
+}
+
+static int sync_last(jsdr_bpsk *h);
 
 static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev, long long stride_i16, long long L,
                     int ic, int qc, hipStream_t st)
@@ -801,8 +989,9 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
     const long long g_first = h->n_ds;
     const long long nds = build_schedule(h, L);
     JSDR_REQUIRE(nds <= h->max_ds, "bpsk: internal: %lld decimated samples exceed capacity %lld", nds, h->max_ds);
+    JSDR_REQUIRE(h->mix >= 0, "bpsk: tuner phase changes sign inside a call (unsupported)");
     if (!h->cache_valid) {
-        JSDR_HIP_TRY(hipMemcpyAsync(h->ktu.p, h->h_ktu.data(), sizeof(short) * (size_t)L, hipMemcpyHostToDevice, st));
+        JSDR_HIP_TRY(hipMemcpyAsync(h->ktu.p, h->h_ktu.data(), (size_t)L + 26, hipMemcpyHostToDevice, st));
         if (nds > 0)
             JSDR_HIP_TRY(hipMemcpyAsync(h->kvco.p, h->h_kvco.data(), (size_t)nds, hipMemcpyHostToDevice, st));
         // the host vectors must stay untouched until the copies ran; pageable memcpyAsync stages
@@ -817,10 +1006,11 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
     fa.nsamples = L;
     fa.ic = ic;
     fa.qc = qc;
+    fa.mix = h->mix;
     fa.ktu = h->ktu.p;
     fa.kvco = h->kvco.p;
     fa.sincos = h->sincos.p;
-    fa.hist_in = h->hist_in[h->hist_cur].p;
+    fa.hist = h->hist_in[h->hist_cur].p;
     fa.dm = h->dm.p;
     fa.dm_stride = h->dm_stride;
     fa.ds_dbg = nullptr;
@@ -829,10 +1019,15 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
     if (nds > 0) {
         ProfScope ps(h, PK_FRONT, st);
         switch (h->decim) {
-            case 4: launch_front<4>(fa, S, nds, st); break;
-            case 5: launch_front<5>(fa, S, nds, st); break;
-            case 10: launch_front<10>(fa, S, nds, st); break;
-            case 20: launch_front<20>(fa, S, nds, st); break;
+            case 4: launch_front<4, 40>(fa, S, nds, st); break;
+            case 5: launch_front<5, 40>(fa, S, nds, st); break;
+            case 10:
+                if (h->front_rd == 80)
+                    launch_front<10, 80>(fa, S, nds, st);
+                else
+                    launch_front<10, 40>(fa, S, nds, st);
+                break;
+            case 20: launch_front<20, 80>(fa, S, nds, st); break;
             default: JSDR_REQUIRE(false, "bpsk: unsupported decimation %d", h->decim);
         }
         JSDR_LAUNCH_CHECK();
@@ -845,8 +1040,6 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
         ha.nsamples = L;
         ha.ic = ic;
         ha.qc = qc;
-        ha.ktu = h->ktu.p;
-        ha.sincos = h->sincos.p;
         ha.hist_old = h->hist_in[h->hist_cur].p;
         ha.hist_new = h->hist_in[h->hist_cur ^ 1].p;
         ha.nstreams = S;
@@ -855,11 +1048,18 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
         JSDR_LAUNCH_CHECK();
         h->hist_cur ^= 1;
     }
+    const int yb = h->y_cur;
+    hipStream_t ts = h->overlap ? h->tail_stream : st;
+    if (h->overlap && h->tail_pending[yb]) {
+        // the tail that last read y[yb] (two calls ago) must be done before the matched filter overwrites it
+        JSDR_HIP_TRY(hipStreamWaitEvent(st, h->ev_tail_done[yb], 0));
+        h->tail_pending[yb] = false;
+    }
     if (nds > 0) {
         MatchedArgs ma;
         ma.dm = h->dm.p;
         ma.dm_stride = h->dm_stride;
-        ma.y = h->y.p;
+        ma.y = h->y[yb].p;
         ma.y_stride = h->y_stride;
         ma.nds = nds;
         ma.g_first = g_first;
@@ -883,9 +1083,13 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
         hipLaunchKernelGGL(k_dm_history, dim3((unsigned)S), dim3(64), 0, st, h->dm.p, h->dm_stride, nds, S);
         JSDR_LAUNCH_CHECK();
     }
+    if (h->overlap) {
+        JSDR_HIP_TRY(hipEventRecord(h->ev_matched, st));
+        JSDR_HIP_TRY(hipStreamWaitEvent(ts, h->ev_matched, 0));
+    }
     {
         TailArgs ta;
-        ta.y = h->y.p;
+        ta.y = h->y[yb].p;
         ta.y_stride = h->y_stride;
         ta.nds = nds;
         ta.g_first = g_first;
@@ -896,13 +1100,13 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
         ta.nbits = h->nbits.p;
         ta.max_bits = h->max_bits;
         ta.nstreams = S;
-        ProfScope ps(h, PK_TAIL, st);
-        hipLaunchKernelGGL(k_tail, dim3((unsigned)S), dim3(64), 0, st, ta);
+        ProfScope ps(h, PK_TAIL, ts);
+        hipLaunchKernelGGL(k_tail, dim3((unsigned)S), dim3(64), 0, ts, ta);
         JSDR_LAUNCH_CHECK();
         h->bitlog_cur ^= 1;
     }
     {
-        JSDR_HIP_TRY(hipMemsetAsync(h->trig_count.p, 0, sizeof(int) * (size_t)S, st));
+        JSDR_HIP_TRY(hipMemsetAsync(h->trig_count.p, 0, sizeof(int) * (size_t)S, ts));
         SyncArgs sa;
         sa.bitlog = h->bitlog[h->bitlog_cur].p;
         sa.bitlog_stride = h->bitlog_stride;
@@ -916,13 +1120,13 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
         if ((long long)gx * 256 > maxnew + 255) gx = (int)((maxnew + 255) / 256);
         if (gx < 1) gx = 1;
         {
-            ProfScope ps(h, PK_SYNC, st);
-            hipLaunchKernelGGL(k_sync, dim3((unsigned)gx, (unsigned)S), dim3(256), 0, st, sa);
+            ProfScope ps(h, PK_SYNC, ts);
+            hipLaunchKernelGGL(k_sync, dim3((unsigned)gx, (unsigned)S), dim3(256), 0, ts, sa);
         }
         JSDR_LAUNCH_CHECK();
         {
-            ProfScope ps(h, PK_SYNCFIN, st);
-            hipLaunchKernelGGL(k_sync_fin, dim3((unsigned)S), dim3(64), 0, st, h->nbits.p, h->corr.p, h->max_bits,
+            ProfScope ps(h, PK_SYNCFIN, ts);
+            hipLaunchKernelGGL(k_sync_fin, dim3((unsigned)S), dim3(64), 0, ts, h->nbits.p, h->corr.p, h->max_bits,
                                h->trig_count.p, h->trig_bits.p, h->tail.p, S);
         }
         JSDR_LAUNCH_CHECK();
@@ -938,9 +1142,15 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
         fa2.last = h->fec_last.p;
         fa2.cnt_dec = h->cnt_dec.p;
         fa2.nstreams = S;
-        ProfScope ps(h, PK_FEC, st);
-        if (launch_fec_bpsk(fa2, st) != JSDR_OK) return JSDR_ERR;
+        ProfScope ps(h, PK_FEC, ts);
+        if (launch_fec_bpsk(fa2, ts) != JSDR_OK) return JSDR_ERR;
     }
+    if (h->overlap) {
+        JSDR_HIP_TRY(hipEventRecord(h->ev_tail_done[yb], ts));
+        h->tail_pending[yb] = true;
+        h->y_cur ^= 1;
+    }
+    h->last_y = yb;
     h->n_in += L;
     h->n_ds += nds;
     h->last_nds = nds;
@@ -977,14 +1187,16 @@ int jsdr_bpsk_create(jsdr_bpsk **out, int rate, int nsamples_per_frame, int tuni
     h->max_ds = max_batch_samples / decim + 2;
     h->max_bits = (int)(h->max_ds / 4 + 16);
     h->tuPhaseInc = 2.0 * JPI * (double)tuning_hz / (double)rate;  // :196
+    if (const char *e = getenv("JSDR_FRONT_RD")) h->front_rd = atoi(e) == 80 ? 80 : 40;
+    if (const char *e = getenv("JSDR_NO_OVERLAP")) h->overlap = atoi(e) == 0;
     const size_t S = (size_t)nstreams;
     h->dm_stride = 64 + h->max_ds + 64;
     h->y_stride = h->max_ds;
     h->bitlog_stride = HIST_BITS + h->max_bits + 64;
-    bool ok = h->sincos.alloc(512) == JSDR_OK && h->ktu.alloc((size_t)h->max_batch) == JSDR_OK &&
+    bool ok = h->sincos.alloc(512) == JSDR_OK && h->ktu.alloc((size_t)h->max_batch + 32) == JSDR_OK &&
               h->kvco.alloc((size_t)h->max_ds) == JSDR_OK && h->hist_in[0].alloc(S * 32) == JSDR_OK &&
               h->hist_in[1].alloc(S * 32) == JSDR_OK && h->dm.alloc(S * (size_t)h->dm_stride) == JSDR_OK &&
-              h->y.alloc(S * (size_t)h->y_stride) == JSDR_OK && h->tail.alloc(S) == JSDR_OK &&
+              h->y[0].alloc(S * (size_t)h->y_stride) == JSDR_OK && h->y[1].alloc(S * (size_t)h->y_stride) == JSDR_OK && h->tail.alloc(S) == JSDR_OK &&
               h->bitlog[0].alloc(S * (size_t)h->bitlog_stride) == JSDR_OK &&
               h->bitlog[1].alloc(S * (size_t)h->bitlog_stride) == JSDR_OK && h->nbits.alloc(S) == JSDR_OK &&
               h->trig_count.alloc(S) == JSDR_OK && h->trig_bits.alloc(S * MAX_TRIG) == JSDR_OK &&
@@ -1030,7 +1242,11 @@ int jsdr_bpsk_create(jsdr_bpsk **out, int rate, int nsamples_per_frame, int tuni
               h->hist_in[0].zero() == JSDR_OK && h->hist_in[1].zero() == JSDR_OK && h->dm.zero() == JSDR_OK &&
               h->bitlog[0].zero() == JSDR_OK && h->bitlog[1].zero() == JSDR_OK && h->decoded.zero() == JSDR_OK &&
               h->nbits.zero() == JSDR_OK && h->trig_count.zero() == JSDR_OK && h->fec_last.zero() == JSDR_OK &&
-              h->cnt_dec.zero() == JSDR_OK && h->y.zero() == JSDR_OK;
+              h->cnt_dec.zero() == JSDR_OK && h->y[0].zero() == JSDR_OK && h->y[1].zero() == JSDR_OK &&
+              hipStreamCreateWithFlags(&h->tail_stream, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreateWithFlags(&h->ev_matched, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&h->ev_tail_done[0], hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&h->ev_tail_done[1], hipEventDisableTiming) == hipSuccess;
     if (!up || hipDeviceSynchronize() != hipSuccess) {
         set_error("jsdr_bpsk_create: device initialisation failed");
         jsdr_bpsk_destroy(h);
@@ -1049,7 +1265,15 @@ int jsdr_bpsk_destroy(jsdr_bpsk *h)
     h->hist_in[0].release();
     h->hist_in[1].release();
     h->dm.release();
-    h->y.release();
+    h->y[0].release();
+    h->y[1].release();
+    if (h->tail_stream) {
+        (void)hipStreamSynchronize(h->tail_stream);
+        (void)hipStreamDestroy(h->tail_stream);
+    }
+    if (h->ev_matched) (void)hipEventDestroy(h->ev_matched);
+    for (int i = 0; i < 2; i++)
+        if (h->ev_tail_done[i]) (void)hipEventDestroy(h->ev_tail_done[i]);
     h->tail.release();
     h->bitlog[0].release();
     h->bitlog[1].release();
@@ -1086,8 +1310,7 @@ int jsdr_bpsk_receive_i16(jsdr_bpsk *h, const int16_t *raw_host, int ic, int qc)
     JSDR_HIP_TRY(hipMemcpy(h->stage_raw.p, raw_host, sizeof(int16_t) * 2 * (size_t)h->nsf, hipMemcpyHostToDevice));
     if (bpsk_run(h, reinterpret_cast<const int16_t *>(h->stage_raw.p), nullptr, 2LL * h->nsf, h->nsf, ic, qc, 0) != JSDR_OK)
         return JSDR_ERR;
-    JSDR_HIP_TRY(hipStreamSynchronize(0));
-    return JSDR_OK;
+    return sync_last(h);
 }
 
 int jsdr_bpsk_receive_f32(jsdr_bpsk *h, const float *iq_host)
@@ -1098,13 +1321,13 @@ int jsdr_bpsk_receive_f32(jsdr_bpsk *h, const float *iq_host)
     JSDR_HIP_TRY(hipMemcpy(h->stage_raw.p, iq_host, sizeof(float) * 2 * (size_t)h->nsf, hipMemcpyHostToDevice));
     if (bpsk_run(h, nullptr, reinterpret_cast<const float *>(h->stage_raw.p), 2LL * h->nsf, h->nsf, 0, 0, 0) != JSDR_OK)
         return JSDR_ERR;
-    JSDR_HIP_TRY(hipStreamSynchronize(0));
-    return JSDR_OK;
+    return sync_last(h);
 }
 
 static int sync_last(jsdr_bpsk *h)
 {
     JSDR_HIP_TRY(hipStreamSynchronize(h->last_stream));
+    if (h->tail_stream) JSDR_HIP_TRY(hipStreamSynchronize(h->tail_stream));
     return JSDR_OK;
 }
 
@@ -1188,7 +1411,7 @@ int jsdr_bpsk_get_trace(jsdr_bpsk *h, int stream, double *out_host, int64_t cap_
     *npairs = h->last_nds;
     long long n = h->last_nds < cap_pairs ? h->last_nds : cap_pairs;
     if (n > 0 && out_host)
-        JSDR_HIP_TRY(hipMemcpy(out_host, h->y.p + (size_t)stream * h->y_stride, sizeof(double2) * (size_t)n,
+        JSDR_HIP_TRY(hipMemcpy(out_host, h->y[h->last_y].p + (size_t)stream * h->y_stride, sizeof(double2) * (size_t)n,
                                hipMemcpyDeviceToHost));
     return JSDR_OK;
 }
@@ -1215,6 +1438,12 @@ int jsdr_bpsk_get_state(jsdr_bpsk *h, int stream, double out[18])
     out[16] = t.lastI;
     out[17] = t.lastQ;
     return JSDR_OK;
+}
+
+int jsdr_bpsk_sync(jsdr_bpsk *h)
+{
+    JSDR_REQUIRE(h, "jsdr_bpsk_sync: null handle");
+    return sync_last(h);
 }
 
 int jsdr_bpsk_profile_enable(jsdr_bpsk *h, int on)
@@ -1313,6 +1542,8 @@ extern "C" int jsdr_bpsk_pack_slots(jsdr_bpsk *h, uint8_t *slots_dev, void *stre
     int64_t slot_bytes = 0;
     int slot_bits = 0;
     jsdr_bpsk_slot_info(h, &slot_bytes, nullptr, nullptr, &slot_bits, nullptr);
+    if (h->overlap && h->tail_pending[h->last_y])  // results of the last call come from the side stream
+        JSDR_HIP_TRY(hipStreamWaitEvent(as_stream(stream), h->ev_tail_done[h->last_y], 0));
     hipLaunchKernelGGL(k_pack_slots, dim3((unsigned)h->nstreams), dim3(256), 0, as_stream(stream), slots_dev,
                        (long long)slot_bytes, slot_bits, h->tail.p, h->nbits.p, h->bitlog[h->bitlog_cur].p,
                        h->bitlog_stride, h->trig_count.p, h->trig_bits.p, h->fec_rc.p, h->fec_data.p, h->fec_last.p,

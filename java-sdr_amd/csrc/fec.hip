@@ -117,11 +117,13 @@ int fec_prepare() { return upload_tables(); }
 
 // ----------------------------------------------------------------------------------------------
 // LDS work area of one wave
+enum { METS_CHUNK = 512 };
 struct FecLds {
-    unsigned char raw[SYMPBLOCK];       // soft symbols in, or re-encoded symbols
-    unsigned char enc[SYMPBLOCK];       // encoder output
-    unsigned long long dec[NBITS + 2];  // decisions per step (== the reference's pp[2k], pp[2k+1])
-    short mets[NBITS][4];               // branch metrics per step
+    unsigned char raw[SYMPBLOCK];       // soft symbols in
+    unsigned long long dec[NBITS + 2];  // decisions per step (== the reference's pp[2k], pp[2k+1]); once the
+                                        // chain-back is done the same bytes hold the RS work arrays, then the
+                                        // re-encoded symbols (fec_enc())
+    short mets[METS_CHUNK][4];          // branch metrics of the current chunk of trellis steps
     unsigned char alpha_to[256];
     unsigned char index_of[256];
     unsigned char vit[320];             // Viterbi output / scrambled byte stream
@@ -129,6 +131,7 @@ struct FecLds {
     unsigned char data[256];            // decoded payload
     int misc[8];
 };
+__device__ __forceinline__ unsigned char *fec_enc(FecLds &L) { return reinterpret_cast<unsigned char *>(&L.dec[0]); }
 
 __device__ __forceinline__ int parity7(int v)
 {
@@ -138,8 +141,9 @@ __device__ __forceinline__ int parity7(int v)
 __device__ __forceinline__ int gf_mod255(int x) { return x % 255; }
 
 // encode_FEC40 (:677-688): data[256] (LDS) -> L.enc[5200]; 64 lanes cooperate.
-__device__ void fec_encode_wave(FecLds &L, const unsigned char *data, int lane)
+__device__ __forceinline__ void fec_encode_wave(FecLds &L, const unsigned char *data, int lane)
 {
+    unsigned char *enc = fec_enc(L);
     // ---- RS parity, two interleaved code words: lanes 0..31 block 0 (even bytes), 32..63 block 1 (odd)
     const int blk = lane >> 5, q = lane & 31;
     int reg = 0;
@@ -161,13 +165,13 @@ __device__ void fec_encode_wave(FecLds &L, const unsigned char *data, int lane)
     // byte stream: 256 data + 64 parity (parity byte 256+2q+b = RS_block[b][q], :665), scrambled (:570)
     for (int i = lane; i < 256; i += 64) L.vit[i] = data[i] ^ c_fec.scrambler[i];
     L.vit[256 + 2 * q + blk] = (unsigned char)(reg ^ c_fec.scrambler[256 + 2 * q + blk]);
-    for (int i = lane; i < SYMPBLOCK; i += 64) L.enc[i] = 0;
+    for (int i = lane; i < SYMPBLOCK; i += 64) enc[i] = 0;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // sync vector in interleaver column 0 (:600-605)
     for (int i = lane; i < 65; i += 64)
-        if (c_fec.sync[i]) L.enc[ROWS * i] = 1;
+        if (c_fec.sync[i]) enc[ROWS * i] = 1;
     // convolutional encoder + interleaver, parallel over the 2566 bits (:559-566, :549-556)
     for (int k = lane; k < NBITS; k += 64) {
         int sr = 0;
@@ -181,9 +185,9 @@ __device__ void fec_encode_wave(FecLds &L, const unsigned char *data, int lane)
         int a = parity7(sr & 0x4f);
         int b = 1 - parity7(sr & 0x6d);
         int bi = COLUMNS + 2 * k;
-        if (a) L.enc[(bi % COLUMNS) * ROWS + bi / COLUMNS] = 1;
+        if (a) enc[(bi % COLUMNS) * ROWS + bi / COLUMNS] = 1;
         bi++;
-        if (b) L.enc[(bi % COLUMNS) * ROWS + bi / COLUMNS] = 1;
+        if (b) enc[(bi % COLUMNS) * ROWS + bi / COLUMNS] = 1;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -192,13 +196,15 @@ __device__ void fec_encode_wave(FecLds &L, const unsigned char *data, int lane)
 
 // decode_rs_8 (:325-519) after the syndromes: one lane per code word, verbatim control flow.
 // s[] in index form.  Returns the number of corrected symbols or -1.
-__device__ __noinline__ int rs_correct_lane(unsigned char *data, const int *s_in, const unsigned char *alpha_to,
-                                            const unsigned char *index_of)
+// The work arrays live in LDS (`w`, 272 shorts per code word), not in private memory: a kernel with scratch
+// makes the runtime size a scratch arena for every dispatch, which costs more than the decode itself.
+__device__ __forceinline__ int rs_correct_lane(unsigned char *data, const int *s_in, const unsigned char *alpha_to,
+                                            const unsigned char *index_of, short *w)
 {
-    int lambda[NROOTS + 1], s[NROOTS], b[NROOTS + 1], t[NROOTS + 1], omega[NROOTS + 1];
-    int root[NROOTS], reg[NROOTS + 1], loc[NROOTS];
+    short *lambda = w, *s = w + 34, *b = w + 68, *t = w + 102, *omega = w + 136;
+    short *root = w + 170, *reg = w + 204, *loc = w + 238;
     int deg_lambda, el, deg_omega, i, j, r, k, q, tmp, num1, num2, den, discr_r, count;
-    for (i = 0; i < NROOTS; i++) s[i] = s_in[i];
+    for (i = 0; i < NROOTS; i++) s[i] = (short)s_in[i];
     for (i = 0; i <= NROOTS; i++) {
         lambda[i] = 0;
         t[i] = 0;
@@ -290,41 +296,45 @@ __device__ __noinline__ int rs_correct_lane(unsigned char *data, const int *s_in
 
 // FECDecode (:703-852) on L.raw; payload to L.data only on success (as the reference leaves
 // RSdecdata untouched on failure).  Returns -1 or the channel error count (wave-uniform).
-__device__ int fec_decode_wave(FecLds &L, int lane)
+__device__ __forceinline__ int fec_decode_wave(FecLds &L, int lane)
 {
-    // ---- step 1+2a: de-interleave (:715-722) fused with the branch metrics (:220-225)
-    for (int k = lane; k < NBITS; k += 64) {
-        int j0 = 2 * k, j1 = 2 * k + 1;
-        int y0 = L.raw[(j0 % COLUMNS) * ROWS + (j0 / COLUMNS + 1)];
-        int y1 = L.raw[(j1 % COLUMNS) * ROWS + (j1 / COLUMNS + 1)];
-#pragma unroll
-        for (int i = 0; i < 4; i++) L.mets[k][i] = (short)(c_fec.mettab[(i >> 1) & 1][y0] + c_fec.mettab[i & 1][y1]);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // ---- step 2b: add-compare-select, lane = state (:229-253).  Metrics fit int32 (|m| < 3e6).
+    // ---- steps 1+2: de-interleave (:715-722) fused with the branch metrics (:220-225), 512 trellis steps at
+    // a time, then add-compare-select with lane = state (:229-253).  Metrics fit int32 (|m| < 3e6).
     {
         // Syms[i] = (Partab[i&0x4f]<<1) | (1-Partab[i&0x6d])   (:105-114)
         const int ia = (parity7(lane & 0x4f) << 1) | (1 - parity7(lane & 0x6d));
         const int ib = (parity7((lane ^ 1) & 0x4f) << 1) | (1 - parity7((lane ^ 1) & 0x6d));
         int metric = (lane == 0) ? 0 : -999999;
         const int src_lo = lane >> 1, src_hi = (lane >> 1) + 32;
-        for (int k = 0; k < NBITS; k++) {
-            const short *m = L.mets[k];
-            int lo = __shfl(metric, src_lo, 64);
-            int hi = __shfl(metric, src_hi, 64);
-            int m0 = lo + (int)m[ia];
-            int m1 = hi + (int)m[ib];
-            bool d = m1 > m0;
-            metric = d ? m1 : m0;
-            unsigned long long mask = __ballot(d);
-            if (lane == 0) L.dec[k] = mask;
+        for (int k0 = 0; k0 < NBITS; k0 += METS_CHUNK) {
+            const int kn = (NBITS - k0) < METS_CHUNK ? (NBITS - k0) : METS_CHUNK;
+            for (int kk = lane; kk < kn; kk += 64) {
+                const int j0 = 2 * (k0 + kk), j1 = j0 + 1;
+                const int y0 = L.raw[(j0 % COLUMNS) * ROWS + (j0 / COLUMNS + 1)];
+                const int y1 = L.raw[(j1 % COLUMNS) * ROWS + (j1 / COLUMNS + 1)];
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    L.mets[kk][i] = (short)(c_fec.mettab[(i >> 1) & 1][y0] + c_fec.mettab[i & 1][y1]);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (int kk = 0; kk < kn; kk++) {
+                const short *m = L.mets[kk];
+                int lo = __shfl(metric, src_lo, 64);
+                int hi = __shfl(metric, src_hi, 64);
+                int m0 = lo + (int)m[ia];
+                int m1 = hi + (int)m[ib];
+                bool d = m1 > m0;
+                metric = d ? m1 : m0;
+                unsigned long long mask = __ballot(d);
+                if (lane == 0) L.dec[k0 + kk] = mask;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // ---- step 2c: chain back from state 0 (:264-276); decision words fetched 64 steps at a time
     {
         for (int i = lane; i < 320; i += 64) L.vit[i] = 0;
@@ -385,7 +395,8 @@ __device__ int fec_decode_wave(FecLds &L, int lane)
     int rserr = 0;
     bool need0 = (nz & 0xffffffffull) != 0, need1 = (nz >> 32) != 0;
     if ((lane == 0 && need0) || (lane == 32 && need1))
-        rserr = rs_correct_lane(L.rs[blk], sidx + blk * 32, L.alpha_to, L.index_of);
+        rserr = rs_correct_lane(L.rs[blk], sidx + blk * 32, L.alpha_to, L.index_of,
+                                reinterpret_cast<short *>(&L.dec[0]) + blk * 272);  // decisions are dead by now
     int e0 = __shfl(rserr, 0, 64), e1 = __shfl(rserr, 32, 64);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -398,7 +409,10 @@ __device__ int fec_decode_wave(FecLds &L, int lane)
     // ---- step 4: re-encode and count channel errors (:831-847)
     fec_encode_wave(L, L.data, lane);
     int errs = 0;
-    for (int i = lane; i < SYMPBLOCK; i += 64) errs += (L.enc[i] != (L.raw[i] >> 7)) ? 1 : 0;
+    {
+        const unsigned char *enc = fec_enc(L);
+        for (int i = lane; i < SYMPBLOCK; i += 64) errs += (enc[i] != (L.raw[i] >> 7)) ? 1 : 0;
+    }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) errs += __shfl_xor(errs, off, 64);
     return errs;
@@ -449,60 +463,74 @@ __global__ __launch_bounds__(64) void k_fec_encode(const unsigned char *__restri
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         fec_encode_wave(L, L.data, lane);
         unsigned *dst = reinterpret_cast<unsigned *>(sym + blk * SYMPBLOCK);
-        for (int i = lane; i < SYMPBLOCK / 4; i += 64) dst[i] = reinterpret_cast<unsigned *>(L.enc)[i];
+        for (int i = lane; i < SYMPBLOCK / 4; i += 64) dst[i] = reinterpret_cast<unsigned *>(fec_enc(L))[i];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
 }
 
+// BPSK hook, stage 1: one wave per (stream, sync hit).  Build the soft block from the +1/-1/0 bit history
+// (FUNcubeBPSKDemod.java:562-564) and decode; payload (on success) and rc go to the per-hit log.
 __global__ __launch_bounds__(64) void k_fec_bpsk(BpskFecArgs a)
 {
     __shared__ FecLds L;
     const int lane = threadIdx.x;
-    bool inited = false;
-    for (int s = blockIdx.x; s < a.nstreams; s += gridDim.x) {
-        int nt = a.trig_count[s];
-        if (nt > a.max_trig) nt = a.max_trig;
-        if (nt <= 0) continue;
-        if (!inited) {
-            fec_lds_init(L, lane);
-            inited = true;
+    // x = stream, y = hit index: consecutive workgroups go to different XCDs, and the few hits per stream
+    // (y small) must not all land on the same one or two XCDs
+    const int s = blockIdx.x, t = blockIdx.y;
+    int nt = a.trig_count[s];
+    if (nt > a.max_trig) nt = a.max_trig;
+    if (t >= nt) return;
+    fec_lds_init(L, lane);
+    const signed char *win = a.bitlog + (long long)s * a.bitlog_stride + (a.trig_bits[s * a.max_trig + t] + 1);
+    for (int i = lane; i < SYMPBLOCK; i += 64) L.raw[i] = (win[i] == 1) ? 0xc0 : 0x40;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int r = fec_decode_wave(L, lane);
+    unsigned char *logd = a.fec_data + ((long long)s * a.max_trig + t) * 256;
+    if (r >= 0)
+        for (int i = lane; i < 256; i += 64) logd[i] = L.data[i];
+    if (lane == 0) a.fec_rc[s * a.max_trig + t] = r;
+}
+
+// stage 2: per stream, in hit order: a successful decode replaces decoded[] (:565-569); a failed one leaves it
+// (FECDecoder.java:780), and its log entry shows the bytes the demodulator still holds.
+__global__ __launch_bounds__(256) void k_fec_fin(BpskFecArgs a)
+{
+    const int s = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (s >= a.nstreams) return;
+    int nt = a.trig_count[s];
+    if (nt > a.max_trig) nt = a.max_trig;
+    if (nt <= 0) return;
+    unsigned char *dst = a.decoded + (long long)s * 256;
+    unsigned cur = reinterpret_cast<unsigned *>(dst)[lane];  // 256 bytes = one dword per lane
+    int ndec = 0, lastrc = 0;
+    for (int t = 0; t < nt; t++) {
+        unsigned *logd = reinterpret_cast<unsigned *>(a.fec_data + ((long long)s * a.max_trig + t) * 256);
+        const int r = a.fec_rc[s * a.max_trig + t];
+        if (r >= 0) {
+            cur = logd[lane];
+            ndec++;
+        } else {
+            logd[lane] = cur;
         }
-        int ndec = 0, lastrc = 0;
-        for (int t = 0; t < nt; t++) {
-            const signed char *win = a.bitlog + (long long)s * a.bitlog_stride + (a.trig_bits[s * a.max_trig + t] + 1);
-            for (int i = lane; i < SYMPBLOCK; i += 64) L.raw[i] = (win[i] == 1) ? 0xc0 : 0x40;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            int r = fec_decode_wave(L, lane);
-            unsigned char *dst = a.decoded + (long long)s * 256;
-            if (r >= 0) {
-                for (int i = lane; i < 256; i += 64) dst[i] = L.data[i];
-                ndec++;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            unsigned char *logd = a.fec_data + ((long long)s * a.max_trig + t) * 256;
-            for (int i = lane; i < 256; i += 64) logd[i] = (r >= 0) ? L.data[i] : dst[i];
-            if (lane == 0) a.fec_rc[s * a.max_trig + t] = r;
-            lastrc = r;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-        }
-        if (lane == 0) {
-            a.last[2 * s] = lastrc;
-            a.last[2 * s + 1] = lastrc < 0 ? 0 : 1;
-            a.cnt_dec[s] += ndec;
-        }
+        lastrc = r;
+    }
+    reinterpret_cast<unsigned *>(dst)[lane] = cur;
+    if (lane == 0) {
+        a.last[2 * s] = lastrc;
+        a.last[2 * s + 1] = lastrc < 0 ? 0 : 1;
+        a.cnt_dec[s] += ndec;
     }
 }
 
 int launch_fec_bpsk(const BpskFecArgs &a, hipStream_t st)
 {
     if (upload_tables() != JSDR_OK) return JSDR_ERR;
-    int grid = a.nstreams < 2048 ? a.nstreams : 2048;
-    hipLaunchKernelGGL(k_fec_bpsk, dim3(grid), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(k_fec_bpsk, dim3((unsigned)a.nstreams, (unsigned)a.max_trig), dim3(64), 0, st, a);
+    JSDR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_fec_fin, dim3((unsigned)((a.nstreams + 3) / 4)), dim3(256), 0, st, a);
     JSDR_LAUNCH_CHECK();
     return JSDR_OK;
 }
