@@ -157,6 +157,7 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     import java_sdr_amd as J
+    from java_sdr_amd import sharding as SH
     import oracle_lib as O  # input tables + cpu_baseline leg only
 
     if not J.have_gpu():
@@ -167,7 +168,8 @@ def main():
     S, L = a.streams, a.samples
     if L % N_FFT:
         raise SystemExit("--samples must be a multiple of 2048")
-    d_iq, pay, nfr = make_inputs(J, O, S, L, rank * S)
+    stream0, _ = SH.shard_streams(N * S, N, rank)  # contiguous shards: rank order == global stream order
+    d_iq, pay, nfr = make_inputs(J, O, S, L, stream0)
     nframes = S * L // N_FFT
     fft = J.Fft(N_FFT, RATE) if a.workload in ("pipeline", "fft") else None
     d_psd = J.DeviceBuffer(nframes * (N_FFT + 2) * 4) if fft else None
@@ -192,7 +194,7 @@ def main():
             dem.batch_i16(d_iq, 2 * L, L)
             if N > 1:
                 dem.pack_slots(slots.data_ptr())
-                dist.all_gather_into_tensor(gathered, slots)
+                dist.all_gather_into_tensor(gathered, slots)  # == sharding.all_gather_slots, into a reused buffer
 
     def sync():
         if dem is not None:

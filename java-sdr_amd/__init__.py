@@ -8,6 +8,7 @@ that symbols can be checked), every compute call needs a HIP device and fails lo
 The directory name has a hyphen (the repo's naming rule); import it as `java_sdr_amd` through the
 shim module of that name at the repo root.
 """
+from . import sharding  # noqa: F401
 from .binding import (  # noqa: F401
     JsdrError, lib, library_path, have_gpu, DeviceBuffer, Fft, Fir, Bpsk, Timer,
     convert_i16, phase_maxabs, phase_columns, fec_decode, fec_encode, fec_decode_batch, fec_encode_batch, fec_encode_dev, fec_decode_dev,

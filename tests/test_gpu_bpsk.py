@@ -141,18 +141,24 @@ def test_bpsk_result_slots_for_the_all_gather():
     n = 458752
     streams = [O.make_dbpsk_stream(20020109, s, n)[0] for s in range(2)]
     d, oracles = run_both(streams, n, [n])
+    from java_sdr_amd import sharding as SH
     info = d.slot_info()
+    assert info == SH.slot_layout(info["slot_bits"], info["nfec_max"])  # kernel layout == the documented one
     slots = J.DeviceBuffer(2 * info["slot_bytes"])
     d.pack_slots(slots)
-    raw = slots.to_host(np.uint8).tobytes()
-    from java_sdr_amd.binding import unpack_slot
+    raw = slots.to_host(np.uint8)
     for s in range(2):
-        u = unpack_slot(raw[s * info["slot_bytes"]:(s + 1) * info["slot_bytes"]], info)
+        blob = raw[s * info["slot_bytes"]:(s + 1) * info["slot_bytes"]]
+        u = SH.unpack_slot(blob, info)
         assert np.array_equal(u["bits"], oracles[s].bits())
-        assert u["header"]["cntFEC"] == oracles[s].counters()["cntFEC"]
         fo = oracles[s].fec_results()
         assert len(u["fec"]) == len(fo)
         assert u["fec"][0][0] == fo[0][0] and np.array_equal(u["fec"][0][2], fo[0][2])
+        c = oracles[s].counters()
+        counters = [c[k] for k in ("cntRaw", "cntDS", "cntBit", "cntFEC", "cntDec", "dmErrBits", "dmCorr", "dmMaxCorr",
+                                   "decodeOK")]
+        want = SH.pack_slot(info, counters, oracles[s].bits(), [(rc, u["fec"][i][1], dat) for i, (rc, _, dat) in enumerate(fo)])
+        assert np.array_equal(blob, want)  # byte for byte what the numpy statement of the layout produces
 
 
 def test_bpsk_roundtrip_property_at_baseline_batch_shape():
