@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-validate", action="store_true")
+    ap.add_argument("--fft-acquire", action="store_true", help="demodulator in FFT-acquire mode (bpsk-dofft=1) instead of tune mode")
     return ap.parse_args()
 
 
@@ -173,7 +174,7 @@ def main():
     nframes = S * L // N_FFT
     fft = J.Fft(N_FFT, RATE) if a.workload in ("pipeline", "fft") else None
     d_psd = J.DeviceBuffer(nframes * (N_FFT + 2) * 4) if fft else None
-    dem = J.Bpsk(rate=RATE, blen=4 * N_FFT, tuning=12000, nstreams=S, max_batch_samples=L) \
+    dem = J.Bpsk(rate=RATE, blen=4 * N_FFT, tuning=12000, do_fft=int(a.fft_acquire), nstreams=S, max_batch_samples=L) \
         if a.workload in ("pipeline", "bpsk") else None
     slots = gathered = None
     if dem is not None and N > 1:
@@ -280,7 +281,7 @@ def main():
                                     "fft": "batched 2048-pt waterfall FFT+PSD (BASELINE config 2)",
                                     "bpsk": "FUNcubeBPSKDemod tune mode + FECDecoder (BASELINE config 4)"}[a.workload],
                        "streams_per_gpu": S, "samples_per_stream": L, "rate_hz": RATE, "frame": N_FFT,
-                       "input_bytes_per_gpu": S * L * 4, "variant": "exact-order FP64 (bit-exact bits/bytes)",
+                       "input_bytes_per_gpu": S * L * 4, "variant": "exact-order FP64 (bit-exact bits/bytes)" + (", FFT-acquire front end" if a.fft_acquire else ", tune mode"),
                        "parallelism": f"streams sharded over {N} GPU(s)" + (", RCCL all-gather of result slots" if N > 1 else "")},
             "roofline": roofline,
             "hbm_read_roofline_frac": round(total / dt * 4.0 / (N * HBM_PEAK_GBS * 1e9), 4),

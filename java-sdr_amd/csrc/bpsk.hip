@@ -18,6 +18,7 @@
 //   k_fec_bpsk  : FECDecode of every triggered window (fec.hip)
 // DESIGN.md has the lane/LDS mapping of each kernel and its roofline.
 #include "bpsk_fec.h"
+#include "bpsk_fft.h"
 #include <math.h>
 #include <stdlib.h>
 #include <vector>
@@ -25,6 +26,8 @@
 namespace jsdr {
 
 enum { DS_N = 27, DM_N = 65, HIST_BITS = 5200, MAX_TRIG = 8, SYNC_N = 65 };
+
+
 
 // FUNcubeBPSKDemod.java:27-55, float literals widened (symmetric, first 14)
 static const float h_ds_half[14] = {-6.103515625000e-004F, -1.220703125000e-004F, +2.380371093750e-003F,
@@ -133,9 +136,9 @@ struct FrontElem<true> {
 };
 
 // one block of D samples (newest first): outputs b-JLO .. b-JHI take part
-template <int D, int RD, bool F32IN, int JLO, int JHI, int NACC>
+template <int D, int RD, bool F32IN, bool MIX, int JLO, int JHI, int NACC>
 __device__ __forceinline__ void front_block(int b, const typename FrontElem<F32IN>::type *xl, const unsigned char *kl,
-                                            const double *sc, int mix, double (&ai)[NACC], double (&aq)[NACC])
+                                            const double *sc, double (&ai)[NACC], double (&aq)[NACC])
 {
 #pragma unroll
     for (int t = D - 1; t >= 0; t--) {
@@ -152,7 +155,8 @@ __device__ __forceinline__ void front_block(int b, const typename FrontElem<F32I
                 di = (double)i16_to_float_java((int)(short)(w & 0xffff));
                 dq = (double)i16_to_float_java(w >> 16);
             }
-            if (mix) {  // :388-390 component-wise, not a complex multiply
+            if constexpr (MIX) {  // :388-390 component-wise, not a complex multiply (a template flag, not a
+                                  // branch: the block stays one basic block and its LDS reads pipeline)
                 const int k = kl[m + 4 * wrap];
                 di = di * sc[k];
                 dq = dq * sc[256 + k];
@@ -169,7 +173,7 @@ __device__ __forceinline__ void front_block(int b, const typename FrontElem<F32I
     }
 }
 
-template <int D, int RD, bool F32IN>
+template <int D, int RD, bool F32IN, bool MIX>
 __global__ __launch_bounds__(128, 4) void k_front(FrontArgs a)
 {
     using G = FrontGeom<D, RD>;
@@ -277,25 +281,25 @@ __global__ __launch_bounds__(128, 4) void k_front(FrontArgs a)
             aq[NACC - 1] = 0.0;
         };
         // top blocks b = R-1+k (k = NACC-1 .. 1): only outputs <= R-1 exist, i.e. j >= k
-        if constexpr (NACC >= 7) { front_block<D, RD, F32IN, 6, NACC - 1, NACC>(R + 5, xl, kl, sc, a.mix, ai, aq); rotate_only(); }
-        if constexpr (NACC >= 6) { front_block<D, RD, F32IN, 5, NACC - 1, NACC>(R + 4, xl, kl, sc, a.mix, ai, aq); rotate_only(); }
-        if constexpr (NACC >= 5) { front_block<D, RD, F32IN, 4, NACC - 1, NACC>(R + 3, xl, kl, sc, a.mix, ai, aq); rotate_only(); }
-        if constexpr (NACC >= 4) { front_block<D, RD, F32IN, 3, NACC - 1, NACC>(R + 2, xl, kl, sc, a.mix, ai, aq); rotate_only(); }
-        if constexpr (NACC >= 3) { front_block<D, RD, F32IN, 2, NACC - 1, NACC>(R + 1, xl, kl, sc, a.mix, ai, aq); rotate_only(); }
-        if constexpr (NACC >= 2) { front_block<D, RD, F32IN, 1, NACC - 1, NACC>(R + 0, xl, kl, sc, a.mix, ai, aq); rotate_only(); }
+        if constexpr (NACC >= 7) { front_block<D, RD, F32IN, MIX, 6, NACC - 1, NACC>(R + 5, xl, kl, sc, ai, aq); rotate_only(); }
+        if constexpr (NACC >= 6) { front_block<D, RD, F32IN, MIX, 5, NACC - 1, NACC>(R + 4, xl, kl, sc, ai, aq); rotate_only(); }
+        if constexpr (NACC >= 5) { front_block<D, RD, F32IN, MIX, 4, NACC - 1, NACC>(R + 3, xl, kl, sc, ai, aq); rotate_only(); }
+        if constexpr (NACC >= 4) { front_block<D, RD, F32IN, MIX, 3, NACC - 1, NACC>(R + 2, xl, kl, sc, ai, aq); rotate_only(); }
+        if constexpr (NACC >= 3) { front_block<D, RD, F32IN, MIX, 2, NACC - 1, NACC>(R + 1, xl, kl, sc, ai, aq); rotate_only(); }
+        if constexpr (NACC >= 2) { front_block<D, RD, F32IN, MIX, 1, NACC - 1, NACC>(R + 0, xl, kl, sc, ai, aq); rotate_only(); }
         // main blocks: every window exists
 #pragma unroll 1
         for (int b = R - 1; b >= NACC - 1; b--) {
-            front_block<D, RD, F32IN, 0, NACC - 1, NACC>(b, xl, kl, sc, a.mix, ai, aq);
+            front_block<D, RD, F32IN, MIX, 0, NACC - 1, NACC>(b, xl, kl, sc, ai, aq);
             finish(b);
         }
         // bottom blocks b = NACC-2 .. 0: outputs below 0 belong to the previous lane
-        if constexpr (NACC >= 7) { front_block<D, RD, F32IN, 0, 5, NACC>(5, xl, kl, sc, a.mix, ai, aq); finish(5); }
-        if constexpr (NACC >= 6) { front_block<D, RD, F32IN, 0, 4, NACC>(4, xl, kl, sc, a.mix, ai, aq); finish(4); }
-        if constexpr (NACC >= 5) { front_block<D, RD, F32IN, 0, 3, NACC>(3, xl, kl, sc, a.mix, ai, aq); finish(3); }
-        if constexpr (NACC >= 4) { front_block<D, RD, F32IN, 0, 2, NACC>(2, xl, kl, sc, a.mix, ai, aq); finish(2); }
-        if constexpr (NACC >= 3) { front_block<D, RD, F32IN, 0, 1, NACC>(1, xl, kl, sc, a.mix, ai, aq); finish(1); }
-        if constexpr (NACC >= 2) { front_block<D, RD, F32IN, 0, 0, NACC>(0, xl, kl, sc, a.mix, ai, aq); finish(0); }
+        if constexpr (NACC >= 7) { front_block<D, RD, F32IN, MIX, 0, 5, NACC>(5, xl, kl, sc, ai, aq); finish(5); }
+        if constexpr (NACC >= 6) { front_block<D, RD, F32IN, MIX, 0, 4, NACC>(4, xl, kl, sc, ai, aq); finish(4); }
+        if constexpr (NACC >= 5) { front_block<D, RD, F32IN, MIX, 0, 3, NACC>(3, xl, kl, sc, ai, aq); finish(3); }
+        if constexpr (NACC >= 4) { front_block<D, RD, F32IN, MIX, 0, 2, NACC>(2, xl, kl, sc, ai, aq); finish(2); }
+        if constexpr (NACC >= 3) { front_block<D, RD, F32IN, MIX, 0, 1, NACC>(1, xl, kl, sc, ai, aq); finish(1); }
+        if constexpr (NACC >= 2) { front_block<D, RD, F32IN, MIX, 0, 0, NACC>(0, xl, kl, sc, ai, aq); finish(0); }
         if constexpr (NACC == 1) { /* D >= 27: every block is a main block */ }
         JSDR_WAVE_SYNC();
     }
@@ -812,6 +816,10 @@ struct jsdr_bpsk {
     DevBuf<signed char> corr;
     DevBuf<unsigned char> fec_data, decoded;
     DevBuf<int> stage_raw;  // one frame for receive_*()
+    DevBuf<FftFrontState> fft_state;  // FFT-acquire mode only
+    DevBuf<double2> fft_tw;
+    DevBuf<double> ds_taps_dev;
+    int logn = 0;
     long long last_nds = 0;
     int last_y = 0;
     hipStream_t last_stream = 0;
@@ -891,12 +899,14 @@ static long long build_schedule(jsdr_bpsk *h, long long L)
     int cnt = h->dsCnt;
     long long nmix = 0;
     for (long long n = 0; n < L; n++) {
-        tu += h->tuPhaseInc;
-        if (tu > two_pi) tu -= two_pi;
         int k = 0;
-        if (tu > 0.0) {  // :388
-            k = (int)(tu * (double)256 / two_pi) % 256;
-            nmix++;
+        if (!h->do_fft) {  // doBufferFFT never runs the tuner (:406-464)
+            tu += h->tuPhaseInc;
+            if (tu > two_pi) tu -= two_pi;
+            if (tu > 0.0) {  // :388
+                k = (int)(tu * (double)256 / two_pi) % 256;
+                nmix++;
+            }
         }
         h->h_ktu[(size_t)n + 26] = (unsigned char)k;
         if (++cnt >= h->decim) {
@@ -945,7 +955,7 @@ static bool bit_clock_is_regular()
     return true;
 }
 
-template <int D, int RD, bool F32IN>
+template <int D, int RD, bool F32IN, bool MIX>
 static void launch_front_t(const FrontArgs &fa, int nstreams, long long nds, hipStream_t st)
 {
     using G = FrontGeom<D, RD>;
@@ -958,20 +968,24 @@ static void launch_front_t(const FrontArgs &fa, int nstreams, long long nds, hip
     if (gx < 1) gx = 1;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_front<D, RD, F32IN>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_front<D, RD, F32IN, MIX>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_done = true;
     }
-    hipLaunchKernelGGL((k_front<D, RD, F32IN>), dim3((unsigned)gx, (unsigned)nstreams), dim3(64 * WAVES), lds, st, fa);
+    hipLaunchKernelGGL((k_front<D, RD, F32IN, MIX>), dim3((unsigned)gx, (unsigned)nstreams), dim3(64 * WAVES), lds, st,
+                       fa);
 }
 
 template <int D, int RD>
 static void launch_front(const FrontArgs &fa, int nstreams, long long nds, hipStream_t st)
 {
-    if (fa.rawf)
-        launch_front_t<D, RD, true>(fa, nstreams, nds, st);
-    else
-        launch_front_t<D, RD, false>(fa, nstreams, nds, st);
+    if (fa.rawf) {
+        if (fa.mix) launch_front_t<D, RD, true, true>(fa, nstreams, nds, st);
+        else launch_front_t<D, RD, true, false>(fa, nstreams, nds, st);
+    } else {
+        if (fa.mix) launch_front_t<D, RD, false, true>(fa, nstreams, nds, st);
+        else launch_front_t<D, RD, false, false>(fa, nstreams, nds, st);
+    }
 }
 
 static int sync_last(jsdr_bpsk *h);
@@ -984,12 +998,12 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
     JSDR_REQUIRE(L > 0 && L <= h->max_batch, "bpsk: nsamples=%lld outside (0, max_batch_samples=%lld]", L, h->max_batch);
     JSDR_REQUIRE((stride_i16 & 1) == 0 && (h->nstreams == 1 || stride_i16 >= 2 * L),
                  "bpsk: stream stride %lld too small for %lld samples", stride_i16, L);
-    JSDR_REQUIRE(!h->do_fft, "bpsk: FFT-acquire mode is handled by bpsk_fft (not linked in this build)");
+    JSDR_REQUIRE(!h->do_fft || (L % h->nsf) == 0, "bpsk: FFT-acquire mode needs whole frames (%lld %% %d != 0)", L, h->nsf);
     const int first_out = h->decim - 1 - h->dsCnt;
     const long long g_first = h->n_ds;
     const long long nds = build_schedule(h, L);
     JSDR_REQUIRE(nds <= h->max_ds, "bpsk: internal: %lld decimated samples exceed capacity %lld", nds, h->max_ds);
-    JSDR_REQUIRE(h->mix >= 0, "bpsk: tuner phase changes sign inside a call (unsupported)");
+    JSDR_REQUIRE(h->do_fft || h->mix >= 0, "bpsk: tuner phase changes sign inside a call (unsupported)");
     if (!h->cache_valid) {
         JSDR_HIP_TRY(hipMemcpyAsync(h->ktu.p, h->h_ktu.data(), (size_t)L + 26, hipMemcpyHostToDevice, st));
         if (nds > 0)
@@ -1016,7 +1030,30 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
     fa.ds_dbg = nullptr;
     fa.nds = nds;
     fa.first_out = first_out;
-    if (nds > 0) {
+    if (h->do_fft) {
+        FftFrontArgs xa;
+        xa.raw = fa.raw;
+        xa.rawf = fa.rawf;
+        xa.stride_pairs = fa.stride_pairs;
+        xa.nframes = (int)(L / h->nsf);
+        xa.n = h->nsf;
+        xa.logn = h->logn;
+        xa.ic = ic;
+        xa.qc = qc;
+        xa.do_up = h->do_up;
+        xa.decim = h->decim;
+        xa.first_out = first_out;
+        xa.kvco = h->kvco.p;
+        xa.sincos = h->sincos.p;
+        xa.tw = h->fft_tw.p;
+        xa.st = h->fft_state.p;
+        xa.dm = h->dm.p;
+        xa.dm_stride = h->dm_stride;
+        xa.nds = nds;
+        xa.ds_taps = h->ds_taps_dev.p;
+        ProfScope ps(h, PK_FRONT, st);
+        if (launch_front_fft(xa, S, st) != JSDR_OK) return JSDR_ERR;
+    } else if (nds > 0) {
         ProfScope ps(h, PK_FRONT, st);
         switch (h->decim) {
             case 4: launch_front<4, 40>(fa, S, nds, st); break;
@@ -1032,7 +1069,7 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
         }
         JSDR_LAUNCH_CHECK();
     }
-    {
+    if (!h->do_fft) {
         HistArgs ha;
         ha.raw = fa.raw;
         ha.rawf = fa.rawf;
@@ -1172,7 +1209,10 @@ int jsdr_bpsk_create(jsdr_bpsk **out, int rate, int nsamples_per_frame, int tuni
                  decim);
     JSDR_REQUIRE(nsamples_per_frame > 0 && nstreams > 0 && nstreams <= 65535, "jsdr_bpsk_create: bad geometry");
     if (max_batch_samples < nsamples_per_frame) max_batch_samples = nsamples_per_frame;
-    JSDR_REQUIRE(!do_fft, "jsdr_bpsk_create: FFT-acquire mode (bpsk-dofft=1) is not in this build yet");
+    JSDR_REQUIRE(!do_fft || (nsamples_per_frame >= 1024 && nsamples_per_frame <= 4096 &&
+                             (nsamples_per_frame & (nsamples_per_frame - 1)) == 0),
+                 "jsdr_bpsk_create: FFT-acquire mode needs a power-of-two frame of 1024..4096 samples (got %d)",
+                 nsamples_per_frame);
     JSDR_REQUIRE(bit_clock_is_regular(), "jsdr_bpsk_create: bit clock schedule is not the regular 8-cycle");
     if (fec_prepare() != JSDR_OK) return JSDR_ERR;
     jsdr_bpsk *h = new jsdr_bpsk();
@@ -1187,6 +1227,8 @@ int jsdr_bpsk_create(jsdr_bpsk **out, int rate, int nsamples_per_frame, int tuni
     h->max_ds = max_batch_samples / decim + 2;
     h->max_bits = (int)(h->max_ds / 4 + 16);
     h->tuPhaseInc = 2.0 * JPI * (double)tuning_hz / (double)rate;  // :196
+    while ((1 << h->logn) < nsamples_per_frame) h->logn++;
+    if (do_fft) h->max_batch = (h->max_batch / nsamples_per_frame) * nsamples_per_frame;
     if (const char *e = getenv("JSDR_FRONT_RD")) h->front_rd = atoi(e) == 80 ? 80 : 40;
     if (const char *e = getenv("JSDR_NO_OVERLAP")) h->overlap = atoi(e) == 0;
     const size_t S = (size_t)nstreams;
@@ -1203,16 +1245,18 @@ int jsdr_bpsk_create(jsdr_bpsk **out, int rate, int nsamples_per_frame, int tuni
               h->fec_rc.alloc(S * MAX_TRIG) == JSDR_OK && h->fec_last.alloc(S * 2) == JSDR_OK &&
               h->cnt_dec.alloc(S) == JSDR_OK && h->corr.alloc(S * (size_t)h->max_bits) == JSDR_OK &&
               h->fec_data.alloc(S * MAX_TRIG * 256) == JSDR_OK && h->decoded.alloc(S * 256) == JSDR_OK &&
-              h->stage_raw.alloc((size_t)nsamples_per_frame * 2) == JSDR_OK;
+              h->stage_raw.alloc((size_t)nsamples_per_frame * 2) == JSDR_OK && h->ds_taps_dev.alloc(32) == JSDR_OK &&
+              (!do_fft || (h->fft_state.alloc(S) == JSDR_OK && h->fft_tw.alloc((size_t)nsamples_per_frame / 2) == JSDR_OK));
     if (!ok) {
         jsdr_bpsk_destroy(h);
         return JSDR_ERR;
     }
     // tables (:159-162): Math.sin/cos are allowed 1 ulp; the host libm stands in (DESIGN.md "tables")
     std::vector<double> sc(512);
-    for (int n = 0; n < 256; n++) {
-        sc[n] = cos(n * 2.0 * JPI / 256);
-        sc[256 + n] = sin(n * 2.0 * JPI / 256);
+    for (int n = 0; n < 256; n++) {  // double argument as in Java, correctly rounded function value
+        double arg = n * 2.0 * JPI / 256;
+        sc[n] = (double)cosl((long double)arg);
+        sc[256 + n] = (double)sinl((long double)arg);
     }
     BpskConst bc;
     memset(&bc, 0, sizeof(bc));
@@ -1232,6 +1276,21 @@ int jsdr_bpsk_create(jsdr_bpsk **out, int rate, int nsamples_per_frame, int tuni
         v ^= v >> 2;
         v ^= v >> 1;
         sr = ((sr << 1) | (v & 1)) & 0xffff;
+    }
+    if (do_fft) {
+        std::vector<double2> tw;
+        fft_twiddles_f64(tw, nsamples_per_frame);
+        if (hipMemcpy(h->fft_tw.p, tw.data(), sizeof(double2) * tw.size(), hipMemcpyHostToDevice) != hipSuccess ||
+            h->fft_state.zero() != JSDR_OK) {
+            set_error("jsdr_bpsk_create: FFT-mode initialisation failed");
+            jsdr_bpsk_destroy(h);
+            return JSDR_ERR;
+        }
+    }
+    if (hipMemcpy(h->ds_taps_dev.p, bc.ds_taps, sizeof(double) * 27, hipMemcpyHostToDevice) != hipSuccess) {
+        set_error("jsdr_bpsk_create: tap upload failed");
+        jsdr_bpsk_destroy(h);
+        return JSDR_ERR;
     }
     std::vector<TailState> ts(S);
     memset(ts.data(), 0, sizeof(TailState) * S);
@@ -1287,6 +1346,9 @@ int jsdr_bpsk_destroy(jsdr_bpsk *h)
     h->fec_data.release();
     h->decoded.release();
     h->stage_raw.release();
+    h->fft_state.release();
+    h->fft_tw.release();
+    h->ds_taps_dev.release();
     for (auto &r : h->prof_recs) {
         (void)hipEventDestroy(r.a);
         (void)hipEventDestroy(r.b);
@@ -1352,6 +1414,11 @@ int jsdr_bpsk_get_counters(jsdr_bpsk *h, int stream, int32_t out[JSDR_BPSK_NCOUN
     out[7] = t.dmMaxCorr;
     out[8] = last[1];
     out[9] = 0;
+    if (h->do_fft) {
+        FftFrontState fs;
+        JSDR_HIP_TRY(hipMemcpy(&fs, h->fft_state.p + stream, sizeof(fs), hipMemcpyDeviceToHost));
+        out[9] = fs.centreBin;
+    }
     return JSDR_OK;
 }
 
@@ -1434,6 +1501,12 @@ int jsdr_bpsk_get_state(jsdr_bpsk *h, int stream, double out[18])
     out[5] = t.energy2;
     out[6] = 0.0;
     out[7] = 0.0;
+    if (h->do_fft) {
+        FftFrontState fs;
+        JSDR_HIP_TRY(hipMemcpy(&fs, h->fft_state.p + stream, sizeof(fs), hipMemcpyDeviceToHost));
+        out[6] = fs.avePeakPower;
+        out[7] = fs.aveCentreBin;
+    }
     for (int i = 0; i < 8; i++) out[8 + i] = t.dmEnergy[i];
     out[16] = t.lastI;
     out[17] = t.lastQ;

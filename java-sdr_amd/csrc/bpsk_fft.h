@@ -1,0 +1,39 @@
+// bpsk_fft.h -- interface of the FFT-acquire front end (bpsk_fft.hip) used by the pipeline host code (bpsk.hip)
+#pragma once
+#include "common.h"
+#include <vector>
+
+namespace jsdr {
+
+struct FftFrontState {
+    double avePeakPower;   // :403
+    double aveCentreBin;   // :404
+    int centreBin;         // :405
+    int pad;
+    double hist[26];       // the 26 values fed to RxDownSample before the next frame (re of the inverse FFT)
+};
+
+struct FftFrontArgs {
+    const int *raw;            // int16 pairs, [S][stride]
+    const float2 *rawf;        // or float frames
+    long long stride_pairs;
+    int nframes;               // frames in this call
+    int n, logn;               // samples per frame
+    int ic, qc;
+    int do_up;
+    int decim;
+    int first_out;             // input index (within the call) that completes output 0
+    const unsigned char *kvco; // [nds]
+    const double *sincos;      // cos[256], sin[256]
+    const double2 *tw;         // [n/2] (cos, -sin)
+    FftFrontState *st;         // [S]
+    double2 *dm;               // [S][dm_stride]
+    long long dm_stride;
+    long long nds;
+    const double *ds_taps;     // [27]
+};
+
+int launch_front_fft(const FftFrontArgs &a, int nstreams, hipStream_t st);
+void fft_twiddles_f64(std::vector<double2> &w, int n);
+
+}  // namespace jsdr

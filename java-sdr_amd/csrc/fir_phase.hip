@@ -7,6 +7,11 @@
 
 namespace jsdr {
 
+// Math.sin/cos on a double argument, evaluated in long double and rounded once (independent of the host
+// compiler's sin/cos -> sincos / vector-libm rewrites; same rule as the oracle)
+static double jsin(double x) { return (double)sinl((long double)x); }
+static double jcos(double x) { return (double)cosl((long double)x); }
+
 // fir.java:198-211.  Output t = (int) sum_{i=0..20} x[t-i]*w[i], accumulated newest sample first,
 // exactly the ring walk `ti=(fof+i)%21`.  xh = 20 history samples followed by the n new ones.
 __global__ void k_fir_filter(const int *__restrict__ xh, const double *__restrict__ w, int *__restrict__ out,
@@ -166,9 +171,9 @@ int jsdr_fir_weights(jsdr_fir *h, int f1, int f2, double w_out[21])
             if (n == ord / 2)
                 v = 2 * (df2 - df1);
             else
-                v = (sin(2 * PI * df2 * (n - ord / 2)) / (PI * (n - ord / 2))) -
-                    (sin(2 * PI * df1 * (n - ord / 2)) / (PI * (n - ord / 2)));
-            h->wfir[n] = v * (0.54 - 0.46 * cos(2 * PI * n / ord));
+                v = (jsin(2 * PI * df2 * (n - ord / 2)) / (PI * (n - ord / 2))) -
+                    (jsin(2 * PI * df1 * (n - ord / 2)) / (PI * (n - ord / 2)));
+            h->wfir[n] = v * (0.54 - 0.46 * jcos(2 * PI * n / ord));
         }
     }
     for (int i = 0; i < 20; i++) h->hist[i] = 0;
@@ -229,7 +234,7 @@ int jsdr_fir_complex_gen(jsdr_fir *h, int freq, int start, int32_t *sig_host, in
         std::vector<int2> tab((size_t)period);
         for (int k = 0; k < period; k++) {
             double w = (2 * PI * freq * k) / h->rate;
-            double c = cos(w) * 4096, s = sin(w) * 4096;
+            double c = jcos(w) * 4096, s = jsin(w) * 4096;
             tab[k] = make_int2((int)c, (int)s);
         }
         if (h->nco_dev.alloc((size_t)period) != JSDR_OK) return JSDR_ERR;

@@ -99,9 +99,13 @@ int jo_bpsk_table(int which, double *out, int cap)
 
 void jo_bpsk_sincos(double sin_tab[256], double cos_tab[256])
 {
+    /* Math.sin/cos(n*2.0*Math.PI/SINCOS_SIZE) (:160-161): the double argument is formed exactly as in Java,
+     * the function is evaluated in long double and rounded once (= the correctly rounded value; Java's own
+     * Math.sin/cos are only specified to 1 ulp, SURVEY.md 7 hard part 7) */
     for (int n = 0; n < SINCOS; n++) {
-        sin_tab[n] = sin(n * 2.0 * JO_PI / SINCOS);
-        cos_tab[n] = cos(n * 2.0 * JO_PI / SINCOS);
+        double arg = n * 2.0 * JO_PI / SINCOS;
+        sin_tab[n] = (double)sinl((long double)arg);
+        cos_tab[n] = (double)cosl((long double)arg);
     }
 }
 

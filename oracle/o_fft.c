@@ -48,10 +48,13 @@ static int ilog2(int n)
 
 void jo_fft_twiddles_f64(double *w, int n)
 {
+    /* evaluated in long double and rounded once: the result does not depend on whether a compiler turns
+     * sin()/cos() pairs into sincos() or a vector-libm call (hipcc's host compiler does, and that differs
+     * from scalar glibc in the last bit for 1 of the 2048 entries at n=4096) */
     for (int k = 0; k < n / 2; k++) {
-        double ang = 2.0 * JO_PI * (double)k / (double)n;
-        w[2 * k] = cos(ang);
-        w[2 * k + 1] = -sin(ang);
+        long double ang = 2.0L * 3.14159265358979323846264338327950288L * (long double)k / (long double)n;
+        w[2 * k] = (double)cosl(ang);
+        w[2 * k + 1] = (double)(-sinl(ang));
     }
     /* exact values on the axes so that trivial twiddles stay trivial */
     w[0] = 1.0;

@@ -7,6 +7,10 @@
 #include <string.h>
 
 #define JO_PI 3.14159265358979323846
+/* Math.sin/cos on a double argument: evaluated in long double and rounded once, so the value does not depend on
+ * how a compiler lowers sin()/cos() (hipcc's host compiler rewrites pairs into sincos / vector calls) */
+static double jsin(double x) { return (double)sinl((long double)x); }
+static double jcos(double x) { return (double)cosl((long double)x); }
 
 /* Java (int) of a double: truncate toward zero, saturate, NaN -> 0 */
 static int java_d2i(double v)
@@ -40,10 +44,10 @@ void jo_fir_weights(jo_fir_t *f, int f1, int f2, float sample_rate)
             if (n == ord / 2) {
                 f->wfir[n] = 2 * (df2 - df1);
             } else {
-                f->wfir[n] = (sin(2 * JO_PI * df2 * (n - ord / 2)) / (JO_PI * (n - ord / 2)))
-                           - (sin(2 * JO_PI * df1 * (n - ord / 2)) / (JO_PI * (n - ord / 2)));
+                f->wfir[n] = (jsin(2 * JO_PI * df2 * (n - ord / 2)) / (JO_PI * (n - ord / 2)))
+                           - (jsin(2 * JO_PI * df1 * (n - ord / 2)) / (JO_PI * (n - ord / 2)));
             }
-            f->wfir[n] = f->wfir[n] * (0.54 - 0.46 * cos(2 * JO_PI * n / ord));
+            f->wfir[n] = f->wfir[n] * (0.54 - 0.46 * jcos(2 * JO_PI * n / ord));
         }
     }
     for (int i = 0; i < len; i++) f->fir[i] = 0;
@@ -69,8 +73,8 @@ int jo_fir_filter(jo_fir_t *f, int in)
 void jo_fir_complex_gen(int sig[2], int wav[2], float sample_rate)
 {
     double w = (2 * JO_PI * wav[0] * wav[1]) / sample_rate;
-    sig[0] = java_d2i(cos(w) * 4096);
-    sig[1] = java_d2i(sin(w) * 4096);
+    sig[0] = java_d2i(jcos(w) * 4096);
+    sig[1] = java_d2i(jsin(w) * 4096);
     wav[1] += 1;
     if (wav[1] >= (int)sample_rate) wav[1] = 0;
 }

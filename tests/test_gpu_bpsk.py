@@ -52,13 +52,15 @@ def test_bpsk_sine4410_fixture_frame_by_frame(golden_dir):
     same_state(d2.state(), o.state())
 
 
-def run_both(iq_streams, nsamples, chunks, rate=96000, tuning=12000, ic=0, qc=0):
+def run_both(iq_streams, nsamples, chunks, rate=96000, tuning=12000, ic=0, qc=0, do_fft=0, do_up=0, blen=8192):
     """feed S streams to the GPU in the given chunk sizes and to one oracle per stream; compare everything"""
     S = len(iq_streams)
-    d = J.Bpsk(rate=rate, blen=8192, tuning=tuning, nstreams=S, max_batch_samples=max(chunks))
+    d = J.Bpsk(rate=rate, blen=blen, tuning=tuning, do_fft=do_fft, do_up=do_up, nstreams=S,
+               max_batch_samples=max(chunks))
     stride = 2 * nsamples
     d_iq = J.DeviceBuffer.from_host(np.concatenate(iq_streams))
-    oracles = [O.Bpsk(rate=rate, blen=4, tuning=tuning, trace=nsamples // (rate // 9600) + 8) for _ in range(S)]
+    oracles = [O.Bpsk(rate=rate, blen=(blen if do_fft else 4), tuning=tuning, do_fft=do_fft, do_up=do_up,
+                      trace=nsamples // (rate // 9600) + 8) for _ in range(S)]
     gbits = [[] for _ in range(S)]
     gtrace = [[] for _ in range(S)]
     gfec = [[] for _ in range(S)]
@@ -81,6 +83,9 @@ def run_both(iq_streams, nsamples, chunks, rate=96000, tuning=12000, ic=0, qc=0)
             assert rc == orc and np.array_equal(data, odata)
         same_counters(d.counters(s), oracles[s].counters())
         same_state(d.state(s), oracles[s].state())
+        if do_fft:
+            assert d.counters(s)["centreBin"] == oracles[s].counters()["centreBin"]
+            assert d.state(s)[6] == oracles[s].state()[6] and d.state(s)[7] == oracles[s].state()[7]
         assert np.array_equal(d.decoded(s), oracles[s].decoded())
     return d, oracles
 
@@ -195,6 +200,54 @@ def test_bpsk_roundtrip_property_at_baseline_batch_shape():
         o.receive_i16(iq)
         assert np.array_equal(d.bits(s), o.bits())
         same_counters(d.counters(s), o.counters())
+
+
+# ------------------------------------------------------------------ FFT-acquire mode (doBufferFFT, :406-464)
+def test_bpsk_fft_mode_sine4410_fixture(golden_dir):
+    raw = np.fromfile(os.path.join(golden_dir, "sine4410.raw"), dtype="<i2")
+    buf = O.convert_i16(raw)
+    d = J.Bpsk(nstreams=1, do_fft=1)
+    o = O.Bpsk(do_fft=1, trace=1024)
+    bits, tr, cb = [], [], []
+    for k in range(2):
+        d.receive(buf[k * 4096:(k + 1) * 4096])
+        o.receive(buf[k * 4096:(k + 1) * 4096])
+        bits.append(d.bits().copy())
+        tr.append(d.trace().copy())
+        cb.append(d.counters()["centreBin"])
+    assert cb == [211, 200]  # SURVEY 8c behavioural KAT
+    assert d.counters()["cntBit"] == 51
+    assert np.array_equal(np.concatenate(bits), G["sine_bpsk1_bits"])
+    assert np.array_equal(np.concatenate(tr), G["sine_bpsk1_trace"])
+    same_counters(d.counters(), o.counters())
+    same_state(d.state(), o.state())
+
+
+@pytest.mark.parametrize("do_up,carrier", [(0, 13200.0), (0, 6000.0), (1, 13200.0), (1, 30000.0)])
+def test_bpsk_fft_mode_streams_bit_exact(do_up, carrier):
+    n = 2048 * 120
+    rng = np.random.default_rng(int(carrier) + do_up)
+    streams = [O.make_dbpsk_stream(41, s, n, carrier_hz=carrier, noise_sigma=600.0 + 900 * s)[0] for s in range(2)]
+    streams.append(rng.integers(-12000, 12000, 2 * n).astype(np.int16))  # noise only: centre bin wanders
+    run_both(streams, n, [2048 * 7, 2048, 2048 * 100, 2048 * 12], do_fft=1, do_up=do_up)
+
+
+def test_bpsk_fft_mode_other_frame_sizes_and_rates():
+    for blen, rate in ((4096, 96000), (16384, 192000)):
+        nsf = blen // 4
+        n = nsf * 24
+        iq = O.make_dbpsk_stream(43, 0, n, rate=rate, carrier_hz=13200.0, noise_sigma=700.0)[0]
+        run_both([iq], n, [nsf * 5, nsf * 19], rate=rate, do_fft=1, blen=blen)
+
+
+def test_bpsk_fft_mode_rejects_partial_frames_and_odd_sizes():
+    d = J.Bpsk(nstreams=1, do_fft=1, max_batch_samples=8192)
+    buf = J.DeviceBuffer(4 * 8192)
+    buf.zero()
+    with pytest.raises(J.JsdrError):
+        d.batch_i16(buf, 2 * 8192, 3000)
+    with pytest.raises(J.JsdrError):
+        J.Bpsk(nstreams=1, do_fft=1, blen=2000)
 
 
 def test_bpsk_api_errors():

@@ -30,6 +30,7 @@ for step in "$@"; do
     bench)       run bench 600 python bench.py ;;
     tests_bpsk)  run tests_bpsk 600 python -m pytest tests/test_gpu_bpsk.py -m gpu -q -x -p no:cacheprovider --timeout 600 ;;
     bench_quick) run bench_quick 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline ;;
+    bench_acq)   run bench_acq 400 python bench.py --workload bpsk --fft-acquire --steps 3 --warmup 1 --no-cpu-baseline ;;
     bench_noov)  JSDR_NO_OVERLAP=1 run bench_noov 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline ;;
     bench_rd80)  JSDR_FRONT_RD=80 run bench_rd80 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline ;;
     fec_bench)   run fec_bench 300 python tools/fec_bench.py ;;
@@ -38,6 +39,7 @@ for step in "$@"; do
                  run pmc_sq1 600 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --output-format csv -d gpurun_out/pmc_sq1_$R -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-validate ;;
     pmc_sq2)     rm -rf gpurun_out/pmc_sq2_$R
                  run pmc_sq2 600 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d gpurun_out/pmc_sq2_$R -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-validate ;;
+    dbg)         run dbg 300 python tools/dbg_fftmode.py ;;
     trig)        run trig 300 python tools/trig_stats.py ;;
     bench_fft)   run bench_fft 300 python bench.py --workload fft --no-cpu-baseline ;;
     bench_bpsk)  run bench_bpsk 400 python bench.py --workload bpsk --no-cpu-baseline ;;
