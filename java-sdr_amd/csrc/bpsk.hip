@@ -305,6 +305,147 @@ __global__ __launch_bounds__(128, 4) void k_front(FrontArgs a)
     }
 }
 
+// ------------------------------------------------------------------------------------------- k_front_dma
+// The int16 fast path of k_front.  Same arithmetic, same order; what changes is how the samples reach the lanes:
+//   stage : LDS-DMA (global_load_lds): every wave instruction copies 64 consecutive raw dwords (resp. 64 tuner
+//           index bytes) straight into a LINEAR LDS image -- no VGPR round trip, no address arithmetic beyond a
+//           clamped index, ~5 VALU per element instead of ~18.
+//   walk  : lane l owns samples RD*l .. RD*l+NS-1 of the tile and reads them four at a time with ds_read_b128
+//           (lane stride RD/4 = 10 quads: a 2-way conflict, 2 LDS cycles per sample); the walk is unrolled over
+//           compile-time sample positions, newest first, exactly as front_block does.
+// DC correction cannot ride on the DMA, so it is applied in the walk (template flag).  History samples arrive
+// already corrected; they are stored "un-corrected" (minus this call's ic/qc, 16-bit wrap) so that the uniform
+// correction in the walk reproduces them.
+template <int D, int RD>
+struct FrontDmaGeom {
+    static_assert(RD % D == 0 && RD % 4 == 0, "lane span: whole outputs, whole quads");
+    static constexpr int R = RD / D;
+    static constexpr int NS = RD - D + 27;
+    static constexpr int NSQ = (NS + 3) / 4;
+    static constexpr int NT = 64 * RD - D + 27;
+    static constexpr int NIT = (NT + 63) / 64;                 // raw: one dword (one sample) per lane per DMA
+    static constexpr int NITK = (NT + 255) / 256;              // tuner indices: one dword (four samples) per lane per DMA
+    static constexpr int RAW_DW = NIT * 64 + 64;               // linear images, whole wave instructions
+    static constexpr int K_BYTES = NITK * 256 + 64;
+};
+
+template <int D, int RD, bool MIX, bool DC>
+__global__ __launch_bounds__(128, 4) void k_front_dma(FrontArgs a)
+{
+    using G = FrontDmaGeom<D, RD>;
+    constexpr int R = G::R;
+    extern __shared__ __align__(16) unsigned char smem[];
+    double *sc = reinterpret_cast<double *>(smem);  // [512]
+    for (int i = threadIdx.x; i < 512; i += blockDim.x) sc[i] = a.sincos[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+    constexpr size_t WAVE_BYTES = (size_t)G::RAW_DW * 4 + G::K_BYTES;
+    unsigned char *wbase = smem + 512 * sizeof(double) + wave * WAVE_BYTES;
+    int *rawL = reinterpret_cast<int *>(wbase);
+    unsigned char *kL = wbase + (size_t)G::RAW_DW * 4;
+    const int s = blockIdx.y;
+    const long long ntiles = (a.nds + 64 * R - 1) / (64 * R);
+    const double HOWARD = 0.9 * 32768.0;  // :469
+    const int *raw = a.raw + (long long)s * a.stride_pairs;
+    const int2 *hist = a.hist + (long long)s * 32;
+    const int Lm1 = (int)(a.nsamples - 1);
+    for (long long tile = (long long)blockIdx.x * nwave + wave; tile < ntiles; tile += (long long)gridDim.x * nwave) {
+        const long long j0 = tile * 64 * R;
+        const int lo = a.first_out + (int)(D * j0) - 26;  // input index of tile sample 0 (call-relative, fits int)
+        // ---- stage by LDS-DMA: element e of the tile <- sample clamp(lo+e) ; linear image
+        typedef __attribute__((address_space(3))) void *lds_ptr_t;
+        typedef const __attribute__((address_space(1))) void *glb_ptr_t;
+#pragma unroll 4
+        for (int it = 0; it < G::NIT; it++) {
+            int n = lo + it * 64 + lane;
+            n = n < 0 ? 0 : (n > Lm1 ? Lm1 : n);
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(raw + n), (lds_ptr_t)(rawL + it * 64), 4, 0, 0);
+        }
+        // tuner indices, four per lane: the host lays the byte table out so that element 26+first_out is dword
+        // aligned (D*j0 is a multiple of 4), and pads it, so neither a clamp nor a byte-wide DMA is needed
+        // (a byte-wide global_load_lds still advances 4 bytes of LDS per lane)
+#pragma unroll
+        for (int it = 0; it < G::NITK; it++)
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(a.ktu + 26 + lo + it * 256 + 4 * lane),
+                                             (lds_ptr_t)(kL + it * 256), 4, 0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        JSDR_WAVE_SYNC();
+        if (lo < 0) {  // first tile of the call: the 26 inputs before it come from the history (already corrected)
+            const int n = lo + lane;
+            if (n < 0) {
+                int w = hist[26 + n].x;
+                if constexpr (DC) {  // undo this call's correction so that the walk re-applies it
+                    int si = (int)(short)((w & 0xffff) - a.ic);
+                    int sq = (int)(short)((w >> 16) - a.qc);
+                    w = (si & 0xffff) | (sq << 16);
+                }
+                rawL[lane] = w;
+                kL[lane] = a.ktu[26 + n];
+            }
+            JSDR_WAVE_SYNC();
+        }
+        // ---- walk this lane's samples from newest to oldest
+        double ai[R], aq[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            ai[r] = 0.0;
+            aq[r] = 0.0;
+        }
+        const int4 *xq = reinterpret_cast<const int4 *>(rawL + RD * lane);
+        const unsigned *kq = reinterpret_cast<const unsigned *>(kL + RD * lane);
+#pragma unroll
+        for (int q = G::NSQ - 1; q >= 0; q--) {
+            const int4 w4 = xq[q];
+            const unsigned k4 = kq[q];
+#pragma unroll
+            for (int t = 3; t >= 0; t--) {
+                const int m = 4 * q + t;
+                if (m < G::NS) {
+                    int w = (t == 0) ? w4.x : (t == 1) ? w4.y : (t == 2) ? w4.z : w4.w;
+                    int si = (int)(short)(w & 0xffff), sq = w >> 16;
+                    if constexpr (DC) {
+                        si = java_short_add(si, a.ic);
+                        sq = java_short_add(sq, a.qc);
+                    }
+                    double di = (double)i16_to_float_java(si);
+                    double dq = (double)i16_to_float_java(sq);
+                    if constexpr (MIX) {  // :388-390 component-wise, not a complex multiply
+                        const int k = (k4 >> (8 * t)) & 0xff;
+                        di = di * sc[k];
+                        dq = dq * sc[256 + k];
+                    }
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        if (m >= D * r && m <= D * r + 26) {  // sample m has age D*r+26-m in the window of output r
+                            const double tp = ds_tap(D * r + 26 - m);
+                            ai[r] += di * tp;
+                            aq[r] += dq * tp;
+                        }
+                    }
+                }
+            }
+            // one quad at a time: without the fences the compiler hoists every LDS read (samples, indices and
+            // their sin/cos table entries) of the unrolled walk to the top and spills them
+#pragma unroll
+            for (int r = 0; r < R; r++) asm volatile("" : "+v"(ai[r]), "+v"(aq[r])::"memory");  // sums are due here
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- x HOWARD_FUDGE_FACTOR (:486), VCO mix (:515-516)
+        const long long jl = j0 + (long long)R * lane;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const long long j = jl + r;
+            if (j < a.nds) {
+                const double oi = ai[r] * HOWARD, oq = aq[r] * HOWARD;
+                if (a.ds_dbg) a.ds_dbg[(long long)s * a.nds + j] = make_double2(oi, oq);
+                const int kv = a.kvco[j];
+                a.dm[(long long)s * a.dm_stride + 64 + j] = make_double2(oi * sc[kv], oq * sc[256 + kv]);
+            }
+        }
+        JSDR_WAVE_SYNC();
+    }
+}
+
 // keep the 26 most recent inputs (DC-corrected int16 pair, or the float pair) for the next call
 struct HistArgs {
     const int *raw;
@@ -793,6 +934,7 @@ struct jsdr_bpsk {
     unsigned char h_khist[26] = {0};   // tuner indices of the 26 samples before the next call
     unsigned char c_khist[26] = {0};
     int mix = 1, c_mix = 1;
+    int c_kshift = -1;
     std::vector<unsigned char> h_kvco;
     // device
     DevBuf<double> sincos;
@@ -823,6 +965,7 @@ struct jsdr_bpsk {
     long long last_nds = 0;
     int last_y = 0;
     hipStream_t last_stream = 0;
+    bool front_dma = true;  // LDS-DMA staged int16 fast path (JSDR_FRONT_DMA=0 selects the generic kernel)
     int front_rd = 40;  // samples per lane span in k_front at 96 kHz (JSDR_FRONT_RD=80 selects the wide variant)
     // optional per-kernel HIP-event timing (bench.py's roofline leg)
     bool prof_on = false;
@@ -976,6 +1119,42 @@ static void launch_front_t(const FrontArgs &fa, int nstreams, long long nds, hip
                        fa);
 }
 
+template <int D, int RD, bool MIX, bool DC>
+static void launch_front_dma_t(const FrontArgs &fa, int nstreams, long long nds, hipStream_t st)
+{
+    using G = FrontDmaGeom<D, RD>;
+    constexpr int WAVES = 2;
+    const size_t lds = 512 * sizeof(double) + WAVES * ((size_t)G::RAW_DW * 4 + G::K_BYTES);
+    long long ntiles = (nds + 64 * G::R - 1) / (64 * G::R);
+    long long gx = (ntiles + WAVES - 1) / WAVES;
+    if (gx > 2048) gx = 2048;
+    if (gx < 1) gx = 1;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_front_dma<D, RD, MIX, DC>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((k_front_dma<D, RD, MIX, DC>), dim3((unsigned)gx, (unsigned)nstreams), dim3(64 * WAVES), lds, st,
+                       fa);
+}
+
+// the LDS-DMA fast path: int16 input, 96 kHz (D=10), samples addressable with 32-bit indices
+template <int D, int RD>
+static bool launch_front_dma(const FrontArgs &fa, int nstreams, long long nds, hipStream_t st)
+{
+    if (fa.rawf || fa.nsamples > 0x3fffffffLL || fa.nsamples < 64) return false;
+    const bool dc = (fa.ic != 0) || (fa.qc != 0);
+    if (fa.mix) {
+        if (dc) launch_front_dma_t<D, RD, true, true>(fa, nstreams, nds, st);
+        else launch_front_dma_t<D, RD, true, false>(fa, nstreams, nds, st);
+    } else {
+        if (dc) launch_front_dma_t<D, RD, false, true>(fa, nstreams, nds, st);
+        else launch_front_dma_t<D, RD, false, false>(fa, nstreams, nds, st);
+    }
+    return true;
+}
+
 template <int D, int RD>
 static void launch_front(const FrontArgs &fa, int nstreams, long long nds, hipStream_t st)
 {
@@ -1004,8 +1183,11 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
     const long long nds = build_schedule(h, L);
     JSDR_REQUIRE(nds <= h->max_ds, "bpsk: internal: %lld decimated samples exceed capacity %lld", nds, h->max_ds);
     JSDR_REQUIRE(h->do_fft || h->mix >= 0, "bpsk: tuner phase changes sign inside a call (unsupported)");
-    if (!h->cache_valid) {
-        JSDR_HIP_TRY(hipMemcpyAsync(h->ktu.p, h->h_ktu.data(), (size_t)L + 26, hipMemcpyHostToDevice, st));
+    // the byte table is shifted by 0..3 so that ktu[26 + first_out] is dword aligned (k_front_dma's dword DMA)
+    const int kshift = (4 - (first_out & 3)) & 3;  // element 26+lo = first_out + D*j0, and D*j0 is a multiple of 4
+    if (!h->cache_valid || kshift != h->c_kshift) {
+        h->c_kshift = kshift;
+        JSDR_HIP_TRY(hipMemcpyAsync(h->ktu.p + kshift, h->h_ktu.data(), (size_t)L + 26, hipMemcpyHostToDevice, st));
         if (nds > 0)
             JSDR_HIP_TRY(hipMemcpyAsync(h->kvco.p, h->h_kvco.data(), (size_t)nds, hipMemcpyHostToDevice, st));
         // the host vectors must stay untouched until the copies ran; pageable memcpyAsync stages
@@ -1021,7 +1203,7 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
     fa.ic = ic;
     fa.qc = qc;
     fa.mix = h->mix;
-    fa.ktu = h->ktu.p;
+    fa.ktu = h->ktu.p + kshift;
     fa.kvco = h->kvco.p;
     fa.sincos = h->sincos.p;
     fa.hist = h->hist_in[h->hist_cur].p;
@@ -1061,7 +1243,7 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
             case 10:
                 if (h->front_rd == 80)
                     launch_front<10, 80>(fa, S, nds, st);
-                else
+                else if (!h->front_dma || !launch_front_dma<10, 40>(fa, S, nds, st))
                     launch_front<10, 40>(fa, S, nds, st);
                 break;
             case 20: launch_front<20, 80>(fa, S, nds, st); break;
@@ -1231,11 +1413,12 @@ int jsdr_bpsk_create(jsdr_bpsk **out, int rate, int nsamples_per_frame, int tuni
     if (do_fft) h->max_batch = (h->max_batch / nsamples_per_frame) * nsamples_per_frame;
     if (const char *e = getenv("JSDR_FRONT_RD")) h->front_rd = atoi(e) == 80 ? 80 : 40;
     if (const char *e = getenv("JSDR_NO_OVERLAP")) h->overlap = atoi(e) == 0;
+    if (const char *e = getenv("JSDR_FRONT_DMA")) h->front_dma = atoi(e) != 0;
     const size_t S = (size_t)nstreams;
     h->dm_stride = 64 + h->max_ds + 64;
     h->y_stride = h->max_ds;
     h->bitlog_stride = HIST_BITS + h->max_bits + 64;
-    bool ok = h->sincos.alloc(512) == JSDR_OK && h->ktu.alloc((size_t)h->max_batch + 32) == JSDR_OK &&
+    bool ok = h->sincos.alloc(512) == JSDR_OK && h->ktu.alloc((size_t)h->max_batch + 8192) == JSDR_OK &&
               h->kvco.alloc((size_t)h->max_ds) == JSDR_OK && h->hist_in[0].alloc(S * 32) == JSDR_OK &&
               h->hist_in[1].alloc(S * 32) == JSDR_OK && h->dm.alloc(S * (size_t)h->dm_stride) == JSDR_OK &&
               h->y[0].alloc(S * (size_t)h->y_stride) == JSDR_OK && h->y[1].alloc(S * (size_t)h->y_stride) == JSDR_OK && h->tail.alloc(S) == JSDR_OK &&

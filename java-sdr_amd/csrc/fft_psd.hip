@@ -182,64 +182,70 @@ __device__ __forceinline__ void fft_pass(const FftArgs &a, long long frame, bool
     constexpr int NB = N / R;
     static_assert(NB % T == 0, "butterflies per pass must be a multiple of the threads per frame");
     constexpr int ITERS = NB / T;
-    float2 v[ITERS][R];
+    // the last pass writes to global memory, not to the LDS image: its butterflies need not all be in flight
+    // before the first store, so they are processed one at a time (half the live registers at ITERS = 2)
+    constexpr int GROUP = LAST ? 1 : ITERS;
 #pragma unroll
-    for (int it = 0; it < ITERS; it++) {
-        const int b = it * T + tid;
-        if constexpr (FIRST) {
-            if (active) {
-                if constexpr (IN == IN_I16) {
-                    const int *src = reinterpret_cast<const int *>(a.in) + frame * N;
+    for (int g0 = 0; g0 < ITERS; g0 += GROUP) {
+        float2 v[GROUP][R];
 #pragma unroll
-                    for (int r = 0; r < R; r++) {
-                        int w = src[b + r * NB];
-                        int si = java_short_add((int)(short)(w & 0xffff), a.ic);
-                        int sq = java_short_add(w >> 16, a.qc);
-                        v[it][r] = make_float2(i16_to_float_java(si), i16_to_float_java(sq));
+        for (int gi = 0; gi < GROUP; gi++) {
+            const int b = (g0 + gi) * T + tid;
+            if constexpr (FIRST) {
+                if (active) {
+                    if constexpr (IN == IN_I16) {
+                        const int *src = reinterpret_cast<const int *>(a.in) + frame * N;
+#pragma unroll
+                        for (int r = 0; r < R; r++) {
+                            int w = src[b + r * NB];
+                            int si = java_short_add((int)(short)(w & 0xffff), a.ic);
+                            int sq = java_short_add(w >> 16, a.qc);
+                            v[gi][r] = make_float2(i16_to_float_java(si), i16_to_float_java(sq));
+                        }
+                    } else {
+                        const float2 *src = reinterpret_cast<const float2 *>(a.in) + frame * N;
+#pragma unroll
+                        for (int r = 0; r < R; r++) v[gi][r] = src[b + r * NB];
                     }
                 } else {
-                    const float2 *src = reinterpret_cast<const float2 *>(a.in) + frame * N;
 #pragma unroll
-                    for (int r = 0; r < R; r++) v[it][r] = src[b + r * NB];
+                    for (int r = 0; r < R; r++) v[gi][r] = make_float2(0.f, 0.f);
                 }
             } else {
 #pragma unroll
-                for (int r = 0; r < R; r++) v[it][r] = make_float2(0.f, 0.f);
+                for (int r = 0; r < R; r++) v[gi][r] = buf[lds_pad(b + r * NB)];
             }
-        } else {
-#pragma unroll
-            for (int r = 0; r < R; r++) v[it][r] = buf[lds_pad(b + r * NB)];
+            apply_twiddles<R, P>(v[gi], b & (P - 1), tab);
+            dft_reg<R>(v[gi]);
         }
-        apply_twiddles<R, P>(v[it], b & (P - 1), tab);
-        dft_reg<R>(v[it]);
-    }
-    if constexpr (!FIRST && !LAST) __syncthreads();
+        if constexpr (!FIRST && !LAST) __syncthreads();
 #pragma unroll
-    for (int it = 0; it < ITERS; it++) {
-        const int b = it * T + tid;
-        const int k = b & (P - 1);
-        const int j0 = (b - k) * R + k;
-        if constexpr (!LAST) {
-            store_lds<R>(buf, v[it], j0, P, std::make_integer_sequence<int, R>{});
-        } else if (active) {
-            if constexpr (OUT == OUT_SPEC) {
-                float2 *dst = reinterpret_cast<float2 *>(a.out) + frame * N;
+        for (int gi = 0; gi < GROUP; gi++) {
+            const int b = (g0 + gi) * T + tid;
+            const int k = b & (P - 1);
+            const int j0 = (b - k) * R + k;
+            if constexpr (!LAST) {
+                store_lds<R>(buf, v[gi], j0, P, std::make_integer_sequence<int, R>{});
+            } else if (active) {
+                if constexpr (OUT == OUT_SPEC) {
+                    float2 *dst = reinterpret_cast<float2 *>(a.out) + frame * N;
 #pragma unroll
-                for (int r = 0; r < R; r++) dst[j0 + r * P] = v[it][cx_bitrev(r, R)];
-            } else {
-                const float cf = (2.0f / (float)N) * (2.0f / (float)N);
-                float *dst = a.out + frame * (N + 2);
+                    for (int r = 0; r < R; r++) dst[j0 + r * P] = v[gi][cx_bitrev(r, R)];
+                } else {
+                    const float cf = (2.0f / (float)N) * (2.0f / (float)N);
+                    float *dst = a.out + frame * (N + 2);
 #pragma unroll
-                for (int r = 0; r < R; r++) {
-                    float2 x = v[it][cx_bitrev(r, R)];
-                    float pw = (x.x * x.x + x.y * x.y) * cf;
-                    // 10*log10(pw) = 10*log10(2) * log2(pw)   (fft.java:207)
-                    float db = 3.0102999566398120f * __log2f(pw);
-                    int bin = j0 + r * P;
-                    dst[bin] = db;
-                    if (db > best.v || (db == best.v && bin < best.k)) {
-                        best.v = db;
-                        best.k = bin;
+                    for (int r = 0; r < R; r++) {
+                        float2 x = v[gi][cx_bitrev(r, R)];
+                        float pw = (x.x * x.x + x.y * x.y) * cf;
+                        // 10*log10(pw) = 10*log10(2) * log2(pw)   (fft.java:207)
+                        float db = 3.0102999566398120f * __log2f(pw);
+                        int bin = j0 + r * P;
+                        dst[bin] = db;
+                        if (db > best.v || (db == best.v && bin < best.k)) {
+                            best.v = db;
+                            best.k = bin;
+                        }
                     }
                 }
             }

@@ -31,6 +31,7 @@ for step in "$@"; do
     tests_bpsk)  run tests_bpsk 600 python -m pytest tests/test_gpu_bpsk.py -m gpu -q -x -p no:cacheprovider --timeout 600 ;;
     bench_quick) run bench_quick 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline ;;
     bench_acq)   run bench_acq 400 python bench.py --workload bpsk --fft-acquire --steps 3 --warmup 1 --no-cpu-baseline ;;
+    bench_nodma) JSDR_FRONT_DMA=0 run bench_nodma 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline ;;
     bench_noov)  JSDR_NO_OVERLAP=1 run bench_noov 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline ;;
     bench_rd80)  JSDR_FRONT_RD=80 run bench_rd80 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline ;;
     fec_bench)   run fec_bench 300 python tools/fec_bench.py ;;
