@@ -155,15 +155,23 @@ def main():
             raise SystemExit(f"--gpus {N} needs WORLD_SIZE={N} (launch with torch.distributed.run); got {world}")
         import torch  # noqa: F811  (first, so libjsdr_hip.so binds to the same HIP runtime)
         import torch.distributed as dist  # noqa: F811
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # rehearsal knobs for a 1-GPU box (never set by the driver): JSDR_BENCH_SAME_DEVICE=1 maps every rank to
+        # device 0 and JSDR_BENCH_BACKEND=gloo swaps RCCL for gloo, so the N>1 code path can be exercised there
+        same_dev = os.environ.get("JSDR_BENCH_SAME_DEVICE", "0") == "1"
+        backend = os.environ.get("JSDR_BENCH_BACKEND", "nccl")
+        dev_index = 0 if same_dev else local_rank
+        torch.cuda.set_device(dev_index)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
     import java_sdr_amd as J
     from java_sdr_amd import sharding as SH
     import oracle_lib as O  # input tables + cpu_baseline leg only
 
     if not J.have_gpu():
         raise SystemExit("bench.py: no HIP device (libjsdr_hip.so has no CPU fallback)")
-    if J.lib().jsdr_set_device(local_rank if N > 1 else 0) != 0:
+    if J.lib().jsdr_set_device((0 if os.environ.get("JSDR_BENCH_SAME_DEVICE", "0") == "1" else local_rank) if N > 1 else 0) != 0:
         raise SystemExit(J.lib().jsdr_last_error())
 
     S, L = a.streams, a.samples
@@ -176,8 +184,11 @@ def main():
     d_psd = J.DeviceBuffer(nframes * (N_FFT + 2) * 4) if fft else None
     dem = J.Bpsk(rate=RATE, blen=4 * N_FFT, tuning=12000, do_fft=int(a.fft_acquire), nstreams=S, max_batch_samples=L) \
         if a.workload in ("pipeline", "bpsk") else None
-    slots = gathered = None
+    slots = gathered = gstream = None
     if dem is not None and N > 1:
+        # the gather runs on its own stream: packing waits there for the side-stream tail of this step, so the
+        # next step's FFT / front end on the main stream is not serialised behind it
+        gstream = torch.cuda.Stream()
         info = dem.slot_info()
         slots = torch.empty(S * info["slot_bytes"], dtype=torch.uint8, device="cuda")
         gathered = torch.empty(N * S * info["slot_bytes"], dtype=torch.uint8, device="cuda")
@@ -194,8 +205,9 @@ def main():
         if dem is not None:
             dem.batch_i16(d_iq, 2 * L, L)
             if N > 1:
-                dem.pack_slots(slots.data_ptr())
-                dist.all_gather_into_tensor(gathered, slots)  # == sharding.all_gather_slots, into a reused buffer
+                dem.pack_slots(slots.data_ptr(), stream=gstream.cuda_stream)
+                with torch.cuda.stream(gstream):
+                    dist.all_gather_into_tensor(gathered, slots)  # == sharding.all_gather_slots, reused buffer
 
     def sync():
         if dem is not None:

@@ -694,14 +694,25 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs a)
             const int idx = (lane < 8) ? lane : v;
             const long long glane = 8 * MB + idx;
             const bool lane_iir = lane < 8, lane_out = (lane == 8) && spec;
-#pragma unroll 4
-            for (int p = 0; p < nper; p++) {
-                const long long g = glane + 8 * p;
-                const bool ok = (g >= g_first) && (g < g_end) && (lane_iir || lane_out);
-                const double xv = enL[p * 8 + idx];
-                const double ne = (e * Kc) + (xv * Sc);  // :535 / :538
+            const bool lane_on = lane_iir || lane_out;
+            // the 64 energies this lane will fold in, fetched up front: the serial chain below then touches
+            // registers only (an LDS read per step would put ~100 cycles of latency on every link of the chain)
+            double xs[64];
+#pragma unroll
+            for (int p = 0; p < 64; p++) xs[p] = enL[p * 8 + idx];
+            // only the first and the last period of a call can be partial
+            const int pfirst = (glane < g_first) ? 1 : 0;  // period 0 of the chunk lacks this lane's sample
+            double es[64];
+#pragma unroll
+            for (int p = 0; p < 64; p++) {
+                const double ne = (e * Kc) + (xs[p] * Sc);  // :535 / :538
+                const bool ok = lane_on && (p >= pfirst) && (glane + 8 * p < g_end);
                 if (ok) e = ne;
-                if (lane_iir) eL[p][lane] = e;
+                es[p] = e;
+            }
+            if (lane_iir) {
+#pragma unroll
+                for (int p = 0; p < 64; p++) eL[p][lane] = es[p];
             }
         }
         JSDR_WAVE_SYNC();
