@@ -60,7 +60,8 @@ int jsdr_convert_i16(const int16_t *raw_dev, int64_t nframes, int chns, int ic, 
  * fft.receive (fft.java:190-228): complex forward FFT (replaces JTransforms FloatFFT_1D,
  * fft.java:194-195), psd[k]=10*log10((re^2+im^2)*(2/n)^2), first strict maximum, bin->Hz in
  * Java int arithmetic; output float[n+2] = what the reference publishes as "fft-psd".
- * n = blen/size (fft.java:67); supported: powers of two 64..8192 (2048 is the tuned size).   */
+ * n = blen/size (fft.java:67); supported: powers of two 64..8192 (2048 is the tuned size) and the
+ * reference's default frames n = 4800 / 9600 (blen = rate*size/10 at 48 / 96 kHz, JavaAudio.java:58-59).  */
 typedef struct jsdr_fft jsdr_fft;
 int jsdr_fft_create(jsdr_fft **h, int n, int rate);
 int jsdr_fft_destroy(jsdr_fft *h);

@@ -21,6 +21,7 @@ COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-
 SOURCES = {
     "runtime.hip": [],
     "fft_psd.hip": [],
+    "fft_mixed.hip": [],
     "fir_phase.hip": ["-ffp-contract=off"],
     "fec.hip": [],
     "synth.hip": [],

@@ -1,0 +1,300 @@
+// fft_mixed.hip -- fft.receive for NON power-of-two frames: n = 9600 (java-sdr's default 96 kHz buffer,
+// blen = rate*size/10, JavaAudio.java:58-59) and n = 4800 (48 kHz).  JTransforms handles such n with a mixed
+// radix 2/3/4/5 decomposition (fft.java:194-195); here: Stockham autosort passes with radices 16/8/4 (the
+// in-register radix-2^k kernels of fft_common.h) and hand-written radix-5 / radix-3 butterflies.
+//
+// One frame per workgroup (n=9600: 512 threads, 81.6 KB padded LDS image + 32 KB of per-pass twiddles); a
+// thread owns ceil((n/R)/T) butterflies per pass.  Same PSD / first-maximum / Hz rules as k_fft.
+// Parity: 1e-5 of the frame peak against the exact DFT (JTransforms' rounding is unknowable).
+#include "fft_common.h"
+#include <math.h>
+#include <vector>
+
+namespace jsdr {
+
+constexpr bool is_pow2(int r) { return (r & (r - 1)) == 0; }
+// position of output r inside the register array after dft_any<R>
+template <int R>
+constexpr int out_slot(int r)
+{
+    return is_pow2(R) ? cx_bitrev(r, R) : r;
+}
+
+__device__ __forceinline__ void dft3(float2 *x)
+{
+    constexpr float S = (float)0.86602540378443864676;  // sin(2 pi/3)
+    const float2 t1 = cadd(x[1], x[2]);
+    const float2 t2 = make_float2(x[0].x - 0.5f * t1.x, x[0].y - 0.5f * t1.y);
+    const float2 d = csub(x[1], x[2]);
+    const float2 t3 = make_float2(d.x * S, d.y * S);
+    x[0] = cadd(x[0], t1);
+    x[1] = make_float2(t2.x + t3.y, t2.y - t3.x);  // t2 - i*t3
+    x[2] = make_float2(t2.x - t3.y, t2.y + t3.x);  // t2 + i*t3
+}
+
+__device__ __forceinline__ void dft5(float2 *x)
+{
+    constexpr float C1 = (float)0.30901699437494742410;   // cos(2 pi/5)
+    constexpr float C2 = (float)-0.80901699437494742410;  // cos(4 pi/5)
+    constexpr float S1 = (float)0.95105651629515357212;   // sin(2 pi/5)
+    constexpr float S2 = (float)0.58778525229247312917;   // sin(4 pi/5)
+    const float2 a1 = cadd(x[1], x[4]), a2 = cadd(x[2], x[3]);
+    const float2 b1 = csub(x[1], x[4]), b2 = csub(x[2], x[3]);
+    const float2 x0 = x[0];
+    const float2 m1 = make_float2(x0.x + C1 * a1.x + C2 * a2.x, x0.y + C1 * a1.y + C2 * a2.y);
+    const float2 m2 = make_float2(x0.x + C2 * a1.x + C1 * a2.x, x0.y + C2 * a1.y + C1 * a2.y);
+    const float2 n1 = make_float2(S1 * b1.x + S2 * b2.x, S1 * b1.y + S2 * b2.y);
+    const float2 n2 = make_float2(S2 * b1.x - S1 * b2.x, S2 * b1.y - S1 * b2.y);
+    x[0] = make_float2(x0.x + a1.x + a2.x, x0.y + a1.y + a2.y);
+    x[1] = make_float2(m1.x + n1.y, m1.y - n1.x);  // m1 - i*n1
+    x[4] = make_float2(m1.x - n1.y, m1.y + n1.x);  // m1 + i*n1
+    x[2] = make_float2(m2.x + n2.y, m2.y - n2.x);
+    x[3] = make_float2(m2.x - n2.y, m2.y + n2.x);
+}
+
+template <int R>
+__device__ __forceinline__ void dft_any(float2 *x)
+{
+    if constexpr (R == 3) dft3(x);
+    else if constexpr (R == 5) dft5(x);
+    else dft_reg<R>(x);
+}
+
+constexpr bool mtw_direct(int P, int R) { return P * R <= 512; }
+constexpr int mtw_size(int P, int R) { return (P <= 1 || R <= 1) ? 0 : (mtw_direct(P, R) ? P * R : P); }
+
+template <int R, int P>
+__device__ __forceinline__ void mixed_twiddles_apply(float2 *v, int k, const float2 *tab)
+{
+    if constexpr (P > 1) {
+        if constexpr (mtw_direct(P, R)) {
+#pragma unroll
+            for (int r = 1; r < R; r++) v[r] = cmul(v[r], tab[r * P + k]);
+        } else {
+            const float2 w1 = tab[k];
+            float2 w[R];
+            w[1] = w1;
+#pragma unroll
+            for (int r = 2; r < R; r++) w[r] = (r & 1) ? cmul(w[r - 1], w1) : cmul(w[r / 2], w[r / 2]);
+#pragma unroll
+            for (int r = 1; r < R; r++) v[r] = cmul(v[r], w[r]);
+        }
+    }
+}
+
+template <int N, int T, int IN, int OUT, int R, int P, bool FIRST, bool LAST>
+__device__ __forceinline__ void mixed_pass(const FftArgs &a, long long frame, int tid, float2 *buf, const float2 *tab,
+                                           Best &best)
+{
+    constexpr int NB = N / R;
+    constexpr int ITERS = (NB + T - 1) / T;
+    float2 v[ITERS][R];
+#pragma unroll
+    for (int it = 0; it < ITERS; it++) {
+        const int b = it * T + tid;
+        if (b < NB) {
+            if constexpr (FIRST) {
+                if constexpr (IN == IN_I16) {
+                    const int *src = reinterpret_cast<const int *>(a.in) + frame * N;
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        int w = src[b + r * NB];
+                        int si = java_short_add((int)(short)(w & 0xffff), a.ic);
+                        int sq = java_short_add(w >> 16, a.qc);
+                        v[it][r] = make_float2(i16_to_float_java(si), i16_to_float_java(sq));
+                    }
+                } else {
+                    const float2 *src = reinterpret_cast<const float2 *>(a.in) + frame * N;
+#pragma unroll
+                    for (int r = 0; r < R; r++) v[it][r] = src[b + r * NB];
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < R; r++) v[it][r] = buf[lds_pad(b + r * NB)];
+            }
+            mixed_twiddles_apply<R, P>(v[it], b % P, tab);
+            dft_any<R>(v[it]);
+        }
+    }
+    if constexpr (!FIRST && !LAST) __syncthreads();
+#pragma unroll
+    for (int it = 0; it < ITERS; it++) {
+        const int b = it * T + tid;
+        if (b < NB) {
+            const int k = b % P;
+            const int j0 = (b - k) * R + k;
+            if constexpr (!LAST) {
+#pragma unroll
+                for (int r = 0; r < R; r++) buf[lds_pad(j0 + r * P)] = v[it][out_slot<R>(r)];
+            } else if constexpr (OUT == OUT_SPEC) {
+                float2 *dst = reinterpret_cast<float2 *>(a.out) + frame * N;
+#pragma unroll
+                for (int r = 0; r < R; r++) dst[j0 + r * P] = v[it][out_slot<R>(r)];
+            } else {
+                const float cf = (2.0f / (float)N) * (2.0f / (float)N);
+                float *dst = a.out + frame * (N + 2);
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const float2 x = v[it][out_slot<R>(r)];
+                    const float pw = (x.x * x.x + x.y * x.y) * cf;
+                    const float db = 3.0102999566398120f * __log2f(pw);  // fft.java:207
+                    const int bin = j0 + r * P;
+                    dst[bin] = db;
+                    if (db > best.v || (db == best.v && bin < best.k)) {
+                        best.v = db;
+                        best.k = bin;
+                    }
+                }
+            }
+        }
+    }
+    if constexpr (!LAST) __syncthreads();
+}
+
+template <int N, int T, int IN, int OUT, int R0, int R1, int R2, int R3, int R4>
+__global__ __launch_bounds__(T) void k_fft_mixed(FftArgs a)
+{
+    static_assert(R0 * R1 * R2 * R3 * R4 == N, "radix plan must multiply to N");
+    extern __shared__ __align__(16) unsigned char smem[];
+    constexpr int O2 = 0, O3 = O2 + mtw_size(R0, R1), O4 = O3 + mtw_size(R0 * R1, R2),
+                  O5 = O4 + mtw_size(R0 * R1 * R2, R3), TWN = O5 + mtw_size(R0 * R1 * R2 * R3, R4);
+    float2 *tw = reinterpret_cast<float2 *>(smem);
+    float2 *buf = tw + TWN;
+    constexpr int NW = (T + 63) / 64;
+    float *red_val = reinterpret_cast<float *>(buf + lds_frame_elems(N));
+    int *red_idx = reinterpret_cast<int *>(red_val + NW);
+    const int tid = threadIdx.x;
+    for (int i = tid; i < TWN; i += T) tw[i] = a.tw[i];
+    __syncthreads();
+    for (long long frame = blockIdx.x; frame < a.nframes; frame += gridDim.x) {
+        Best best;
+        best.v = -3.402823466e+38f;
+        best.k = 0x7fffffff;
+        mixed_pass<N, T, IN, OUT, R0, 1, true, false>(a, frame, tid, buf, tw, best);
+        mixed_pass<N, T, IN, OUT, R1, R0, false, false>(a, frame, tid, buf, tw + O2, best);
+        mixed_pass<N, T, IN, OUT, R2, R0 * R1, false, false>(a, frame, tid, buf, tw + O3, best);
+        mixed_pass<N, T, IN, OUT, R3, R0 * R1 * R2, false, false>(a, frame, tid, buf, tw + O4, best);
+        mixed_pass<N, T, IN, OUT, R4, R0 * R1 * R2 * R3, false, true>(a, frame, tid, buf, tw + O5, best);
+        if constexpr (OUT == OUT_PSD) {
+            float bestv = best.v;
+            int bestk = best.k;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                float ov = __shfl_xor(bestv, off, 64);
+                int ok = __shfl_xor(bestk, off, 64);
+                if (ov > bestv || (ov == bestv && ok < bestk)) {
+                    bestv = ov;
+                    bestk = ok;
+                }
+            }
+            if ((tid & 63) == 0) {
+                red_val[tid >> 6] = bestv;
+                red_idx[tid >> 6] = bestk;
+            }
+            __syncthreads();
+            if (tid == 0) {
+                for (int w = 1; w < NW; w++) {
+                    float ov = red_val[w];
+                    int ok = red_idx[w];
+                    if (ov > bestv || (ov == bestv && ok < bestk)) {
+                        bestv = ov;
+                        bestk = ok;
+                    }
+                }
+                // fft.java:201-224
+                int p = (bestv > -3.402823466e+38f) ? 2 * bestk : -1;
+                float m = (p >= 0) ? bestv : -3.402823466e+38f;
+                const int datlen = 2 * N;
+                if (p >= datlen / 2) p -= datlen;
+                int hz = (int)((unsigned)p * (unsigned)a.rate) / datlen;
+                float *dst = a.out + frame * (N + 2);
+                dst[N] = (float)hz;
+                dst[N + 1] = m;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int N, int T, int R0, int R1, int R2, int R3, int R4>
+static int mixed_launch_t(const MixedPlan &p, const FftArgs &a, int in_kind, int out_kind, int grid, hipStream_t st)
+{
+    auto go = [&](auto kern) -> int {
+        static bool attr_done = false;
+        if (!attr_done) {
+            JSDR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));
+            attr_done = true;
+        }
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(T), p.lds_bytes, st, a);
+        JSDR_LAUNCH_CHECK();
+        return JSDR_OK;
+    };
+    if (in_kind == IN_I16 && out_kind == OUT_PSD) return go(k_fft_mixed<N, T, IN_I16, OUT_PSD, R0, R1, R2, R3, R4>);
+    if (in_kind == IN_F32 && out_kind == OUT_PSD) return go(k_fft_mixed<N, T, IN_F32, OUT_PSD, R0, R1, R2, R3, R4>);
+    if (in_kind == IN_F32 && out_kind == OUT_SPEC) return go(k_fft_mixed<N, T, IN_F32, OUT_SPEC, R0, R1, R2, R3, R4>);
+    set_error("fft: no mixed-radix kernel for in=%d out=%d", in_kind, out_kind);
+    return JSDR_ERR;
+}
+
+bool mixed_plan(int n, MixedPlan &p)
+{
+    p = MixedPlan();
+    if (n == 9600) {
+        const int r[5] = {16, 8, 5, 5, 3};
+        p.n = n;
+        p.nrad = 5;
+        for (int i = 0; i < 5; i++) p.radix[i] = r[i];
+        p.threads = 512;
+    } else if (n == 4800) {
+        const int r[5] = {16, 4, 5, 5, 3};
+        p.n = n;
+        p.nrad = 5;
+        for (int i = 0; i < 5; i++) p.radix[i] = r[i];
+        p.threads = 320;
+    } else {
+        return false;
+    }
+    int P = p.radix[0];
+    p.tw_count = 0;
+    for (int i = 1; i < p.nrad; i++) {
+        p.tw_count += mtw_size(P, p.radix[i]);
+        P *= p.radix[i];
+    }
+    const int nw = (p.threads + 63) / 64;
+    p.lds_bytes = sizeof(float2) * ((size_t)p.tw_count + lds_frame_elems(n)) + (sizeof(float) + sizeof(int)) * nw + 16;
+    return true;
+}
+
+void mixed_twiddles(const MixedPlan &p, float2 *out)
+{
+    int P = p.radix[0];
+    size_t o = 0;
+    for (int i = 1; i < p.nrad; i++) {
+        const int R = p.radix[i];
+        const long double base = -2.0L * 3.14159265358979323846264338327950288L / ((long double)P * (long double)R);
+        if (mtw_direct(P, R)) {
+            for (int r = 0; r < R; r++)
+                for (int k = 0; k < P; k++) {
+                    long double ang = base * (long double)k * (long double)r;
+                    out[o++] = make_float2((float)cosl(ang), (float)sinl(ang));
+                }
+        } else {
+            for (int k = 0; k < P; k++) {
+                long double ang = base * (long double)k;
+                out[o++] = make_float2((float)cosl(ang), (float)sinl(ang));
+            }
+        }
+        P *= R;
+    }
+}
+
+int mixed_launch(const MixedPlan &p, const FftArgs &a, int in_kind, int out_kind, int grid, hipStream_t st)
+{
+    if (p.n == 9600) return mixed_launch_t<9600, 512, 16, 8, 5, 5, 3>(p, a, in_kind, out_kind, grid, st);
+    if (p.n == 4800) return mixed_launch_t<4800, 320, 16, 4, 5, 5, 3>(p, a, in_kind, out_kind, grid, st);
+    set_error("fft: no mixed-radix plan for n=%d", p.n);
+    return JSDR_ERR;
+}
+
+}  // namespace jsdr

@@ -11,127 +11,13 @@
 // PSD stores likewise.  HBM traffic = 4 B in + 4 B out per sample: the kernel is HBM bound.
 // Float arithmetic may contract to FMA here: parity for this path is the 1e-5 (peak-normalised)
 // tolerance of BASELINE.json, JTransforms' own rounding being unknowable (source absent).
-#include "common.h"
+#include "fft_common.h"
 #include <math.h>
-#include <utility>
 #include <vector>
 
 namespace jsdr {
 
-// ------------------------------------------------------------------ compile-time twiddles
-constexpr double cx_pi = 3.14159265358979323846264338327950288;
-
-constexpr double cx_sin_small(double x)  // |x| <= pi/4
-{
-    double x2 = x * x, term = x, sum = x;
-    for (int i = 1; i < 12; i++) {
-        term *= -x2 / ((2 * i) * (2 * i + 1));
-        sum += term;
-    }
-    return sum;
-}
-constexpr double cx_cos_small(double x)
-{
-    double x2 = x * x, term = 1.0, sum = 1.0;
-    for (int i = 1; i < 12; i++) {
-        term *= -x2 / ((2 * i - 1) * (2 * i));
-        sum += term;
-    }
-    return sum;
-}
-// cos/sin of 2*pi*j/len for 0 <= j < len, exact symmetries first
-constexpr double cx_cos_turn(int j, int len)
-{
-    j %= len;
-    if (8 * j <= len) return cx_cos_small(2 * cx_pi * j / len);
-    if (8 * j <= 3 * len) return -cx_sin_small(2 * cx_pi * (j - 0.25 * len) / len);
-    if (8 * j <= 5 * len) return -cx_cos_small(2 * cx_pi * (j - 0.5 * len) / len);
-    if (8 * j <= 7 * len) return cx_sin_small(2 * cx_pi * (j - 0.75 * len) / len);
-    return cx_cos_small(2 * cx_pi * (j - len) / len);
-}
-constexpr double cx_sin_turn(int j, int len) { return cx_cos_turn(4 * j + 3 * len, 4 * len); }
-
-__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ float2 cmul(float2 a, float2 w)
-{
-    return make_float2(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x);
-}
-
-// d * exp(-2 pi i J/LEN) with the trivial cases folded
-template <int LEN, int J>
-__device__ __forceinline__ float2 mul_w(float2 d)
-{
-    if constexpr (J == 0) {
-        return d;
-    } else if constexpr (4 * J == LEN) {
-        return make_float2(d.y, -d.x);
-    } else if constexpr (8 * J == LEN) {
-        constexpr float c = (float)0.70710678118654752440;
-        return make_float2((d.x + d.y) * c, (d.y - d.x) * c);
-    } else if constexpr (8 * J == 3 * LEN) {
-        constexpr float c = (float)0.70710678118654752440;
-        return make_float2((d.y - d.x) * c, -(d.x + d.y) * c);
-    } else {
-        constexpr float c = (float)cx_cos_turn(J, LEN);
-        constexpr float s = (float)cx_sin_turn(J, LEN);
-        return make_float2(d.x * c + d.y * s, d.y * c - d.x * s);
-    }
-}
-
-template <int LEN, int BASE, int J>
-__device__ __forceinline__ void bfly(float2 *x)
-{
-    constexpr int H = LEN / 2;
-    float2 a = x[BASE + J], b = x[BASE + J + H];
-    x[BASE + J] = cadd(a, b);
-    x[BASE + J + H] = mul_w<LEN, J>(csub(a, b));
-}
-template <int LEN, int BASE, int... Js>
-__device__ __forceinline__ void bfly_group(float2 *x, std::integer_sequence<int, Js...>)
-{
-    (bfly<LEN, BASE, Js>(x), ...);
-}
-template <int R, int LEN, int... Bs>
-__device__ __forceinline__ void bfly_stage(float2 *x, std::integer_sequence<int, Bs...>)
-{
-    (bfly_group<LEN, Bs * LEN>(x, std::make_integer_sequence<int, LEN / 2>{}), ...);
-}
-// in-register radix-R DFT, decimation in frequency: natural order in, BIT-REVERSED order out
-template <int R, int LEN = R>
-__device__ __forceinline__ void dft_reg(float2 *x)
-{
-    if constexpr (LEN >= 2) {
-        bfly_stage<R, LEN>(x, std::make_integer_sequence<int, R / LEN>{});
-        dft_reg<R, LEN / 2>(x);
-    }
-}
-constexpr int cx_bitrev(int v, int r)
-{
-    int o = 0;
-    for (int b = 1; b < r; b <<= 1) {
-        o = (o << 1) | (v & 1);
-        v >>= 1;
-    }
-    return o;
-}
-
-__device__ __forceinline__ int lds_pad(int idx) { return idx + (idx >> 4); }
-constexpr int lds_frame_elems(int n) { return n + (n >> 4) + 1; }
-
 // ------------------------------------------------------------------ kernel
-enum { IN_I16 = 0, IN_F32 = 1 };
-enum { OUT_PSD = 0, OUT_SPEC = 1 };
-
-struct FftArgs {
-    const void *in;      // int16 pairs or float pairs, [nframes][n]
-    float *out;          // psd [nframes][n+2] or spectrum [nframes][2n]
-    const float2 *tw;    // per-pass twiddle tables, concatenated (see tw_layout)
-    long long nframes;
-    int rate;
-    int ic, qc;
-};
-
 // Twiddle tables of pass with radix R and P = product of earlier radices (P > 1):
 //   P*R <= 512 : "direct"  D[r*P + k] = exp(-2 pi i k r/(P R)), r < R, k < P   (k fastest: conflict-free)
 //   else       : "base"    B[k]       = exp(-2 pi i k  /(P R)), k < P; powers r=2.. by repeated products
@@ -166,11 +52,6 @@ __device__ __forceinline__ void store_lds(float2 *dst, const float2 *v, int j0, 
 {
     ((dst[lds_pad(j0 + Rs * p)] = v[cx_bitrev(Rs, R)]), ...);
 }
-
-struct Best {
-    float v;
-    int k;
-};
 
 // One Stockham pass of one frame by T threads.  Each thread owns ITERS = (N/R)/T butterflies, loads
 // them all (global for the first pass, LDS otherwise), transforms in registers, and only after a
@@ -411,6 +292,8 @@ struct jsdr_fft {
     DevBuf<unsigned char> in_stage;  // one frame, for the host-buffer receive() forms
     DevBuf<float> out_stage;
     int num_cu = 256;
+    bool mixed = false;  // non power-of-two frame: fft_mixed.hip
+    MixedPlan mplan;
 };
 
 static int fft_run(jsdr_fft *h, const void *in_dev, int in_kind, int out_kind, long long nframes, int ic, int qc,
@@ -420,9 +303,20 @@ static int fft_run(jsdr_fft *h, const void *in_dev, int in_kind, int out_kind, l
     JSDR_REQUIRE(in_dev && out_dev, "fft: null buffer");
     JSDR_REQUIRE(nframes >= 0, "fft: negative frame count");
     if (nframes == 0) return JSDR_OK;
+    FftArgs a;
+    if (h->mixed) {
+        a.in = in_dev;
+        a.out = out_dev;
+        a.tw = h->tw.p;
+        a.nframes = nframes;
+        a.rate = h->rate;
+        a.ic = ic;
+        a.qc = qc;
+        long long cap = (long long)h->num_cu * 2;
+        return mixed_launch(h->mplan, a, in_kind, out_kind, (int)(nframes < cap ? nframes : cap), s);
+    }
     Launcher l = pick_launcher(h->n, in_kind, out_kind);
     JSDR_REQUIRE(l.launch, "fft: no kernel for n=%d in=%d out=%d", h->n, in_kind, out_kind);
-    FftArgs a;
     a.in = in_dev;
     a.out = out_dev;
     a.tw = h->tw.p;
@@ -448,9 +342,12 @@ int jsdr_fft_create(jsdr_fft **out, int n, int rate)
 {
     JSDR_REQUIRE(out, "jsdr_fft_create: null handle pointer");
     *out = nullptr;
-    JSDR_REQUIRE(n >= 64 && n <= 8192 && (n & (n - 1)) == 0,
-                 "jsdr_fft_create: n=%d unsupported (powers of two 64..8192; the reference's default "
-                 "9600-sample frame needs the mixed-radix path, SURVEY.md 8f next-2)", n);
+    MixedPlan mp;
+    const bool pow2 = n >= 64 && n <= 8192 && (n & (n - 1)) == 0;
+    const bool mixed = !pow2 && mixed_plan(n, mp);
+    JSDR_REQUIRE(pow2 || mixed,
+                 "jsdr_fft_create: n=%d unsupported (powers of two 64..8192, and 4800 / 9600 = the reference's "
+                 "default 48 / 96 kHz frames)", n);
     JSDR_REQUIRE(rate > 0, "jsdr_fft_create: rate must be positive");
     int dev = 0;
     JSDR_HIP_TRY(hipGetDevice(&dev));
@@ -460,6 +357,21 @@ int jsdr_fft_create(jsdr_fft **out, int n, int rate)
     h->n = n;
     h->rate = rate;
     h->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (mixed) {
+        h->mixed = true;
+        h->mplan = mp;
+        std::vector<float2> mtw((size_t)mp.tw_count);
+        mixed_twiddles(mp, mtw.data());
+        if (h->tw.alloc(mtw.size()) != JSDR_OK || h->in_stage.alloc((size_t)n * 8) != JSDR_OK ||
+            h->out_stage.alloc((size_t)n + 2) != JSDR_OK ||
+            hipMemcpy(h->tw.p, mtw.data(), sizeof(float2) * mtw.size(), hipMemcpyHostToDevice) != hipSuccess) {
+            set_error("jsdr_fft_create: mixed-radix setup failed");
+            jsdr_fft_destroy(h);
+            return JSDR_ERR;
+        }
+        *out = h;
+        return JSDR_OK;
+    }
     // per-pass twiddle tables in the layout fft_pass expects (tw_direct / tw_size above)
     Launcher l = pick_launcher(n, IN_I16, OUT_PSD);
     std::vector<float2> tw;

@@ -213,7 +213,16 @@ void jo_fft_receive(const float *buf, int n, int rate, float *psd)
 {
     float *dat = (float *)malloc(sizeof(float) * 2 * (size_t)n);
     memcpy(dat, buf, sizeof(float) * 2 * (size_t)n);
-    jo_fft_f32(dat, n);
+    if ((n & (n - 1)) == 0) {
+        jo_fft_f32(dat, n);
+    } else {
+        /* non power-of-two frame (the reference's default n=9600): JTransforms uses a mixed-radix plan; the
+         * stand-in is the exact DFT rounded to float (parity for this path is the 1e-5 tolerance anyway) */
+        double *x = (double *)malloc(sizeof(double) * 2 * (size_t)n);
+        jo_dft_exact(buf, n, x);
+        for (int i = 0; i < 2 * n; i++) dat[i] = (float)x[i];
+        free(x);
+    }
     jo_fft_psd_from_spectrum(dat, n, rate, psd);
     free(dat);
 }

@@ -134,8 +134,36 @@ def test_fft_golden_tones():
         check_psd(psd[k], G["tones_psd"][k], 2048)
 
 
+@pytest.mark.parametrize("n,rate", [(9600, 96000), (4800, 48000)])
+def test_fft_default_non_power_of_two_frames(n, rate):
+    """java-sdr's default buffer is rate*size/10 bytes -> n = 9600 @96 kHz (JavaAudio.java:58-59): mixed radix
+    2^k.3.5^2.  Spectrum against the exact DFT (1e-5 of the peak), PSD / argmax / Hz against the oracle's rule."""
+    rng = np.random.default_rng(n)
+    t = np.arange(n)
+    bufs = np.zeros((3, 2 * n), np.float32)
+    x = 0.3 * np.exp(2j * np.pi * 1234 * t / n) + 0.05 * np.exp(-2j * np.pi * 777.5 * t / n)
+    bufs[0, 0::2], bufs[0, 1::2] = x.real, x.imag
+    bufs[1] = (rng.standard_normal(2 * n) * 0.2).astype(np.float32)
+    bufs[2, 0::2] = 0.4 * np.cos(2 * np.pi * 1001.25 * t / n)
+    f = J.Fft(n, rate)
+    spec = f.spectrum(bufs).astype(np.float64)
+    for k in range(3):
+        want = np.fft.fft(bufs[k, 0::2].astype(np.float64) + 1j * bufs[k, 1::2].astype(np.float64))
+        got = spec[k, 0::2] + 1j * spec[k, 1::2]
+        assert np.abs(got - want).max() <= FFT_RTOL * np.abs(want).max()
+    for k in range(3):
+        check_psd(f.receive(bufs[k]), O.fft_receive(bufs[k], rate), n)
+    # raw (IRawHandler) form with DC correction, batched, ragged count
+    raw = rng.integers(-20000, 20000, (5, 2 * n)).astype(np.int16)
+    psd = f.batch_host_i16(raw, ic=11, qc=-7)
+    for k in range(5):
+        check_psd(psd[k], O.fft_receive(O.convert_i16(raw[k], ic=11, qc=-7), rate), n)
+    z = f.receive(np.zeros(2 * n, np.float32))
+    assert np.all(np.isneginf(z[:n])) and z[n] == float(int(-1 * rate / (2 * n))) and z[n + 1] == -np.finfo(np.float32).max
+
+
 def test_fft_rejects_unsupported_sizes():
-    for n in (9600, 100, 32, 16384):
+    for n in (19200, 100, 32, 16384, 9601):
         with pytest.raises(J.JsdrError):
             J.Fft(n, 96000)
 

@@ -36,9 +36,29 @@ def test_harness_on_sine4410(golden_dir):
         assert int(m.group(9)) == 12000
 
 
+def test_harness_at_the_reference_default_frame(tmp_path):
+    """unmodified jsdr uses blen = rate*size/10 = 38400 bytes -> n = 9600 samples (JavaAudio.java:58-59)"""
+    n = 9600
+    iq, _, _ = O.make_dbpsk_stream(3, 0, 2 * n)
+    fx = tmp_path / "two_frames.raw"
+    iq.tofile(fx)
+    r = subprocess.run([HARNESS, str(fx), "96000", "38400"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("frame")]
+    assert len(lines) == 2
+    buf = O.convert_i16(iq)
+    o = O.Bpsk(blen=38400)
+    for k, line in enumerate(lines):
+        m = re.search(r"max (\S+) dB @ (\S+) Hz .* ds=(\d+) bit=(\d+)", line)
+        ref = O.fft_receive(buf[k * 2 * n:(k + 1) * 2 * n], 96000)
+        assert abs(float(m.group(1)) - ref[n + 1]) < 1e-3 and float(m.group(2)) == ref[n]
+        o.receive(buf[k * 2 * n:(k + 1) * 2 * n])
+        assert int(m.group(3)) == o.counters()["cntDS"] and int(m.group(4)) == o.counters()["cntBit"]
+
+
 def test_harness_reports_handler_failure_like_the_audio_loop(golden_dir):
-    # blen 38400 -> n=9600 (the reference's default frame): no power-of-two kernel yet -> the fft plugin's
-    # setup fails, the loop ends with a status message and a non-zero exit instead of wrong data
+    # blen 40000 -> n=10000: no kernel for that frame size -> the fft plugin's setup fails, the loop ends with a
+    # status message and a non-zero exit instead of wrong data
     fx = os.path.join(golden_dir, "sine4410.raw")
-    r = subprocess.run([HARNESS, fx, "96000", "38400"], capture_output=True, text=True, timeout=120)
+    r = subprocess.run([HARNESS, fx, "96000", "40000"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 1 and "Audio oops" in r.stderr

@@ -368,3 +368,18 @@ def test_bpsk_fir_stages_against_numpy_restatement(rate, tuning):
         dsPos = dsPos - 1 if dsPos > 0 else 26
     assert np.array_equal(ds, np.array(dss))
     assert np.array_equal(tr, np.array(outs))
+
+
+def test_fft_oracle_standin_for_the_default_9600_frame():
+    """non power-of-two frames go through the exact DFT; the Hz rule divides by 2n = 19200"""
+    n = 9600
+    t = np.arange(n)
+    for k in (1234, 9000):
+        x = 0.5 * np.exp(2j * np.pi * k * t / n)
+        buf = np.empty(2 * n, np.float32)
+        buf[0::2], buf[1::2] = x.real, x.imag
+        psd = O.fft_receive(buf, 96000)
+        assert int(np.argmax(psd[:n])) == k
+        p = 2 * k
+        want = int(p * 96000 / (2 * n)) if p < n else int((p - 2 * n) * 96000 / (2 * n))
+        assert psd[n] == float(want)
