@@ -638,7 +638,6 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs a)
     __shared__ double enL[512];
     __shared__ double eL[64][9];       // dmEnergy[c] after each period (row padded: conflict-free column walk)
     __shared__ unsigned char maskL[64];
-    __shared__ signed char npL[64];
     __shared__ short declist[136];
     const int lane = threadIdx.x;
     const int s = blockIdx.x;
@@ -733,6 +732,7 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs a)
                 }
             }
         }
+        bool replay = false;
         const bool bad = (np >= 0) && (np != v);
         const bool held = spec && (__ballot(bad) == 0ull);
         if (held) {
@@ -742,33 +742,29 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs a)
             }
             // peakPos stays v; every measured peak was v, so newPeak stays v as well
         } else {
-            // replay the chunk with the reference's state machine; dmEnergyOut restarts from its saved value
-            if (lane < 64) npL[lane] = (signed char)np;
-            if (lane == 8) e = e_in;
-            JSDR_WAVE_SYNC();
+            // The peak moved (acquisition, fades, frame seams of the FFT-acquire mode).  The peakPos/newPeak
+            // machine of :537,:577-579,:592 is integer only -- its inputs are the per-period argmax values np,
+            // which do not depend on dmEnergyOut -- so it runs as scalar code over the periods, one mask per
+            // period; dmEnergyOut is then redone from its saved value along the decision list further down.
+            int mymask_r = 0;
             for (int p = 0; p < nper; p++) {
                 const long long gbase = 8 * (MB + p);
                 const int cfirst = (gbase < g_first) ? (int)(g_first - gbase) : 0;
                 const int clast = (gbase + 7 >= g_end) ? (int)(g_end - 1 - gbase) : 7;
-                int mask = 0, c1 = -1, c2 = -1;
-                for (int c = cfirst; c <= clast; c++) {
-                    if (c == peakPos) {  // decision point (:537)
-                        mask |= 1 << c;
-                        if (c1 < 0) c1 = c; else c2 = c;
+                int mask = 0;
+                if (peakPos == newPeak) {  // nothing can change inside the period
+                    if (peakPos >= cfirst && peakPos <= clast) mask = 1 << peakPos;
+                } else {
+                    for (int c = cfirst; c <= clast; c++) {
+                        if (c == peakPos) mask |= 1 << c;                          // decision point (:537)
+                        if (c == ((peakPos + 4) & 7)) peakPos = newPeak;           // dmHalfTable (:500,:577-578)
                     }
-                    if (c == ((peakPos + 4) & 7)) peakPos = newPeak;  // dmHalfTable (:500,:577-578)
                 }
-                if (c1 >= 0) {
-                    const double ne = (e * Kc) + (enL[p * 8 + c1] * Sc);
-                    if (lane == 8) e = ne;
-                }
-                if (c2 >= 0) {  // two decision points in one period: the peak moved forward
-                    const double ne = (e * Kc) + (enL[p * 8 + c2] * Sc);
-                    if (lane == 8) e = ne;
-                }
-                if (lane == 0) maskL[p] = (unsigned char)mask;
-                if (clast == 7) newPeak = __builtin_amdgcn_readfirstlane((int)npL[p]);
+                if (lane == p) mymask_r = mask;
+                if (clast == 7) newPeak = __builtin_amdgcn_readlane(np, p);
             }
+            if (lane < 64) maskL[lane] = (unsigned char)mymask_r;
+            replay = true;
         }
         JSDR_WAVE_SYNC();
         // ---------------- decision list of the chunk, in time order
@@ -791,6 +787,21 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs a)
             }
         }
         JSDR_WAVE_SYNC();
+        if (replay) {
+            // dmEnergyOut (:538) over the decisions in time order: the products x*S2 lane-parallel, the chain
+            // e = e*K2 + (x*S2) on broadcast values, in the reference's operation order
+            double xa = 0.0, xb = 0.0;
+            if (lane < nd) xa = enL[declist[lane]] * S2;
+            if (lane + 64 < nd) xb = enL[declist[lane + 64]] * S2;
+            double eo = __shfl(e_in, 8, 64);
+            for (int d = 0; d < nd; d++) {  // d is uniform: v_readlane, no LDS round trip on the chain
+                const double xs = (d < 64) ? xa : xb;
+                const int lo = __builtin_amdgcn_readlane(__double2loint(xs), d & 63);
+                const int hi = __builtin_amdgcn_readlane(__double2hiint(xs), d & 63);
+                eo = (eo * K2) + __hiloint2double(hi, lo);
+            }
+            if (lane == 8) e = eo;
+        }
         // ---------------- parallel: differential detector per decision (:539-545)
         for (int d0 = 0; d0 < nd; d0 += 64) {
             const int d = d0 + lane;
@@ -972,6 +983,10 @@ struct jsdr_bpsk {
     DevBuf<FftFrontState> fft_state;  // FFT-acquire mode only
     DevBuf<double2> fft_tw;
     DevBuf<double> ds_taps_dev;
+    DevBuf<double2> vco_cs;       // FFT-acquire mode: (cos, sin) of the VCO table entry of every decimated sample of the call
+    std::vector<double> h_sincos;
+    std::vector<double2> h_vco_cs;
+    DevBuf<long long> phase_clk;  // JSDR_FFT_PHASECLK=1: k_front_fft's per-phase cycle counts, printed at destroy
     int logn = 0;
     long long last_nds = 0;
     int last_y = 0;
@@ -1201,6 +1216,12 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
         JSDR_HIP_TRY(hipMemcpyAsync(h->ktu.p + kshift, h->h_ktu.data(), (size_t)L + 26, hipMemcpyHostToDevice, st));
         if (nds > 0)
             JSDR_HIP_TRY(hipMemcpyAsync(h->kvco.p, h->h_kvco.data(), (size_t)nds, hipMemcpyHostToDevice, st));
+        if (nds > 0 && h->do_fft) {
+            h->h_vco_cs.resize((size_t)nds);
+            for (long long j = 0; j < nds; j++)
+                h->h_vco_cs[(size_t)j] = make_double2(h->h_sincos[h->h_kvco[(size_t)j]], h->h_sincos[256 + h->h_kvco[(size_t)j]]);
+            JSDR_HIP_TRY(hipMemcpyAsync(h->vco_cs.p, h->h_vco_cs.data(), sizeof(double2) * (size_t)nds, hipMemcpyHostToDevice, st));
+        }
         // the host vectors must stay untouched until the copies ran; pageable memcpyAsync stages
         // synchronously, so they are safe to reuse on return
         h->cache_valid = true;
@@ -1236,14 +1257,14 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
         xa.do_up = h->do_up;
         xa.decim = h->decim;
         xa.first_out = first_out;
-        xa.kvco = h->kvco.p;
-        xa.sincos = h->sincos.p;
+        xa.vco_cs = h->vco_cs.p;
         xa.tw = h->fft_tw.p;
         xa.st = h->fft_state.p;
         xa.dm = h->dm.p;
         xa.dm_stride = h->dm_stride;
         xa.nds = nds;
         xa.ds_taps = h->ds_taps_dev.p;
+        xa.phase_clk = h->phase_clk.p;
         ProfScope ps(h, PK_FRONT, st);
         if (launch_front_fft(xa, S, st) != JSDR_OK) return JSDR_ERR;
     } else if (nds > 0) {
@@ -1440,7 +1461,8 @@ int jsdr_bpsk_create(jsdr_bpsk **out, int rate, int nsamples_per_frame, int tuni
               h->cnt_dec.alloc(S) == JSDR_OK && h->corr.alloc(S * (size_t)h->max_bits) == JSDR_OK &&
               h->fec_data.alloc(S * MAX_TRIG * 256) == JSDR_OK && h->decoded.alloc(S * 256) == JSDR_OK &&
               h->stage_raw.alloc((size_t)nsamples_per_frame * 2) == JSDR_OK && h->ds_taps_dev.alloc(32) == JSDR_OK &&
-              (!do_fft || (h->fft_state.alloc(S) == JSDR_OK && h->fft_tw.alloc((size_t)nsamples_per_frame / 2) == JSDR_OK));
+              (!do_fft || (h->fft_state.alloc(S) == JSDR_OK && h->fft_tw.alloc((size_t)nsamples_per_frame) == JSDR_OK &&
+                            h->vco_cs.alloc((size_t)h->max_ds) == JSDR_OK));
     if (!ok) {
         jsdr_bpsk_destroy(h);
         return JSDR_ERR;
@@ -1480,6 +1502,8 @@ int jsdr_bpsk_create(jsdr_bpsk **out, int rate, int nsamples_per_frame, int tuni
             jsdr_bpsk_destroy(h);
             return JSDR_ERR;
         }
+        if (const char *e = getenv("JSDR_FFT_PHASECLK"))
+            if (atoi(e) != 0 && (h->phase_clk.alloc(8) != JSDR_OK || h->phase_clk.zero() != JSDR_OK)) h->phase_clk.release();
     }
     if (hipMemcpy(h->ds_taps_dev.p, bc.ds_taps, sizeof(double) * 27, hipMemcpyHostToDevice) != hipSuccess) {
         set_error("jsdr_bpsk_create: tap upload failed");
@@ -1489,6 +1513,7 @@ int jsdr_bpsk_create(jsdr_bpsk **out, int rate, int nsamples_per_frame, int tuni
     std::vector<TailState> ts(S);
     memset(ts.data(), 0, sizeof(TailState) * S);
     for (size_t i = 0; i < S; i++) ts[i].dmEnergyOut = 1.0;  // :499
+    h->h_sincos = sc;
     bool up = hipMemcpy(h->sincos.p, sc.data(), sizeof(double) * 512, hipMemcpyHostToDevice) == hipSuccess &&
               hipMemcpyToSymbol(HIP_SYMBOL(c_bpsk), &bc, sizeof(bc)) == hipSuccess &&
               hipMemcpy(h->tail.p, ts.data(), sizeof(TailState) * S, hipMemcpyHostToDevice) == hipSuccess &&
@@ -1542,6 +1567,21 @@ int jsdr_bpsk_destroy(jsdr_bpsk *h)
     h->stage_raw.release();
     h->fft_state.release();
     h->fft_tw.release();
+    h->vco_cs.release();
+    if (h->phase_clk.p) {
+        static const char *const names[8] = {"load+scatter", "forward FFT", "|X|", "boxcar+argmax", "centre-bin rule",
+                                             "gather/zero", "inverse FFT", "scale+RxDownSample"};
+        long long c[8] = {0};
+        if (hipDeviceSynchronize() == hipSuccess &&
+            hipMemcpy(c, h->phase_clk.p, sizeof(c), hipMemcpyDeviceToHost) == hipSuccess) {
+            long long tot = 0;
+            for (int k = 0; k < 8; k++) tot += c[k];
+            for (int k = 0; k < 8; k++)
+                fprintf(stderr, "[jsdr] k_front_fft phase %-20s %12lld ticks  %5.1f %%\n", names[k], c[k],
+                        tot ? 100.0 * (double)c[k] / (double)tot : 0.0);
+        }
+        h->phase_clk.release();
+    }
     h->ds_taps_dev.release();
     for (auto &r : h->prof_recs) {
         (void)hipEventDestroy(r.a);

@@ -23,14 +23,14 @@ struct FftFrontArgs {
     int do_up;
     int decim;
     int first_out;             // input index (within the call) that completes output 0
-    const unsigned char *kvco; // [nds]
-    const double *sincos;      // cos[256], sin[256]
-    const double2 *tw;         // [n/2] (cos, -sin)
+    const double2 *vco_cs;     // [nds] (cos, sin) of the VCO phase table entry of every decimated sample
+    const double2 *tw;         // [n-1] per-stage (cos, -sin), fft_twiddles_f64
     FftFrontState *st;         // [S]
     double2 *dm;               // [S][dm_stride]
     long long dm_stride;
     long long nds;
     const double *ds_taps;     // [27]
+    long long *phase_clk;      // diagnostics: [8] cycle counts per phase of stream 0's workgroup, or null
 };
 
 int launch_front_fft(const FftFrontArgs &a, int nstreams, hipStream_t st);

@@ -13,110 +13,294 @@
 // rounding is unknowable (source absent): parity with the Java library itself is unpinned.
 //
 // MI355X mapping: one 256-thread workgroup per stream, persistent over the frames of the call (the centre-bin
-// state is sequential from frame to frame).  The frame lives in LDS as double2[N] (32 KB at N=2048) next to the
-// twiddle table (16 KB) and the |X| / boxcar arrays; every FFT stage is 4 butterflies per thread between two
-// barriers.  FP64-issue bound: ~225k FP64 ops per frame.
+// state is sequential from frame to frame); four workgroups share a CU at N=2048 (38.9 KB of LDS and <=128 VGPRs
+// each), i.e. the 1024 streams of the benchmark are resident at once.  The kernel is LDS-bandwidth bound, so the
+// structure is about LDS bytes:
+//   * the frame is a padded double2 image in LDS (slot e + e/8: conflict-free for all pass shapes);
+//   * THREE radix-2 stages per LDS round trip with the 8 points of a group in registers (4 passes, not 11);
+//   * the first pass of the forward FFT takes its inputs straight from the global-load registers (prefetched
+//     one frame ahead), the first pass of the inverse FFT straight from the spectrum (204 bins + zeros): no
+//     bit-reversal scatter, no zero fill;
+//   * the last inverse pass scales and stores only the real parts (all RxDownSample reads);
+//   * twiddles: stages with wing <= 32 from a 1 KB LDS table, the first pass from scalar loads (uniform),
+//     the wide stages from the per-stage contiguous global table through L1 (coalesced 16 B per lane);
+//   * |X| and the boxcar sums reuse the dead upper part of the image.
 #include "bpsk_fft.h"
 #include <math.h>
 
 namespace jsdr {
 
-// one radix-2 DIT stage over X[n] (in place), `half` = distance between butterfly wings
-__device__ __forceinline__ void fft_stage(double2 *X, const double2 *W, int n, int half, int step, bool inverse, int tid)
+// LDS image of the frame: element e lives at slot e + (e >> 3).
+__device__ __forceinline__ int xpad(int e) { return e + (e >> 3); }
+
+template <int BITS>
+__device__ __forceinline__ int brevn(int x)
 {
-    for (int idx = tid; idx < n / 2; idx += 256) {
-        const int j = idx & (half - 1);
-        const int ia = ((idx - j) << 1) + j;
-        const int ib = ia + half;
-        const double2 w = W[j * step];
-        const double wr = w.x;
-        const double wi = inverse ? -w.y : w.y;
-        const double2 b = X[ib];
-        const double p1 = wr * b.x, p2 = wi * b.y, p3 = wr * b.y, p4 = wi * b.x;
-        const double tr = p1 - p2;
-        const double ti = p3 + p4;
-        const double2 a = X[ia];
-        X[ia] = make_double2(a.x + tr, a.y + ti);
-        X[ib] = make_double2(a.x - tr, a.y - ti);
+    return (int)(__brev((unsigned)x) >> (32 - BITS));
+}
+
+constexpr int kLdsTwiddleWing = 32;  // stages with half <= 32 read LDS (63 entries)
+
+// twiddle jj of the stage with wing distance HALF: Ts[HALF-1+jj] = W_n^(jj * n/(2*HALF))
+template <int HALF, bool UNIFORM>
+__device__ __forceinline__ double2 tw_get(const double2 *TsL, const double2 *__restrict__ tsg, int jj)
+{
+    if (!UNIFORM && HALF <= kLdsTwiddleWing) return TsL[HALF - 1 + jj];
+    return tsg[(unsigned)(HALF - 1 + jj)];  // 32-bit offset on the scalar base
+}
+
+// G consecutive stages of the radix-2 DIT network on the 2^G values v[m] = x[base + j + HALF0*m].  Every
+// butterfly is the oracle's:  t = w*b (tr = wr*br - wi*bi, ti = wr*bi + wi*br), a' = a + t, b' = a - t;
+// only the grouping differs from jo_fft_f64, not a single operation.
+template <int G, int HALF0, bool INVERSE, bool UNIFORM>
+__device__ __forceinline__ void dit_stages(double2 (&v)[1 << G], int j, const double2 *TsL, const double2 *__restrict__ tsg)
+{
+    constexpr int M = 1 << G;
+#pragma unroll
+    for (int t = 0; t < G; t++) {
+        double2 w[1 << (G - 1)];
+#pragma unroll
+        for (int u = 0; u < (1 << t); u++) {
+            // stage wing HALF0 << t
+            if (t == 0) w[u] = tw_get<HALF0, UNIFORM>(TsL, tsg, j + HALF0 * u);
+            if (t == 1) w[u] = tw_get<HALF0 * 2, UNIFORM>(TsL, tsg, j + HALF0 * u);
+            if (t == 2) w[u] = tw_get<HALF0 * 4, UNIFORM>(TsL, tsg, j + HALF0 * u);
+        }
+#pragma unroll
+        for (int m = 0; m < M; m++) {
+            if ((m >> t) & 1) continue;  // m is the upper wing's index
+            const double2 wv = w[m & ((1 << t) - 1)];
+            const double wr = wv.x;
+            const double wi = INVERSE ? -wv.y : wv.y;
+            const double2 bq = v[m + (1 << t)];
+            const double p1 = wr * bq.x, p2 = wi * bq.y, p3 = wr * bq.y, p4 = wi * bq.x;
+            const double tr = p1 - p2;
+            const double ti = p3 + p4;
+            const double2 aq = v[m];
+            v[m] = make_double2(aq.x + tr, aq.y + ti);
+            v[m + (1 << t)] = make_double2(aq.x - tr, aq.y - ti);
+        }
     }
 }
 
-__device__ __forceinline__ void fft_inplace(double2 *X, const double2 *W, int n, bool inverse, int tid)
+// one LDS round trip: G stages starting at wing HALF0 over the whole frame.  REAL_OUT: scale and store only
+// the real part (last pass of the inverse transform; :462 reads nothing else).
+template <int G, int HALF0, bool INVERSE, int LOGN, bool REAL_OUT>
+__device__ __forceinline__ void dit_pass(double2 *X, const double2 *TsL, const double2 *__restrict__ tsg, int tid, double norm)
 {
-    for (int half = 1; half < n; half <<= 1) {
-        __syncthreads();
-        fft_stage(X, W, n, half, n / (2 * half), inverse, tid);
+    constexpr int M = 1 << G;
+    constexpr int GROUPS = 1 << (LOGN - G);
+    __syncthreads();
+#pragma unroll
+    for (int q0 = 0; q0 < GROUPS; q0 += 256) {
+        int q = q0 + tid;
+        if (GROUPS < 256 && q >= GROUPS) continue;
+        // opaque per frame: keeps the per-pass address arithmetic (64-bit twiddle addresses!) from being hoisted
+        // out of the frame loop into registers the allocator then spills
+        asm volatile("" : "+v"(q));
+        const int j = q & (HALF0 - 1);
+        const int base = (q - j) << G;
+        static_assert(HALF0 % 8 == 0, "wing distances of the LDS passes are multiples of 8");
+        double2 *x0 = X + xpad(base + j);  // element + HALF0*m sits (HALF0 + HALF0/8)*m slots further: immediate offsets
+        constexpr int STEP = HALF0 + HALF0 / 8;
+        double2 v[M];
+#pragma unroll
+        for (int m = 0; m < M; m++) v[m] = x0[STEP * m];
+        dit_stages<G, HALF0, INVERSE, false>(v, j, TsL, tsg);
+#pragma unroll
+        for (int m = 0; m < M; m++) {
+            if (REAL_OUT)
+                x0[STEP * m].x = v[m].x * norm;
+            else
+                x0[STEP * m] = v[m];
+        }
+    }
+}
+
+// the passes after the first: wings 8,64,512 (and what is left)
+template <bool INVERSE, int LOGN, bool SKIP8>
+__device__ __forceinline__ void fft_rest(double2 *X, const double2 *TsL, const double2 *__restrict__ tsg, int tid, double norm)
+{
+    static_assert(LOGN >= 10 && LOGN <= 12, "frame sizes 1024..4096");
+    if (!SKIP8) dit_pass<3, 8, INVERSE, LOGN, false>(X, TsL, tsg, tid, norm);
+    if (LOGN == 12) {
+        dit_pass<3, 64, INVERSE, LOGN, false>(X, TsL, tsg, tid, norm);
+        dit_pass<3, 512, INVERSE, LOGN, INVERSE>(X, TsL, tsg, tid, norm);
+    } else if (LOGN == 11) {
+        dit_pass<3, 64, INVERSE, LOGN, false>(X, TsL, tsg, tid, norm);
+        dit_pass<2, 512, INVERSE, LOGN, INVERSE>(X, TsL, tsg, tid, norm);
+    } else {
+        dit_pass<3, 64, INVERSE, LOGN, false>(X, TsL, tsg, tid, norm);
+        dit_pass<1, 512, INVERSE, LOGN, INVERSE>(X, TsL, tsg, tid, norm);
     }
     __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void k_front_fft(FftFrontArgs a)
+template <int LOGN, bool F32IN>
+__global__ __launch_bounds__(256, (LOGN <= 11 ? 4 : 2)) void k_front_fft(FftFrontArgs a)
 {
+    constexpr int N = 1 << LOGN;
+    constexpr int XSLOTS = N + (N >> 3);
+    constexpr int G1 = (N / 8 + 255) / 256;        // first-pass groups per thread
+    constexpr int KBP = ((N / 4 - 150) / 2 + 1 + 255) / 256;  // boxcar output pairs per thread
+    constexpr int JB = (N / 4 + 1 + 255) / 256;    // RxDownSample outputs per thread and frame (decimation >= 4)
     extern __shared__ __align__(16) unsigned char smem[];
-    const int n = a.n;
-    double2 *X = reinterpret_cast<double2 *>(smem);                 // [n]
-    double2 *W = X + n;                                              // [n/2]
-    double *P = reinterpret_cast<double *>(W + n / 2);               // [n/2]  |X| of the lower half
-    double *A = P + n / 2;                                           // [n/2]  boxcar sums (zero outside the searched band)
-    double *sc = A + n / 2;                                          // [512]
-    double *hist = sc + 512;                                         // [32]
-    double *redv = hist + 32;                                        // [4] per-wave best value
-    int *redi = reinterpret_cast<int *>(redv + 4);                   // [4] per-wave best index, [4] = centreBin broadcast
+    double2 *X = reinterpret_cast<double2 *>(smem);       // [XSLOTS], padded image
+    double2 *TsL = X + XSLOTS;                            // [64] twiddles of the narrow stages
+    double *hist = reinterpret_cast<double *>(TsL + 64);  // [32]
+    double *taps = hist + 32;                             // [32]
+    double *redv = taps + 32;                             // [4] per-wave best value
+    int *redi = reinterpret_cast<int *>(redv + 4);        // [4] per-wave best index
+    // |X| and the boxcar sums: above redi for small frames, inside the (dead) upper part of X for N >= 2048
+    double *P = (N >= 2048) ? reinterpret_cast<double *>(X + xpad(N / 2 + 104))  // bins up to N/2+101 are gathered
+                            : reinterpret_cast<double *>(redi + 8);
+    double *A = P + N / 2;
+    const double2 *__restrict__ tsg = a.tw;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int s = blockIdx.x;
-    for (int i = tid; i < n / 2; i += 256) W[i] = a.tw[i];
-    for (int i = tid; i < 512; i += 256) sc[i] = a.sincos[i];
+    if (tid < 2 * kLdsTwiddleWing - 1) TsL[tid] = tsg[tid];
     FftFrontState *sp = &a.st[s];
     if (tid < 26) hist[tid] = sp->hist[tid];
+    if (tid < 27) taps[tid] = a.ds_taps[tid];
     double avePeakPower = sp->avePeakPower, aveCentreBin = sp->aveCentreBin;
     int centreBin = sp->centreBin;
     // :399-402 -- float expressions widened to double
     const double CFREQ_INV = (double)(1.0F - (2.0F / (1 + 1))), CFREQ_AVG = (double)(2.0F / (1 + 1));
     const double PSD_INV = (double)(1.0F - (2.0F / (10 + 1))), PSD_AVG = (double)(2.0F / (10 + 1));
     const double HOWARD = 0.9 * 32768.0;
-    const int beg = a.do_up ? n / 4 : 0;
-    const int end = a.do_up ? n / 2 : n / 4;
+    const int beg = a.do_up ? N / 4 : 0;
+    const int end = a.do_up ? N / 2 : N / 4;
     const int D = a.decim;
-    const double norm = 1.0 / (double)n;
-    const int *raw = a.raw + (long long)s * a.stride_pairs;
-    const float2 *rawf = a.rawf + (long long)s * a.stride_pairs;
+    const double norm = 1.0 / (double)N;
+    const int *__restrict__ raw = a.raw + (long long)s * a.stride_pairs;
+    const float2 *__restrict__ rawf = a.rawf + (long long)s * a.stride_pairs;
     double2 *dm = a.dm + (long long)s * a.dm_stride;
+    // diagnostics (JSDR_FFT_PHASECLK=1): thread 0 of stream 0 accumulates the clock ticks of every phase in LDS
+    long long *clk = reinterpret_cast<long long *>(redi + 8 + (N >= 2048 ? 0 : 2 * N));
+    long long tprev = 0;
+    const bool timing = a.phase_clk != nullptr && s == 0 && tid == 0;
+    if (timing)
+        for (int k = 0; k < 8; k++) clk[k] = 0;
+#define PHASE(k)                                     \
+    if (timing) {                                    \
+        const long long now_ = (long long)clock64(); \
+        clk[k] += now_ - tprev;                      \
+        tprev = now_;                                \
+    }
+    // First-pass group q = tid + 256*c owns slots 8q..8q+7, i.e. the frame elements brev(8q+m) =
+    // brev3(m)*N/8 + brev(q): eight loads N/8 apart.  Frame 0 now; every later frame is fetched while its
+    // predecessor is processed.
+    int bq[G1];
+    int pre[G1][8];
+    float2 pref[G1][8];
+#pragma unroll
+    for (int c = 0; c < G1; c++) {
+        const int q = tid + 256 * c;
+        bq[c] = brevn<LOGN - 3>(q & (N / 8 - 1));
+        if (N / 8 >= 256 || q < N / 8) {
+#pragma unroll
+            for (int m = 0; m < 8; m++) {
+                const int t = brevn<3>(m) * (N / 8) + bq[c];
+                if (F32IN)
+                    pref[c][m] = rawf[t];
+                else
+                    pre[c][m] = raw[t];
+            }
+        }
+    }
     __syncthreads();
+    if (timing) tprev = (long long)clock64();
 
     for (int f = 0; f < a.nframes; f++) {
-        // ---- frame -> LDS in bit-reversed order (:416-421)
-        for (int t = tid; t < n; t += 256) {
-            double di, dq;
-            const long long g = (long long)f * n + t;
-            if (a.rawf) {
-                const float2 v = rawf[g];
-                di = (double)v.x;
-                dq = (double)v.y;
-            } else {
-                const int w = raw[g];
-                di = (double)i16_to_float_java(java_short_add((int)(short)(w & 0xffff), a.ic));
-                dq = (double)i16_to_float_java(java_short_add(w >> 16, a.qc));
-            }
-            X[__brev((unsigned)t) >> (32 - a.logn)] = make_double2(di, dq);
+        const long long t0 = (long long)f * N;  // call-relative index of the frame's first sample
+        // VCO factors of this frame's RxDownSample outputs: in flight during the transforms
+        long long jlo = (t0 - a.first_out + D - 1) / D;
+        if (t0 <= a.first_out) jlo = 0;
+        double2 cs0 = make_double2(0.0, 0.0);
+        {
+            const long long j = jlo + tid;
+            const long long te = (long long)a.first_out + (long long)D * j;
+            if (te < t0 + N && j < a.nds) cs0 = a.vco_cs[j];
         }
-        fft_inplace(X, W, n, false, tid);  // :422-423
-        // ---- |X| (:425-427), cleared boxcar array
-        for (int i = tid; i < n / 2; i += 256) {
-            const double2 v = X[i];
+        // ---- forward FFT (:416-423): first pass from the load registers
+#pragma unroll
+        for (int c = 0; c < G1; c++) {
+            const int q = tid + 256 * c;
+            if (N / 8 >= 256 || q < N / 8) {
+                double2 v[8];
+#pragma unroll
+                for (int m = 0; m < 8; m++) {
+                    if (F32IN) {
+                        v[m] = make_double2((double)pref[c][m].x, (double)pref[c][m].y);
+                    } else {
+                        const int w = pre[c][m];
+                        v[m] = make_double2((double)i16_to_float_java(java_short_add((int)(short)(w & 0xffff), a.ic)),
+                                            (double)i16_to_float_java(java_short_add(w >> 16, a.qc)));
+                    }
+                }
+                if (f + 1 < a.nframes) {
+#pragma unroll
+                    for (int m = 0; m < 8; m++) {
+                        const long long t = t0 + N + brevn<3>(m) * (N / 8) + bq[c];
+                        if (F32IN)
+                            pref[c][m] = rawf[t];
+                        else
+                            pre[c][m] = raw[t];
+                    }
+                }
+                dit_stages<3, 1, false, true>(v, 0, TsL, tsg);
+#pragma unroll
+                for (int m = 0; m < 8; m++) X[xpad(8 * q + m)] = v[m];
+            }
+        }
+        PHASE(0)
+        fft_rest<false, LOGN, false>(X, TsL, tsg, tid, norm);
+        PHASE(1)
+        // ---- |X| (:425-427)
+#pragma unroll
+        for (int i0 = 0; i0 < N / 2; i0 += 256) {
+            const int i = i0 + tid;
+            const double2 v = X[xpad(i)];
             P[i] = sqrt(v.x * v.x + v.y * v.y);
-            A[i] = 0.0;
         }
         __syncthreads();
-        // ---- 100-wide boxcar, summed j ascending for every i (:433-437); first maximum (:439-442)
+        PHASE(2)
+        // ---- 100-wide boxcar, summed j ascending for every i (:433-437); first maximum (:439-442).  A thread owns
+        // the outputs i (even) and i+1: their windows P[i-50..i+49] and P[i-49..i+50] come out of the same 51
+        // aligned 16-byte reads, each summed in its own ascending chain.
         double bestv = 0.0;  // maxBin starts at 0.0, binPos at -1
         int besti = -1;
-        for (int i = beg + 75 + tid; i < end - 75; i += 256) {
-            double acc = 0.0;
-            for (int j = i - 50; j < i + 50; j++) acc += P[j];
-            A[i] = acc;
-            if (bestv < acc) {  // within a thread i ascends: strict '<' keeps the first maximum
-                bestv = acc;
-                besti = i;
+#pragma unroll
+        for (int b = 0; b < KBP; b++) {
+            const int i = beg + 74 + 2 * (tid + 256 * b);  // beg is a multiple of 4: i - 50 is even
+            if (i < end - 75) {
+                const double2 *w = reinterpret_cast<const double2 *>(P + i - 50);
+                double a0 = 0.0, a1 = 0.0;
+                double2 cur = w[0];
+                a0 += cur.x;
+#pragma unroll 10
+                for (int k = 1; k <= 50; k++) {
+                    const double2 nxt = w[k];
+                    a0 += cur.y;
+                    a1 += cur.y;
+                    if (k < 50) a0 += nxt.x;
+                    a1 += nxt.x;
+                    cur = nxt;
+                }
+                if (i >= beg + 75) {
+                    A[i] = a0;
+                    if (bestv < a0) {  // i ascends within a thread: strict '<' keeps the first maximum
+                        bestv = a0;
+                        besti = i;
+                    }
+                }
+                if (i + 1 < end - 75) {
+                    A[i + 1] = a1;
+                    if (bestv < a1) {
+                        bestv = a1;
+                        besti = i + 1;
+                    }
+                }
             }
         }
 #pragma unroll
@@ -133,9 +317,12 @@ __global__ __launch_bounds__(256) void k_front_fft(FftFrontArgs a)
             redi[wave] = besti;
         }
         __syncthreads();
-        if (tid == 0) {
+        PHASE(3)
+        // ---- centre-bin rule (:444-453), evaluated by every thread on the same values
+        {
             double maxBin = 0.0;
             int binPos = -1;
+#pragma unroll
             for (int w = 0; w < 4; w++) {
                 const double ov = redv[w];
                 const int oi = redi[w];
@@ -144,88 +331,183 @@ __global__ __launch_bounds__(256) void k_front_fft(FftFrontArgs a)
                     binPos = oi;
                 }
             }
-            // :444-453
             if (centreBin < 0) centreBin = 0;
             if (centreBin > end - 1) centreBin = end - 1;
-            avePeakPower = (PSD_AVG * A[centreBin]) + (PSD_INV * avePeakPower);
+            // aveTemp is cleared per frame (:431) and only [beg+75, end-75) is filled
+            const double atc = (centreBin >= beg + 75 && centreBin < end - 75) ? A[centreBin] : 0.0;
+            avePeakPower = (PSD_AVG * atc) + (PSD_INV * avePeakPower);
             if (maxBin > (avePeakPower / 4) * 5 && binPos > 0) {
                 aveCentreBin = (CFREQ_AVG * (double)(float)binPos) + (CFREQ_INV * aveCentreBin);
                 centreBin = (int)(aveCentreBin + (double)1.0F);
             }
             if (centreBin < 102) centreBin = 102;
-            redi[4] = centreBin;
         }
-        __syncthreads();
-        const int cb = redi[4];
-        // ---- 204 bins around the centre move to bin 0 of a zeroed array (:458), bit-reversed for the DIT network
-        double2 keep = make_double2(0.0, 0.0);
-        if (tid < 204) keep = X[cb - 102 + tid];
-        __syncthreads();
-        for (int i = tid; i < n; i += 256) X[i] = make_double2(0.0, 0.0);
-        __syncthreads();
-        if (tid < 204) X[__brev((unsigned)tid) >> (32 - a.logn)] = keep;
-        fft_inplace(X, W, n, true, tid);  // :459 complexInverse(fftRev, true)
-        for (int i = tid; i < n; i += 256) X[i].x = X[i].x * norm;  // only the real parts are used (:462)
-        __syncthreads();
-        // ---- RxDownSample(re, re) (:461-463, :470-492): outputs whose window ends inside this frame
-        {
-            const long long t0 = (long long)f * n;  // call-relative index of the frame's first sample
-            // outputs j with t0 <= first_out + D*j < t0 + n
-            long long jlo = (t0 - a.first_out + D - 1) / D;
-            if (t0 <= a.first_out) jlo = 0;
-            for (long long j = jlo + tid;; j += 256) {
-                const long long te = (long long)a.first_out + (long long)D * j;  // window end, call-relative
-                if (te >= t0 + n || j >= a.nds) break;
-                const int e = (int)(te - t0);  // 0..n-1 within the frame
-                double fi = 0.0;
+        PHASE(4)
+        // ---- inverse FFT of the 204 bins around the centre moved to bin 0 of a zeroed array (:458-459)
+        if constexpr (LOGN >= 11) {
+            // Only input 0 of every first-pass group can be non-zero (bins >= N/8 > 204 are zero), and a butterfly
+            // whose second operand is +0 returns its first operand twice -- unless that is -0, where IEEE gives
+            // (-0)+(+0) = +0: such a value takes the full first pass.  So the first pass is a broadcast, and the
+            // wing-8 pass reads its eight inputs straight from the spectrum.
+            constexpr int G2 = (N / 8) / 256;  // wing-8 groups per thread
+            double2 vin[G2][8];
 #pragma unroll
-                for (int k = 0; k < 27; k++) {  // newest first (:479-483)
-                    const int idx = e - k;
-                    const double v = (idx >= 0) ? X[idx].x : hist[26 + idx];
-                    fi += v * a.ds_taps[k];
+            for (int c = 0; c < G2; c++) {
+                const int q = tid + 256 * c;
+                const int rb = brevn<LOGN - 6>(q >> 3);
+#pragma unroll
+                for (int m = 0; m < 8; m++) {
+                    vin[c][m] = make_double2(0.0, 0.0);
+                    if ((brevn<3>(m) << (LOGN - 6)) < 204) {  // compile time
+                        const int k = (brevn<3>(m) << (LOGN - 6)) | rb;
+                        if (k < 204) vin[c][m] = X[xpad(centreBin - 102 + k)];
+                    }
+                }
+            }
+            __syncthreads();  // every spectrum read is done before the image is overwritten
+#pragma unroll
+            for (int c = 0; c < G2; c++) {
+                int q = tid + 256 * c;
+                asm volatile("" : "+v"(q));
+                const int j = q & 7;
+#pragma unroll
+                for (int m = 0; m < 8; m++) {
+                    const double2 v0 = vin[c][m];
+                    const long long NEGZ = (long long)0x8000000000000000ull;
+                    if (__double_as_longlong(v0.x) == NEGZ || __double_as_longlong(v0.y) == NEGZ) {
+                        double2 t[8];
+                        t[0] = v0;
+#pragma unroll
+                        for (int i = 1; i < 8; i++) t[i] = make_double2(0.0, 0.0);
+                        dit_stages<3, 1, true, true>(t, 0, TsL, tsg);
+                        double2 r = t[0];
+#pragma unroll
+                        for (int i = 1; i < 8; i++)
+                            if (j == i) r = t[i];
+                        vin[c][m] = r;
+                    }
+                }
+                dit_stages<3, 8, true, false>(vin[c], j, TsL, tsg);
+                double2 *x0 = X + xpad(((q - j) << 3) + j);
+#pragma unroll
+                for (int m = 0; m < 8; m++) x0[9 * m] = vin[c][m];
+            }
+            PHASE(5)
+            fft_rest<true, LOGN, true>(X, TsL, tsg, tid, norm);  // leaves re/N in .x (:462)
+        } else {
+            // N = 1024: two inputs of a first-pass group can be non-zero; the first pass runs in full on registers
+            double2 vin[G1][8];
+#pragma unroll
+            for (int c = 0; c < G1; c++) {
+#pragma unroll
+                for (int m = 0; m < 8; m++) {
+                    vin[c][m] = make_double2(0.0, 0.0);
+                    if (brevn<3>(m) * (N / 8) < 204) {  // compile time: the only slots a bin below 204 can land in
+                        const int k = brevn<3>(m) * (N / 8) + bq[c];
+                        if (k < 204) vin[c][m] = X[xpad(centreBin - 102 + k)];
+                    }
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int c = 0; c < G1; c++) {
+                const int q = tid + 256 * c;
+                if (N / 8 >= 256 || q < N / 8) {
+                    dit_stages<3, 1, true, true>(vin[c], 0, TsL, tsg);
+#pragma unroll
+                    for (int m = 0; m < 8; m++) X[xpad(8 * q + m)] = vin[c][m];
+                }
+            }
+            PHASE(5)
+            fft_rest<true, LOGN, false>(X, TsL, tsg, tid, norm);  // leaves re/N in .x (:462)
+        }
+        PHASE(6)
+        // ---- RxDownSample(re, re) (:461-463, :470-492): outputs whose window ends inside this frame
+#pragma unroll
+        for (int b = 0; b < JB; b++) {
+            const long long j = jlo + tid + 256 * b;
+            const long long te = (long long)a.first_out + (long long)D * j;  // window end, call-relative
+            if (te < t0 + N && j < a.nds) {
+                const int e = (int)(te - t0);  // 0..N-1 within the frame
+                double fi = 0.0;
+                if (e >= 26) {
+#pragma unroll
+                    for (int k = 0; k < 27; k++) fi += X[xpad(e - k)].x * taps[k];  // newest first (:479-483)
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 27; k++) {
+                        const int idx = e - k;
+                        const double v = (idx >= 0) ? X[xpad(idx)].x : hist[26 + idx];
+                        fi += v * taps[k];
+                    }
                 }
                 const double o = fi * HOWARD;  // fi == fq: both rails get the same samples
-                const int kv = a.kvco[j];
-                dm[64 + j] = make_double2(o * sc[kv], o * sc[256 + kv]);  // :515-516
+                const double2 cs = (b == 0) ? cs0 : a.vco_cs[j];
+                dm[64 + j] = make_double2(o * cs.x, o * cs.y);  // :515-516
             }
         }
+        double hnew = 0.0;
+        if (tid < 26) hnew = X[xpad(N - 26 + tid)].x;
         __syncthreads();
-        if (tid < 26) hist[tid] = X[n - 26 + tid].x;
-        __syncthreads();
+        if (tid < 26) hist[tid] = hnew;
+        PHASE(7)
     }
+#undef PHASE
+    __syncthreads();
     if (tid < 26) sp->hist[tid] = hist[tid];
     if (tid == 0) {
         sp->avePeakPower = avePeakPower;
         sp->aveCentreBin = aveCentreBin;
         sp->centreBin = centreBin;
+        if (timing)
+            for (int k = 0; k < 8; k++) a.phase_clk[k] = clk[k];
     }
 }
 
-int launch_front_fft(const FftFrontArgs &a, int nstreams, hipStream_t st)
+template <int LOGN, bool F32IN>
+static int launch_front_fft_t(const FftFrontArgs &a, int nstreams, hipStream_t st)
 {
-    const size_t lds = sizeof(double2) * ((size_t)a.n + a.n / 2) + sizeof(double) * ((size_t)a.n + 512 + 32 + 4) + 64;
-    static size_t attr_for = 0;
-    if (attr_for < lds) {
-        JSDR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_front_fft),
+    constexpr int N = 1 << LOGN;
+    constexpr size_t lds = sizeof(double2) * ((size_t)N + (N >> 3) + 64) + sizeof(double) * (32 + 32 + 4) + 32 + 64 +
+                           (N >= 2048 ? 0 : sizeof(double) * (size_t)N);
+    static bool attr_set = false;
+    if (!attr_set) {
+        JSDR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_front_fft<LOGN, F32IN>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_for = lds;
+        attr_set = true;
     }
-    hipLaunchKernelGGL(k_front_fft, dim3((unsigned)nstreams), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((k_front_fft<LOGN, F32IN>), dim3((unsigned)nstreams), dim3(256), lds, st, a);
     JSDR_LAUNCH_CHECK();
     return JSDR_OK;
 }
 
-// twiddle table identical to oracle/o_fft.c jo_fft_twiddles_f64 (same libm, exact values on the axes)
+int launch_front_fft(const FftFrontArgs &a, int nstreams, hipStream_t st)
+{
+    const bool f32 = a.rawf != nullptr;
+    switch (a.logn) {
+        case 10: return f32 ? launch_front_fft_t<10, true>(a, nstreams, st) : launch_front_fft_t<10, false>(a, nstreams, st);
+        case 11: return f32 ? launch_front_fft_t<11, true>(a, nstreams, st) : launch_front_fft_t<11, false>(a, nstreams, st);
+        case 12: return f32 ? launch_front_fft_t<12, true>(a, nstreams, st) : launch_front_fft_t<12, false>(a, nstreams, st);
+        default: JSDR_REQUIRE(false, "bpsk: FFT-acquire frame of 2^%d samples is not supported (1024..4096)", a.logn);
+    }
+}
+
+// per-stage twiddles Ts[half-1+j] = W_n^(j*n/(2*half)), j < half, half = 1,2,..,n/2 (n-1 entries), every value taken
+// from the SAME table as oracle/o_fft.c jo_fft_twiddles_f64 builds (long double + one rounding, exact on the axes)
 void fft_twiddles_f64(std::vector<double2> &w, int n)
 {
-    w.resize((size_t)n / 2);
-    // long double + one rounding: independent of sin/cos -> sincos / vector-libm rewrites by the host compiler
+    std::vector<double2> base((size_t)n / 2);
     for (int k = 0; k < n / 2; k++) {
         long double ang = 2.0L * 3.14159265358979323846264338327950288L * (long double)k / (long double)n;
-        w[k] = make_double2((double)cosl(ang), (double)(-sinl(ang)));
+        base[k] = make_double2((double)cosl(ang), (double)(-sinl(ang)));
     }
-    w[0] = make_double2(1.0, -0.0);
-    if (n >= 4) w[n / 4] = make_double2(0.0, -1.0);
+    base[0] = make_double2(1.0, -0.0);
+    if (n >= 4) base[n / 4] = make_double2(0.0, -1.0);
+    w.assign((size_t)n, make_double2(0.0, 0.0));
+    for (int half = 1; half < n; half <<= 1) {
+        const int step = n / (2 * half);
+        for (int j = 0; j < half; j++) w[(size_t)half - 1 + j] = base[(size_t)j * step];
+    }
 }
 
 }  // namespace jsdr

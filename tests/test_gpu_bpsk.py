@@ -240,6 +240,29 @@ def test_bpsk_fft_mode_other_frame_sizes_and_rates():
         run_both([iq], n, [nsf * 5, nsf * 19], rate=rate, do_fft=1, blen=blen)
 
 
+def test_bpsk_fft_mode_negative_zero_spectrum_bins():
+    """float frames of -0.0 (with a few impulses) leave -0.0 in spectrum bins: there a butterfly with a zero second
+    operand does NOT return its first operand ((-0)+(+0) = +0), so the broadcast first inverse pass of
+    k_front_fft must take its full-arithmetic branch -- compared including the sign of zeros"""
+    rng = np.random.default_rng(5)
+    d = J.Bpsk(nstreams=1, do_fft=1)
+    o = O.Bpsk(blen=8192, do_fft=1, trace=4096)
+    gt = []
+    for k in range(5):
+        buf = np.full(4096, -0.0, np.float32)
+        if k in (1, 2, 4):
+            buf[rng.integers(0, 4096, 3)] = (rng.standard_normal(3) * 0.3).astype(np.float32)
+        d.receive(buf)
+        o.receive(buf)
+        gt.append(d.trace().copy())
+    gt = np.concatenate(gt)
+    ot = o.trace()
+    assert np.array_equal(gt, ot)
+    assert np.array_equal(np.signbit(gt), np.signbit(ot))
+    same_counters(d.counters(), o.counters())
+    same_state(d.state(), o.state())
+
+
 def test_bpsk_fft_mode_rejects_partial_frames_and_odd_sizes():
     d = J.Bpsk(nstreams=1, do_fft=1, max_batch_samples=8192)
     buf = J.DeviceBuffer(4 * 8192)
