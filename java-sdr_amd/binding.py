@@ -11,7 +11,8 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-_SO = os.path.join(HERE, "libjsdr_hip.so")
+# JSDR_LIB: developer knob for same-box A/B timing of two builds (tools/build_variant.sh)
+_SO = os.environ.get("JSDR_LIB") or os.path.join(HERE, "libjsdr_hip.so")
 
 
 class JsdrError(RuntimeError):

@@ -61,18 +61,17 @@ struct DevBuf {
 };
 
 // ---- int16 -> float, JavaAudio.java:281-288:  (float)s / (float)Short.MAX_VALUE -----------------
-// IEEE-correct float division costs ~10 VALU ops (v_div_scale/fmas/fixup).  For the 65536
-// possible dividends and the constant divisor 32767 the two-FMA refinement below returns the
-// correctly rounded quotient (q0 = s*r, e = fma(-q0, d, s), q = fma(e, r, q0) with r = RN(1/d));
-// tests/test_gpu_convert.py checks all 65536 inputs against the CPU's division.
+// IEEE-correct float division costs ~10 VALU ops (v_div_scale/fmas/fixup).  For the 65536 possible
+// dividends and the constant divisor 32767 the quotient is q = fma(a, rh, a*rl) with rh = RN(1/d) and
+// rl = RN(1/d - rh): rh+rl carries 1/d to 2^-48 and no a/32767 lies that close to a rounding boundary.
+// Checked for every input in exact rational arithmetic and on the GPU against the CPU's
+// division (tests/test_gpu_fft.py, all 65536 inputs).
 __device__ __forceinline__ float i16_to_float_java(int s)
 {
-    const float d = 32767.0f;
-    const float r = 1.0f / 32767.0f;
-    float a = (float)s;
-    float q0 = a * r;
-    float e = __builtin_fmaf(-q0, d, a);
-    return __builtin_fmaf(e, r, q0);
+    const float rh = 0x1.0002p-15f;
+    const float rl = 0x1.0002p-45f;
+    const float a = (float)s;
+    return __builtin_fmaf(a, rh, a * rl);
 }
 
 // `short s = getShort(); s += (short)corr;` -- 16-bit wrap-around add

@@ -39,31 +39,48 @@ constexpr double cx_cos_turn(int j, int len)
 }
 constexpr double cx_sin_turn(int j, int len) { return cx_cos_turn(4 * j + 3 * len, 4 * len); }
 
-__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ float2 cmul(float2 a, float2 w)
+// Complex arithmetic on the native two-float vector type: the IR then holds <2 x float> operations from the
+// start, i.e. v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32.  Two rules keep register shuffles out (measured on
+// the ISA): a half swap must be a shufflevector (it folds into op_sel), and a sign on ONE half must sit in a
+// constant pair such as (1,-1) (a whole-vector negation folds into neg_lo/neg_hi, a partial one becomes
+// v_xor + v_mov).
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f to_v(float2 a) { return (v2f){a.x, a.y}; }
+__device__ __forceinline__ float2 from_v(v2f v) { return make_float2(v.x, v.y); }
+__device__ __forceinline__ v2f vswap(v2f v) { return __builtin_shufflevector(v, v, 1, 0); }
+__device__ __forceinline__ v2f vfma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return from_v(to_v(a) + to_v(b)); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return from_v(to_v(a) - to_v(b)); }
+// a * w with w' = (-w.y, w.x) supplied: (a.x w.x - a.y w.y, a.x w.y + a.y w.x) = a.x * w + a.y * w'
+__device__ __forceinline__ float2 cmul2(float2 a, float2 w, float2 wq)
 {
-    return make_float2(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x);
+    const v2f va = to_v(a);
+    return from_v(vfma(__builtin_shufflevector(va, va, 1, 1), to_v(wq), __builtin_shufflevector(va, va, 0, 0) * to_v(w)));
 }
+// w' = (-w.y, w.x) = swap(w) * (-1, 1)
+__device__ __forceinline__ float2 cquad(float2 w) { return from_v(vswap(to_v(w)) * (v2f){-1.0f, 1.0f}); }
+__device__ __forceinline__ float2 cmul(float2 a, float2 w) { return cmul2(a, w, cquad(w)); }
 
 // d * exp(-2 pi i J/LEN) with the trivial cases folded
 template <int LEN, int J>
 __device__ __forceinline__ float2 mul_w(float2 d)
 {
+    const v2f vd = to_v(d);
     if constexpr (J == 0) {
         return d;
-    } else if constexpr (4 * J == LEN) {
-        return make_float2(d.y, -d.x);
-    } else if constexpr (8 * J == LEN) {
+    } else if constexpr (4 * J == LEN) {  // (d.y, -d.x)
+        return from_v(vswap(vd) * (v2f){1.0f, -1.0f});
+    } else if constexpr (8 * J == LEN) {  // ((d.x + d.y) c, (d.y - d.x) c)
         constexpr float c = (float)0.70710678118654752440;
-        return make_float2((d.x + d.y) * c, (d.y - d.x) * c);
-    } else if constexpr (8 * J == 3 * LEN) {
+        return from_v(vfma(vswap(vd), (v2f){c, -c}, vd * c));
+    } else if constexpr (8 * J == 3 * LEN) {  // ((d.y - d.x) c, -(d.x + d.y) c)
         constexpr float c = (float)0.70710678118654752440;
-        return make_float2((d.y - d.x) * c, -(d.x + d.y) * c);
-    } else {
+        return from_v(vfma(vswap(vd), (v2f){c, -c}, vd * -c));
+    } else {  // (d.x c + d.y s, d.y c - d.x s)
         constexpr float c = (float)cx_cos_turn(J, LEN);
         constexpr float s = (float)cx_sin_turn(J, LEN);
-        return make_float2(d.x * c + d.y * s, d.y * c - d.x * s);
+        return from_v(vfma(vswap(vd), (v2f){s, -s}, vd * c));
     }
 }
 

@@ -72,12 +72,16 @@ __device__ __forceinline__ void mixed_twiddles_apply(float2 *v, int k, const flo
             for (int r = 1; r < R; r++) v[r] = cmul(v[r], tab[r * P + k]);
         } else {
             const float2 w1 = tab[k];
-            float2 w[R];
+            float2 w[R], wq[R];  // wq = (-w.y, w.x): a*w = a.x*w + a.y*wq, two packed instructions
             w[1] = w1;
+            wq[1] = cquad(w1);
 #pragma unroll
-            for (int r = 2; r < R; r++) w[r] = (r & 1) ? cmul(w[r - 1], w1) : cmul(w[r / 2], w[r / 2]);
+            for (int r = 2; r < R; r++) {
+                w[r] = (r & 1) ? cmul2(w[r - 1], w1, wq[1]) : cmul2(w[r / 2], w[r / 2], wq[r / 2]);
+                wq[r] = cquad(w[r]);
+            }
 #pragma unroll
-            for (int r = 1; r < R; r++) v[r] = cmul(v[r], w[r]);
+            for (int r = 1; r < R; r++) v[r] = cmul2(v[r], w[r], wq[r]);
         }
     }
 }

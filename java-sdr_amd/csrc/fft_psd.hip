@@ -19,14 +19,17 @@ namespace jsdr {
 
 // ------------------------------------------------------------------ kernel
 // Twiddle tables of pass with radix R and P = product of earlier radices (P > 1):
-//   P*R <= 512 : "direct"  D[r*P + k] = exp(-2 pi i k r/(P R)), r < R, k < P   (k fastest: conflict-free)
+//   P*R <= 512 : "direct"  D[r*P + k] = (w, w') with w = exp(-2 pi i k r/(P R)), w' = (-w.y, w.x), r < R, k < P
+//                          (k fastest: conflict-free 16-byte reads; a*w = a.x*w + a.y*w' is two packed instructions)
 //   else       : "base"    B[k]       = exp(-2 pi i k  /(P R)), k < P; powers r=2.. by repeated products
 constexpr bool tw_direct(int P, int R) { return P * R <= 512; }
-constexpr int tw_size(int P, int R) { return P <= 1 ? 0 : (tw_direct(P, R) ? P * R : P); }
+constexpr int tw_size(int P, int R) { return P <= 1 ? 0 : (tw_direct(P, R) ? 2 * P * R : P); }  // in float2 units
 constexpr int tw_total(int R0, int R1, int R2, int R3)
 {
     return tw_size(R0, R1) + (R2 > 1 ? tw_size(R0 * R1, R2) : 0) + (R3 > 1 ? tw_size(R0 * R1 * R2, R3) : 0);
 }
+
+constexpr int ilog2_c(int n) { return n <= 1 ? 0 : 1 + ilog2_c(n / 2); }
 
 template <int R, int P>
 __device__ __forceinline__ void apply_twiddles(float2 *v, int k, const float2 *tab)
@@ -34,15 +37,22 @@ __device__ __forceinline__ void apply_twiddles(float2 *v, int k, const float2 *t
     if constexpr (P > 1) {
         if constexpr (tw_direct(P, R)) {
 #pragma unroll
-            for (int r = 1; r < R; r++) v[r] = cmul(v[r], tab[r * P + k]);
+            for (int r = 1; r < R; r++) {
+                const float4 t = reinterpret_cast<const float4 *>(tab)[r * P + k];
+                v[r] = cmul2(v[r], make_float2(t.x, t.y), make_float2(t.z, t.w));
+            }
         } else {
             float2 w1 = tab[k];
-            float2 w[R];
+            float2 w[R], wq[R];  // wq = (-w.y, w.x): a*w = a.x*w + a.y*wq, two packed instructions
             w[1] = w1;
+            wq[1] = cquad(w1);
 #pragma unroll
-            for (int r = 2; r < R; r++) w[r] = (r & 1) ? cmul(w[r - 1], w1) : cmul(w[r / 2], w[r / 2]);
+            for (int r = 2; r < R; r++) {
+                w[r] = (r & 1) ? cmul2(w[r - 1], w1, wq[1]) : cmul2(w[r / 2], w[r / 2], wq[r / 2]);
+                wq[r] = cquad(w[r]);
+            }
 #pragma unroll
-            for (int r = 1; r < R; r++) v[r] = cmul(v[r], w[r]);
+            for (int r = 1; r < R; r++) v[r] = cmul2(v[r], w[r], wq[r]);
         }
     }
 }
@@ -76,12 +86,21 @@ __device__ __forceinline__ void fft_pass(const FftArgs &a, long long frame, bool
                 if (active) {
                     if constexpr (IN == IN_I16) {
                         const int *src = reinterpret_cast<const int *>(a.in) + frame * N;
+                        int w[R];
 #pragma unroll
-                        for (int r = 0; r < R; r++) {
-                            int w = src[b + r * NB];
-                            int si = java_short_add((int)(short)(w & 0xffff), a.ic);
-                            int sq = java_short_add(w >> 16, a.qc);
-                            v[gi][r] = make_float2(i16_to_float_java(si), i16_to_float_java(sq));
+                        for (int r = 0; r < R; r++) w[r] = src[b + r * NB];
+                        if ((a.ic | a.qc) == 0) {  // uniform: no DC correction (the usual case), two adds per sample less
+#pragma unroll
+                            for (int r = 0; r < R; r++)
+                                v[gi][r] = make_float2(i16_to_float_java((int)(short)(w[r] & 0xffff)),
+                                                       i16_to_float_java(w[r] >> 16));
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < R; r++) {
+                                int si = java_short_add((int)(short)(w[r] & 0xffff), a.ic);
+                                int sq = java_short_add(w[r] >> 16, a.qc);
+                                v[gi][r] = make_float2(i16_to_float_java(si), i16_to_float_java(sq));
+                            }
                         }
                     } else {
                         const float2 *src = reinterpret_cast<const float2 *>(a.in) + frame * N;
@@ -113,21 +132,30 @@ __device__ __forceinline__ void fft_pass(const FftArgs &a, long long frame, bool
 #pragma unroll
                     for (int r = 0; r < R; r++) dst[j0 + r * P] = v[gi][cx_bitrev(r, R)];
                 } else {
-                    const float cf = (2.0f / (float)N) * (2.0f / (float)N);
+                    // fft.java:205-207: 10*log10((re^2+im^2) * (2/N)^2) = 10*log10(2) * (log2(re^2+im^2) + 2 - 2*log2(N)):
+                    // N is a power of two, so the scale is an exact integer offset of the base-2 logarithm
+                    constexpr float L2 = 3.0102999566398120f;
+                    constexpr float OFF = 3.0102999566398120f * (2.0f - 2.0f * (float)ilog2_c(N));
                     float *dst = a.out + frame * (N + 2);
+                    float db[R];
 #pragma unroll
                     for (int r = 0; r < R; r++) {
                         float2 x = v[gi][cx_bitrev(r, R)];
-                        float pw = (x.x * x.x + x.y * x.y) * cf;
-                        // 10*log10(pw) = 10*log10(2) * log2(pw)   (fft.java:207)
-                        float db = 3.0102999566398120f * __log2f(pw);
-                        int bin = j0 + r * P;
-                        dst[bin] = db;
-                        if (db > best.v || (db == best.v && bin < best.k)) {
-                            best.v = db;
-                            best.k = bin;
-                        }
+                        db[r] = L2 * __log2f(x.x * x.x + x.y * x.y) + OFF;
+                        dst[j0 + r * P] = db[r];
                     }
+                    // first strict maximum of this thread's bins (fft.java:208-211): the group's maximum
+                    // (fmaxf ignores NaN, like the reference's '>'), then the lowest bin that holds it
+                    // (bins ascend with r), folded into the running best once per group
+                    float gm = db[0];
+#pragma unroll
+                    for (int r = 1; r < R; r++) gm = fmaxf(gm, db[r]);
+                    int gk = 0x7fffffff;
+#pragma unroll
+                    for (int r = R - 1; r >= 0; r--) gk = (db[r] == gm) ? j0 + r * P : gk;
+                    const bool take = (gm > best.v) | ((gm == best.v) & (gk < best.k));  // branch-free
+                    best.v = take ? gm : best.v;
+                    best.k = take ? gk : best.k;
                 }
             }
         }
@@ -163,10 +191,9 @@ __device__ __forceinline__ void fft_frame(const FftArgs &a, long long frame, boo
         for (int off = W / 2; off >= 1; off >>= 1) {
             float ov = __shfl_xor(bestv, off, W);
             int ok = __shfl_xor(bestk, off, W);
-            if (ov > bestv || (ov == bestv && ok < bestk)) {
-                bestv = ov;
-                bestk = ok;
-            }
+            const bool take = (ov > bestv) | ((ov == bestv) & (ok < bestk));  // branch-free
+            bestv = take ? ov : bestv;
+            bestk = take ? ok : bestk;
         }
         if constexpr (T > 64) {
             constexpr int NW = T / 64;
@@ -201,7 +228,7 @@ __device__ __forceinline__ void fft_frame(const FftArgs &a, long long frame, boo
 }
 
 template <int N, int T, int FPB, int IN, int OUT, int R0, int R1, int R2, int R3>
-__global__ __launch_bounds__(T *FPB) void k_fft(FftArgs a)
+__global__ __launch_bounds__(T *FPB, (N == 2048 ? 4 : 1)) void k_fft(FftArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int FE = lds_frame_elems(N);
@@ -219,10 +246,14 @@ __global__ __launch_bounds__(T *FPB) void k_fft(FftArgs a)
     const int tid = tid_b - fib * T;
     float2 *buf = bufs + (size_t)fib * FE;
     const long long ngroups = (a.nframes + FPB - 1) / FPB;
+    // a surplus part-workgroup (frame count not a multiple of FPB) redoes the last frame: identical values to
+    // identical addresses, and no predicate on any load, store or barrier
+    auto frame_of = [&](long long g) {
+        long long f = g * FPB + fib;
+        return f < a.nframes ? f : a.nframes - 1;
+    };
     for (long long g = blockIdx.x; g < ngroups; g += gridDim.x) {
-        long long frame = g * FPB + fib;
-        bool active = frame < a.nframes;
-        fft_frame<N, T, IN, OUT, R0, R1, R2, R3>(a, frame, active, tid, buf, tw_lds, red_val, red_idx, fib);
+        fft_frame<N, T, IN, OUT, R0, R1, R2, R3>(a, frame_of(g), true, tid, buf, tw_lds, red_val, red_idx, fib);
         __syncthreads();
     }
 }
@@ -383,7 +414,9 @@ int jsdr_fft_create(jsdr_fft **out, int n, int rate)
             for (int r = 0; r < R; r++)
                 for (int k = 0; k < P; k++) {
                     double ang = base * (double)k * (double)r;
-                    tw.push_back(make_float2((float)cos(ang), (float)sin(ang)));
+                    const float2 w = make_float2((float)cos(ang), (float)sin(ang));
+                    tw.push_back(w);
+                    tw.push_back(make_float2(-w.y, w.x));
                 }
         } else {
             for (int k = 0; k < P; k++) {

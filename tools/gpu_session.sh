@@ -45,6 +45,8 @@ for step in "$@"; do
     dbg)         run dbg 300 python tools/dbg_fftmode.py ;;
     trig)        run trig 300 python tools/trig_stats.py ;;
     bench_fft)   run bench_fft 300 python bench.py --workload fft --no-cpu-baseline ;;
+    bench_fft_b) JSDR_LIB=$PWD/java-sdr_amd/libjsdr_hip_b.so run bench_fft_b 300 python bench.py --workload fft --no-cpu-baseline ;;
+    bench_quick_b) JSDR_LIB=$PWD/java-sdr_amd/libjsdr_hip_b.so run bench_quick_b 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline ;;
     bench_bpsk)  run bench_bpsk 400 python bench.py --workload bpsk --no-cpu-baseline ;;
     prof)        rm -rf gpurun_out/prof_$R
                  run prof 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$R -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline ;;
