@@ -19,11 +19,11 @@ namespace jsdr {
 
 // ------------------------------------------------------------------ kernel
 // Twiddle tables of pass with radix R and P = product of earlier radices (P > 1):
-//   P*R <= 512 : "direct"  D[r*P + k] = (w, w') with w = exp(-2 pi i k r/(P R)), w' = (-w.y, w.x), r < R, k < P
+//   P*R <= 512 : "direct"  D[(r-1)*P + k] = (w, w') with w = exp(-2 pi i k r/(P R)), w' = (-w.y, w.x), 1 <= r < R, k < P
 //                          (k fastest: conflict-free 16-byte reads; a*w = a.x*w + a.y*w' is two packed instructions)
 //   else       : "base"    B[k]       = exp(-2 pi i k  /(P R)), k < P; powers r=2.. by repeated products
 constexpr bool tw_direct(int P, int R) { return P * R <= 512; }
-constexpr int tw_size(int P, int R) { return P <= 1 ? 0 : (tw_direct(P, R) ? 2 * P * R : P); }  // in float2 units
+constexpr int tw_size(int P, int R) { return P <= 1 ? 0 : (tw_direct(P, R) ? 2 * P * (R - 1) : P); }  // in float2 units
 constexpr int tw_total(int R0, int R1, int R2, int R3)
 {
     return tw_size(R0, R1) + (R2 > 1 ? tw_size(R0 * R1, R2) : 0) + (R3 > 1 ? tw_size(R0 * R1 * R2, R3) : 0);
@@ -38,7 +38,7 @@ __device__ __forceinline__ void apply_twiddles(float2 *v, int k, const float2 *t
         if constexpr (tw_direct(P, R)) {
 #pragma unroll
             for (int r = 1; r < R; r++) {
-                const float4 t = reinterpret_cast<const float4 *>(tab)[r * P + k];
+                const float4 t = reinterpret_cast<const float4 *>(tab)[(r - 1) * P + k];
                 v[r] = cmul2(v[r], make_float2(t.x, t.y), make_float2(t.z, t.w));
             }
         } else {
@@ -411,7 +411,8 @@ int jsdr_fft_create(jsdr_fft **out, int n, int rate)
         const int R = l.radix[pass];
         const double base = -2.0 * 3.14159265358979323846 / ((double)P * (double)R);
         if (tw_direct(P, R)) {
-            for (int r = 0; r < R; r++)
+            for (int r = 1; r < R; r++)  // row 0 is all ones and never read (and its 256 bytes decide whether a
+                                         // fourth 2048-point workgroup fits a CU's LDS)
                 for (int k = 0; k < P; k++) {
                     double ang = base * (double)k * (double)r;
                     const float2 w = make_float2((float)cos(ang), (float)sin(ang));

@@ -42,6 +42,12 @@ for step in "$@"; do
                  run pmc_sq1 600 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --output-format csv -d gpurun_out/pmc_sq1_$R -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-validate ;;
     pmc_sq2)     rm -rf gpurun_out/pmc_sq2_$R
                  run pmc_sq2 600 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d gpurun_out/pmc_sq2_$R -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-validate ;;
+    pmc_fft1)    rm -rf gpurun_out/pmc_fft1_$R
+                 run pmc_fft1 600 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --output-format csv -d gpurun_out/pmc_fft1_$R -- python3 bench.py --workload fft --steps 2 --warmup 1 --no-cpu-baseline --no-validate
+                 python tools/pmc_summary.py gpurun_out/pmc_fft1_$R | tee gpurun_out/pmc_fft1_summary.txt ;;
+    pmc_fft2)    rm -rf gpurun_out/pmc_fft2_$R
+                 run pmc_fft2 600 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d gpurun_out/pmc_fft2_$R -- python3 bench.py --workload fft --steps 2 --warmup 1 --no-cpu-baseline --no-validate
+                 python tools/pmc_summary.py gpurun_out/pmc_fft2_$R | tee gpurun_out/pmc_fft2_summary.txt ;;
     dbg)         run dbg 300 python tools/dbg_fftmode.py ;;
     trig)        run trig 300 python tools/trig_stats.py ;;
     bench_fft)   run bench_fft 300 python bench.py --workload fft --no-cpu-baseline ;;
