@@ -13,6 +13,7 @@
 // tolerance of BASELINE.json, JTransforms' own rounding being unknowable (source absent).
 #include "fft_common.h"
 #include <math.h>
+#include <stdlib.h>
 #include <vector>
 
 namespace jsdr {
@@ -360,7 +361,12 @@ static int fft_run(jsdr_fft *h, const void *in_dev, int in_kind, int out_kind, l
     long long per_cu = (long long)(160 * 1024 / l.lds_bytes);
     if (per_cu < 1) per_cu = 1;
     if (per_cu * l.block > 2048) per_cu = 2048 / l.block;
-    long long cap = (long long)h->num_cu * per_cu * 4;
+    static const int mult = [] {
+        const char *e = getenv("JSDR_FFT_GRID_MULT");  // tuning knob: workgroups per resident slot
+        const int v = e ? atoi(e) : 0;
+        return v > 0 ? v : 4;
+    }();
+    long long cap = (long long)h->num_cu * per_cu * mult;
     int grid = (int)(groups < cap ? groups : cap);
     l.launch(a, grid, s);
     JSDR_LAUNCH_CHECK();

@@ -37,6 +37,8 @@ for step in "$@"; do
     bench_noov)  JSDR_NO_OVERLAP=1 run bench_noov 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline ;;
     bench_rd80)  JSDR_FRONT_RD=80 run bench_rd80 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline ;;
     fec_bench)   run fec_bench 300 python tools/fec_bench.py ;;
+    hbm)         run hbm_build 120 hipcc --offload-arch=gfx950 -O3 -o /tmp/mb_hbm tools/microbench_hbm.hip
+                 run hbm 120 /tmp/mb_hbm ;;
     counters)    run counters 120 rocprofv3 -L ;;
     pmc_sq1)     rm -rf gpurun_out/pmc_sq1_$R
                  run pmc_sq1 600 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --output-format csv -d gpurun_out/pmc_sq1_$R -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-validate ;;
@@ -51,6 +53,10 @@ for step in "$@"; do
     dbg)         run dbg 300 python tools/dbg_fftmode.py ;;
     trig)        run trig 300 python tools/trig_stats.py ;;
     bench_fft)   run bench_fft 300 python bench.py --workload fft --no-cpu-baseline ;;
+    bench_fft_m16) JSDR_FFT_GRID_MULT=16 run bench_fft_m16 300 python bench.py --workload fft --no-cpu-baseline ;;
+    bench_fft_m64) JSDR_FFT_GRID_MULT=64 run bench_fft_m64 300 python bench.py --workload fft --no-cpu-baseline ;;
+    bench_fft_m1k) JSDR_FFT_GRID_MULT=1024 run bench_fft_m1k 300 python bench.py --workload fft --no-cpu-baseline ;;
+    bench_fft_m1) JSDR_FFT_GRID_MULT=1 run bench_fft_m1 300 python bench.py --workload fft --no-cpu-baseline ;;
     bench_fft_b) JSDR_LIB=$PWD/java-sdr_amd/libjsdr_hip_b.so run bench_fft_b 300 python bench.py --workload fft --no-cpu-baseline ;;
     bench_quick_b) JSDR_LIB=$PWD/java-sdr_amd/libjsdr_hip_b.so run bench_quick_b 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline ;;
     bench_bpsk)  run bench_bpsk 400 python bench.py --workload bpsk --no-cpu-baseline ;;
