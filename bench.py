@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-validate", action="store_true")
+    ap.add_argument("--waterfall-width", type=int, default=0,
+                    help="also paint every PSD frame as a waterfall pixel row of this width (waterfall.java:87-109)")
     ap.add_argument("--fft-acquire", action="store_true", help="demodulator in FFT-acquire mode (bpsk-dofft=1) instead of tune mode")
     return ap.parse_args()
 
@@ -194,6 +196,9 @@ def main():
         gathered = torch.empty(N * S * info["slot_bytes"], dtype=torch.uint8, device="cuda")
 
     fft_timer = [J.Timer() for _ in range(a.steps)] if fft else []
+    wf = a.waterfall_width if fft else 0
+    d_pix = J.DeviceBuffer(nframes * wf * 4) if wf else None
+    wf_timer = [J.Timer() for _ in range(a.steps)] if wf else []
 
     def step(i, timed):
         if fft is not None:
@@ -202,6 +207,12 @@ def main():
             fft.batch_i16(d_iq, nframes, d_psd)
             if timed:
                 fft_timer[i].stop(None)
+            if wf:
+                if timed:
+                    wf_timer[i].start(None)
+                J.waterfall_lines_dev(d_psd, nframes, N_FFT, wf, d_pix)
+                if timed:
+                    wf_timer[i].stop(None)
         if dem is not None:
             dem.batch_i16(d_iq, 2 * L, L)
             if N > 1:
@@ -242,6 +253,9 @@ def main():
     if fft is not None:
         ms = [t.elapsed_ms() for t in fft_timer]
         kern["k_fft"] = (float(np.sum(ms)), len(ms), BYTES_PER_SAMPLE["fft"])
+    if wf:
+        ms = [t.elapsed_ms() for t in wf_timer]
+        kern["k_waterfall"] = (float(np.sum(ms)), len(ms), 4.0 + 4.0 * wf / N_FFT)  # reads the PSD, writes the pixels
     if dem is not None:
         for name, (ms, cnt) in dem.profile_read().items():
             if cnt:

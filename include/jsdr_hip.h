@@ -158,6 +158,37 @@ int jsdr_synth_tones(int16_t *out_dev, int64_t frame0, int64_t nframes, int n, c
                      int noise_gain, uint64_t key, void *stream);
 int jsdr_synth_payloads(uint64_t seed, int stream0, int nstreams, int nframes, uint8_t *out_dev, void *stream);
 
+/* ------------------------------------------------------------------ formats either side of the path
+ * waterfall.paintLine / getMax (waterfall.java:87-109): one pixel row per PSD frame as fft.receive publishes it
+ * ("fft-psd", n bins + 2).  step = (float)n/width; pixel p = max of bins [(int)(p*step), +(int)step), mapped
+ * 255-(int)(m*-2.55f), clamped to 0..255, scaled into the peak colour (0xRRGGBB, Color.CYAN = 0x00ffff in the
+ * reference) with /256, stored at column (p + width/2) % width as ARGB with alpha 0xff.  Bit-exact.          */
+int jsdr_waterfall_lines(const float *psd_dev /*[nframes][n+2]*/, int64_t nframes, int n, int width,
+                         uint32_t peak_rgb, uint32_t *pix_dev /*[nframes][width]*/, void *stream);
+
+/* IQ recordings -> the stream-major device layout raw[S][stride] of the batch calls.
+ * JavaAudio.openFile (JavaAudio.java:369-395): a file AudioSystem reads as PCM_SIGNED 16-bit little-endian with
+ * the configured channel count and rate (compareFormat :397-406); RIFF/WAVE is parsed here, other containers and
+ * the AudioSystem format conversion are not.  A file without a RIFF header is taken as the headerless dump
+ * recorder.receive (recorder.java:66-74) / FCD.main (FCD.java:286-303) write.                                  */
+#define JSDR_REC_RAW 0
+#define JSDR_REC_WAV 1
+typedef struct jsdr_recording_info {
+    int format;          /* JSDR_REC_RAW / JSDR_REC_WAV */
+    int encoding;        /* WAVE format tag: 1 = PCM */
+    int channels, rate, bits;
+    int64_t frames;      /* sample frames (one per IQ pair) in the file */
+    int64_t data_offset; /* byte offset of the first sample */
+} jsdr_recording_info;
+int jsdr_recording_probe(const char *path, int raw_channels, jsdr_recording_info *info);
+/* loads frames [first_frame, first_frame+nframes) of every file to raw_dev + s*stream_stride_i16 as int16 (I,Q)
+ * pairs; a mono file (channels = 1, audio-mode-I) becomes (I,0) pairs -- equal to JavaAudio.java:286-288 as long
+ * as the Q correction passed to the kernels is 0; a short file is zero-filled and frames_loaded[s] (optional)
+ * says how many frames were real.  Format mismatch -> JSDR_ERR "Incompatible audio format" (:388).             */
+int jsdr_recordings_load(const char *const *paths, int nstreams, int channels, int rate, int64_t first_frame,
+                         int64_t nframes, int16_t *raw_dev, int64_t stream_stride_i16, int64_t *frames_loaded,
+                         void *stream);
+
 #ifdef __cplusplus
 }
 #endif

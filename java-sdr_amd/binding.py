@@ -440,6 +440,42 @@ def unpack_slot(slot, info):
     return dict(header=dict(zip(names, (int(v) for v in hdr[:11]))), bits=bits, fec=fec)
 
 
+# ------------------------------------------------------------------ formats either side
+class RecordingInfo(C.Structure):
+    _fields_ = [("format", C.c_int), ("encoding", C.c_int), ("channels", C.c_int), ("rate", C.c_int),
+                ("bits", C.c_int), ("frames", C.c_int64), ("data_offset", C.c_int64)]
+
+
+def waterfall_lines(psd, n, width, peak_rgb=0x00FFFF):
+    """waterfall.paintLine for every frame of psd [nframes][n+2] -> uint32 ARGB [nframes][width]"""
+    psd = np.ascontiguousarray(psd, np.float32).reshape(-1, n + 2)
+    d_in = DeviceBuffer.from_host(psd)
+    d_out = DeviceBuffer(4 * psd.shape[0] * width)
+    _check(lib().jsdr_waterfall_lines(_addr(d_in), C.c_int64(psd.shape[0]), n, width, C.c_uint32(peak_rgb),
+                                      _addr(d_out), None), "jsdr_waterfall_lines")
+    return d_out.to_host(np.uint32).reshape(psd.shape[0], width)
+
+
+def waterfall_lines_dev(psd_dev, nframes, n, width, pix_dev, peak_rgb=0x00FFFF, stream=None):
+    _check(lib().jsdr_waterfall_lines(_addr(psd_dev), C.c_int64(nframes), n, width, C.c_uint32(peak_rgb),
+                                      _addr(pix_dev), stream), "jsdr_waterfall_lines")
+
+
+def recording_probe(path, raw_channels=2):
+    info = RecordingInfo()
+    _check(lib().jsdr_recording_probe(os.fsencode(path), raw_channels, C.byref(info)), "jsdr_recording_probe")
+    return info
+
+
+def recordings_load(paths, channels, rate, first_frame, nframes, raw_dev, stream_stride_i16):
+    """files -> raw_dev[s*stride ...] as int16 (I,Q) pairs; returns the frames really read per stream"""
+    arr = (C.c_char_p * len(paths))(*[os.fsencode(p) for p in paths])
+    got = (C.c_int64 * len(paths))()
+    _check(lib().jsdr_recordings_load(arr, len(paths), channels, rate, C.c_int64(first_frame), C.c_int64(nframes),
+                                      _addr(raw_dev), C.c_int64(stream_stride_i16), got, None), "jsdr_recordings_load")
+    return list(got)
+
+
 # ------------------------------------------------------------------ synthetic inputs
 def synth_payloads(seed, stream0, nstreams, nframes, out_dev=None, stream=None):
     own = out_dev is None

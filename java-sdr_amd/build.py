@@ -25,6 +25,7 @@ SOURCES = {
     "fir_phase.hip": ["-ffp-contract=off"],
     "fec.hip": [],
     "synth.hip": [],
+    "formats.hip": [],
     "bpsk.hip": ["-ffp-contract=off"],
     "bpsk_fft.hip": ["-ffp-contract=off"],
 }

@@ -1,7 +1,10 @@
 // harness.cpp -- headless stand-in for JavaAudio.run (JavaAudio.java:195-329) that drives the C++ plugin
 // mirror exactly as the reference's audio thread drives its handlers: read blen bytes, hand them to the
 // raw handlers, convert int16 -> float with the I/Q corrections (:276-293), hand the float frame to every
-// IAudioHandler in registration order.   usage: jsdr_harness <file.raw> [rate=96000] [blen=8192] [ic] [qc]
+// IAudioHandler in registration order.  A RIFF/WAVE recording is accepted like JavaAudio.openFile does
+// (:369-395: PCM-16, 2 channels, the configured rate -- otherwise "Incompatible audio format"); anything else
+// is a headerless dump (recorder.java:66-74).
+//   usage: jsdr_harness <file.raw|file.wav> [rate=96000] [blen=8192] [ic] [qc]
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -58,8 +61,18 @@ int main(int argc, char **argv)
     }
     const int rate = argc > 2 ? atoi(argv[2]) : 96000, blen = argc > 3 ? atoi(argv[3]) : 8192;
     const int ic = argc > 4 ? atoi(argv[4]) : 0, qc = argc > 5 ? atoi(argv[5]) : 0;
+    jsdr_recording_info info;
+    if (jsdr_recording_probe(argv[1], 2, &info) != JSDR_OK) {
+        fprintf(stderr, "%s\n", jsdr_last_error());
+        return 2;
+    }
+    if (info.format == JSDR_REC_WAV && (info.encoding != 1 || info.bits != 16 || info.channels != 2 || info.rate != rate)) {
+        fprintf(stderr, "Incompatible audio format: %s: encoding %d, %d Hz, %d bit, %d channel(s)\n", argv[1], info.encoding,
+                info.rate, info.bits, info.channels);
+        return 2;
+    }
     FILE *fp = fopen(argv[1], "rb");
-    if (!fp) {
+    if (!fp || fseek(fp, (long)info.data_offset, SEEK_SET) != 0) {
         perror(argv[1]);
         return 2;
     }
@@ -69,6 +82,7 @@ int main(int argc, char **argv)
         FileAudio audio(rate, blen, ic, qc);
         phase ph(&cfg, &bus, &audio);
         fft ff(&cfg, &bus, &audio);
+        waterfall wf(&bus, &audio, 1024, 64);
         FUNcubeBPSKDemod dem(0, &cfg, &bus, &audio);
         std::vector<uint8_t> raw((size_t)blen);
         std::vector<float> buf((size_t)2 * blen / 4);
@@ -88,9 +102,13 @@ int main(int argc, char **argv)
             const auto &psd = bus.vals["fft-psd"].f;
             int32_t c[JSDR_BPSK_NCOUNTERS];
             dem.counters(c);
-            printf("frame %d fft-psd max %.4f dB @ %.1f Hz phase-max %.6f bpsk raw=%d ds=%d bit=%d fec=%d dec=%d tune=%d\n",
+            const uint32_t *row = wf.pixels().data();
+            int bright = 0;
+            for (int p = 1; p < wf.getWidth(); p++)
+                if ((row[p] & 0xff) > (row[bright] & 0xff)) bright = p;
+            printf("frame %d fft-psd max %.4f dB @ %.1f Hz phase-max %.6f bpsk raw=%d ds=%d bit=%d fec=%d dec=%d tune=%d wf-peak-col=%d\n",
                    frame, psd[psd.size() - 1], psd[psd.size() - 2], ph.maxAbs(), c[0], c[1], c[2], c[3], c[4],
-                   bus.vals["FUNcube0-bpsk-tune"].i);
+                   bus.vals["FUNcube0-bpsk-tune"].i, bright);
             frame++;
         }
     } catch (const std::exception &e) {

@@ -136,6 +136,55 @@ class fft : public IAudioHandler, public IRawHandler {
     std::vector<float> psd;
 };
 
+// ------------------------------------------------------------------ waterfall.java (headless: the pixel array)
+// Listens for "fft-psd" (waterfall.java:28-36) and keeps the pixel image paintComponent maintains (:62-80): every
+// new PSD scrolls the image down one row and paints the top row with paintLine (:87-100) -- computed on the device.
+class waterfall : public IPublishListener {
+  public:
+    waterfall(IPublish *pub, IAudio *, int width_, int height_) : width(width_), height(height_)
+    {
+        pixs.assign((size_t)width * height, 0xff000000u);  // g.fillRect black (:49-50)
+        if (jsdr_malloc(&d_pix, sizeof(uint32_t) * (size_t)width) != JSDR_OK) jsdr_throw("waterfall");
+        pub->listen(this);
+    }
+    ~waterfall() override
+    {
+        jsdr_free(d_pix);
+        jsdr_free(d_psd);
+    }
+    void notify(const std::string &key, const PublishValue &val) override
+    {
+        if (key != "fft-psd" || val.is_int || val.f.size() < 3) return;
+        const int n = (int)val.f.size() - 2;
+        if (n != bins) {  // "audio-change": a new frame size restarts the image (:38-45)
+            jsdr_free(d_psd);
+            d_psd = nullptr;
+            if (jsdr_malloc(&d_psd, sizeof(float) * val.f.size()) != JSDR_OK) jsdr_throw("waterfall");
+            bins = n;
+            std::fill(pixs.begin(), pixs.end(), 0xff000000u);
+        }
+        if (jsdr_memcpy_h2d(d_psd, val.f.data(), sizeof(float) * val.f.size()) != JSDR_OK ||
+            jsdr_waterfall_lines(static_cast<const float *>(d_psd), 1, n, width, peak, static_cast<uint32_t *>(d_pix),
+                                 nullptr) != JSDR_OK)
+            jsdr_throw("waterfall.paintLine");
+        // System.arraycopy(pixs, 0, pixs, width, len - width) then the new top row (:76-78)
+        std::memmove(pixs.data() + width, pixs.data(), sizeof(uint32_t) * (size_t)width * (size_t)(height - 1));
+        if (jsdr_memcpy_d2h(pixs.data(), d_pix, sizeof(uint32_t) * (size_t)width) != JSDR_OK) jsdr_throw("waterfall");
+        lines++;
+    }
+    const std::vector<uint32_t> &pixels() const { return pixs; }
+    int getWidth() const { return width; }
+    int getHeight() const { return height; }
+    long linesPainted() const { return lines; }
+    uint32_t peak = 0x00ffff;  // Color.CYAN (:15)
+
+  private:
+    int width, height, bins = -1;
+    long lines = 0;
+    std::vector<uint32_t> pixs;
+    void *d_psd = nullptr, *d_pix = nullptr;
+};
+
 // ------------------------------------------------------------------ FECDecoder.java
 class FECDecoder {
   public:

@@ -64,6 +64,9 @@ float jo_phase_maxabs(const float *dpy, int len);                /* :75-80 */
 /* column means: returns number of columns emitted; pix[c], avgi[c], avgq[c]      */
 int   jo_phase_columns(const float *dpy, int len, int bx, int *pix, float *avgi, float *avgq);
 
+/* ---- waterfall.java:87-109 (the consumer of the PSD) ------------ */
+void jo_waterfall_line(const float *psd, int n, int width, unsigned peak_rgb, unsigned *pix);
+
 /* ---- FECDecoder.java ----------------------------------------------------------- */
 int  jo_fec_decode(const uint8_t raw[5200], uint8_t out[256]);   /* :703-852 */
 void jo_fec_encode(const uint8_t data[256], uint8_t sym[5200]);  /* :538-688 (encode_FEC40) */

@@ -79,6 +79,8 @@ def _proto(L):
     L.jo_phase_maxabs.restype = C.c_float
     L.jo_phase_maxabs.argtypes = [vp, C.c_int]
     L.jo_phase_columns.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp]
+    L.jo_waterfall_line.restype = None
+    L.jo_waterfall_line.argtypes = [vp, C.c_int, C.c_int, C.c_uint, vp]
     L.jo_mix64.restype = C.c_uint64
     L.jo_mix64.argtypes = [C.c_uint64]
     L.jo_synth_payload.argtypes = [C.c_uint64, C.c_int, C.c_int, vp]
@@ -186,6 +188,15 @@ def fir_complex_mod(a, b):
     for i in range(a.shape[0]):
         lib().jo_fir_complex_mod(ptr(a[i]), ptr(b[i]), ptr(out[i]))
     return out
+
+
+# ---------------------------------------------------------------- waterfall.java
+def waterfall_line(psd, n, width, peak_rgb=0x00FFFF):
+    psd = np.ascontiguousarray(psd, np.float32)
+    assert psd.size == n + 2
+    pix = np.empty(width, np.uint32)
+    lib().jo_waterfall_line(ptr(psd), n, width, peak_rgb, ptr(pix))
+    return pix
 
 
 # ---------------------------------------------------------------- phase.java

@@ -62,3 +62,27 @@ def test_harness_reports_handler_failure_like_the_audio_loop(golden_dir):
     fx = os.path.join(golden_dir, "sine4410.raw")
     r = subprocess.run([HARNESS, fx, "96000", "40000"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 1 and "Audio oops" in r.stderr
+
+
+def test_harness_reads_wav_like_openfile_and_paints_the_waterfall(golden_dir):
+    """JavaAudio.openFile (:369-395): the reference's own WAV fixture (44.1 kHz stereo PCM-16) is accepted at the
+    matching rate, refused ("Incompatible audio format") at another; the waterfall listener's top row puts the
+    tone where waterfall.paintLine would"""
+    import wave
+    fx = os.path.join(golden_dir, "sine4410.wav")
+    r = subprocess.run([HARNESS, fx, "44100", "8192"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("frame")]
+    with wave.open(fx, "rb") as w:
+        data = np.frombuffer(w.readframes(w.getnframes()), "<i2")
+    assert len(lines) == data.size // 4096
+    buf = O.convert_i16(data)
+    for k in (0, 1, len(lines) - 1):
+        m = re.search(r"max (\S+) dB @ (\S+) Hz .* wf-peak-col=(\d+)", lines[k])
+        ref = O.fft_receive(buf[k * 4096:(k + 1) * 4096], 44100)
+        assert abs(float(m.group(1)) - ref[2049]) < 1e-3 and float(m.group(2)) == ref[2048]
+        row = O.waterfall_line(ref, 2048, 1024)
+        want_cols = np.flatnonzero((row & 0xFF) == (row & 0xFF).max())
+        assert int(m.group(3)) in want_cols
+    r = subprocess.run([HARNESS, fx, "96000", "8192"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2 and "Incompatible audio format" in r.stderr

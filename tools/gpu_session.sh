@@ -28,6 +28,8 @@ for step in "$@"; do
                  run micro 120 /tmp/mb_fp64 ;;
     bench_small) run bench_small 300 python bench.py --steps 3 --warmup 1 --streams 128 --samples 1048576 --cpu-seconds 3 ;;
     bench)       run bench 600 python bench.py ;;
+    tests_fmt)   run tests_fmt 600 python -m pytest tests/test_gpu_formats.py -m gpu -q -x -p no:cacheprovider --timeout 600 ;;
+    tests_host)  run tests_host 600 python -m pytest tests/test_gpu_host.py -m gpu -q -x -p no:cacheprovider --timeout 600 ;;
     tests_bpsk)  run tests_bpsk 600 python -m pytest tests/test_gpu_bpsk.py -m gpu -q -x -p no:cacheprovider --timeout 600 ;;
     bench_quick) run bench_quick 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline ;;
     bench_acq)   run bench_acq 400 python bench.py --workload bpsk --fft-acquire --steps 3 --warmup 1 --no-cpu-baseline ;;
@@ -57,6 +59,7 @@ for step in "$@"; do
     bench_fft_m64) JSDR_FFT_GRID_MULT=64 run bench_fft_m64 300 python bench.py --workload fft --no-cpu-baseline ;;
     bench_fft_m1k) JSDR_FFT_GRID_MULT=1024 run bench_fft_m1k 300 python bench.py --workload fft --no-cpu-baseline ;;
     bench_fft_m1) JSDR_FFT_GRID_MULT=1 run bench_fft_m1 300 python bench.py --workload fft --no-cpu-baseline ;;
+    bench_fft_wf) run bench_fft_wf 300 python bench.py --workload fft --waterfall-width 1024 --no-cpu-baseline ;;
     bench_fft_b) JSDR_LIB=$PWD/java-sdr_amd/libjsdr_hip_b.so run bench_fft_b 300 python bench.py --workload fft --no-cpu-baseline ;;
     bench_quick_b) JSDR_LIB=$PWD/java-sdr_amd/libjsdr_hip_b.so run bench_quick_b 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline ;;
     bench_bpsk)  run bench_bpsk 400 python bench.py --workload bpsk --no-cpu-baseline ;;
