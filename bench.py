@@ -33,7 +33,9 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # algorithmic HBM bytes per IQ sample: 4 B int16 pair read; fft writes 4 B psd (+8 B/frame);
 # the demodulator writes ~0.0125 B of bits
-BYTES_PER_SAMPLE = {"fft": 4.0 + 4.0 * 2050.0 / 2048.0, "bpsk": 4.0125, "pipeline": 4.0 + 4.0 * 2050.0 / 2048.0 + 0.0125}
+BYTES_PER_SAMPLE = {"fft": 4.0 + 4.0 * 2050.0 / 2048.0, "bpsk": 4.0125, "pipeline": 4.0 + 4.0 * 2050.0 / 2048.0 + 0.0125,
+                    "demod": 8.0}  # demod.java: 4 B read, one (L,R) int16 pair written per sample
+DEMOD_MODES = {"raw": 1, "am": 2, "nfm": 3, "wfm": 4}
 N_FFT = 2048
 RATE = 96000
 SEED = 20020109
@@ -44,12 +46,14 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="pipeline", choices=["pipeline", "fft", "bpsk"])
+    ap.add_argument("--workload", default="pipeline", choices=["pipeline", "fft", "bpsk", "demod"])
     ap.add_argument("--streams", type=int, default=1024, help="streams per GPU")
     ap.add_argument("--samples", type=int, default=1048576, help="IQ samples per stream per step")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-validate", action="store_true")
+    ap.add_argument("--demod-mode", default="am", choices=["am", "nfm", "wfm", "raw"],
+                    help="--workload demod: the demod.java chain (8f next-3) with filter, down-conversion and AGC on")
     ap.add_argument("--waterfall-width", type=int, default=0,
                     help="also paint every PSD frame as a waterfall pixel row of this width (waterfall.java:87-109)")
     ap.add_argument("--fft-acquire", action="store_true", help="demodulator in FFT-acquire mode (bpsk-dofft=1) instead of tune mode")
@@ -106,17 +110,31 @@ def cpu_baseline(O, workload, L, seconds):
     psd = np.empty(N_FFT + 2, np.float32)
 
     def one_pass(s, dem):
+        if workload.startswith("demod"):
+            buf = streams_f[s]
+            for f in range(nframes):
+                dem.receive(buf[2 * f * N_FFT:2 * (f + 1) * N_FFT])
+            return
         if workload in ("pipeline", "fft"):
             O.lib().jo_bench_fft(streams[s].ctypes.data, nframes, N_FFT, RATE, psd.ctypes.data if s == 0 else None)
         if workload in ("pipeline", "bpsk"):
             dem.receive_i16(streams[s])
 
+    def make_dem():
+        if not workload.startswith("demod"):
+            return O.Bpsk()
+        d = O.Demod(RATE)
+        d.configure(DEMOD_MODES[workload.split(":")[1]], 1, 1, 1)
+        d.weights(3000, 15000)
+        return d
+
+    streams_f = [O.convert_i16(x) for x in streams] if workload.startswith("demod") else None
     # calibrate on one thread
-    dem0 = O.Bpsk()
+    dem0 = make_dem()
     t0 = time.perf_counter()
     one_pass(0, dem0)
     t1 = time.perf_counter() - t0
-    dems = [O.Bpsk() for _ in range(cores)]
+    dems = [make_dem() for _ in range(cores)]
     # one parallel round to see what a pass costs with every thread busy (shared caches, CPU quota)
     th = [threading.Thread(target=one_pass, args=(s, dems[s])) for s in range(cores)]
     t0 = time.perf_counter()
@@ -186,6 +204,12 @@ def main():
     d_psd = J.DeviceBuffer(nframes * (N_FFT + 2) * 4) if fft else None
     dem = J.Bpsk(rate=RATE, blen=4 * N_FFT, tuning=12000, do_fft=int(a.fft_acquire), nstreams=S, max_batch_samples=L) \
         if a.workload in ("pipeline", "bpsk") else None
+    amfm = d_audio = None
+    if a.workload == "demod":
+        amfm = J.Demod(rate=RATE, n=N_FFT, nstreams=S, max_batch_samples=L)
+        amfm.configure(DEMOD_MODES[a.demod_mode], 1, 1, 1)
+        amfm.weights(3000, 15000)
+        d_audio = J.DeviceBuffer(S * L * 4)
     slots = gathered = gstream = None
     if dem is not None and N > 1:
         # the gather runs on its own stream: packing waits there for the side-stream tail of this step, so the
@@ -213,6 +237,8 @@ def main():
                 J.waterfall_lines_dev(d_psd, nframes, N_FFT, wf, d_pix)
                 if timed:
                     wf_timer[i].stop(None)
+        if amfm is not None:
+            amfm.batch_i16(d_iq, 2 * L, L, d_audio, 2 * L)
         if dem is not None:
             dem.batch_i16(d_iq, 2 * L, L)
             if N > 1:
@@ -236,6 +262,9 @@ def main():
     if dem is not None:
         dem.profile_read()
         dem.profile_enable(True)
+    if amfm is not None:
+        amfm.profile_read()
+        amfm.profile_enable(True)
     t0 = time.perf_counter()
     for i in range(a.steps):
         step(i, True)
@@ -256,6 +285,11 @@ def main():
     if wf:
         ms = [t.elapsed_ms() for t in wf_timer]
         kern["k_waterfall"] = (float(np.sum(ms)), len(ms), 4.0 + 4.0 * wf / N_FFT)  # reads the PSD, writes the pixels
+    if amfm is not None:
+        amfm.profile_enable(False)
+        for name, (ms, cnt) in amfm.profile_read().items():
+            if cnt:
+                kern[name] = (ms, cnt, BYTES_PER_SAMPLE["demod"])
     if dem is not None:
         for name, (ms, cnt) in dem.profile_read().items():
             if cnt:
@@ -300,21 +334,24 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f64" if a.workload != "fft" else "f32",
+            "dtype": "f64" if a.workload in ("pipeline", "bpsk") else "f32",
             "data": "synthetic",
             "config": {"workload": {"pipeline": "fft.java PSD of every 2048-sample frame + FUNcubeBPSKDemod "
                                                 "(tune mode) + FECDecoder, same HBM-resident IQ",
                                     "fft": "batched 2048-pt waterfall FFT+PSD (BASELINE config 2)",
-                                    "bpsk": "FUNcubeBPSKDemod tune mode + FECDecoder (BASELINE config 4)"}[a.workload],
+                                    "bpsk": "FUNcubeBPSKDemod tune mode + FECDecoder (BASELINE config 4)",
+                                    "demod": f"demod.java {a.demod_mode.upper()} chain (8f next-3): 21-tap complex FIR + NCO "
+                                             "+ detector + AGC -> int16 stereo, 2048-sample frames"}[a.workload],
                        "streams_per_gpu": S, "samples_per_stream": L, "rate_hz": RATE, "frame": N_FFT,
-                       "input_bytes_per_gpu": S * L * 4, "variant": "exact-order FP64 (bit-exact bits/bytes)" + (", FFT-acquire front end" if a.fft_acquire else ", tune mode"),
+                       "input_bytes_per_gpu": S * L * 4, "variant": ("exact-order float32 (bit-exact int16 audio)" if a.workload == "demod" else
+                                   "exact-order FP64 (bit-exact bits/bytes)" + (", FFT-acquire front end" if a.fft_acquire else ", tune mode")),
                        "parallelism": f"streams sharded over {N} GPU(s)" + (", RCCL all-gather of result slots" if N > 1 else "")},
             "roofline": roofline,
             "hbm_read_roofline_frac": round(total / dt * 4.0 / (N * HBM_PEAK_GBS * 1e9), 4),
             "validated": validated,
         }
         if N == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(O, a.workload, L, a.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(O, a.workload if a.workload != "demod" else "demod:" + a.demod_mode, L, a.cpu_seconds)
         print(json.dumps(out), flush=True)
     if N > 1:
         dist.barrier()

@@ -158,6 +158,44 @@ int jsdr_synth_tones(int16_t *out_dev, int64_t frame0, int64_t nframes, int n, c
                      int noise_gain, uint64_t key, void *stream);
 int jsdr_synth_payloads(uint64_t seed, int stream0, int nstreams, int nframes, uint8_t *out_dev, void *stream);
 
+/* ------------------------------------------------------------------ demod.java
+ * The AM/FM IAudioHandler, demod.receive (demod.java:398-483), batched over `nstreams` independent streams that
+ * share one set of controls: 21-tap complex float band-pass (filter(), :378-396), down-conversion NCO
+ * (:423-434), AM envelope minus its running mean (:448-451) or FM quadrature-delay detector (:453-461), the
+ * frame maximum, AGC and the (short)(x*32767f) stereo output (:465-481).  Float arithmetic in the reference's
+ * order (no FMA), so int16 outputs are bit-identical to the CPU restatement; cos/sin of the NCO phase come
+ * from the device math library.  A frame is blen/size samples (`sam.length/2`, :229-231); AGC and
+ * the AM mean are per frame, the filter, NCO and FM states run on across frames and calls.                    */
+typedef struct jsdr_demod jsdr_demod;
+#define JSDR_DEMOD_OFF 0 /* demod.java:39-43 */
+#define JSDR_DEMOD_RAW 1
+#define JSDR_DEMOD_AM 2
+#define JSDR_DEMOD_NFM 3
+#define JSDR_DEMOD_WFM 4
+int jsdr_demod_create(jsdr_demod **h, int rate, int nsamples_per_frame, int nstreams, int64_t max_batch_samples);
+int jsdr_demod_destroy(jsdr_demod *h);
+/* "demod-mode", "demod-fir-enable", the down-conversion toggle, "demod-agc-enable" (:36-38,198-203) */
+int jsdr_demod_configure(jsdr_demod *h, int mode, int dofir, int dodwn, int doagc);
+/* demod.weights() (:341-375) for the band [flo, fhi] Hz (flo = INT_MIN: the all-pass impulse); clears every
+ * stream's delay line and (band-pass) restarts the carrier phase; returns the 21 weights and phi if asked.
+ * The range check of filterMove (:300-312) is the caller's (host mirror: java_sdr::demod).                     */
+int jsdr_demod_weights(jsdr_demod *h, int flo, int fhi, float w_out[21], float *phi_out);
+/* whole frames of every stream; audio_dev receives one (L,R) int16 pair per input sample (:473-478) */
+int jsdr_demod_batch_i16(jsdr_demod *h, const int16_t *raw_dev, int64_t stream_stride_i16, int64_t nsamples,
+                         int ic, int qc, int16_t *audio_dev, int64_t audio_stride_i16, void *stream);
+int jsdr_demod_batch_f32(jsdr_demod *h, const float *iq_dev, int64_t stream_stride_f32, int64_t nsamples,
+                         int16_t *audio_dev, int64_t audio_stride_i16, void *stream);
+/* IAudioHandler.receive(float[]) for a 1-stream handle: one frame (2n floats) in, 2n int16 out */
+int jsdr_demod_receive_f32(jsdr_demod *h, const float *buf_host, int16_t *audio_host);
+/* the reference's `max` / `avg` fields after the last frame of the last call (:465-467) */
+int jsdr_demod_frame_stats(jsdr_demod *h, int stream, float *max_out, float *avg_out);
+int jsdr_demod_state(jsdr_demod *h, float *car_out, float *phi_out);
+/* per-kernel HIP-event timing of the batch calls (bench.py), as jsdr_bpsk_profile_* */
+int jsdr_demod_profile_enable(jsdr_demod *h, int on);
+int jsdr_demod_profile_count(void);
+const char *jsdr_demod_profile_name(int kernel);
+int jsdr_demod_profile_read(jsdr_demod *h, double *ms_total, int *launches);
+
 /* ------------------------------------------------------------------ formats either side of the path
  * waterfall.paintLine / getMax (waterfall.java:87-109): one pixel row per PSD frame as fft.receive publishes it
  * ("fft-psd", n bins + 2).  step = (float)n/width; pixel p = max of bins [(int)(p*step), +(int)step), mapped

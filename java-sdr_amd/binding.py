@@ -44,8 +44,9 @@ def lib():
         _lib = C.CDLL(_SO)
         _lib.jsdr_last_error.restype = C.c_char_p
         _lib.jsdr_bpsk_profile_name.restype = C.c_char_p
+        _lib.jsdr_demod_profile_name.restype = C.c_char_p
         for name in EXPORTED_SYMBOLS:
-            if name not in ("jsdr_last_error", "jsdr_bpsk_profile_name"):
+            if name not in ("jsdr_last_error", "jsdr_bpsk_profile_name", "jsdr_demod_profile_name"):
                 getattr(_lib, name).restype = C.c_int
     return _lib
 
@@ -438,6 +439,72 @@ def unpack_slot(slot, info):
         fec.append((int(rc), int(bi), np.frombuffer(slot[o + 8:o + 264], np.uint8)))
     names = ["nbits", "nfec"] + COUNTER_NAMES[:9]
     return dict(header=dict(zip(names, (int(v) for v in hdr[:11]))), bits=bits, fec=fec)
+
+
+# ------------------------------------------------------------------ demod.java
+class Demod:
+    """demod.receive batched over streams: mode 0 OFF, 1 RAW, 2 AM, 3 NFM, 4 WFM (demod.java:39-43)"""
+
+    def __init__(self, rate=96000, n=2048, nstreams=1, max_batch_samples=None):
+        self.rate, self.n, self.S = rate, n, nstreams
+        self.max_batch = max_batch_samples or n
+        self.h = C.c_void_p()
+        _check(lib().jsdr_demod_create(C.byref(self.h), rate, n, nstreams, C.c_int64(self.max_batch)), "jsdr_demod_create")
+
+    def configure(self, mode, dofir=0, dodwn=0, doagc=0):
+        _check(lib().jsdr_demod_configure(self.h, mode, dofir, dodwn, doagc), "jsdr_demod_configure")
+
+    def weights(self, flo, fhi):
+        w = np.empty(21, np.float32)
+        phi = C.c_float()
+        _check(lib().jsdr_demod_weights(self.h, flo, fhi, _addr(w), C.byref(phi)), "jsdr_demod_weights")
+        return w, np.float32(phi.value)
+
+    def batch_i16(self, raw_dev, stride_i16, nsamples, audio_dev, audio_stride_i16, ic=0, qc=0, stream=None):
+        _check(lib().jsdr_demod_batch_i16(self.h, _addr(raw_dev), C.c_int64(stride_i16), C.c_int64(nsamples), ic, qc,
+                                          _addr(audio_dev), C.c_int64(audio_stride_i16), C.c_void_p(stream)),
+               "jsdr_demod_batch_i16")
+
+    def batch_host_i16(self, raw, nsamples, ic=0, qc=0):
+        """raw: int16 [S][2*nsamples] on the host -> audio int16 [S][2*nsamples]"""
+        raw = np.ascontiguousarray(raw, np.int16).reshape(self.S, 2 * nsamples)
+        d_in = DeviceBuffer.from_host(raw)
+        d_out = DeviceBuffer(raw.nbytes)
+        self.batch_i16(d_in, 2 * nsamples, nsamples, d_out, 2 * nsamples, ic, qc)
+        return d_out.to_host(np.int16).reshape(self.S, 2 * nsamples)
+
+    def receive(self, buf):
+        buf = np.ascontiguousarray(buf, np.float32)
+        assert buf.size == 2 * self.n
+        out = np.empty(2 * self.n, np.int16)
+        _check(lib().jsdr_demod_receive_f32(self.h, _addr(buf), _addr(out)), "jsdr_demod_receive_f32")
+        return out
+
+    def frame_stats(self, stream=0):
+        mx, av = C.c_float(), C.c_float()
+        _check(lib().jsdr_demod_frame_stats(self.h, stream, C.byref(mx), C.byref(av)), "jsdr_demod_frame_stats")
+        return np.float32(mx.value), np.float32(av.value)
+
+    def state(self):
+        car, phi = C.c_float(), C.c_float()
+        _check(lib().jsdr_demod_state(self.h, C.byref(car), C.byref(phi)), "jsdr_demod_state")
+        return np.float32(car.value), np.float32(phi.value)
+
+    def profile_enable(self, on):
+        _check(lib().jsdr_demod_profile_enable(self.h, int(on)), "jsdr_demod_profile_enable")
+
+    def profile_read(self):
+        k = lib().jsdr_demod_profile_count()
+        ms = np.zeros(k, np.float64)
+        cnt = np.zeros(k, np.int32)
+        _check(lib().jsdr_demod_profile_read(self.h, _addr(ms), _addr(cnt)), "jsdr_demod_profile_read")
+        return {lib().jsdr_demod_profile_name(i).decode(): (float(ms[i]), int(cnt[i])) for i in range(k)}
+
+    def __del__(self):
+        try:
+            lib().jsdr_demod_destroy(self.h)
+        except Exception:
+            pass
 
 
 # ------------------------------------------------------------------ formats either side (SURVEY 8f next-4)

@@ -26,6 +26,7 @@ SOURCES = {
     "fec.hip": [],
     "synth.hip": [],
     "formats.hip": [],
+    "demod.hip": ["-ffp-contract=off"],
     "bpsk.hip": ["-ffp-contract=off"],
     "bpsk_fft.hip": ["-ffp-contract=off"],
 }

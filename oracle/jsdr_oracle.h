@@ -64,6 +64,20 @@ float jo_phase_maxabs(const float *dpy, int len);                /* :75-80 */
 /* column means: returns number of columns emitted; pix[c], avgi[c], avgq[c]      */
 int   jo_phase_columns(const float *dpy, int len, int bx, int *pix, float *avgi, float *avgq);
 
+/* ---- demod.java:341-483 (the AM/FM IAudioHandler) ---------------- */
+enum { JO_MODE_OFF = 0, JO_MODE_RAW = 1, JO_MODE_AM = 2, JO_MODE_NFM = 3, JO_MODE_WFM = 4 }; /* :39-43 */
+#define JO_DEMOD_MAX_FRAME 32768
+typedef struct {
+    int rate, mode, dofir, dodwn, doagc, flo, fhi, fof;
+    float fir[42], wfir[21];
+    float car, phi, max, avg, li, lq;
+    float sam[2 * JO_DEMOD_MAX_FRAME];
+} jo_demod_t;
+void jo_demod_init(jo_demod_t *d, int rate);
+void jo_demod_weights(jo_demod_t *d);                               /* :341-375 */
+int  jo_demod_filter_move(jo_demod_t *d, int lo, int hi);           /* :300-312 */
+void jo_demod_receive(jo_demod_t *d, const float *buf, int len, int16_t *out); /* :398-483 */
+
 /* ---- waterfall.java:87-109 (the consumer of the PSD) ------------ */
 void jo_waterfall_line(const float *psd, int n, int width, unsigned peak_rgb, unsigned *pix);
 

@@ -80,6 +80,12 @@ def _proto(L):
     L.jo_phase_maxabs.argtypes = [vp, C.c_int]
     L.jo_phase_columns.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp]
     L.jo_waterfall_line.restype = None
+    for fn in (L.jo_demod_init, L.jo_demod_weights, L.jo_demod_receive):
+        fn.restype = None
+    L.jo_demod_init.argtypes = [vp, C.c_int]
+    L.jo_demod_weights.argtypes = [vp]
+    L.jo_demod_filter_move.argtypes = [vp, C.c_int, C.c_int]
+    L.jo_demod_receive.argtypes = [vp, vp, C.c_int, vp]
     L.jo_waterfall_line.argtypes = [vp, C.c_int, C.c_int, C.c_uint, vp]
     L.jo_mix64.restype = C.c_uint64
     L.jo_mix64.argtypes = [C.c_uint64]
@@ -188,6 +194,51 @@ def fir_complex_mod(a, b):
     for i in range(a.shape[0]):
         lib().jo_fir_complex_mod(ptr(a[i]), ptr(b[i]), ptr(out[i]))
     return out
+
+
+# ---------------------------------------------------------------- demod.java
+class _JoDemod(C.Structure):
+    _fields_ = [("rate", C.c_int), ("mode", C.c_int), ("dofir", C.c_int), ("dodwn", C.c_int), ("doagc", C.c_int),
+                ("flo", C.c_int), ("fhi", C.c_int), ("fof", C.c_int), ("fir", C.c_float * 42), ("wfir", C.c_float * 21),
+                ("car", C.c_float), ("phi", C.c_float), ("max", C.c_float), ("avg", C.c_float), ("li", C.c_float),
+                ("lq", C.c_float), ("sam", C.c_float * (2 * 32768))]
+
+
+class Demod:
+    """one stream of demod.java (demod.java:341-483)"""
+
+    def __init__(self, rate=96000):
+        self.d = _JoDemod()
+        lib().jo_demod_init(C.byref(self.d), rate)
+
+    def configure(self, mode, dofir=0, dodwn=0, doagc=0):
+        self.d.mode, self.d.dofir, self.d.dodwn, self.d.doagc = mode, dofir, dodwn, doagc
+
+    def weights(self, flo, fhi):
+        self.d.flo, self.d.fhi = flo, fhi
+        lib().jo_demod_weights(C.byref(self.d))
+        return np.array(self.d.wfir[:], np.float32), np.float32(self.d.phi)
+
+    def filter_move(self, lo, hi):
+        return bool(lib().jo_demod_filter_move(C.byref(self.d), lo, hi))
+
+    def receive(self, buf):
+        buf = np.ascontiguousarray(buf, np.float32)
+        out = np.empty(buf.size, np.int16)
+        lib().jo_demod_receive(C.byref(self.d), ptr(buf), buf.size, ptr(out))
+        return out
+
+    @property
+    def max(self):
+        return np.float32(self.d.max)
+
+    @property
+    def avg(self):
+        return np.float32(self.d.avg)
+
+    @property
+    def car(self):
+        return np.float32(self.d.car)
 
 
 # ---------------------------------------------------------------- waterfall.java

@@ -28,6 +28,7 @@ for step in "$@"; do
                  run micro 120 /tmp/mb_fp64 ;;
     bench_small) run bench_small 300 python bench.py --steps 3 --warmup 1 --streams 128 --samples 1048576 --cpu-seconds 3 ;;
     bench)       run bench 600 python bench.py ;;
+    tests_demod) run tests_demod 600 python -m pytest tests/test_gpu_demod.py -m gpu -q -x -p no:cacheprovider --timeout 600 ;;
     tests_fmt)   run tests_fmt 600 python -m pytest tests/test_gpu_formats.py -m gpu -q -x -p no:cacheprovider --timeout 600 ;;
     tests_host)  run tests_host 600 python -m pytest tests/test_gpu_host.py -m gpu -q -x -p no:cacheprovider --timeout 600 ;;
     tests_bpsk)  run tests_bpsk 600 python -m pytest tests/test_gpu_bpsk.py -m gpu -q -x -p no:cacheprovider --timeout 600 ;;
@@ -53,12 +54,15 @@ for step in "$@"; do
                  run pmc_fft2 600 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d gpurun_out/pmc_fft2_$R -- python3 bench.py --workload fft --steps 2 --warmup 1 --no-cpu-baseline --no-validate
                  python tools/pmc_summary.py gpurun_out/pmc_fft2_$R | tee gpurun_out/pmc_fft2_summary.txt ;;
     dbg)         run dbg 300 python tools/dbg_fftmode.py ;;
+    dbg_demod)   run dbg_demod 300 python tools/dbg_demod.py ;;
     trig)        run trig 300 python tools/trig_stats.py ;;
     bench_fft)   run bench_fft 300 python bench.py --workload fft --no-cpu-baseline ;;
     bench_fft_m16) JSDR_FFT_GRID_MULT=16 run bench_fft_m16 300 python bench.py --workload fft --no-cpu-baseline ;;
     bench_fft_m64) JSDR_FFT_GRID_MULT=64 run bench_fft_m64 300 python bench.py --workload fft --no-cpu-baseline ;;
     bench_fft_m1k) JSDR_FFT_GRID_MULT=1024 run bench_fft_m1k 300 python bench.py --workload fft --no-cpu-baseline ;;
     bench_fft_m1) JSDR_FFT_GRID_MULT=1 run bench_fft_m1 300 python bench.py --workload fft --no-cpu-baseline ;;
+    bench_demod) run bench_demod 400 python bench.py --workload demod --steps 5 --warmup 2 --cpu-seconds 4 ;;
+    bench_demod_fm) run bench_demod_fm 400 python bench.py --workload demod --demod-mode nfm --steps 5 --warmup 2 --no-cpu-baseline ;;
     bench_fft_wf) run bench_fft_wf 300 python bench.py --workload fft --waterfall-width 1024 --no-cpu-baseline ;;
     bench_fft_b) JSDR_LIB=$PWD/java-sdr_amd/libjsdr_hip_b.so run bench_fft_b 300 python bench.py --workload fft --no-cpu-baseline ;;
     bench_quick_b) JSDR_LIB=$PWD/java-sdr_amd/libjsdr_hip_b.so run bench_quick_b 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline ;;
