@@ -84,6 +84,12 @@ int main(int argc, char **argv)
         fft ff(&cfg, &bus, &audio);
         waterfall wf(&bus, &audio, 1024, 64);
         FUNcubeBPSKDemod dem(0, &cfg, &bus, &audio);
+        cfg.setIntConfig("demod-mode", demod::MODE_AM);
+        cfg.setIntConfig("demod-fir-enable", 1);
+        cfg.setIntConfig("demod-agc-enable", 1);
+        cfg.setIntConfig("demod-filter-low", -12000);
+        cfg.setIntConfig("demod-filter-high", -6000);
+        demod am(&cfg, &bus, &audio);
         std::vector<uint8_t> raw((size_t)blen);
         std::vector<float> buf((size_t)2 * blen / 4);
         int frame = 0;
@@ -106,9 +112,14 @@ int main(int argc, char **argv)
             int bright = 0;
             for (int p = 1; p < wf.getWidth(); p++)
                 if ((row[p] & 0xff) > (row[bright] & 0xff)) bright = p;
-            printf("frame %d fft-psd max %.4f dB @ %.1f Hz phase-max %.6f bpsk raw=%d ds=%d bit=%d fec=%d dec=%d tune=%d wf-peak-col=%d\n",
+            float amax = 0, aavg = 0;
+            am.levels(amax, aavg);
+            long asum = 0;
+            for (int16_t v : am.audioBytes()) asum += v;
+            printf("frame %d fft-psd max %.4f dB @ %.1f Hz phase-max %.6f bpsk raw=%d ds=%d bit=%d fec=%d dec=%d tune=%d wf-peak-col=%d "
+                   "am-max=%.9g am-avg=%.9g am-sum=%ld\n",
                    frame, psd[psd.size() - 1], psd[psd.size() - 2], ph.maxAbs(), c[0], c[1], c[2], c[3], c[4],
-                   bus.vals["FUNcube0-bpsk-tune"].i, bright);
+                   bus.vals["FUNcube0-bpsk-tune"].i, bright, amax, aavg, asum);
             frame++;
         }
     } catch (const std::exception &e) {

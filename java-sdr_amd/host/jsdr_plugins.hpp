@@ -268,6 +268,102 @@ class FUNcubeBPSKDemod : public IAudioHandler {
     bool doFFT = false;
 };
 
+// ------------------------------------------------------------------ demod.java
+// The AM/FM IAudioHandler (demod.java:31-483) without its Swing menu and javax.sound output: config keys, the
+// filterMove range check (:300-312, the only caller of weights()), the mode / toggle actions (:184-203) and
+// receive() -> the frame's audio bytes (what the reference writes to `bbf`, :469-481).
+class demod : public IAudioHandler {
+  public:
+    static constexpr int MODE_OFF = 0, MODE_RAW = 1, MODE_AM = 2, MODE_NFM = 3, MODE_WFM = 4;  // :39-43
+    demod(IConfig *cfg, IPublish *pub, IAudio *aud) : config(cfg), publish(pub)
+    {
+        mode = cfg->getIntConfig("demod-mode", MODE_OFF);                  // :82
+        dofir = cfg->getIntConfig("demod-fir-enable", 0) > 0;              // :83
+        doagc = cfg->getIntConfig("demod-agc-enable", 0) > 0;              // :84
+        flo = cfg->getIntConfig("demod-filter-low", INT32_MIN);            // :86
+        fhi = cfg->getIntConfig("demod-filter-high", INT32_MAX);           // :87
+        setup(aud);
+    }
+    ~demod() override
+    {
+        if (audio) audio->remHandler(this);
+        jsdr_demod_destroy(h);
+    }
+    // demod.java:220-241
+    void setup(IAudio *aud)
+    {
+        audio = aud;
+        AudioDescriptor ad = audio->getAudioDescriptor();
+        if (h) jsdr_demod_destroy(h);
+        h = nullptr;
+        n = ad.blen / ad.size;  // sam.length / 2
+        rate = ad.rate;
+        if (jsdr_demod_create(&h, ad.rate, n, 1, n) != JSDR_OK) jsdr_throw("demod.setup");
+        audioOut.assign((size_t)2 * n, 0);
+        apply();
+        filterMove(0, 0);
+        audio->remHandler(this);
+        audio->addHandler(this);
+    }
+    // the menu actions (:184-203)
+    void setMode(int m)
+    {
+        mode = m;
+        config->setIntConfig("demod-mode", mode);
+        apply();
+    }
+    void toggleAgc() { doagc = !doagc; config->setIntConfig("demod-agc-enable", doagc ? 1 : 0); apply(); }
+    void toggleFir() { dofir = !dofir; config->setIntConfig("demod-fir-enable", dofir ? 1 : 0); apply(); }
+    void toggleDown() { dodwn = !dodwn; apply(); }
+    // demod.java:300-312: move the band edges; weights() only runs when the new band is ordered and inside
+    // (-rate/2, rate/2) -- at the default filter points it never does and the weights stay zero
+    bool filterMove(int lo, int hi)
+    {
+        lo = (int)((uint32_t)lo + (uint32_t)flo);  // Java int arithmetic wraps
+        hi = (int)((uint32_t)hi + (uint32_t)fhi);
+        if (lo < hi && lo > (-rate / 2) && hi < rate / 2) {
+            flo = lo;
+            fhi = hi;
+            if (jsdr_demod_weights(h, flo, fhi, nullptr, nullptr) != JSDR_OK) jsdr_throw("demod.weights");
+            if (publish) {
+                PublishValue v;
+                v.i = flo;
+                publish->setPublish("demod-filter-low", v);
+                v.i = fhi;
+                publish->setPublish("demod-filter-high", v);
+            }
+            return true;
+        }
+        return false;
+    }
+    // demod.java:398-483
+    void receive(const float *buf, size_t len) override
+    {
+        if (len != (size_t)2 * n) throw std::runtime_error("demod.receive: buffer length != 2*blen/size");
+        if (jsdr_demod_receive_f32(h, buf, audioOut.data()) != JSDR_OK) jsdr_throw("demod.receive");
+    }
+    const std::vector<int16_t> &audioBytes() const { return audioOut; }  // L,R per sample (:473-478)
+    void levels(float &max, float &avg)
+    {
+        if (jsdr_demod_frame_stats(h, 0, &max, &avg) != JSDR_OK) jsdr_throw("demod.levels");
+    }
+    int filterLow() const { return flo; }
+    int filterHigh() const { return fhi; }
+
+  private:
+    void apply()
+    {
+        if (h && jsdr_demod_configure(h, mode, dofir, dodwn, doagc) != JSDR_OK) jsdr_throw("demod.configure");
+    }
+    IConfig *config = nullptr;
+    IPublish *publish = nullptr;
+    IAudio *audio = nullptr;
+    jsdr_demod *h = nullptr;
+    int n = 0, rate = 0, mode = MODE_OFF, flo = INT32_MIN, fhi = INT32_MAX;
+    bool dofir = false, dodwn = false, doagc = false;
+    std::vector<int16_t> audioOut;
+};
+
 // ------------------------------------------------------------------ phase.java
 class phase : public IAudioHandler {
   public:

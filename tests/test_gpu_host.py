@@ -86,3 +86,22 @@ def test_harness_reads_wav_like_openfile_and_paints_the_waterfall(golden_dir):
         assert int(m.group(3)) in want_cols
     r = subprocess.run([HARNESS, fx, "96000", "8192"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 2 and "Incompatible audio format" in r.stderr
+
+
+def test_harness_demod_handler_matches_oracle(golden_dir):
+    """the demod mirror in the audio loop (AM, filter + AGC on, band -12..-6 kHz around the fixture's tone):
+    per-frame max / avg and the sum of the audio bytes equal the oracle's"""
+    fx = os.path.join(golden_dir, "sine4410.raw")
+    r = subprocess.run([HARNESS, fx, "96000", "8192"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("frame")]
+    buf = O.convert_i16(np.fromfile(fx, dtype="<i2"))
+    o = O.Demod(96000)
+    o.configure(2, 1, 0, 1)
+    o.d.flo, o.d.fhi = -12000, -6000
+    assert o.filter_move(0, 0)  # setup() -> filterMove(0,0) -> weights()
+    for k, line in enumerate(lines):
+        m = re.search(r"am-max=(\S+) am-avg=(\S+) am-sum=(-?\d+)", line)
+        audio = o.receive(buf[k * 4096:(k + 1) * 4096])
+        assert np.float32(float(m.group(1))) == o.max and np.float32(float(m.group(2))) == o.avg
+        assert int(m.group(3)) == int(audio.astype(np.int64).sum())
