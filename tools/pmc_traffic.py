@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""tools/pmc_traffic.py <fetch_dir> <write_dir> <out.json> -- per-kernel HBM bytes per launch from the two separate
+rocprofv3 passes (--pmc FETCH_SIZE, --pmc WRITE_SIZE).  Units and the gfx950 correction as MI355X_MICROARCH.md
+prescribes: counters are KiB; FETCH_SIZE reports half the bytes of coalesced streaming reads => hbm = 2*FETCH + WRITE."""
+import collections
+import csv
+import glob
+import json
+import re
+import sys
+
+
+def per_kernel(d, counter):
+    acc = collections.defaultdict(list)
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != counter:
+                continue
+            name = r["Kernel_Name"]
+            m = re.search(r"(k_[a-z0-9_]+)", name)
+            if not m:
+                continue
+            key = m.group(1)
+            if key == "k_front_dma":
+                key = "k_front"  # bench.py names the front end k_front whichever variant runs
+            acc[key].append(float(r["Counter_Value"]) * 1024.0)
+    return {k: sum(v) / len(v) for k, v in acc.items()}
+
+
+fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
+write = per_kernel(sys.argv[2], "WRITE_SIZE")
+out = {"_note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (tools/gpu_session.sh pmc_rd pmc_wr), "
+                "bench.py --steps 2 --warmup 1, S=1024 x L=2^20.  Counter unit = KiB.  Per MI355X_MICROARCH.md the gfx950 "
+                "FETCH_SIZE reports half the bytes of coalesced streaming reads: hbm_bytes = 2*FETCH + WRITE "
+                "(calibration: k_synth_dbpsk writes exactly 4.295e9 B; k_fft reads 4.295e9 B of int16 IQ)."}
+for k in sorted(set(fetch) | set(write)):
+    f, w = fetch.get(k, 0.0), write.get(k, 0.0)
+    out[k] = {"fetch_size_bytes_raw": int(f), "write_size_bytes": int(w), "hbm_bytes_per_launch": int(2 * f + w)}
+json.dump(out, open(sys.argv[3], "w"), indent=1)
+print(json.dumps({k: v["hbm_bytes_per_launch"] for k, v in out.items() if k != "_note"}))
