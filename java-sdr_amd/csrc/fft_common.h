@@ -135,6 +135,7 @@ struct FftArgs {
     long long nframes;
     int rate;
     int ic, qc;
+    int split = 0;  // 1: frame f of the kernel is the even (f&1 == 0) / odd half of input frame f>>1 (2N samples)
 };
 
 struct Best {
@@ -148,9 +149,15 @@ struct MixedPlan {
     int threads = 0;
     size_t lds_bytes = 0;
     int tw_count = 0;
+    // n = 2*half (19200 = 2*9600): two half-size transforms of the even / odd samples + one radix-2 combine pass
+    bool split2 = false;
+    int half_tw_count = 0;  // the half plan's tables come first; `half` combine twiddles follow
 };
 bool mixed_plan(int n, MixedPlan &p);
 void mixed_twiddles(const MixedPlan &p, float2 *out);
 int mixed_launch(const MixedPlan &p, const FftArgs &a, int in_kind, int out_kind, int grid, hipStream_t st);
+// split2 plans: half-size spectra of `nframes` frames into tmp [2*nframes][n/2], then the combine pass
+int mixed_launch_split2(const MixedPlan &p, const FftArgs &a, int in_kind, int out_kind, int num_cu, float2 *tmp,
+                        long long tmp_frames, hipStream_t st);
 
 }  // namespace jsdr

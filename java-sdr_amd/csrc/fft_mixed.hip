@@ -98,19 +98,22 @@ __device__ __forceinline__ void mixed_pass(const FftArgs &a, long long frame, in
         const int b = it * T + tid;
         if (b < NB) {
             if constexpr (FIRST) {
+                // split: this transform is the even / odd half of input frame (frame >> 1), 2N samples long
+                const long long fbase = a.split ? (frame >> 1) * (2LL * N) + (frame & 1) : frame * (long long)N;
+                const int st = a.split ? 2 : 1;
                 if constexpr (IN == IN_I16) {
-                    const int *src = reinterpret_cast<const int *>(a.in) + frame * N;
+                    const int *src = reinterpret_cast<const int *>(a.in) + fbase;
 #pragma unroll
                     for (int r = 0; r < R; r++) {
-                        int w = src[b + r * NB];
+                        int w = src[(b + r * NB) * st];
                         int si = java_short_add((int)(short)(w & 0xffff), a.ic);
                         int sq = java_short_add(w >> 16, a.qc);
                         v[it][r] = make_float2(i16_to_float_java(si), i16_to_float_java(sq));
                     }
                 } else {
-                    const float2 *src = reinterpret_cast<const float2 *>(a.in) + frame * N;
+                    const float2 *src = reinterpret_cast<const float2 *>(a.in) + fbase;
 #pragma unroll
-                    for (int r = 0; r < R; r++) v[it][r] = src[b + r * NB];
+                    for (int r = 0; r < R; r++) v[it][r] = src[(b + r * NB) * st];
                 }
             } else {
 #pragma unroll
@@ -237,6 +240,7 @@ static int mixed_launch_t(const MixedPlan &p, const FftArgs &a, int in_kind, int
     if (in_kind == IN_I16 && out_kind == OUT_PSD) return go(k_fft_mixed<N, T, IN_I16, OUT_PSD, R0, R1, R2, R3, R4>);
     if (in_kind == IN_F32 && out_kind == OUT_PSD) return go(k_fft_mixed<N, T, IN_F32, OUT_PSD, R0, R1, R2, R3, R4>);
     if (in_kind == IN_F32 && out_kind == OUT_SPEC) return go(k_fft_mixed<N, T, IN_F32, OUT_SPEC, R0, R1, R2, R3, R4>);
+    if (in_kind == IN_I16 && out_kind == OUT_SPEC) return go(k_fft_mixed<N, T, IN_I16, OUT_SPEC, R0, R1, R2, R3, R4>);
     set_error("fft: no mixed-radix kernel for in=%d out=%d", in_kind, out_kind);
     return JSDR_ERR;
 }
@@ -256,6 +260,17 @@ bool mixed_plan(int n, MixedPlan &p)
         p.nrad = 5;
         for (int i = 0; i < 5; i++) p.radix[i] = r[i];
         p.threads = 320;
+    } else if (n == 19200) {
+        // 192 kHz (FUNcube Dongle Pro+): the frame does not fit one workgroup's LDS; X[k] = E[k] + W^k O[k],
+        // X[k+n/2] = E[k] - W^k O[k] with E, O the 9600-point transforms of the even / odd samples
+        MixedPlan hp;
+        if (!mixed_plan(9600, hp)) return false;
+        p = hp;
+        p.n = n;
+        p.split2 = true;
+        p.half_tw_count = hp.tw_count;
+        p.tw_count = hp.tw_count + n / 2;
+        return true;
     } else {
         return false;
     }
@@ -272,6 +287,16 @@ bool mixed_plan(int n, MixedPlan &p)
 
 void mixed_twiddles(const MixedPlan &p, float2 *out)
 {
+    if (p.split2) {
+        MixedPlan hp;
+        mixed_plan(p.n / 2, hp);
+        mixed_twiddles(hp, out);
+        for (int k = 0; k < p.n / 2; k++) {
+            const long double ang = -2.0L * 3.14159265358979323846264338327950288L * (long double)k / (long double)p.n;
+            out[p.half_tw_count + k] = make_float2((float)cosl(ang), (float)sinl(ang));
+        }
+        return;
+    }
     int P = p.radix[0];
     size_t o = 0;
     for (int i = 1; i < p.nrad; i++) {
@@ -291,6 +316,119 @@ void mixed_twiddles(const MixedPlan &p, float2 *out)
         }
         P *= R;
     }
+}
+
+// radix-2 combine of the even / odd half spectra (one 256-thread workgroup per frame) + the PSD epilogue of
+// fft.receive (fft.java:201-227) or the plain spectrum
+template <int OUT>
+__global__ __launch_bounds__(256) void k_fft_combine2(const float2 *__restrict__ tmp, const float2 *__restrict__ w, int half,
+                                                      long long nframes, int rate, float *__restrict__ out)
+{
+    __shared__ float red_val[4];
+    __shared__ int red_idx[4];
+    const int tid = threadIdx.x;
+    const int N = 2 * half;
+    for (long long frame = blockIdx.x; frame < nframes; frame += gridDim.x) {
+        const float2 *E = tmp + (2 * frame) * half, *O = E + half;
+        Best best;
+        best.v = -3.402823466e+38f;
+        best.k = 0x7fffffff;
+        for (int k = tid; k < half; k += 256) {
+            const float2 e = E[k];
+            const float2 t = cmul(O[k], w[k]);
+            const float2 x0 = cadd(e, t), x1 = csub(e, t);
+            if constexpr (OUT == OUT_SPEC) {
+                float2 *dst = reinterpret_cast<float2 *>(out) + frame * N;
+                dst[k] = x0;
+                dst[k + half] = x1;
+            } else {
+                const float cf = (2.0f / (float)N) * (2.0f / (float)N);
+                float *dst = out + frame * (N + 2);
+                const float d0 = 3.0102999566398120f * __log2f((x0.x * x0.x + x0.y * x0.y) * cf);  // fft.java:207
+                const float d1 = 3.0102999566398120f * __log2f((x1.x * x1.x + x1.y * x1.y) * cf);
+                dst[k] = d0;
+                dst[k + half] = d1;
+                if (d0 > best.v || (d0 == best.v && k < best.k)) {
+                    best.v = d0;
+                    best.k = k;
+                }
+                if (d1 > best.v || (d1 == best.v && k + half < best.k)) {
+                    best.v = d1;
+                    best.k = k + half;
+                }
+            }
+        }
+        if constexpr (OUT == OUT_PSD) {
+            float bestv = best.v;
+            int bestk = best.k;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const float ov = __shfl_xor(bestv, off, 64);
+                const int ok = __shfl_xor(bestk, off, 64);
+                if (ov > bestv || (ov == bestv && ok < bestk)) {
+                    bestv = ov;
+                    bestk = ok;
+                }
+            }
+            if ((tid & 63) == 0) {
+                red_val[tid >> 6] = bestv;
+                red_idx[tid >> 6] = bestk;
+            }
+            __syncthreads();
+            if (tid == 0) {
+                for (int wv = 1; wv < 4; wv++) {
+                    const float ov = red_val[wv];
+                    const int ok = red_idx[wv];
+                    if (ov > bestv || (ov == bestv && ok < bestk)) {
+                        bestv = ov;
+                        bestk = ok;
+                    }
+                }
+                // fft.java:201-224
+                int p = (bestv > -3.402823466e+38f) ? 2 * bestk : -1;
+                const float m = (p >= 0) ? bestv : -3.402823466e+38f;
+                const int datlen = 2 * N;
+                if (p >= datlen / 2) p -= datlen;
+                const int hz = (int)((unsigned)p * (unsigned)rate) / datlen;
+                float *dst = out + frame * (N + 2);
+                dst[N] = (float)hz;
+                dst[N + 1] = m;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+int mixed_launch_split2(const MixedPlan &p, const FftArgs &a, int in_kind, int out_kind, int num_cu, float2 *tmp,
+                        long long tmp_frames, hipStream_t st)
+{
+    MixedPlan hp;
+    if (!mixed_plan(p.n / 2, hp)) {
+        set_error("fft: no half plan for n=%d", p.n);
+        return JSDR_ERR;
+    }
+    const int half = p.n / 2;
+    const size_t in_elem = (in_kind == IN_I16) ? sizeof(int) : sizeof(float2);
+    for (long long f0 = 0; f0 < a.nframes; f0 += tmp_frames) {
+        const long long nf = (a.nframes - f0) < tmp_frames ? (a.nframes - f0) : tmp_frames;
+        FftArgs h = a;
+        h.in = static_cast<const unsigned char *>(a.in) + (size_t)f0 * (size_t)p.n * in_elem;
+        h.out = reinterpret_cast<float *>(tmp);
+        h.nframes = 2 * nf;
+        h.split = 1;
+        const long long cap = (long long)num_cu * 2;
+        if (mixed_launch(hp, h, in_kind, OUT_SPEC, (int)(h.nframes < cap ? h.nframes : cap), st) != JSDR_OK) return JSDR_ERR;
+        const long long gcap = (long long)num_cu * 8;
+        const unsigned grid = (unsigned)(nf < gcap ? nf : gcap);
+        if (out_kind == OUT_PSD)
+            hipLaunchKernelGGL(k_fft_combine2<OUT_PSD>, dim3(grid), dim3(256), 0, st, tmp, a.tw + p.half_tw_count, half, nf, a.rate,
+                               a.out + (size_t)f0 * ((size_t)p.n + 2));
+        else
+            hipLaunchKernelGGL(k_fft_combine2<OUT_SPEC>, dim3(grid), dim3(256), 0, st, tmp, a.tw + p.half_tw_count, half, nf,
+                               a.rate, a.out + (size_t)f0 * 2 * (size_t)p.n);
+        JSDR_LAUNCH_CHECK();
+    }
+    return JSDR_OK;
 }
 
 int mixed_launch(const MixedPlan &p, const FftArgs &a, int in_kind, int out_kind, int grid, hipStream_t st)

@@ -326,6 +326,8 @@ struct jsdr_fft {
     int num_cu = 256;
     bool mixed = false;  // non power-of-two frame: fft_mixed.hip
     MixedPlan mplan;
+    DevBuf<float2> split_tmp;  // split2 plans: half spectra of a chunk of frames
+    long long split_frames = 0;
 };
 
 static int fft_run(jsdr_fft *h, const void *in_dev, int in_kind, int out_kind, long long nframes, int ic, int qc,
@@ -344,6 +346,8 @@ static int fft_run(jsdr_fft *h, const void *in_dev, int in_kind, int out_kind, l
         a.rate = h->rate;
         a.ic = ic;
         a.qc = qc;
+        if (h->mplan.split2)
+            return mixed_launch_split2(h->mplan, a, in_kind, out_kind, h->num_cu, h->split_tmp.p, h->split_frames, s);
         long long cap = (long long)h->num_cu * 2;
         return mixed_launch(h->mplan, a, in_kind, out_kind, (int)(nframes < cap ? nframes : cap), s);
     }
@@ -383,8 +387,8 @@ int jsdr_fft_create(jsdr_fft **out, int n, int rate)
     const bool pow2 = n >= 64 && n <= 8192 && (n & (n - 1)) == 0;
     const bool mixed = !pow2 && mixed_plan(n, mp);
     JSDR_REQUIRE(pow2 || mixed,
-                 "jsdr_fft_create: n=%d unsupported (powers of two 64..8192, and 4800 / 9600 = the reference's "
-                 "default 48 / 96 kHz frames)", n);
+                 "jsdr_fft_create: n=%d unsupported (powers of two 64..8192, and 4800 / 9600 / 19200 = the reference's "
+                 "default 48 / 96 / 192 kHz frames)", n);
     JSDR_REQUIRE(rate > 0, "jsdr_fft_create: rate must be positive");
     int dev = 0;
     JSDR_HIP_TRY(hipGetDevice(&dev));
@@ -405,6 +409,13 @@ int jsdr_fft_create(jsdr_fft **out, int n, int rate)
             set_error("jsdr_fft_create: mixed-radix setup failed");
             jsdr_fft_destroy(h);
             return JSDR_ERR;
+        }
+        if (mp.split2) {
+            h->split_frames = 2048;  // 2048 x 19200 x 8 B = 315 MB of half spectra per chunk
+            if (h->split_tmp.alloc((size_t)h->split_frames * (size_t)n) != JSDR_OK) {
+                jsdr_fft_destroy(h);
+                return JSDR_ERR;
+            }
         }
         *out = h;
         return JSDR_OK;
@@ -458,6 +469,7 @@ int jsdr_fft_destroy(jsdr_fft *h)
     h->tw.release();
     h->in_stage.release();
     h->out_stage.release();
+    h->split_tmp.release();
     delete h;
     return JSDR_OK;
 }

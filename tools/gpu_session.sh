@@ -29,6 +29,7 @@ for step in "$@"; do
     bench_small) run bench_small 300 python bench.py --steps 3 --warmup 1 --streams 128 --samples 1048576 --cpu-seconds 3 ;;
     bench)       run bench 600 python bench.py ;;
     tests_demod) run tests_demod 600 python -m pytest tests/test_gpu_demod.py -m gpu -q -x -p no:cacheprovider --timeout 600 ;;
+    tests_fft)   run tests_fft 900 python -m pytest tests/test_gpu_fft.py -m gpu -q -x -p no:cacheprovider --timeout 800 ;;
     tests_fmt)   run tests_fmt 600 python -m pytest tests/test_gpu_formats.py -m gpu -q -x -p no:cacheprovider --timeout 600 ;;
     tests_host)  run tests_host 600 python -m pytest tests/test_gpu_host.py -m gpu -q -x -p no:cacheprovider --timeout 600 ;;
     tests_bpsk)  run tests_bpsk 600 python -m pytest tests/test_gpu_bpsk.py -m gpu -q -x -p no:cacheprovider --timeout 600 ;;
