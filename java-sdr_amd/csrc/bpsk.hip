@@ -393,10 +393,37 @@ __global__ __launch_bounds__(128, 4) void k_front_dma(FrontArgs a)
         }
         const int4 *xq = reinterpret_cast<const int4 *>(rawL + RD * lane);
         const unsigned *kq = reinterpret_cast<const unsigned *>(kL + RD * lane);
+        // The walk is software pipelined two quads deep: while quad q is multiplied out, the sin/cos entries of
+        // quad q-1 and the samples / tuner indices of quad q-2 are on their way from LDS.  (Per quad there are two
+        // DEPENDENT LDS round trips -- indices first, then the table entries they select -- and the kernel is
+        // latency bound: 1.81 ms at 5 workgroups per CU, 3.3 ms at 2.)  The fences keep the compiler from hoisting
+        // the whole unrolled walk's reads to the top (it spills) while leaving this much in flight.
+        int4 W[G::NSQ];
+        unsigned K[G::NSQ];
+        double CS[G::NSQ][8];
+        auto load_raw = [&](int q) {
+            W[q] = xq[q];
+            K[q] = kq[q];
+        };
+        auto load_sc = [&](int q) {
+            if constexpr (MIX) {
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    const int k = (K[q] >> (8 * t)) & 0xff;
+                    CS[q][2 * t] = sc[k];
+                    CS[q][2 * t + 1] = sc[256 + k];
+                }
+            }
+        };
+        load_raw(G::NSQ - 1);
+        if constexpr (G::NSQ >= 2) load_raw(G::NSQ - 2);
+        load_sc(G::NSQ - 1);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int q = G::NSQ - 1; q >= 0; q--) {
-            const int4 w4 = xq[q];
-            const unsigned k4 = kq[q];
+            if (q - 2 >= 0) load_raw(q - 2);
+            if (q - 1 >= 0) load_sc(q - 1);
+            const int4 w4 = W[q];
 #pragma unroll
             for (int t = 3; t >= 0; t--) {
                 const int m = 4 * q + t;
@@ -410,9 +437,8 @@ __global__ __launch_bounds__(128, 4) void k_front_dma(FrontArgs a)
                     double di = (double)i16_to_float_java(si);
                     double dq = (double)i16_to_float_java(sq);
                     if constexpr (MIX) {  // :388-390 component-wise, not a complex multiply
-                        const int k = (k4 >> (8 * t)) & 0xff;
-                        di = di * sc[k];
-                        dq = dq * sc[256 + k];
+                        di = di * CS[q][2 * t];
+                        dq = dq * CS[q][2 * t + 1];
                     }
 #pragma unroll
                     for (int r = 0; r < R; r++) {
@@ -424,8 +450,6 @@ __global__ __launch_bounds__(128, 4) void k_front_dma(FrontArgs a)
                     }
                 }
             }
-            // one quad at a time: without the fences the compiler hoists every LDS read (samples, indices and
-            // their sin/cos table entries) of the unrolled walk to the top and spills them
 #pragma unroll
             for (int r = 0; r < R; r++) asm volatile("" : "+v"(ai[r]), "+v"(aq[r])::"memory");  // sums are due here
             __builtin_amdgcn_sched_barrier(0);
@@ -1150,7 +1174,11 @@ static void launch_front_dma_t(const FrontArgs &fa, int nstreams, long long nds,
 {
     using G = FrontDmaGeom<D, RD>;
     constexpr int WAVES = 2;
-    const size_t lds = 512 * sizeof(double) + WAVES * ((size_t)G::RAW_DW * 4 + G::K_BYTES);
+    static const size_t lds_pad = [] {
+        const char *e = getenv("JSDR_FRONT_LDS_PAD");  // experiment knob: extra LDS per workgroup = lower occupancy
+        return e ? (size_t)atoi(e) : (size_t)0;
+    }();
+    const size_t lds = 512 * sizeof(double) + WAVES * ((size_t)G::RAW_DW * 4 + G::K_BYTES) + lds_pad;
     long long ntiles = (nds + 64 * G::R - 1) / (64 * G::R);
     // five tiles per wave: a workgroup that walks several tiles loads the 4 KB sin/cos table once for all of them
     // (2.00 -> 1.82 ms; JSDR_FRONT_TPW overrides).  Tried and dropped: double-buffered tiles with the next tile's

@@ -38,6 +38,9 @@ for step in "$@"; do
     bench_acq_clk) JSDR_FFT_PHASECLK=1 run bench_acq_clk 400 python bench.py --workload bpsk --fft-acquire --steps 2 --warmup 1 --no-cpu-baseline ;;
     bench_nodma) JSDR_FRONT_DMA=0 run bench_nodma 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline ;;
     bench_n2)    JSDR_BENCH_SAME_DEVICE=1 JSDR_BENCH_BACKEND=gloo run bench_n2 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 3 --warmup 1 --streams 256 ;;
+    bench_pad20) JSDR_FRONT_LDS_PAD=20000 JSDR_NO_OVERLAP=1 run bench_pad20 300 python bench.py --workload bpsk --steps 5 --warmup 2 --no-cpu-baseline ;;
+    bench_pad45) JSDR_FRONT_LDS_PAD=45000 JSDR_NO_OVERLAP=1 run bench_pad45 300 python bench.py --workload bpsk --steps 5 --warmup 2 --no-cpu-baseline ;;
+    bench_pad0) JSDR_NO_OVERLAP=1 run bench_pad0 300 python bench.py --workload bpsk --steps 5 --warmup 2 --no-cpu-baseline ;;
     bench_noov)  JSDR_NO_OVERLAP=1 run bench_noov 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline ;;
     bench_rd80)  JSDR_FRONT_RD=80 run bench_rd80 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline ;;
     fec_bench)   run fec_bench 300 python tools/fec_bench.py ;;
