@@ -29,6 +29,7 @@ SOURCES = {
     "demod.hip": ["-ffp-contract=off"],
     "bpsk.hip": ["-ffp-contract=off"],
     "bpsk_fft.hip": ["-ffp-contract=off"],
+    "bpsk_fftm.hip": ["-ffp-contract=off"],
 }
 
 

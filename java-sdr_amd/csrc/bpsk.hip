@@ -1012,6 +1012,8 @@ struct jsdr_bpsk {
     std::vector<double2> h_vco_cs;
     DevBuf<long long> phase_clk;  // JSDR_FFT_PHASECLK=1: k_front_fft's per-phase cycle counts, printed at destroy
     int logn = 0;
+    bool fft_mixed = false;  // FFT-acquire frame is not a power of two (bpsk_fftm.hip)
+    int fm_np = 0, fm_rad[12] = {0}, fm_off[12] = {0};
     long long last_nds = 0;
     int last_y = 0;
     hipStream_t last_stream = 0;
@@ -1302,7 +1304,8 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
         xa.ds_taps = h->ds_taps_dev.p;
         xa.phase_clk = h->phase_clk.p;
         ProfScope ps(h, PK_FRONT, st);
-        if (launch_front_fft(xa, S, st) != JSDR_OK) return JSDR_ERR;
+        if ((h->fft_mixed ? launch_front_fftm(xa, h->fm_np, h->fm_rad, h->fm_off, S, st) : launch_front_fft(xa, S, st)) != JSDR_OK)
+            return JSDR_ERR;
     } else if (nds > 0) {
         ProfScope ps(h, PK_FRONT, st);
         switch (h->decim) {
@@ -1459,9 +1462,11 @@ int jsdr_bpsk_create(jsdr_bpsk **out, int rate, int nsamples_per_frame, int tuni
                  decim);
     JSDR_REQUIRE(nsamples_per_frame > 0 && nstreams > 0 && nstreams <= 65535, "jsdr_bpsk_create: bad geometry");
     if (max_batch_samples < nsamples_per_frame) max_batch_samples = nsamples_per_frame;
-    JSDR_REQUIRE(!do_fft || (nsamples_per_frame >= 1024 && nsamples_per_frame <= 4096 &&
-                             (nsamples_per_frame & (nsamples_per_frame - 1)) == 0),
-                 "jsdr_bpsk_create: FFT-acquire mode needs a power-of-two frame of 1024..4096 samples (got %d)",
+    const bool fft_pow2 = nsamples_per_frame >= 1024 && nsamples_per_frame <= 4096 &&
+                          (nsamples_per_frame & (nsamples_per_frame - 1)) == 0;
+    JSDR_REQUIRE(!do_fft || fft_pow2 || fftm_supported(nsamples_per_frame),
+                 "jsdr_bpsk_create: FFT-acquire mode needs a frame of 1024 / 2048 / 4096 samples, or n = 2^a 3^b 5^c with "
+                 "n %% 16 == 0 and 1024 < n <= 9600 such as the default 9600 / 4800 (got %d)",
                  nsamples_per_frame);
     JSDR_REQUIRE(bit_clock_is_regular(), "jsdr_bpsk_create: bit clock schedule is not the regular 8-cycle");
     if (fec_prepare() != JSDR_OK) return JSDR_ERR;
@@ -1497,7 +1502,7 @@ int jsdr_bpsk_create(jsdr_bpsk **out, int rate, int nsamples_per_frame, int tuni
               h->cnt_dec.alloc(S) == JSDR_OK && h->corr.alloc(S * (size_t)h->max_bits) == JSDR_OK &&
               h->fec_data.alloc(S * MAX_TRIG * 256) == JSDR_OK && h->decoded.alloc(S * 256) == JSDR_OK &&
               h->stage_raw.alloc((size_t)nsamples_per_frame * 2) == JSDR_OK && h->ds_taps_dev.alloc(32) == JSDR_OK &&
-              (!do_fft || (h->fft_state.alloc(S) == JSDR_OK && h->fft_tw.alloc((size_t)nsamples_per_frame) == JSDR_OK &&
+              (!do_fft || (h->fft_state.alloc(S) == JSDR_OK && h->fft_tw.alloc(fft_pow2 ? (size_t)nsamples_per_frame : (size_t)32768) == JSDR_OK &&
                             h->vco_cs.alloc((size_t)h->max_ds) == JSDR_OK));
     if (!ok) {
         jsdr_bpsk_destroy(h);
@@ -1531,8 +1536,12 @@ int jsdr_bpsk_create(jsdr_bpsk **out, int rate, int nsamples_per_frame, int tuni
     }
     if (do_fft) {
         std::vector<double2> tw;
-        fft_twiddles_f64(tw, nsamples_per_frame);
-        if (hipMemcpy(h->fft_tw.p, tw.data(), sizeof(double2) * tw.size(), hipMemcpyHostToDevice) != hipSuccess ||
+        h->fft_mixed = !fft_pow2;
+        if (fft_pow2)
+            fft_twiddles_f64(tw, nsamples_per_frame);
+        else
+            fftm_twiddles(tw, nsamples_per_frame, &h->fm_np, h->fm_rad, h->fm_off);
+        if (tw.size() > h->fft_tw.n || hipMemcpy(h->fft_tw.p, tw.data(), sizeof(double2) * tw.size(), hipMemcpyHostToDevice) != hipSuccess ||
             h->fft_state.zero() != JSDR_OK) {
             set_error("jsdr_bpsk_create: FFT-mode initialisation failed");
             jsdr_bpsk_destroy(h);

@@ -1,0 +1,395 @@
+// bpsk_fftm.hip -- FUNcubeBPSKDemod FFT-acquire front end (doBufferFFT, FUNcubeBPSKDemod.java:406-464) for frames
+// that are NOT a power of two: n = 2^a 3^b 5^c up to 9600, i.e. the reference's own default frame
+// (blen = rate*size/10 => n = 9600 at 96 kHz, 4800 at 48 kHz; JavaAudio.java:58-59).
+//
+// Compiled with -ffp-contract=off.  The transform is the oracle's mixed-radix definition (oracle/o_fft.c,
+// fft_f64_mixed): Stockham autosort passes with radices 4,..,(2),3..,5.. in this order, the same per-pass twiddle
+// tables (long double + one rounding, exact on the axes), the same fixed-order 2/3/4/5-point butterflies, the
+// inverse as conj o forward o conj -- so centre bins, traces, bits and FEC bytes are bit-identical to the
+// oracle.  JTransforms' own rounding is unknowable (source absent): parity with the Java library itself is unpinned.
+//
+// MI355X mapping: one 1024-thread workgroup per stream, persistent over the frames of the call (the centre-bin
+// state is sequential).  The frame lives in LDS as double2[n] (153.6 KB at n = 9600: one workgroup per CU); a
+// pass loads every butterfly into registers (<= 12 double2 per thread), barrier, stores to the autosort
+// positions -- in place, no second image.  |X| and the boxcar sums of the searched quarter band reuse the dead
+// upper part of the image.  The rest (boxcar, first maximum, centre-bin rule, 204 bins to bin 0, RxDownSample,
+// VCO) is k_front_fft's, with run-time sizes.
+#include "bpsk_fft.h"
+#include <math.h>
+
+namespace jsdr {
+
+constexpr int FM_T = 1024;
+constexpr int FM_NMAX = 9600;
+constexpr int FM_MAXPASS = 12;
+
+struct FftmArgs {
+    FftFrontArgs f;  // n, raw, state, dm, ... (logn unused; f.tw = concatenated per-pass tables)
+    int np;
+    int rad[FM_MAXPASS];
+    int tw_off[FM_MAXPASS];  // offset of pass p's table T[m] = exp(-2 pi i m/(P r)), m < P r
+};
+
+__device__ __forceinline__ double2 cdadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ double2 cdsub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ double2 cdmul(double2 u, double2 w)
+{
+    return make_double2(u.x * w.x - u.y * w.y, u.x * w.y + u.y * w.x);
+}
+
+// the oracle's dft_r(), operation for operation
+template <int R>
+__device__ __forceinline__ void dft_r(double2 *v)
+{
+    if constexpr (R == 2) {
+        const double2 a = cdadd(v[0], v[1]), b = cdsub(v[0], v[1]);
+        v[0] = a;
+        v[1] = b;
+    } else if constexpr (R == 4) {
+        const double2 a = cdadd(v[0], v[2]), b = cdsub(v[0], v[2]), c = cdadd(v[1], v[3]), d = cdsub(v[1], v[3]);
+        v[0] = cdadd(a, c);
+        v[2] = cdsub(a, c);
+        v[1] = make_double2(b.x + d.y, b.y - d.x);  // b - i d
+        v[3] = make_double2(b.x - d.y, b.y + d.x);  // b + i d
+    } else if constexpr (R == 3) {
+        const double S = 0.86602540378443864676;  // sin(2 pi/3)
+        const double2 t1 = cdadd(v[1], v[2]);
+        const double2 t2 = make_double2(v[0].x - 0.5 * t1.x, v[0].y - 0.5 * t1.y);
+        const double2 d = cdsub(v[1], v[2]);
+        const double2 t3 = make_double2(S * d.x, S * d.y);
+        v[0] = cdadd(v[0], t1);
+        v[1] = make_double2(t2.x + t3.y, t2.y - t3.x);
+        v[2] = make_double2(t2.x - t3.y, t2.y + t3.x);
+    } else {
+        static_assert(R == 5, "radices 2, 3, 4, 5");
+        const double C1 = 0.30901699437494742410, C2 = -0.80901699437494742410;  // cos(2 pi/5), cos(4 pi/5)
+        const double S1 = 0.95105651629515357212, S2 = 0.58778525229247312917;   // sin(2 pi/5), sin(4 pi/5)
+        const double2 a1 = cdadd(v[1], v[4]), a2 = cdadd(v[2], v[3]), b1 = cdsub(v[1], v[4]), b2 = cdsub(v[2], v[3]);
+        const double2 x0 = v[0];
+        const double2 m1 = make_double2((x0.x + C1 * a1.x) + C2 * a2.x, (x0.y + C1 * a1.y) + C2 * a2.y);
+        const double2 m2 = make_double2((x0.x + C2 * a1.x) + C1 * a2.x, (x0.y + C2 * a1.y) + C1 * a2.y);
+        const double2 n1 = make_double2(S1 * b1.x + S2 * b2.x, S1 * b1.y + S2 * b2.y);
+        const double2 n2 = make_double2(S2 * b1.x - S1 * b2.x, S2 * b1.y - S1 * b2.y);
+        v[0] = make_double2((x0.x + a1.x) + a2.x, (x0.y + a1.y) + a2.y);
+        v[1] = make_double2(m1.x + n1.y, m1.y - n1.x);
+        v[4] = make_double2(m1.x - n1.y, m1.y + n1.x);
+        v[2] = make_double2(m2.x + n2.y, m2.y - n2.x);
+        v[3] = make_double2(m2.x - n2.y, m2.y + n2.x);
+    }
+}
+
+// one Stockham pass, in place: every butterfly of the pass is in registers before the first store
+template <int R>
+__device__ __forceinline__ void fm_pass(double2 *X, const double2 *__restrict__ tw, int n, int P, int tid)
+{
+    constexpr int ITERS = ((FM_NMAX / R) + FM_T - 1) / FM_T;
+    const int nb = n / R;
+    double2 v[ITERS][R];
+#pragma unroll
+    for (int it = 0; it < ITERS; it++) {
+        const int b = it * FM_T + tid;
+        if (b < nb) {
+            const int k = b % P;
+#pragma unroll
+            for (int j = 0; j < R; j++) {
+                v[it][j] = X[b + j * nb];
+                if (j >= 1 && P > 1) v[it][j] = cdmul(v[it][j], tw[k * j]);
+            }
+            dft_r<R>(v[it]);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < ITERS; it++) {
+        const int b = it * FM_T + tid;
+        if (b < nb) {
+            const int k = b % P;
+            const int j0 = (b - k) * R + k;
+#pragma unroll
+            for (int q = 0; q < R; q++) X[j0 + q * P] = v[it][q];
+        }
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void fm_forward(double2 *X, const FftmArgs &a, int tid)
+{
+    int P = 1;
+    for (int p = 0; p < a.np; p++) {
+        const int r = a.rad[p];
+        const double2 *tw = a.f.tw + a.tw_off[p];
+        if (r == 4)
+            fm_pass<4>(X, tw, a.f.n, P, tid);
+        else if (r == 2)
+            fm_pass<2>(X, tw, a.f.n, P, tid);
+        else if (r == 3)
+            fm_pass<3>(X, tw, a.f.n, P, tid);
+        else
+            fm_pass<5>(X, tw, a.f.n, P, tid);
+        P *= r;
+    }
+}
+
+template <bool F32IN>
+__global__ __launch_bounds__(FM_T) void k_front_fftm(FftmArgs aa)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const FftFrontArgs &a = aa.f;
+    const int n = a.n;
+    double2 *X = reinterpret_cast<double2 *>(smem);      // [n]
+    double *hist = reinterpret_cast<double *>(X + n);    // [32]
+    double *taps = hist + 32;                            // [32]
+    double *redv = taps + 32;                            // [16] per-wave best value
+    int *redi = reinterpret_cast<int *>(redv + 16);      // [16] per-wave best index
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int s = blockIdx.x;
+    const int beg = a.do_up ? n / 4 : 0;
+    const int end = a.do_up ? n / 2 : n / 4;
+    // |X| over [beg+24, end-24) and the boxcar sums over [beg+74, end-74) live in the upper part of the image, dead
+    // after the forward transform (bins up to n/2+101 are still gathered below); beg is a multiple of 4
+    const int pbase = beg + 24;
+    double *P = reinterpret_cast<double *>(X + (n / 2 + 104));
+    double *A = P + (n / 4 - 48);
+    const int abase = beg + 74;
+    FftFrontState *sp = &a.st[s];
+    if (tid < 26) hist[tid] = sp->hist[tid];
+    if (tid < 27) taps[tid] = a.ds_taps[tid];
+    double avePeakPower = sp->avePeakPower, aveCentreBin = sp->aveCentreBin;
+    int centreBin = sp->centreBin;
+    // :399-402 -- float expressions widened to double
+    const double CFREQ_INV = (double)(1.0F - (2.0F / (1 + 1))), CFREQ_AVG = (double)(2.0F / (1 + 1));
+    const double PSD_INV = (double)(1.0F - (2.0F / (10 + 1))), PSD_AVG = (double)(2.0F / (10 + 1));
+    const double HOWARD = 0.9 * 32768.0;
+    const int D = a.decim;
+    const double norm = 1.0 / (double)n;
+    const int *__restrict__ raw = a.raw + (long long)s * a.stride_pairs;
+    const float2 *__restrict__ rawf = a.rawf + (long long)s * a.stride_pairs;
+    double2 *dm = a.dm + (long long)s * a.dm_stride;
+    __syncthreads();
+
+    for (int f = 0; f < a.nframes; f++) {
+        const long long t0 = (long long)f * n;  // call-relative index of the frame's first sample
+        // ---- frame -> LDS, natural order (:416-421)
+        for (int t = tid; t < n; t += FM_T) {
+            double di, dq;
+            if (F32IN) {
+                const float2 v = rawf[t0 + t];
+                di = (double)v.x;
+                dq = (double)v.y;
+            } else {
+                const int w = raw[t0 + t];
+                di = (double)i16_to_float_java(java_short_add((int)(short)(w & 0xffff), a.ic));
+                dq = (double)i16_to_float_java(java_short_add(w >> 16, a.qc));
+            }
+            X[t] = make_double2(di, dq);
+        }
+        __syncthreads();
+        fm_forward(X, aa, tid);  // :422-423
+        // ---- |X| (:425-427) over the band the boxcar reads
+        for (int i = pbase + tid; i < end - 24; i += FM_T) {
+            const double2 v = X[i];
+            P[i - pbase] = sqrt(v.x * v.x + v.y * v.y);
+        }
+        __syncthreads();
+        // ---- 100-wide boxcar, summed j ascending for every i (:433-437); first maximum (:439-442).  A thread owns
+        // the outputs i (even) and i+1: both windows come out of the same 51 aligned 16-byte reads.
+        double bestv = 0.0;  // maxBin starts at 0.0, binPos at -1
+        int besti = -1;
+        for (int i = beg + 74 + 2 * tid; i < end - 75; i += 2 * FM_T) {
+            const double2 *w = reinterpret_cast<const double2 *>(P + (i - 50 - pbase));
+            double a0 = 0.0, a1 = 0.0;
+            double2 cur = w[0];
+            a0 += cur.x;
+#pragma unroll 10
+            for (int k = 1; k <= 50; k++) {
+                const double2 nxt = w[k];
+                a0 += cur.y;
+                a1 += cur.y;
+                if (k < 50) a0 += nxt.x;
+                a1 += nxt.x;
+                cur = nxt;
+            }
+            if (i >= beg + 75) {
+                A[i - abase] = a0;
+                if (bestv < a0) {  // i ascends within a thread: strict '<' keeps the first maximum
+                    bestv = a0;
+                    besti = i;
+                }
+            }
+            if (i + 1 < end - 75) {
+                A[i + 1 - abase] = a1;
+                if (bestv < a1) {
+                    bestv = a1;
+                    besti = i + 1;
+                }
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const double ov = __shfl_xor(bestv, off, 64);
+            const int oi = __shfl_xor(besti, off, 64);
+            if (oi >= 0 && (ov > bestv || (ov == bestv && (besti < 0 || oi < besti)))) {
+                bestv = ov;
+                besti = oi;
+            }
+        }
+        if (lane == 0) {
+            redv[wave] = bestv;
+            redi[wave] = besti;
+        }
+        __syncthreads();
+        // ---- centre-bin rule (:444-453), evaluated by every thread on the same values
+        {
+            double maxBin = 0.0;
+            int binPos = -1;
+            for (int w = 0; w < FM_T / 64; w++) {
+                const double ov = redv[w];
+                const int oi = redi[w];
+                if (oi >= 0 && (ov > maxBin || (ov == maxBin && (binPos < 0 || oi < binPos)))) {
+                    maxBin = ov;
+                    binPos = oi;
+                }
+            }
+            if (centreBin < 0) centreBin = 0;
+            if (centreBin > end - 1) centreBin = end - 1;
+            // aveTemp is cleared per frame (:431) and only [beg+75, end-75) is filled
+            const double atc = (centreBin >= beg + 75 && centreBin < end - 75) ? A[centreBin - abase] : 0.0;
+            avePeakPower = (PSD_AVG * atc) + (PSD_INV * avePeakPower);
+            if (maxBin > (avePeakPower / 4) * 5 && binPos > 0) {
+                aveCentreBin = (CFREQ_AVG * (double)(float)binPos) + (CFREQ_INV * aveCentreBin);
+                centreBin = (int)(aveCentreBin + (double)1.0F);
+            }
+            if (centreBin < 102) centreBin = 102;
+        }
+        // ---- 204 bins around the centre to bin 0 of a zeroed array (:458), inverse transform (:459) as
+        // conj o forward o conj; only real parts are read afterwards, so the closing conjugation is dropped
+        double2 keep = make_double2(0.0, 0.0);
+        if (tid < 204) keep = X[centreBin - 102 + tid];
+        __syncthreads();
+        for (int i = tid; i < n; i += FM_T) X[i] = make_double2(0.0, -0.0);  // conj of the zeroed array: -0.0 imaginary parts
+        __syncthreads();
+        if (tid < 204) X[tid] = make_double2(keep.x, -keep.y);
+        __syncthreads();
+        fm_forward(X, aa, tid);
+        // ---- RxDownSample(re, re) (:461-463, :470-492): outputs whose window ends inside this frame
+        {
+            long long jlo = (t0 - a.first_out + D - 1) / D;
+            if (t0 <= a.first_out) jlo = 0;
+            for (long long j = jlo + tid;; j += FM_T) {
+                const long long te = (long long)a.first_out + (long long)D * j;  // window end, call-relative
+                if (te >= t0 + n || j >= a.nds) break;
+                const double2 cs = a.vco_cs[j];
+                const int e = (int)(te - t0);  // 0..n-1 within the frame
+                double fi = 0.0;
+#pragma unroll
+                for (int k = 0; k < 27; k++) {  // newest first (:479-483); re = X.x / n (:462)
+                    const int idx = e - k;
+                    const double v = (idx >= 0) ? X[idx].x * norm : hist[26 + idx];
+                    fi += v * taps[k];
+                }
+                const double o = fi * HOWARD;  // fi == fq: both rails get the same samples
+                dm[64 + j] = make_double2(o * cs.x, o * cs.y);  // :515-516
+            }
+        }
+        double hnew = 0.0;
+        if (tid < 26) hnew = X[n - 26 + tid].x * norm;
+        __syncthreads();
+        if (tid < 26) hist[tid] = hnew;
+        __syncthreads();
+    }
+    if (tid < 26) sp->hist[tid] = hist[tid];
+    if (tid == 0) {
+        sp->avePeakPower = avePeakPower;
+        sp->aveCentreBin = aveCentreBin;
+        sp->centreBin = centreBin;
+    }
+}
+
+// radix list for n = 2^a 3^b 5^c (the oracle's jo_fft_mixed_radices); 0: unsupported
+int fftm_radices(int n, int *rad)
+{
+    int c = 0;
+    if (n < 2) return 0;
+    while (n % 4 == 0 && c < FM_MAXPASS) {
+        rad[c++] = 4;
+        n /= 4;
+    }
+    if (n % 2 == 0 && c < FM_MAXPASS) {
+        rad[c++] = 2;
+        n /= 2;
+    }
+    while (n % 3 == 0 && c < FM_MAXPASS) {
+        rad[c++] = 3;
+        n /= 3;
+    }
+    while (n % 5 == 0 && c < FM_MAXPASS) {
+        rad[c++] = 5;
+        n /= 5;
+    }
+    return n == 1 ? c : 0;
+}
+
+bool fftm_supported(int n)
+{
+    int rad[FM_MAXPASS];
+    // the band arithmetic needs n/4 > 150 and beg = n/4 a multiple of 4; the image must fit the LDS
+    return n >= 1024 && n <= FM_NMAX && (n % 16) == 0 && (n & (n - 1)) != 0 && fftm_radices(n, rad) > 0;
+}
+
+// per-pass tables T[m] = exp(-2 pi i m/(P r)), m < P r: long double + one rounding, exact on the axes -- the same
+// values as the oracle's jo_fft_mixed_table
+void fftm_twiddles(std::vector<double2> &w, int n, int *np_out, int *rad, int *tw_off)
+{
+    const int np = fftm_radices(n, rad);
+    *np_out = np;
+    w.clear();
+    int P = 1;
+    for (int p = 0; p < np; p++) {
+        const int len = P * rad[p];
+        tw_off[p] = (int)w.size();
+        const size_t o = w.size();
+        w.resize(o + (size_t)len);
+        for (int m = 0; m < len; m++) {
+            const long double ang = 2.0L * 3.14159265358979323846264338327950288L * (long double)m / (long double)len;
+            w[o + m] = make_double2((double)cosl(ang), (double)(-sinl(ang)));
+        }
+        w[o] = make_double2(1.0, -0.0);
+        if (len % 4 == 0) {
+            w[o + len / 4] = make_double2(0.0, -1.0);
+            w[o + 3 * len / 4] = make_double2(-0.0, 1.0);
+        }
+        if (len % 2 == 0) w[o + len / 2] = make_double2(-1.0, -0.0);
+        P *= rad[p];
+    }
+}
+
+int launch_front_fftm(const FftFrontArgs &a, int np, const int *rad, const int *tw_off, int nstreams, hipStream_t st)
+{
+    FftmArgs aa;
+    aa.f = a;
+    aa.np = np;
+    for (int p = 0; p < FM_MAXPASS; p++) {
+        aa.rad[p] = p < np ? rad[p] : 1;
+        aa.tw_off[p] = p < np ? tw_off[p] : 0;
+    }
+    const size_t lds = sizeof(double2) * (size_t)a.n + sizeof(double) * (32 + 32 + 16) + sizeof(int) * 16 + 64;
+    const bool f32 = a.rawf != nullptr;
+    static size_t attr_for[2] = {0, 0};
+    if (attr_for[f32] < lds) {
+        if (f32)
+            JSDR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_front_fftm<true>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        else
+            JSDR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_front_fftm<false>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_for[f32] = lds;
+    }
+    if (f32)
+        hipLaunchKernelGGL(k_front_fftm<true>, dim3((unsigned)nstreams), dim3(FM_T), lds, st, aa);
+    else
+        hipLaunchKernelGGL(k_front_fftm<false>, dim3((unsigned)nstreams), dim3(FM_T), lds, st, aa);
+    JSDR_LAUNCH_CHECK();
+    return JSDR_OK;
+}
+
+}  // namespace jsdr

@@ -72,8 +72,143 @@ void jo_fft_twiddles_f64(double *w, int n)
  *     a' = a + t ; b' = a - t
  * The HIP double FFT (csrc/bpsk_fft.hip) performs the same butterflies on the same
  * twiddle table, so both are bit-identical.  PARITY UNPINNED vs JTransforms.          */
+/* ---- non power-of-two frames (n = 2^a 3^b 5^c, e.g. the reference's default 9600 = blen/size):
+ * Stockham autosort passes, radices 4,4,..,(2),3..,5.. in this order; pass with radix r and P = product of the
+ * earlier radices takes butterfly b (k = b mod P) from in[b + j*n/r], j < r, multiplies input j >= 1 by the
+ * table entry T[k*j] = exp(-2 pi i k j/(P r)) (cosl/sinl rounded once; exact on the axes), applies the fixed-order
+ * r-point DFT below and stores output q at out[(b-k)*r + k + q*P].  The inverse transform is
+ * conj o forward o conj (conjugation is exact), scaled by 1/n afterwards.  The HIP kernel (csrc/bpsk_fftm.hip)
+ * performs the same operations on the same tables.  PARITY UNPINNED vs JTransforms.                            */
+typedef struct { double x, y; } cd_t;
+static cd_t cd(double x, double y) { cd_t r = {x, y}; return r; }
+static cd_t cadd(cd_t a, cd_t b) { return cd(a.x + b.x, a.y + b.y); }
+static cd_t csub(cd_t a, cd_t b) { return cd(a.x - b.x, a.y - b.y); }
+static cd_t cmul(cd_t u, cd_t w) { return cd(u.x * w.x - u.y * w.y, u.x * w.y + u.y * w.x); }
+
+static void dft_r(cd_t *v, int r)
+{
+    if (r == 2) {
+        cd_t a = cadd(v[0], v[1]), b = csub(v[0], v[1]);
+        v[0] = a;
+        v[1] = b;
+    } else if (r == 4) {
+        cd_t a = cadd(v[0], v[2]), b = csub(v[0], v[2]), c = cadd(v[1], v[3]), d = csub(v[1], v[3]);
+        v[0] = cadd(a, c);
+        v[2] = csub(a, c);
+        v[1] = cd(b.x + d.y, b.y - d.x); /* b - i d */
+        v[3] = cd(b.x - d.y, b.y + d.x); /* b + i d */
+    } else if (r == 3) {
+        const double S = 0.86602540378443864676; /* sin(2 pi/3) */
+        cd_t t1 = cadd(v[1], v[2]);
+        cd_t t2 = cd(v[0].x - 0.5 * t1.x, v[0].y - 0.5 * t1.y);
+        cd_t d = csub(v[1], v[2]);
+        cd_t t3 = cd(S * d.x, S * d.y);
+        v[0] = cadd(v[0], t1);
+        v[1] = cd(t2.x + t3.y, t2.y - t3.x);
+        v[2] = cd(t2.x - t3.y, t2.y + t3.x);
+    } else { /* 5 */
+        const double C1 = 0.30901699437494742410, C2 = -0.80901699437494742410; /* cos(2 pi/5), cos(4 pi/5) */
+        const double S1 = 0.95105651629515357212, S2 = 0.58778525229247312917; /* sin(2 pi/5), sin(4 pi/5) */
+        cd_t a1 = cadd(v[1], v[4]), a2 = cadd(v[2], v[3]), b1 = csub(v[1], v[4]), b2 = csub(v[2], v[3]);
+        cd_t x0 = v[0];
+        cd_t m1 = cd((x0.x + C1 * a1.x) + C2 * a2.x, (x0.y + C1 * a1.y) + C2 * a2.y);
+        cd_t m2 = cd((x0.x + C2 * a1.x) + C1 * a2.x, (x0.y + C2 * a1.y) + C1 * a2.y);
+        cd_t n1 = cd(S1 * b1.x + S2 * b2.x, S1 * b1.y + S2 * b2.y);
+        cd_t n2 = cd(S2 * b1.x - S1 * b2.x, S2 * b1.y - S1 * b2.y);
+        v[0] = cd((x0.x + a1.x) + a2.x, (x0.y + a1.y) + a2.y);
+        v[1] = cd(m1.x + n1.y, m1.y - n1.x);
+        v[4] = cd(m1.x - n1.y, m1.y + n1.x);
+        v[2] = cd(m2.x + n2.y, m2.y - n2.x);
+        v[3] = cd(m2.x - n2.y, m2.y + n2.x);
+    }
+}
+
+/* radix list for n = 2^a 3^b 5^c; returns the count (0: unsupported) */
+int jo_fft_mixed_radices(int n, int *rad)
+{
+    int c = 0;
+    if (n < 2) return 0;
+    while (n % 4 == 0) { rad[c++] = 4; n /= 4; }
+    if (n % 2 == 0) { rad[c++] = 2; n /= 2; }
+    while (n % 3 == 0) { rad[c++] = 3; n /= 3; }
+    while (n % 5 == 0) { rad[c++] = 5; n /= 5; }
+    return n == 1 ? c : 0;
+}
+
+/* T[m] = exp(-2 pi i m/len), m < len, long double + one rounding; exact on the axes */
+void jo_fft_mixed_table(double *t, int len)
+{
+    for (int m = 0; m < len; m++) {
+        long double ang = 2.0L * 3.14159265358979323846264338327950288L * (long double)m / (long double)len;
+        t[2 * m] = (double)cosl(ang);
+        t[2 * m + 1] = (double)(-sinl(ang));
+    }
+    t[0] = 1.0;
+    t[1] = -0.0;
+    if (len % 4 == 0) {
+        t[2 * (len / 4)] = 0.0;
+        t[2 * (len / 4) + 1] = -1.0;
+        t[2 * (3 * len / 4)] = -0.0;
+        t[2 * (3 * len / 4) + 1] = 1.0;
+    }
+    if (len % 2 == 0) {
+        t[2 * (len / 2)] = -1.0;
+        t[2 * (len / 2) + 1] = -0.0;
+    }
+}
+
+static void fft_f64_mixed_forward(cd_t *a, int n)
+{
+    int rad[32];
+    int np = jo_fft_mixed_radices(n, rad);
+    cd_t *b = (cd_t *)malloc(sizeof(cd_t) * (size_t)n);
+    cd_t *in = a, *out = b;
+    int P = 1;
+    for (int p = 0; p < np; p++) {
+        const int r = rad[p], nb = n / r, len = P * r;
+        double *t = (double *)malloc(sizeof(double) * 2 * (size_t)len);
+        jo_fft_mixed_table(t, len);
+        for (int bf = 0; bf < nb; bf++) {
+            const int k = bf % P;
+            cd_t v[5];
+            for (int j = 0; j < r; j++) {
+                v[j] = in[bf + j * nb];
+                if (j >= 1 && P > 1) v[j] = cmul(v[j], cd(t[2 * (k * j)], t[2 * (k * j) + 1]));
+            }
+            dft_r(v, r);
+            for (int q = 0; q < r; q++) out[(bf - k) * r + k + q * P] = v[q];
+        }
+        free(t);
+        P *= r;
+        cd_t *tmp = in;
+        in = out;
+        out = tmp;
+    }
+    if (in != a) memcpy(a, in, sizeof(cd_t) * (size_t)n);
+    free(b);
+}
+
+static void fft_f64_mixed(double *a, int n, int inverse, int scale)
+{
+    cd_t *c = (cd_t *)a;
+    if (inverse)
+        for (int i = 0; i < n; i++) c[i].y = -c[i].y;
+    fft_f64_mixed_forward(c, n);
+    if (inverse) {
+        for (int i = 0; i < n; i++) c[i].y = -c[i].y;
+        if (scale) {
+            double norm = 1.0 / (double)n;
+            for (int i = 0; i < 2 * n; i++) a[i] *= norm;
+        }
+    }
+}
+
 void jo_fft_f64(double *a, int n, int inverse, int scale)
 {
+    if (n & (n - 1)) {
+        fft_f64_mixed(a, n, inverse, scale);
+        return;
+    }
     int bits = ilog2(n);
     double *w = (double *)malloc(sizeof(double) * (size_t)n);
     jo_fft_twiddles_f64(w, n);

@@ -240,6 +240,30 @@ def test_bpsk_fft_mode_other_frame_sizes_and_rates():
         run_both([iq], n, [nsf * 5, nsf * 19], rate=rate, do_fft=1, blen=blen)
 
 
+def test_bpsk_fft_mode_at_the_reference_default_frames():
+    """bpsk-dofft with java-sdr's own default buffers: blen = rate*size/10 -> n = 9600 @96 kHz, 4800 @48 kHz
+    (JavaAudio.java:58-59): the mixed-radix exact-order FP64 transform of bpsk_fftm.hip against the oracle's"""
+    for blen, rate, do_up, carrier in ((38400, 96000, 0, 13200.0), (38400, 96000, 1, 31200.0), (19200, 48000, 0, 7300.0)):
+        nsf = blen // 4
+        n = nsf * 26
+        iq = O.make_dbpsk_stream(77, 0, n, rate=rate, carrier_hz=carrier, noise_sigma=900.0)[0]
+        iq2 = O.make_dbpsk_stream(77, 1, n, rate=rate, carrier_hz=carrier + 350.0, noise_sigma=400.0)[0]
+        d, oracles = run_both([iq, iq2], n, [nsf * 7, nsf * 19], rate=rate, do_fft=1, do_up=do_up, blen=blen)
+        assert oracles[0].counters()["centreBin"] > 102  # the carrier was acquired, not the clamp value
+    # float frames through receive(), one frame at a time
+    d = J.Bpsk(rate=96000, blen=38400, nstreams=1, do_fft=1)
+    o = O.Bpsk(rate=96000, blen=38400, do_fft=1, trace=4096)
+    buf = O.convert_i16(O.make_dbpsk_stream(78, 0, 9600 * 3, carrier_hz=12800.0)[0])
+    tr = []
+    for k in range(3):
+        d.receive(buf[k * 19200:(k + 1) * 19200])
+        o.receive(buf[k * 19200:(k + 1) * 19200])
+        tr.append(d.trace().copy())
+    assert np.array_equal(np.concatenate(tr), o.trace())
+    same_counters(d.counters(), o.counters())
+    same_state(d.state(), o.state())
+
+
 def test_bpsk_fft_mode_negative_zero_spectrum_bins():
     """float frames of -0.0 (with a few impulses) leave -0.0 in spectrum bins: there a butterfly with a zero second
     operand does NOT return its first operand ((-0)+(+0) = +0), so the broadcast first inverse pass of
@@ -271,6 +295,10 @@ def test_bpsk_fft_mode_rejects_partial_frames_and_odd_sizes():
         d.batch_i16(buf, 2 * 8192, 3000)
     with pytest.raises(J.JsdrError):
         J.Bpsk(nstreams=1, do_fft=1, blen=2000)
+    with pytest.raises(J.JsdrError):
+        J.Bpsk(nstreams=1, do_fft=1, blen=76800, rate=192000)  # n = 19200 does not fit the FP64 LDS image
+    with pytest.raises(J.JsdrError):
+        J.Bpsk(nstreams=1, do_fft=1, blen=4 * 7000)  # 7000 = 2^3 5^3 7: no radix-7
 
 
 def test_bpsk_api_errors():

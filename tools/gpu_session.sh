@@ -58,6 +58,8 @@ for step in "$@"; do
                  run pmc_fft2 600 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d gpurun_out/pmc_fft2_$R -- python3 bench.py --workload fft --steps 2 --warmup 1 --no-cpu-baseline --no-validate
                  python tools/pmc_summary.py gpurun_out/pmc_fft2_$R | tee gpurun_out/pmc_fft2_summary.txt ;;
     dbg)         run dbg 300 python tools/dbg_fftmode.py ;;
+    fftm_bench)  run fftm_bench 300 python tools/fftm_bench.py ;;
+    fftm_small)  FM_S=8 FM_NFR=20 run fftm_small 300 python tools/fftm_bench.py ;;
     dbg_demod)   run dbg_demod 300 python tools/dbg_demod.py ;;
     trig)        run trig 300 python tools/trig_stats.py ;;
     bench_fft)   run bench_fft 300 python bench.py --workload fft --no-cpu-baseline ;;
