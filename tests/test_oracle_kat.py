@@ -383,3 +383,34 @@ def test_fft_oracle_standin_for_the_default_9600_frame():
         p = 2 * k
         want = int(p * 96000 / (2 * n)) if p < n else int((p - 2 * n) * 96000 / (2 * n))
         assert psd[n] == float(want)
+
+
+def test_oracle_mixed_radix_f64_transform_against_numpy():
+    """the oracle's definition of the FFT-acquire transform for frames that are not a power of two (the reference's
+    default n = 9600 / 4800): Stockham radices 4,..,(2),3..,5.. -- an accurate DFT, and inverse(forward(x)) = x"""
+    import ctypes as C
+    L = O.lib()
+    L.jo_fft_f64.restype = None
+    L.jo_fft_f64.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+    L.jo_fft_mixed_radices.argtypes = [C.c_int, C.c_void_p]
+    rad = np.zeros(32, np.int32)
+    assert L.jo_fft_mixed_radices(9600, rad.ctypes.data) == 7 and list(rad[:7]) == [4, 4, 4, 2, 3, 5, 5]
+    assert L.jo_fft_mixed_radices(4800, rad.ctypes.data) == 6 and list(rad[:6]) == [4, 4, 4, 3, 5, 5]
+    assert L.jo_fft_mixed_radices(7000, rad.ctypes.data) == 0  # a factor 7
+    rng = np.random.default_rng(12)
+    for n in (9600, 4800, 2400, 60, 15, 6):
+        x = rng.standard_normal(2 * n)
+        a = x.copy()
+        L.jo_fft_f64(a.ctypes.data, n, 0, 0)
+        want = np.fft.fft(x[0::2] + 1j * x[1::2])
+        assert np.abs((a[0::2] + 1j * a[1::2]) - want).max() <= 2e-15 * np.abs(want).max() * np.log2(n)
+        L.jo_fft_f64(a.ctypes.data, n, 1, 1)
+        assert np.abs(a - x).max() < 1e-13
+    # a single tone lands in its bin exactly like the power-of-two network's
+    n = 9600
+    t = np.arange(n)
+    x = np.zeros(2 * n)
+    x[0::2], x[1::2] = np.cos(2 * np.pi * 1320 * t / n), np.sin(2 * np.pi * 1320 * t / n)
+    L.jo_fft_f64(x.ctypes.data, n, 0, 0)
+    mag = np.hypot(x[0::2], x[1::2])
+    assert int(np.argmax(mag)) == 1320 and abs(mag[1320] - n) < 1e-8 and np.delete(mag, 1320).max() < 1e-8
