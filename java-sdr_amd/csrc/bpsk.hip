@@ -1462,10 +1462,10 @@ int jsdr_bpsk_create(jsdr_bpsk **out, int rate, int nsamples_per_frame, int tuni
                  decim);
     JSDR_REQUIRE(nsamples_per_frame > 0 && nstreams > 0 && nstreams <= 65535, "jsdr_bpsk_create: bad geometry");
     if (max_batch_samples < nsamples_per_frame) max_batch_samples = nsamples_per_frame;
-    const bool fft_pow2 = nsamples_per_frame >= 1024 && nsamples_per_frame <= 4096 &&
+    const bool fft_pow2 = nsamples_per_frame >= 1024 && nsamples_per_frame <= 8192 &&
                           (nsamples_per_frame & (nsamples_per_frame - 1)) == 0;
     JSDR_REQUIRE(!do_fft || fft_pow2 || fftm_supported(nsamples_per_frame),
-                 "jsdr_bpsk_create: FFT-acquire mode needs a frame of 1024 / 2048 / 4096 samples, or n = 2^a 3^b 5^c with "
+                 "jsdr_bpsk_create: FFT-acquire mode needs a frame of 1024 / 2048 / 4096 / 8192 samples, or n = 2^a 3^b 5^c with "
                  "n %% 16 == 0 and 1024 < n <= 9600 such as the default 9600 / 4800 (got %d)",
                  nsamples_per_frame);
     JSDR_REQUIRE(bit_clock_is_regular(), "jsdr_bpsk_create: bit clock schedule is not the regular 8-cycle");

@@ -121,9 +121,13 @@ __device__ __forceinline__ void dit_pass(double2 *X, const double2 *TsL, const d
 template <bool INVERSE, int LOGN, bool SKIP8>
 __device__ __forceinline__ void fft_rest(double2 *X, const double2 *TsL, const double2 *__restrict__ tsg, int tid, double norm)
 {
-    static_assert(LOGN >= 10 && LOGN <= 12, "frame sizes 1024..4096");
+    static_assert(LOGN >= 10 && LOGN <= 13, "frame sizes 1024..8192");
     if (!SKIP8) dit_pass<3, 8, INVERSE, LOGN, false>(X, TsL, tsg, tid, norm);
-    if (LOGN == 12) {
+    if (LOGN == 13) {
+        dit_pass<3, 64, INVERSE, LOGN, false>(X, TsL, tsg, tid, norm);
+        dit_pass<3, 512, INVERSE, LOGN, false>(X, TsL, tsg, tid, norm);
+        dit_pass<1, 4096, INVERSE, LOGN, INVERSE>(X, TsL, tsg, tid, norm);
+    } else if (LOGN == 12) {
         dit_pass<3, 64, INVERSE, LOGN, false>(X, TsL, tsg, tid, norm);
         dit_pass<3, 512, INVERSE, LOGN, INVERSE>(X, TsL, tsg, tid, norm);
     } else if (LOGN == 11) {
@@ -137,7 +141,7 @@ __device__ __forceinline__ void fft_rest(double2 *X, const double2 *TsL, const d
 }
 
 template <int LOGN, bool F32IN>
-__global__ __launch_bounds__(256, (LOGN <= 11 ? 4 : 2)) void k_front_fft(FftFrontArgs a)
+__global__ __launch_bounds__(256, (LOGN <= 11 ? 4 : (LOGN == 12 ? 2 : 1))) void k_front_fft(FftFrontArgs a)
 {
     constexpr int N = 1 << LOGN;
     constexpr int XSLOTS = N + (N >> 3);
@@ -488,7 +492,8 @@ int launch_front_fft(const FftFrontArgs &a, int nstreams, hipStream_t st)
         case 10: return f32 ? launch_front_fft_t<10, true>(a, nstreams, st) : launch_front_fft_t<10, false>(a, nstreams, st);
         case 11: return f32 ? launch_front_fft_t<11, true>(a, nstreams, st) : launch_front_fft_t<11, false>(a, nstreams, st);
         case 12: return f32 ? launch_front_fft_t<12, true>(a, nstreams, st) : launch_front_fft_t<12, false>(a, nstreams, st);
-        default: JSDR_REQUIRE(false, "bpsk: FFT-acquire frame of 2^%d samples is not supported (1024..4096)", a.logn);
+        case 13: return f32 ? launch_front_fft_t<13, true>(a, nstreams, st) : launch_front_fft_t<13, false>(a, nstreams, st);
+        default: JSDR_REQUIRE(false, "bpsk: FFT-acquire frame of 2^%d samples is not supported (1024..8192)", a.logn);
     }
 }
 

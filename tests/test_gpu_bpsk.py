@@ -233,7 +233,7 @@ def test_bpsk_fft_mode_streams_bit_exact(do_up, carrier):
 
 
 def test_bpsk_fft_mode_other_frame_sizes_and_rates():
-    for blen, rate in ((4096, 96000), (16384, 192000)):
+    for blen, rate in ((4096, 96000), (16384, 192000), (32768, 96000)):
         nsf = blen // 4
         n = nsf * 24
         iq = O.make_dbpsk_stream(43, 0, n, rate=rate, carrier_hz=13200.0, noise_sigma=700.0)[0]
