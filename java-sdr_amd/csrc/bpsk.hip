@@ -1003,6 +1003,7 @@ struct jsdr_bpsk {
     DevBuf<int> nbits, trig_count, trig_bits, fec_rc, fec_last, cnt_dec;
     DevBuf<signed char> corr;
     DevBuf<unsigned char> fec_data, decoded;
+    DevBuf<unsigned long long> fec_scratch;  // Viterbi decision words of every (stream, hit) block
     DevBuf<int> stage_raw;  // one frame for receive_*()
     DevBuf<FftFrontState> fft_state;  // FFT-acquire mode only
     DevBuf<double2> fft_tw;
@@ -1432,8 +1433,10 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
         fa2.last = h->fec_last.p;
         fa2.cnt_dec = h->cnt_dec.p;
         fa2.nstreams = S;
+        fa2.dec_scratch = h->fec_scratch.p;
         ProfScope ps(h, PK_FEC, ts);
-        if (launch_fec_bpsk(fa2, ts) != JSDR_OK) return JSDR_ERR;
+        static const bool skip_fec = getenv("JSDR_EXPERIMENT_SKIP_FEC") != nullptr;  // timing experiment only
+        if (!skip_fec && launch_fec_bpsk(fa2, ts) != JSDR_OK) return JSDR_ERR;
     }
     if (h->overlap) {
         JSDR_HIP_TRY(hipEventRecord(h->ev_tail_done[yb], ts));
@@ -1498,6 +1501,7 @@ int jsdr_bpsk_create(jsdr_bpsk **out, int rate, int nsamples_per_frame, int tuni
               h->bitlog[0].alloc(S * (size_t)h->bitlog_stride) == JSDR_OK &&
               h->bitlog[1].alloc(S * (size_t)h->bitlog_stride) == JSDR_OK && h->nbits.alloc(S) == JSDR_OK &&
               h->trig_count.alloc(S) == JSDR_OK && h->trig_bits.alloc(S * MAX_TRIG) == JSDR_OK &&
+              h->fec_scratch.alloc(S * MAX_TRIG * (size_t)fec_dec_scratch_words()) == JSDR_OK &&
               h->fec_rc.alloc(S * MAX_TRIG) == JSDR_OK && h->fec_last.alloc(S * 2) == JSDR_OK &&
               h->cnt_dec.alloc(S) == JSDR_OK && h->corr.alloc(S * (size_t)h->max_bits) == JSDR_OK &&
               h->fec_data.alloc(S * MAX_TRIG * 256) == JSDR_OK && h->decoded.alloc(S * 256) == JSDR_OK &&
@@ -1608,6 +1612,7 @@ int jsdr_bpsk_destroy(jsdr_bpsk *h)
     h->cnt_dec.release();
     h->corr.release();
     h->fec_data.release();
+    h->fec_scratch.release();
     h->decoded.release();
     h->stage_raw.release();
     h->fft_state.release();

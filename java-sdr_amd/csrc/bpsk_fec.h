@@ -19,9 +19,11 @@ struct BpskFecArgs {
     int *last;                  // [nstreams][2]: dmErrBits, decodeOK (:565-568)
     int *cnt_dec;               // [nstreams] cntDec (:569)
     int nstreams;
+    unsigned long long *dec_scratch;  // [nstreams][max_trig][fec_dec_scratch_words()] Viterbi decision words
 };
 
 int launch_fec_bpsk(const BpskFecArgs &a, hipStream_t st);
 int fec_prepare();
+int fec_dec_scratch_words();
 
 }  // namespace jsdr

@@ -118,9 +118,15 @@ int fec_prepare() { return upload_tables(); }
 // ----------------------------------------------------------------------------------------------
 // LDS work area of one wave
 enum { METS_CHUNK = 512 };
-struct FecLds {
+// DECW = NBITS+2: the decision words live in LDS (31.5 KB per block).  DECW = DECW_WORK: they live in a global
+// scratch area and LDS keeps only the work area behind them (16.2 KB per block): the demodulator's FEC kernel runs
+// under the throughput kernels of the next call, where every LDS byte it holds is a workgroup of theirs that
+// cannot start.
+enum { DECW_LDS = NBITS + 2, DECW_WORK = (SYMPBLOCK + 7) / 8 + 6, DEC_SCRATCH_WORDS = ((NBITS + 2 + 63) / 64) * 64 };
+template <int DECW>
+struct FecLdsT {
     unsigned char raw[SYMPBLOCK];       // soft symbols in
-    unsigned long long dec[NBITS + 2];  // decisions per step (== the reference's pp[2k], pp[2k+1]); once the
+    unsigned long long dec[DECW];       // decisions per step (== the reference's pp[2k], pp[2k+1]); once the
                                         // chain-back is done the same bytes hold the RS work arrays, then the
                                         // re-encoded symbols (fec_enc())
     short mets[METS_CHUNK][4];          // branch metrics of the current chunk of trellis steps
@@ -131,7 +137,9 @@ struct FecLds {
     unsigned char data[256];            // decoded payload
     int misc[8];
 };
-__device__ __forceinline__ unsigned char *fec_enc(FecLds &L) { return reinterpret_cast<unsigned char *>(&L.dec[0]); }
+typedef FecLdsT<DECW_LDS> FecLds;
+template <int DECW>
+__device__ __forceinline__ unsigned char *fec_enc(FecLdsT<DECW> &L) { return reinterpret_cast<unsigned char *>(&L.dec[0]); }
 
 __device__ __forceinline__ int parity7(int v)
 {
@@ -141,7 +149,8 @@ __device__ __forceinline__ int parity7(int v)
 __device__ __forceinline__ int gf_mod255(int x) { return x % 255; }
 
 // encode_FEC40 (:677-688): data[256] (LDS) -> L.enc[5200]; 64 lanes cooperate.
-__device__ __forceinline__ void fec_encode_wave(FecLds &L, const unsigned char *data, int lane)
+template <int DECW>
+__device__ __forceinline__ void fec_encode_wave(FecLdsT<DECW> &L, const unsigned char *data, int lane)
 {
     unsigned char *enc = fec_enc(L);
     // ---- RS parity, two interleaved code words: lanes 0..31 block 0 (even bytes), 32..63 block 1 (odd)
@@ -296,8 +305,10 @@ __device__ __forceinline__ int rs_correct_lane(unsigned char *data, const int *s
 
 // FECDecode (:703-852) on L.raw; payload to L.data only on success (as the reference leaves
 // RSdecdata untouched on failure).  Returns -1 or the channel error count (wave-uniform).
-__device__ __forceinline__ int fec_decode_wave(FecLds &L, int lane)
+template <int DECW>
+__device__ __forceinline__ int fec_decode_wave(FecLdsT<DECW> &L, int lane, unsigned long long *decg = nullptr)
 {
+    constexpr bool DEC_GLOBAL = DECW != DECW_LDS;  // decision words in the global scratch decg[DEC_SCRATCH_WORDS]
     // ---- steps 1+2: de-interleave (:715-722) fused with the branch metrics (:220-225), 512 trellis steps at
     // a time, then add-compare-select with lane = state (:229-253).  Metrics fit int32 (|m| < 3e6).
     {
@@ -306,6 +317,7 @@ __device__ __forceinline__ int fec_decode_wave(FecLds &L, int lane)
         const int ib = (parity7((lane ^ 1) & 0x4f) << 1) | (1 - parity7((lane ^ 1) & 0x6d));
         int metric = (lane == 0) ? 0 : -999999;
         const int src_lo = lane >> 1, src_hi = (lane >> 1) + 32;
+        unsigned dlo = 0, dhi = 0;  // DEC_GLOBAL: lane (k & 63) collects the word of step k; flushed every 64 steps
         for (int k0 = 0; k0 < NBITS; k0 += METS_CHUNK) {
             const int kn = (NBITS - k0) < METS_CHUNK ? (NBITS - k0) : METS_CHUNK;
             for (int kk = lane; kk < kn; kk += 64) {
@@ -328,7 +340,16 @@ __device__ __forceinline__ int fec_decode_wave(FecLds &L, int lane)
                 bool d = m1 > m0;
                 metric = d ? m1 : m0;
                 unsigned long long mask = __ballot(d);
-                if (lane == 0) L.dec[k0 + kk] = mask;
+                if constexpr (DEC_GLOBAL) {
+                    const int k = k0 + kk, slot = k & 63;
+                    const bool mine = lane == slot;
+                    dlo = mine ? (unsigned)mask : dlo;
+                    dhi = mine ? (unsigned)(mask >> 32) : dhi;
+                    if (slot == 63 || k == NBITS - 1)  // one coalesced 512-byte store per 64 trellis steps
+                        decg[(k & ~63) + lane] = ((unsigned long long)dhi << 32) | dlo;
+                } else {
+                    if (lane == 0) L.dec[k0 + kk] = mask;
+                }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -342,10 +363,25 @@ __device__ __forceinline__ int fec_decode_wave(FecLds &L, int lane)
         __builtin_amdgcn_wave_barrier();
         int beststate = 0;
         int cur = 0;  // byte being assembled (bits of 8 consecutive i)
+        // DEC_GLOBAL: the words were written by this wave; they are read back past the L1 (a grid-stride
+        // caller may have cached the same scratch lines from an earlier block), one chunk ahead of their use
+        auto fetch = [&](int hi) -> unsigned long long {
+            const int my = hi - lane;
+            if (hi < 0 || my < 0) return 0ull;
+            if constexpr (DEC_GLOBAL)
+                return __hip_atomic_load(&decg[my + 6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else
+                return L.dec[my + 6];
+        };
+        if constexpr (DEC_GLOBAL) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // the decision stores have reached L2
+            __builtin_amdgcn_wave_barrier();
+        }
+        unsigned long long wnext = fetch(NBITS - 7);
         for (int hi_i = NBITS - 7; hi_i >= 0; hi_i -= 64) {
             // this chunk covers i = hi_i .. max(hi_i-63,0); step index k = i + 6
-            int my_i = hi_i - lane;
-            unsigned long long w = (my_i >= 0) ? L.dec[my_i + 6] : 0ull;
+            unsigned long long w = wnext;
+            wnext = fetch(hi_i - 64);
             unsigned wl = (unsigned)w, wh = (unsigned)(w >> 32);
             int nsteps = hi_i + 1 < 64 ? hi_i + 1 : 64;
             for (int t = 0; t < nsteps; t++) {
@@ -418,7 +454,8 @@ __device__ __forceinline__ int fec_decode_wave(FecLds &L, int lane)
     return errs;
 }
 
-__device__ __forceinline__ void fec_lds_init(FecLds &L, int lane)
+template <int DECW>
+__device__ __forceinline__ void fec_lds_init(FecLdsT<DECW> &L, int lane)
 {
     for (int i = lane; i < 256; i += 64) {
         L.alpha_to[i] = c_fec.alpha_to[i];
@@ -473,7 +510,7 @@ __global__ __launch_bounds__(64) void k_fec_encode(const unsigned char *__restri
 // (FUNcubeBPSKDemod.java:562-564) and decode; payload (on success) and rc go to the per-hit log.
 __global__ __launch_bounds__(64) void k_fec_bpsk(BpskFecArgs a)
 {
-    __shared__ FecLds L;
+    __shared__ FecLdsT<DECW_WORK> L;
     const int lane = threadIdx.x;
     // x = stream, y = hit index: consecutive workgroups go to different XCDs, and the few hits per stream
     // (y small) must not all land on the same one or two XCDs
@@ -487,7 +524,7 @@ __global__ __launch_bounds__(64) void k_fec_bpsk(BpskFecArgs a)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int r = fec_decode_wave(L, lane);
+    const int r = fec_decode_wave(L, lane, a.dec_scratch + ((long long)s * a.max_trig + t) * DEC_SCRATCH_WORDS);
     unsigned char *logd = a.fec_data + ((long long)s * a.max_trig + t) * 256;
     if (r >= 0)
         for (int i = lane; i < 256; i += 64) logd[i] = L.data[i];
@@ -524,6 +561,8 @@ __global__ __launch_bounds__(256) void k_fec_fin(BpskFecArgs a)
         a.cnt_dec[s] += ndec;
     }
 }
+
+int fec_dec_scratch_words() { return DEC_SCRATCH_WORDS; }
 
 int launch_fec_bpsk(const BpskFecArgs &a, hipStream_t st)
 {

@@ -41,6 +41,7 @@ for step in "$@"; do
     bench_pad20) JSDR_FRONT_LDS_PAD=20000 JSDR_NO_OVERLAP=1 run bench_pad20 300 python bench.py --workload bpsk --steps 5 --warmup 2 --no-cpu-baseline ;;
     bench_pad45) JSDR_FRONT_LDS_PAD=45000 JSDR_NO_OVERLAP=1 run bench_pad45 300 python bench.py --workload bpsk --steps 5 --warmup 2 --no-cpu-baseline ;;
     bench_pad0) JSDR_NO_OVERLAP=1 run bench_pad0 300 python bench.py --workload bpsk --steps 5 --warmup 2 --no-cpu-baseline ;;
+    bench_nofec) JSDR_EXPERIMENT_SKIP_FEC=1 run bench_nofec 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-validate ;;
     bench_noov)  JSDR_NO_OVERLAP=1 run bench_noov 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline ;;
     bench_rd80)  JSDR_FRONT_RD=80 run bench_rd80 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline ;;
     fec_bench)   run fec_bench 300 python tools/fec_bench.py ;;
