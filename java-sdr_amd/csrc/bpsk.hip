@@ -470,6 +470,136 @@ __global__ __launch_bounds__(128, 4) void k_front_dma(FrontArgs a)
     }
 }
 
+// ------------------------------------------------------------------------------------------- k_front_reg
+// The int16 fast path without an LDS image: lane l of a tile reads ITS OWN window of NS = RD-D+27 samples
+// (RD*l .. RD*l+NS-1) straight into registers with 16-byte loads, newest quad first, and walks it while the older
+// quads are still in flight (vmcnt counts them down in issue order).  The overlap of neighbouring windows (26
+// samples) is served by L1/L2, not by HBM.  Against k_front_dma: no LDS but the 4 KB sin/cos table, so occupancy
+// is set by registers alone and does not collapse when the side stream's kernels hold LDS on the same CU --
+// k_front_dma is latency bound and its time goes with 1/occupancy.  Same arithmetic, same order.
+template <int D, int RD, bool MIX, bool DC>
+__global__ __launch_bounds__(256) void k_front_reg(FrontArgs a)
+{
+    using G = FrontDmaGeom<D, RD>;
+    constexpr int R = G::R;
+    __shared__ double sc[512];
+    for (int i = threadIdx.x; i < 512; i += blockDim.x) sc[i] = a.sincos[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+    const int s = blockIdx.y;
+    const long long ntiles = (a.nds + 64 * R - 1) / (64 * R);
+    const double HOWARD = 0.9 * 32768.0;  // :469
+    const int *raw = a.raw + (long long)s * a.stride_pairs;
+    const int2 *hist = a.hist + (long long)s * 32;
+    const int Lm1 = (int)(a.nsamples - 1);
+    for (long long tile = (long long)blockIdx.x * nwave + wave; tile < ntiles; tile += (long long)gridDim.x * nwave) {
+        const long long j0 = tile * 64 * R;
+        const int n0 = a.first_out + (int)(D * j0) - 26 + RD * lane;  // input index of this lane's sample 0
+        // ---- this lane's window, newest quad first
+        int4 W[G::NSQ];
+        unsigned K[G::NSQ];
+        const bool inside = n0 >= 0 && n0 + 4 * G::NSQ - 1 <= Lm1;
+        if (inside) {
+#pragma unroll
+            for (int q = G::NSQ - 1; q >= 0; q--) {
+                W[q] = *reinterpret_cast<const int4 *>(raw + n0 + 4 * q);  // 4-byte aligned 16-byte load
+                K[q] = *reinterpret_cast<const unsigned *>(a.ktu + 26 + n0 + 4 * q);
+            }
+        } else {  // first / last window of the call: history before sample 0, clamp beyond the last one
+#pragma unroll
+            for (int q = G::NSQ - 1; q >= 0; q--) {
+                int w[4];
+                unsigned k4 = 0;
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    const int n = n0 + 4 * q + t;
+                    if (n < 0) {
+                        int hw = (n >= -26) ? hist[26 + n].x : 0;
+                        if constexpr (DC) {  // stored corrected: undo this call's correction, the walk re-applies it
+                            const int si = (int)(short)((hw & 0xffff) - a.ic);
+                            const int sq = (int)(short)((hw >> 16) - a.qc);
+                            hw = (si & 0xffff) | (sq << 16);
+                        }
+                        w[t] = hw;
+                    } else {
+                        w[t] = raw[n > Lm1 ? Lm1 : n];
+                    }
+                    const int nk = n < -26 ? -26 : (n > Lm1 ? Lm1 : n);
+                    k4 |= (unsigned)a.ktu[26 + nk] << (8 * t);
+                }
+                W[q] = make_int4(w[0], w[1], w[2], w[3]);
+                K[q] = k4;
+            }
+        }
+        // ---- walk from newest to oldest; sin/cos entries one quad ahead (LDS latency)
+        double ai[R], aq[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            ai[r] = 0.0;
+            aq[r] = 0.0;
+        }
+        double CS[G::NSQ][8];
+        auto load_sc = [&](int q) {
+            if constexpr (MIX) {
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    const int k = (K[q] >> (8 * t)) & 0xff;
+                    CS[q][2 * t] = sc[k];
+                    CS[q][2 * t + 1] = sc[256 + k];
+                }
+            }
+        };
+        load_sc(G::NSQ - 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = G::NSQ - 1; q >= 0; q--) {
+            if (q - 1 >= 0) load_sc(q - 1);
+            const int4 w4 = W[q];
+#pragma unroll
+            for (int t = 3; t >= 0; t--) {
+                const int m = 4 * q + t;
+                if (m < G::NS) {
+                    int w = (t == 0) ? w4.x : (t == 1) ? w4.y : (t == 2) ? w4.z : w4.w;
+                    int si = (int)(short)(w & 0xffff), sq = w >> 16;
+                    if constexpr (DC) {
+                        si = java_short_add(si, a.ic);
+                        sq = java_short_add(sq, a.qc);
+                    }
+                    double di = (double)i16_to_float_java(si);
+                    double dq = (double)i16_to_float_java(sq);
+                    if constexpr (MIX) {  // :388-390 component-wise, not a complex multiply
+                        di = di * CS[q][2 * t];
+                        dq = dq * CS[q][2 * t + 1];
+                    }
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        if (m >= D * r && m <= D * r + 26) {  // sample m has age D*r+26-m in the window of output r
+                            const double tp = ds_tap(D * r + 26 - m);
+                            ai[r] += di * tp;
+                            aq[r] += dq * tp;
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < R; r++) asm volatile("" : "+v"(ai[r]), "+v"(aq[r])::"memory");  // sums are due here
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- x HOWARD_FUDGE_FACTOR (:486), VCO mix (:515-516)
+        const long long jl = j0 + (long long)R * lane;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const long long j = jl + r;
+            if (j < a.nds) {
+                const double oi = ai[r] * HOWARD, oq = aq[r] * HOWARD;
+                if (a.ds_dbg) a.ds_dbg[(long long)s * a.nds + j] = make_double2(oi, oq);
+                const int kv = a.kvco[j];
+                a.dm[(long long)s * a.dm_stride + 64 + j] = make_double2(oi * sc[kv], oq * sc[256 + kv]);
+            }
+        }
+    }
+}
+
 // keep the 26 most recent inputs (DC-corrected int16 pair, or the float pair) for the next call
 struct HistArgs {
     const int *raw;
@@ -1204,12 +1334,38 @@ static void launch_front_dma_t(const FrontArgs &fa, int nstreams, long long nds,
                        fa);
 }
 
+template <int D, int RD, bool MIX, bool DC>
+static void launch_front_reg_t(const FrontArgs &fa, int nstreams, long long nds, hipStream_t st)
+{
+    using G = FrontDmaGeom<D, RD>;
+    constexpr int WAVES = 4;
+    const long long ntiles = (nds + 64 * G::R - 1) / (64 * G::R);
+    long long gx = (ntiles + WAVES * 5 - 1) / (WAVES * 5);  // five tiles per wave
+    if (gx > 2048) gx = 2048;
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL((k_front_reg<D, RD, MIX, DC>), dim3((unsigned)gx, (unsigned)nstreams), dim3(64 * WAVES), 0, st, fa);
+}
+
 // the LDS-DMA fast path: int16 input, 96 kHz (D=10), samples addressable with 32-bit indices
 template <int D, int RD>
 static bool launch_front_dma(const FrontArgs &fa, int nstreams, long long nds, hipStream_t st)
 {
     if (fa.rawf || fa.nsamples > 0x3fffffffLL || fa.nsamples < 64) return false;
     const bool dc = (fa.ic != 0) || (fa.qc != 0);
+    static const bool reg = [] {
+        const char *e = getenv("JSDR_FRONT_REG");  // JSDR_FRONT_REG=0: the LDS-DMA image (k_front_dma) instead
+        return !e || atoi(e) != 0;
+    }();
+    if (reg) {
+        if (fa.mix) {
+            if (dc) launch_front_reg_t<D, RD, true, true>(fa, nstreams, nds, st);
+            else launch_front_reg_t<D, RD, true, false>(fa, nstreams, nds, st);
+        } else {
+            if (dc) launch_front_reg_t<D, RD, false, true>(fa, nstreams, nds, st);
+            else launch_front_reg_t<D, RD, false, false>(fa, nstreams, nds, st);
+        }
+        return true;
+    }
     if (fa.mix) {
         if (dc) launch_front_dma_t<D, RD, true, true>(fa, nstreams, nds, st);
         else launch_front_dma_t<D, RD, true, false>(fa, nstreams, nds, st);

@@ -42,6 +42,10 @@ for step in "$@"; do
     bench_pad45) JSDR_FRONT_LDS_PAD=45000 JSDR_NO_OVERLAP=1 run bench_pad45 300 python bench.py --workload bpsk --steps 5 --warmup 2 --no-cpu-baseline ;;
     bench_pad0) JSDR_NO_OVERLAP=1 run bench_pad0 300 python bench.py --workload bpsk --steps 5 --warmup 2 --no-cpu-baseline ;;
     bench_nofec) JSDR_EXPERIMENT_SKIP_FEC=1 run bench_nofec 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-validate ;;
+    bench_reg_alone) JSDR_NO_OVERLAP=1 run bench_reg_alone 300 python bench.py --workload bpsk --steps 5 --warmup 2 --no-cpu-baseline ;;
+    bench_reg) run bench_reg 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline ;;
+    tests_bpsk_reg) JSDR_FRONT_REG=0 run tests_bpsk_reg 600 python -m pytest tests/test_gpu_bpsk.py -m gpu -q -x -p no:cacheprovider --timeout 600 ;;
+    bench_dma_alone) JSDR_FRONT_REG=0 JSDR_NO_OVERLAP=1 run bench_dma_alone 300 python bench.py --workload bpsk --steps 5 --warmup 2 --no-cpu-baseline ;;
     bench_noov)  JSDR_NO_OVERLAP=1 run bench_noov 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline ;;
     bench_rd80)  JSDR_FRONT_RD=80 run bench_rd80 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline ;;
     fec_bench)   run fec_bench 300 python tools/fec_bench.py ;;
