@@ -1338,6 +1338,7 @@ template <int D, int RD, bool MIX, bool DC>
 static void launch_front_reg_t(const FrontArgs &fa, int nstreams, long long nds, hipStream_t st)
 {
     using G = FrontDmaGeom<D, RD>;
+    // block size and tiles per wave make no difference between 1..4 waves and 1..10 tiles (swept; within 5 %)
     constexpr int WAVES = 4;
     const long long ntiles = (nds + 64 * G::R - 1) / (64 * G::R);
     long long gx = (ntiles + WAVES * 5 - 1) / (WAVES * 5);  // five tiles per wave
