@@ -294,7 +294,11 @@ def main():
         for name, (ms, cnt) in dem.profile_read().items():
             if cnt:
                 kern[name] = (ms, cnt, BYTES_PER_SAMPLE["bpsk"])
-    dom = max(kern, key=lambda k: kern[k][0])
+    # the dominant kernel is taken on the critical path: the tail / sync / FEC kernels run on the handle's side
+    # stream under the next step's throughput kernels (their times are listed, they do not bound the step)
+    SIDE = ("k_tail", "k_sync", "k_sync_fin", "k_fec_bpsk")
+    main = {k: v for k, v in kern.items() if k not in SIDE or a.fft_acquire}
+    dom = max(main, key=lambda k: main[k][0])
     dom_ms = kern[dom][0] / kern[dom][1]
     alg_bytes = kern[dom][2] * S * L
     achieved = alg_bytes / (dom_ms * 1e-3) / 1e9

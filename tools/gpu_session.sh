@@ -46,6 +46,9 @@ for step in "$@"; do
     bench_reg) run bench_reg 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline ;;
     tests_bpsk_reg) JSDR_FRONT_REG=0 run tests_bpsk_reg 600 python -m pytest tests/test_gpu_bpsk.py -m gpu -q -x -p no:cacheprovider --timeout 600 ;;
     bench_dma_alone) JSDR_FRONT_REG=0 JSDR_NO_OVERLAP=1 run bench_dma_alone 300 python bench.py --workload bpsk --steps 5 --warmup 2 --no-cpu-baseline ;;
+    bench_m64) JSDR_FFT_GRID_MULT=64 run bench_m64 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline ;;
+    bench_m256) JSDR_FFT_GRID_MULT=256 run bench_m256 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline ;;
+    bench_m16) JSDR_FFT_GRID_MULT=16 run bench_m16 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline ;;
     bench_noov)  JSDR_NO_OVERLAP=1 run bench_noov 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline ;;
     bench_rd80)  JSDR_FRONT_RD=80 run bench_rd80 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline ;;
     fec_bench)   run fec_bench 300 python tools/fec_bench.py ;;

@@ -21,7 +21,7 @@ def per_kernel(d, counter):
             if not m:
                 continue
             key = m.group(1)
-            if key == "k_front_dma":
+            if key in ("k_front_dma", "k_front_reg", "k_front_fft", "k_front_fftm"):
                 key = "k_front"  # bench.py names the front end k_front whichever variant runs
             acc[key].append(float(r["Counter_Value"]) * 1024.0)
     return {k: sum(v) / len(v) for k, v in acc.items()}
