@@ -116,3 +116,28 @@ def test_demod_api_errors():
         d.batch_i16(buf, 2 * 8192, 8192, buf, 2 * 8192)  # beyond max_batch_samples
     with pytest.raises(J.JsdrError):
         d.frame_stats(0)  # nothing processed yet
+
+
+def test_demod_full_length_batch_sampled_streams_vs_oracle():
+    """BASELINE's batch length (2^20 samples per stream, 512 frames of 2048) in one call: the first and the last
+    stream against the oracle, every frame -- the FM detector / filter / NCO state run through all 512 frames"""
+    rate, n, S, L = 96000, 2048, 8, 1 << 20
+    rng = np.random.default_rng(21)
+    base = fm_am_signal(rng, L, rate, fc=6500.0)
+    raws = [np.roll(base, 2 * 997 * s) for s in range(S)]  # cheap distinct streams (circular shifts, I/Q kept paired)
+    for mode in (2, 3):
+        d = J.Demod(rate=rate, n=n, nstreams=S, max_batch_samples=L)
+        d.configure(mode, 1, 1, 1)
+        d.weights(2000, 12000)
+        got = d.batch_host_i16(np.stack(raws), L)
+        for s in (0, S - 1):
+            o = O.Demod(rate)
+            o.configure(mode, 1, 1, 1)
+            o.weights(2000, 12000)
+            buf = O.convert_i16(raws[s])
+            for f in range(L // n):
+                want = o.receive(buf[2 * f * n:2 * (f + 1) * n])
+                assert np.array_equal(got[s, 2 * f * n:2 * (f + 1) * n], want), (mode, s, f)
+            mx, av = d.frame_stats(s)
+            assert same(mx, o.max) and same(av, o.avg)
+        assert d.state()[0] == o.car

@@ -117,3 +117,22 @@ def test_recordings_mono_and_format_errors(golden_dir, tmp_path):
         J.recordings_load([p8], 2, 48000, 0, 16, dev, 2 * 4096)
     with pytest.raises(J.JsdrError, match="Not readable"):
         J.recordings_load([str(tmp_path / "missing.wav")], 2, 48000, 0, 16, dev, 2 * 4096)
+
+
+def test_waterfall_rows_of_a_full_batch():
+    """4096 PSD frames straight from the batch fft kernel (device to device), every 97th row against the oracle"""
+    n, nframes, width = 2048, 4096, 1280
+    ct, _ = O.synth_tables(6000)
+    d_ct = J.DeviceBuffer.from_host(ct)
+    d_raw = J.DeviceBuffer(nframes * n * 4)
+    J.synth_tones(d_raw, 0, nframes, n, d_ct, 250, O.mix64(7))
+    f = J.Fft(n, 96000)
+    d_psd = J.DeviceBuffer(nframes * (n + 2) * 4)
+    f.batch_i16(d_raw, nframes, d_psd)
+    d_pix = J.DeviceBuffer(nframes * width * 4)
+    J.waterfall_lines_dev(d_psd, nframes, n, width, d_pix)
+    J.lib().jsdr_stream_sync(None)
+    psd = d_psd.to_host(np.float32).reshape(nframes, n + 2)
+    pix = d_pix.to_host(np.uint32).reshape(nframes, width)
+    for k in range(0, nframes, 97):
+        assert np.array_equal(pix[k], O.waterfall_line(psd[k], n, width)), k
