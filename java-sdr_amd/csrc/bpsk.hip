@@ -9,8 +9,10 @@
 // Pipeline per batch of L input samples x S streams (all on one HIP stream):
 //   host        : input-independent schedules (tuner / VCO table indices per sample) in exact double,
 //                 cached while the phase state repeats (it is an exact 8-cycle at 12 kHz / 96 kHz)
-//   k_front     : int16 -> float -> double, tuner mix, 27-tap low-pass at the decimated instants
+//   k_front*    : int16 -> float -> double, tuner mix, 27-tap low-pass at the decimated instants
 //                 (newest-first order, :479-483), x HOWARD_FUDGE_FACTOR, VCO mix  -> dm[s][64+j]
+//                 (k_front_reg: register-staged lane windows, the default for int16 at 96 kHz; k_front_dma:
+//                 LDS image filled by LDS-DMA; k_front: generic; bpsk_fft.hip / bpsk_fftm.hip: FFT-acquire mode)
 //   k_matched   : 65-tap matched filter in RING-SLOT order with rotated taps (:519-523) -> y[s][j]=(fi,fq)
 //   k_tail      : bit-energy IIRs, peak tracking, differential slicer (:534-593) -> bits
 //   k_sync      : 65-symbol sync correlation at stride 80 over the 5200-bit window (:556-560)
