@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 def test_waterfall_rows_bit_exact():
     rng = np.random.default_rng(3)
-    for n, width in ((2048, 1024), (2048, 801), (2048, 2048), (2048, 2500), (9600, 1920), (64, 5)):
+    for n, width in ((2048, 1024), (2048, 801), (2048, 2048), (2048, 2500), (9600, 1920), (19200, 1600), (64, 5)):
         psd = (rng.standard_normal((9, n + 2)) * 35 - 70).astype(np.float32)
         psd[2, rng.integers(0, n, 40)] = -np.inf
         psd[3, rng.integers(0, n, 40)] = np.nan
