@@ -105,3 +105,24 @@ def test_harness_demod_handler_matches_oracle(golden_dir):
         audio = o.receive(buf[k * 4096:(k + 1) * 4096])
         assert np.float32(float(m.group(1))) == o.max and np.float32(float(m.group(2))) == o.avg
         assert int(m.group(3)) == int(audio.astype(np.int64).sum())
+
+
+def test_harness_at_the_192k_default_frame(tmp_path):
+    """FUNcube Dongle Pro+ rate: blen = 192000*4/10 = 76800 bytes -> n = 19200 samples per frame: every handler
+    of the harness (fft as 2 x 9600 + combine, phase, waterfall, BPSK at decimation 20, demod) takes it"""
+    n = 19200
+    iq, _, _ = O.make_dbpsk_stream(4, 0, 2 * n, rate=192000)
+    fx = tmp_path / "two_frames_192k.raw"
+    iq.tofile(fx)
+    r = subprocess.run([HARNESS, str(fx), "192000", "76800"], capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0, r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("frame")]
+    assert len(lines) == 2
+    buf = O.convert_i16(iq)
+    o = O.Bpsk(rate=192000, blen=76800)
+    for k, line in enumerate(lines):
+        m = re.search(r"max (\S+) dB @ (\S+) Hz .* ds=(\d+) bit=(\d+)", line)
+        ref = O.fft_receive(buf[k * 2 * n:(k + 1) * 2 * n], 192000)
+        assert abs(float(m.group(1)) - ref[n + 1]) < 1e-3 and float(m.group(2)) == ref[n]
+        o.receive(buf[k * 2 * n:(k + 1) * 2 * n])
+        assert int(m.group(3)) == o.counters()["cntDS"] and int(m.group(4)) == o.counters()["cntBit"]
