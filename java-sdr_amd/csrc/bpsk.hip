@@ -715,11 +715,25 @@ __global__ __launch_bounds__(512) void k_matched(MatchedArgs a)
     const int s = blockIdx.y;
     const long long G = a.tile0 + 4160LL * blockIdx.x;
     const double2 *dm = a.dm + (long long)s * a.dm_stride;
-    for (int i = threadIdx.x; i < 64 + 4160; i += 512) {
-        long long rel = (G - 64 + i) - a.g_first;  // index relative to the first new sample
-        double2 v = make_double2(0.0, 0.0);
-        if (rel >= -64 && rel < a.nds) v = dm[64 + rel];
-        X[i] = v;
+    {
+        // all nine loads of a thread are in flight before the first LDS store: as a plain loop the compiler issues
+        // one load, waits for it, stores, and pays the full memory latency nine times per workgroup
+        constexpr int NLD = (64 + 4160 + 511) / 512;
+        double2 v[NLD];
+#pragma unroll
+        for (int q = 0; q < NLD; q++) {
+            const int i = threadIdx.x + 512 * q;
+            const long long rel = (G - 64 + i) - a.g_first;  // index relative to the first new sample
+            const bool in = i < 64 + 4160 && rel >= -64 && rel < a.nds;
+            // clamped address, masked value: no branch between the loads
+            const double2 x = dm[64 + (in ? rel : 0)];
+            v[q] = in ? x : make_double2(0.0, 0.0);
+        }
+#pragma unroll
+        for (int q = 0; q < NLD; q++) {
+            const int i = threadIdx.x + 512 * q;
+            if (i < 64 + 4160) X[i] = v[q];
+        }
     }
     __syncthreads();
     const int lane = threadIdx.x & 63;
