@@ -116,8 +116,41 @@ __global__ __launch_bounds__(256) void k_demod_front(DemodArgs a)
     const float2 *rawf = a.rawf + (long long)s * a.stride_pairs;
     const float2 *hist = a.hist + (long long)s * DHALO;
     // xs[xpad8(i)] = x(g0 - 21 + i); beyond the tile's end: zeros (their outputs are never stored)
-    for (int i = tid; i < DTILE + DHALO; i += 256)
-        xs[xpad8(i)] = (i < len + DHALO) ? demod_in<F32IN>(a, raw, rawf, hist, g0 - DHALO + i) : make_float2(0.0f, 0.0f);
+    if (g0 >= DHALO) {
+        // every tile but the call's first: all nine loads of a thread are in flight before the first conversion /
+        // LDS store (as a plain loop the compiler waits for each load in turn: nine memory latencies per tile)
+        constexpr int NLD = (DTILE + DHALO + 255) / 256;
+        const long long lastg = a.L - 1;
+        int w[NLD];
+        float2 wf[NLD];
+#pragma unroll
+        for (int q = 0; q < NLD; q++) {
+            long long g = g0 - DHALO + tid + 256 * q;
+            g = g > lastg ? lastg : g;  // beyond the tile's (and the call's) end: any valid address, the value is dropped
+            if (F32IN)
+                wf[q] = rawf[g];
+            else
+                w[q] = raw[g];
+        }
+#pragma unroll
+        for (int q = 0; q < NLD; q++) {
+            const int i = tid + 256 * q;
+            if (i < DTILE + DHALO) {
+                float2 v = make_float2(0.0f, 0.0f);
+                if (i < len + DHALO) {
+                    if (F32IN)
+                        v = wf[q];
+                    else
+                        v = make_float2(i16_to_float_java(java_short_add((int)(short)(w[q] & 0xffff), a.ic)),
+                                        i16_to_float_java(java_short_add(w[q] >> 16, a.qc)));
+                }
+                xs[xpad8(i)] = v;
+            }
+        }
+    } else {
+        for (int i = tid; i < DTILE + DHALO; i += 256)
+            xs[xpad8(i)] = (i < len + DHALO) ? demod_in<F32IN>(a, raw, rawf, hist, g0 - DHALO + i) : make_float2(0.0f, 0.0f);
+    }
     __syncthreads();
     const int t0 = tid * PER;  // first sample of this thread within the tile
     v2f m[PER];                // filtered + mixed samples
