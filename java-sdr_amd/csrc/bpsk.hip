@@ -819,9 +819,24 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs a)
     const int cntBit0 = sp->cntBit;
     // carry the 5200-bit shift register (dmFECCorr, :503) over from the previous call's log
     {
+        // (the source is byte aligned only; 82 byte loads per lane, in two batches kept in flight together -- a
+        // load / wait / store loop would pay the memory latency 82 times before the first chunk starts)
         const signed char *old = a.bitlog_old + (long long)s * a.bitlog_stride + nbits_prev;
-#pragma unroll 4
-        for (int i = lane; i < HIST_BITS; i += 64) blog[i] = old[i];
+        constexpr int NQ = (HIST_BITS + 63) / 64, HALF = (NQ + 1) / 2;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            signed char t[HALF];
+#pragma unroll
+            for (int q = 0; q < HALF; q++) {
+                const int i = lane + 64 * (h * HALF + q);
+                t[q] = old[i < HIST_BITS ? i : HIST_BITS - 1];
+            }
+#pragma unroll
+            for (int q = 0; q < HALF; q++) {
+                const int i = lane + 64 * (h * HALF + q);
+                if (i < HIST_BITS) blog[i] = t[q];
+            }
+        }
     }
     const double K1 = 1.0 - 1.0 / 200.0, S1 = 1.0 / 200.0;  // BIT_SMOOTH1 (:89)
     const double K2 = 1.0 - 1.0 / 800.0, S2 = 1.0 / 800.0;  // BIT_SMOOTH2 (:90)

@@ -49,6 +49,8 @@ for step in "$@"; do
     bench_m64) JSDR_FFT_GRID_MULT=64 run bench_m64 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline ;;
     bench_m256) JSDR_FFT_GRID_MULT=256 run bench_m256 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline ;;
     bench_m16) JSDR_FFT_GRID_MULT=16 run bench_m16 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline ;;
+    bench_alone_b) JSDR_LIB=$PWD/java-sdr_amd/libjsdr_hip_b.so JSDR_NO_OVERLAP=1 run bench_alone_b 300 python bench.py --workload bpsk --steps 5 --warmup 2 --no-cpu-baseline ;;
+    bench_alone) JSDR_NO_OVERLAP=1 run bench_alone 300 python bench.py --workload bpsk --steps 5 --warmup 2 --no-cpu-baseline ;;
     bench_noov)  JSDR_NO_OVERLAP=1 run bench_noov 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline ;;
     bench_rd80)  JSDR_FRONT_RD=80 run bench_rd80 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline ;;
     fec_bench)   run fec_bench 300 python tools/fec_bench.py ;;
