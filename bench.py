@@ -316,7 +316,10 @@ def main():
 
     # ---- validation outside the timed region: every sampled stream decodes what it was sent
     validated = None
-    if dem is not None and not a.no_validate:
+    # (FFT-acquire mode is not validated by payload: the reference's block-wise FFT filter puts a seam into the
+    #  signal every frame, and at 2048-sample frames its own demodulator -- the oracle bit for bit, see
+    #  tests/test_gpu_bpsk.py -- rarely brings a 5200-bit FEC block through; parity for that mode is the tests')
+    if dem is not None and not a.no_validate and not a.fft_acquire:
         payloads = pay.to_host(np.uint8).reshape(S, nfr, 256)
         ok = True
         for s in sorted(set([0, S // 2, S - 1])):
