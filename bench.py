@@ -56,6 +56,9 @@ def parse():
                     help="--workload demod: the demod.java chain (8f next-3) with filter, down-conversion and AGC on")
     ap.add_argument("--waterfall-width", type=int, default=0,
                     help="also paint every PSD frame as a waterfall pixel row of this width (waterfall.java:87-109)")
+    ap.add_argument("--bpsk-frame", type=int, default=N_FFT,
+                    help="--workload bpsk: samples per demodulator frame (blen/size); 9600 = the reference's default, the "
+                         "only size at which its FFT-acquire mode (10 Hz bins) brings FEC blocks through")
     ap.add_argument("--fft-acquire", action="store_true", help="demodulator in FFT-acquire mode (bpsk-dofft=1) instead of tune mode")
     return ap.parse_args()
 
@@ -195,14 +198,18 @@ def main():
         raise SystemExit(J.lib().jsdr_last_error())
 
     S, L = a.streams, a.samples
-    if L % N_FFT:
+    if a.bpsk_frame != N_FFT:
+        if a.workload != "bpsk":
+            raise SystemExit("--bpsk-frame needs --workload bpsk")
+        L = (L // a.bpsk_frame) * a.bpsk_frame
+    elif L % N_FFT:
         raise SystemExit("--samples must be a multiple of 2048")
     stream0, _ = SH.shard_streams(N * S, N, rank)  # contiguous shards: rank order == global stream order
     d_iq, pay, nfr = make_inputs(J, O, S, L, stream0)
     nframes = S * L // N_FFT
     fft = J.Fft(N_FFT, RATE) if a.workload in ("pipeline", "fft") else None
     d_psd = J.DeviceBuffer(nframes * (N_FFT + 2) * 4) if fft else None
-    dem = J.Bpsk(rate=RATE, blen=4 * N_FFT, tuning=12000, do_fft=int(a.fft_acquire), nstreams=S, max_batch_samples=L) \
+    dem = J.Bpsk(rate=RATE, blen=4 * a.bpsk_frame, tuning=12000, do_fft=int(a.fft_acquire), nstreams=S, max_batch_samples=L) \
         if a.workload in ("pipeline", "bpsk") else None
     amfm = d_audio = None
     if a.workload == "demod":
@@ -319,7 +326,7 @@ def main():
     # (FFT-acquire mode is not validated by payload: the reference's block-wise FFT filter puts a seam into the
     #  signal every frame, and at 2048-sample frames its own demodulator -- the oracle bit for bit, see
     #  tests/test_gpu_bpsk.py -- rarely brings a 5200-bit FEC block through; parity for that mode is the tests')
-    if dem is not None and not a.no_validate and not a.fft_acquire:
+    if dem is not None and not a.no_validate and not (a.fft_acquire and a.bpsk_frame != 9600):
         payloads = pay.to_host(np.uint8).reshape(S, nfr, 256)
         ok = True
         for s in sorted(set([0, S // 2, S - 1])):
@@ -349,7 +356,7 @@ def main():
                                     "bpsk": "FUNcubeBPSKDemod tune mode + FECDecoder (BASELINE config 4)",
                                     "demod": f"demod.java {a.demod_mode.upper()} chain (8f next-3): 21-tap complex FIR + NCO "
                                              "+ detector + AGC -> int16 stereo, 2048-sample frames"}[a.workload],
-                       "streams_per_gpu": S, "samples_per_stream": L, "rate_hz": RATE, "frame": N_FFT,
+                       "streams_per_gpu": S, "samples_per_stream": L, "rate_hz": RATE, "frame": a.bpsk_frame if a.workload == "bpsk" else N_FFT,
                        "input_bytes_per_gpu": S * L * 4, "variant": ("exact-order float32 (bit-exact int16 audio)" if a.workload == "demod" else
                                    "exact-order FP64 (bit-exact bits/bytes)" + (", FFT-acquire front end" if a.fft_acquire else ", tune mode")),
                        "parallelism": f"streams sharded over {N} GPU(s)" + (", RCCL all-gather of result slots" if N > 1 else "")},

@@ -35,6 +35,7 @@ for step in "$@"; do
     tests_bpsk)  run tests_bpsk 600 python -m pytest tests/test_gpu_bpsk.py -m gpu -q -x -p no:cacheprovider --timeout 600 ;;
     bench_quick) run bench_quick 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline ;;
     bench_acq)   run bench_acq 400 python bench.py --workload bpsk --fft-acquire --steps 3 --warmup 1 --no-cpu-baseline ;;
+    bench_acq9600) run bench_acq9600 400 python bench.py --workload bpsk --fft-acquire --bpsk-frame 9600 --steps 3 --warmup 1 --no-cpu-baseline ;;
     bench_acq_clk) JSDR_FFT_PHASECLK=1 run bench_acq_clk 400 python bench.py --workload bpsk --fft-acquire --steps 2 --warmup 1 --no-cpu-baseline ;;
     bench_nodma) JSDR_FRONT_DMA=0 run bench_nodma 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline ;;
     bench_n2)    JSDR_BENCH_SAME_DEVICE=1 JSDR_BENCH_BACKEND=gloo run bench_n2 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 3 --warmup 1 --streams 256 ;;
