@@ -28,6 +28,8 @@ struct FftmArgs {
     int np;
     int rad[FM_MAXPASS];
     int tw_off[FM_MAXPASS];  // offset of pass p's table T[m] = exp(-2 pi i m/(P r)), m < P r
+    unsigned pmagic[FM_MAXPASS];  // b / P == (b * pmagic) >> 32 for b < 2^16 (P = product of the earlier radices)
+    int lds_tw;              // the tables of the first passes, lds_tw entries in all, are copied to LDS
 };
 
 __device__ __forceinline__ double2 cdadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
@@ -80,7 +82,7 @@ __device__ __forceinline__ void dft_r(double2 *v)
 
 // one Stockham pass, in place: every butterfly of the pass is in registers before the first store
 template <int R>
-__device__ __forceinline__ void fm_pass(double2 *X, const double2 *__restrict__ tw, int n, int P, int tid)
+__device__ __forceinline__ void fm_pass(double2 *X, const double2 *tw, int n, int P, unsigned pmagic, int tid)
 {
     constexpr int ITERS = ((FM_NMAX / R) + FM_T - 1) / FM_T;
     const int nb = n / R;
@@ -89,7 +91,7 @@ __device__ __forceinline__ void fm_pass(double2 *X, const double2 *__restrict__ 
     for (int it = 0; it < ITERS; it++) {
         const int b = it * FM_T + tid;
         if (b < nb) {
-            const int k = b % P;
+            const int k = (P == 1) ? 0 : b - (int)__umulhi((unsigned)b, pmagic) * P;  // b % P without the division sequence
 #pragma unroll
             for (int j = 0; j < R; j++) {
                 v[it][j] = X[b + j * nb];
@@ -103,7 +105,7 @@ __device__ __forceinline__ void fm_pass(double2 *X, const double2 *__restrict__ 
     for (int it = 0; it < ITERS; it++) {
         const int b = it * FM_T + tid;
         if (b < nb) {
-            const int k = b % P;
+            const int k = (P == 1) ? 0 : b - (int)__umulhi((unsigned)b, pmagic) * P;  // (2^32/1 does not fit the magic)
             const int j0 = (b - k) * R + k;
 #pragma unroll
             for (int q = 0; q < R; q++) X[j0 + q * P] = v[it][q];
@@ -112,20 +114,22 @@ __device__ __forceinline__ void fm_pass(double2 *X, const double2 *__restrict__ 
     __syncthreads();
 }
 
-__device__ __forceinline__ void fm_forward(double2 *X, const FftmArgs &a, int tid)
+__device__ __forceinline__ void fm_forward(double2 *X, const double2 *twL, const FftmArgs &a, int tid)
 {
     int P = 1;
     for (int p = 0; p < a.np; p++) {
         const int r = a.rad[p];
-        const double2 *tw = a.f.tw + a.tw_off[p];
+        // the narrow tables sit in LDS: a pass that starts with a round trip to L2 for its twiddles costs ~2 us,
+        // 14 times per frame, with nothing else to run on the CU
+        const double2 *tw = (a.tw_off[p] + P * r <= a.lds_tw) ? twL + a.tw_off[p] : a.f.tw + a.tw_off[p];
         if (r == 4)
-            fm_pass<4>(X, tw, a.f.n, P, tid);
+            fm_pass<4>(X, tw, a.f.n, P, a.pmagic[p], tid);
         else if (r == 2)
-            fm_pass<2>(X, tw, a.f.n, P, tid);
+            fm_pass<2>(X, tw, a.f.n, P, a.pmagic[p], tid);
         else if (r == 3)
-            fm_pass<3>(X, tw, a.f.n, P, tid);
+            fm_pass<3>(X, tw, a.f.n, P, a.pmagic[p], tid);
         else
-            fm_pass<5>(X, tw, a.f.n, P, tid);
+            fm_pass<5>(X, tw, a.f.n, P, a.pmagic[p], tid);
         P *= r;
     }
 }
@@ -141,7 +145,9 @@ __global__ __launch_bounds__(FM_T) void k_front_fftm(FftmArgs aa)
     double *taps = hist + 32;                            // [32]
     double *redv = taps + 32;                            // [16] per-wave best value
     int *redi = reinterpret_cast<int *>(redv + 16);      // [16] per-wave best index
+    double2 *twL = reinterpret_cast<double2 *>(redi + 16);  // [lds_tw] twiddle tables of the first passes
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < aa.lds_tw; i += FM_T) twL[i] = aa.f.tw[i];
     const int s = blockIdx.x;
     const int beg = a.do_up ? n / 4 : 0;
     const int end = a.do_up ? n / 2 : n / 4;
@@ -184,7 +190,7 @@ __global__ __launch_bounds__(FM_T) void k_front_fftm(FftmArgs aa)
             X[t] = make_double2(di, dq);
         }
         __syncthreads();
-        fm_forward(X, aa, tid);  // :422-423
+        fm_forward(X, twL, aa, tid);  // :422-423
         // ---- |X| (:425-427) over the band the boxcar reads
         for (int i = pbase + tid; i < end - 24; i += FM_T) {
             const double2 v = X[i];
@@ -270,7 +276,7 @@ __global__ __launch_bounds__(FM_T) void k_front_fftm(FftmArgs aa)
         __syncthreads();
         if (tid < 204) X[tid] = make_double2(keep.x, -keep.y);
         __syncthreads();
-        fm_forward(X, aa, tid);
+        fm_forward(X, twL, aa, tid);
         // ---- RxDownSample(re, re) (:461-463, :470-492): outputs whose window ends inside this frame
         {
             long long jlo = (t0 - a.first_out + D - 1) / D;
@@ -368,11 +374,21 @@ int launch_front_fftm(const FftFrontArgs &a, int np, const int *rad, const int *
     FftmArgs aa;
     aa.f = a;
     aa.np = np;
+    const size_t fixed = sizeof(double2) * (size_t)a.n + sizeof(double) * (32 + 32 + 16) + sizeof(int) * 16 + 64;
+    const size_t room = (size_t)160 * 1024 - fixed - 256;  // LDS left for twiddle tables
+    aa.lds_tw = 0;
+    int P = 1;
     for (int p = 0; p < FM_MAXPASS; p++) {
         aa.rad[p] = p < np ? rad[p] : 1;
         aa.tw_off[p] = p < np ? tw_off[p] : 0;
+        aa.pmagic[p] = (unsigned)(((1ull << 32) + (unsigned)P - 1) / (unsigned)P);  // exact for b < 2^16, P <= 9600
+        if (p < np) {
+            const size_t end = (size_t)tw_off[p] + (size_t)P * rad[p];
+            if (end == (size_t)aa.lds_tw + (size_t)P * rad[p] && end * sizeof(double2) <= room) aa.lds_tw = (int)end;  // a prefix
+            P *= rad[p];
+        }
     }
-    const size_t lds = sizeof(double2) * (size_t)a.n + sizeof(double) * (32 + 32 + 16) + sizeof(int) * 16 + 64;
+    const size_t lds = fixed + sizeof(double2) * (size_t)aa.lds_tw;
     const bool f32 = a.rawf != nullptr;
     static size_t attr_for[2] = {0, 0};
     if (attr_for[f32] < lds) {
