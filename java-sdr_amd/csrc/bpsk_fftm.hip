@@ -8,10 +8,10 @@
 // inverse as conj o forward o conj -- so centre bins, traces, bits and FEC bytes are bit-identical to the
 // oracle.  JTransforms' own rounding is unknowable (source absent): parity with the Java library itself is unpinned.
 //
-// MI355X mapping: one 1024-thread workgroup per stream, persistent over the frames of the call (the centre-bin
+// MI355X mapping: one 512-thread workgroup per stream, persistent over the frames of the call (the centre-bin
 // state is sequential).  The frame lives in LDS as double2[n] (153.6 KB at n = 9600: one workgroup per CU); a
-// pass loads every butterfly into registers (<= 12 double2 per thread), barrier, stores to the autosort
-// positions -- in place, no second image.  |X| and the boxcar sums of the searched quarter band reuse the dead
+// pass loads every butterfly into registers (<= 24 double2 per thread; 1024 threads would cap a thread at 128
+// VGPRs and spill), barrier, stores to the autosort positions -- in place, no second image.  |X| and the boxcar sums of the searched quarter band reuse the dead
 // upper part of the image.  The rest (boxcar, first maximum, centre-bin rule, 204 bins to bin 0, RxDownSample,
 // VCO) is k_front_fft's, with run-time sizes.
 #include "bpsk_fft.h"
