@@ -93,29 +93,44 @@ __device__ __forceinline__ void mixed_pass(const FftArgs &a, long long frame, in
     constexpr int NB = N / R;
     constexpr int ITERS = (NB + T - 1) / T;
     float2 v[ITERS][R];
+    if constexpr (FIRST) {
+        // all of a thread's samples are requested before the first one is converted: loads under a per-butterfly
+        // guard were issued one at a time, each waiting for the one before (R * ITERS memory latencies per frame)
+        // split: this transform is the even / odd half of input frame (frame >> 1), 2N samples long
+        const long long fbase = a.split ? (frame >> 1) * (2LL * N) + (frame & 1) : frame * (long long)N;
+        const int st = a.split ? 2 : 1;
+        if constexpr (IN == IN_I16) {
+            const int *src = reinterpret_cast<const int *>(a.in) + fbase;
+            int w[ITERS][R];
+#pragma unroll
+            for (int it = 0; it < ITERS; it++) {
+                const int b = (it * T + tid) < NB ? (it * T + tid) : NB - 1;  // clamped: the surplus butterfly is dropped
+#pragma unroll
+                for (int r = 0; r < R; r++) w[it][r] = src[(b + r * NB) * st];
+            }
+#pragma unroll
+            for (int it = 0; it < ITERS; it++)
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const int si = java_short_add((int)(short)(w[it][r] & 0xffff), a.ic);
+                    const int sq = java_short_add(w[it][r] >> 16, a.qc);
+                    v[it][r] = make_float2(i16_to_float_java(si), i16_to_float_java(sq));
+                }
+        } else {
+            const float2 *src = reinterpret_cast<const float2 *>(a.in) + fbase;
+#pragma unroll
+            for (int it = 0; it < ITERS; it++) {
+                const int b = (it * T + tid) < NB ? (it * T + tid) : NB - 1;
+#pragma unroll
+                for (int r = 0; r < R; r++) v[it][r] = src[(b + r * NB) * st];
+            }
+        }
+    }
 #pragma unroll
     for (int it = 0; it < ITERS; it++) {
         const int b = it * T + tid;
         if (b < NB) {
-            if constexpr (FIRST) {
-                // split: this transform is the even / odd half of input frame (frame >> 1), 2N samples long
-                const long long fbase = a.split ? (frame >> 1) * (2LL * N) + (frame & 1) : frame * (long long)N;
-                const int st = a.split ? 2 : 1;
-                if constexpr (IN == IN_I16) {
-                    const int *src = reinterpret_cast<const int *>(a.in) + fbase;
-#pragma unroll
-                    for (int r = 0; r < R; r++) {
-                        int w = src[(b + r * NB) * st];
-                        int si = java_short_add((int)(short)(w & 0xffff), a.ic);
-                        int sq = java_short_add(w >> 16, a.qc);
-                        v[it][r] = make_float2(i16_to_float_java(si), i16_to_float_java(sq));
-                    }
-                } else {
-                    const float2 *src = reinterpret_cast<const float2 *>(a.in) + fbase;
-#pragma unroll
-                    for (int r = 0; r < R; r++) v[it][r] = src[(b + r * NB) * st];
-                }
-            } else {
+            if constexpr (!FIRST) {
 #pragma unroll
                 for (int r = 0; r < R; r++) v[it][r] = buf[lds_pad(b + r * NB)];
             }

@@ -70,6 +70,9 @@ for step in "$@"; do
                  python tools/pmc_summary.py gpurun_out/pmc_fft2_$R | tee gpurun_out/pmc_fft2_summary.txt ;;
     dbg)         run dbg 300 python tools/dbg_fftmode.py ;;
     fftm_bench)  run fftm_bench 300 python tools/fftm_bench.py ;;
+    fft9600)     run fft9600 300 python tools/fft_n_bench.py 9600 ;;
+    fft19200)    run fft19200 300 python tools/fft_n_bench.py 19200 ;;
+    fft4800)     run fft4800 300 python tools/fft_n_bench.py 4800 ;;
     fftm_small)  FM_S=8 FM_NFR=20 run fftm_small 300 python tools/fftm_bench.py ;;
     dbg_demod)   run dbg_demod 300 python tools/dbg_demod.py ;;
     trig)        run trig 300 python tools/trig_stats.py ;;
