@@ -274,7 +274,7 @@ bool mixed_plan(int n, MixedPlan &p)
         p.n = n;
         p.nrad = 5;
         for (int i = 0; i < 5; i++) p.radix[i] = r[i];
-        p.threads = 320;
+        p.threads = 512;
     } else if (n == 19200) {
         // 192 kHz (FUNcube Dongle Pro+): the frame does not fit one workgroup's LDS; X[k] = E[k] + W^k O[k],
         // X[k+n/2] = E[k] - W^k O[k] with E, O the 9600-point transforms of the even / odd samples
@@ -449,7 +449,7 @@ int mixed_launch_split2(const MixedPlan &p, const FftArgs &a, int in_kind, int o
 int mixed_launch(const MixedPlan &p, const FftArgs &a, int in_kind, int out_kind, int grid, hipStream_t st)
 {
     if (p.n == 9600) return mixed_launch_t<9600, 512, 16, 8, 5, 5, 3>(p, a, in_kind, out_kind, grid, st);
-    if (p.n == 4800) return mixed_launch_t<4800, 320, 16, 4, 5, 5, 3>(p, a, in_kind, out_kind, grid, st);
+    if (p.n == 4800) return mixed_launch_t<4800, 512, 16, 4, 5, 5, 3>(p, a, in_kind, out_kind, grid, st);
     set_error("fft: no mixed-radix plan for n=%d", p.n);
     return JSDR_ERR;
 }
