@@ -54,14 +54,30 @@ __global__ void k_phase_maxabs(const float *__restrict__ iq, int len, float *__r
 {
     const float *p = iq + (long long)blockIdx.x * len;
     float m = -1.0f;
-    for (int i = threadIdx.x * 4; i < len; i += blockDim.x * 4) {
+    auto take = [&](float4 v) {
+        const float a0 = fabsf(v.x), a1 = fabsf(v.y), a2 = fabsf(v.z), a3 = fabsf(v.w);
+        if (m < a0) m = a0;
+        if (m < a1) m = a1;
+        if (m < a2) m = a2;
+        if (m < a3) m = a3;
+    };
+    // four 16-byte loads of a thread in flight together (the whole 2048-sample frame of a 256-thread workgroup in
+    // one go); the max is order independent ('<' never lets a NaN in, whichever way the frame is walked)
+    const int stride = blockDim.x * 4;
+    int i = threadIdx.x * 4;
+    for (; i + 3 * stride + 3 < len; i += 4 * stride) {
+        const float4 v0 = *reinterpret_cast<const float4 *>(p + i);
+        const float4 v1 = *reinterpret_cast<const float4 *>(p + i + stride);
+        const float4 v2 = *reinterpret_cast<const float4 *>(p + i + 2 * stride);
+        const float4 v3 = *reinterpret_cast<const float4 *>(p + i + 3 * stride);
+        take(v0);
+        take(v1);
+        take(v2);
+        take(v3);
+    }
+    for (; i < len; i += stride) {
         if (i + 3 < len) {
-            float4 v = *reinterpret_cast<const float4 *>(p + i);
-            float a0 = fabsf(v.x), a1 = fabsf(v.y), a2 = fabsf(v.z), a3 = fabsf(v.w);
-            if (m < a0) m = a0;
-            if (m < a1) m = a1;
-            if (m < a2) m = a2;
-            if (m < a3) m = a3;
+            take(*reinterpret_cast<const float4 *>(p + i));
         } else {
             for (int j = i; j < len; j++) {
                 float a = fabsf(p[j]);

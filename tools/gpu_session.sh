@@ -30,6 +30,7 @@ for step in "$@"; do
     bench)       run bench 600 python bench.py ;;
     tests_demod) run tests_demod 600 python -m pytest tests/test_gpu_demod.py -m gpu -q -x -p no:cacheprovider --timeout 600 ;;
     tests_fft)   run tests_fft 900 python -m pytest tests/test_gpu_fft.py -m gpu -q -x -p no:cacheprovider --timeout 800 ;;
+    tests_misc)  run tests_misc 600 python -m pytest tests/test_gpu_fir_phase_fec.py tests/test_gpu_host.py -m gpu -q -x -p no:cacheprovider --timeout 600 ;;
     tests_fmt)   run tests_fmt 600 python -m pytest tests/test_gpu_formats.py -m gpu -q -x -p no:cacheprovider --timeout 600 ;;
     tests_host)  run tests_host 600 python -m pytest tests/test_gpu_host.py -m gpu -q -x -p no:cacheprovider --timeout 600 ;;
     tests_bpsk)  run tests_bpsk 600 python -m pytest tests/test_gpu_bpsk.py -m gpu -q -x -p no:cacheprovider --timeout 600 ;;
