@@ -1378,6 +1378,26 @@ static void launch_front_reg_t(const FrontArgs &fa, int nstreams, long long nds,
     hipLaunchKernelGGL((k_front_reg<D, RD, MIX, DC>), dim3((unsigned)gx, (unsigned)nstreams), dim3(64 * WAVES), 0, st, fa);
 }
 
+// the register-staged fast path at the other rates (44.1 / 48 / 192 kHz): int16 input, 32-bit sample indices
+template <int D, int RD>
+static bool launch_front_reg(const FrontArgs &fa, int nstreams, long long nds, hipStream_t st)
+{
+    static const bool reg = [] {
+        const char *e = getenv("JSDR_FRONT_REG");  // JSDR_FRONT_REG=0: the generic kernel instead
+        return !e || atoi(e) != 0;
+    }();
+    if (!reg || fa.rawf || fa.nsamples > 0x3fffffffLL || fa.nsamples < 64) return false;
+    const bool dc = (fa.ic != 0) || (fa.qc != 0);
+    if (fa.mix) {
+        if (dc) launch_front_reg_t<D, RD, true, true>(fa, nstreams, nds, st);
+        else launch_front_reg_t<D, RD, true, false>(fa, nstreams, nds, st);
+    } else {
+        if (dc) launch_front_reg_t<D, RD, false, true>(fa, nstreams, nds, st);
+        else launch_front_reg_t<D, RD, false, false>(fa, nstreams, nds, st);
+    }
+    return true;
+}
+
 // the LDS-DMA fast path: int16 input, 96 kHz (D=10), samples addressable with 32-bit indices
 template <int D, int RD>
 static bool launch_front_dma(const FrontArgs &fa, int nstreams, long long nds, hipStream_t st)
@@ -1498,15 +1518,21 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
     } else if (nds > 0) {
         ProfScope ps(h, PK_FRONT, st);
         switch (h->decim) {
-            case 4: launch_front<4, 40>(fa, S, nds, st); break;
-            case 5: launch_front<5, 40>(fa, S, nds, st); break;
+            case 4:
+                if (!launch_front_reg<4, 20>(fa, S, nds, st)) launch_front<4, 40>(fa, S, nds, st);
+                break;
+            case 5:
+                if (!launch_front_reg<5, 20>(fa, S, nds, st)) launch_front<5, 40>(fa, S, nds, st);
+                break;
             case 10:
                 if (h->front_rd == 80)
                     launch_front<10, 80>(fa, S, nds, st);
                 else if (!h->front_dma || !launch_front_dma<10, 40>(fa, S, nds, st))
                     launch_front<10, 40>(fa, S, nds, st);
                 break;
-            case 20: launch_front<20, 80>(fa, S, nds, st); break;
+            case 20:
+                if (!launch_front_reg<20, 80>(fa, S, nds, st)) launch_front<20, 80>(fa, S, nds, st);
+                break;
             default: JSDR_REQUIRE(false, "bpsk: unsupported decimation %d", h->decim);
         }
         JSDR_LAUNCH_CHECK();

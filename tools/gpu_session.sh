@@ -71,6 +71,9 @@ for step in "$@"; do
                  python tools/pmc_summary.py gpurun_out/pmc_fft2_$R | tee gpurun_out/pmc_fft2_summary.txt ;;
     dbg)         run dbg 300 python tools/dbg_fftmode.py ;;
     fftm_bench)  run fftm_bench 300 python tools/fftm_bench.py ;;
+    rate192)     JSDR_NO_OVERLAP=1 run rate192 300 python tools/rate_bench.py 192000 ;;
+    rate48)      JSDR_NO_OVERLAP=1 run rate48 300 python tools/rate_bench.py 48000 ;;
+    rate44)      JSDR_NO_OVERLAP=1 run rate44 300 python tools/rate_bench.py 44100 ;;
     fft9600)     run fft9600 300 python tools/fft_n_bench.py 9600 ;;
     fft19200)    run fft19200 300 python tools/fft_n_bench.py 19200 ;;
     fft4800)     run fft4800 300 python tools/fft_n_bench.py 4800 ;;
