@@ -300,18 +300,41 @@ __global__ __launch_bounds__(64) void k_demod_mean(const float *__restrict__ d, 
     const int nrows = (int)((nframes_total - F0) < 64 ? (nframes_total - F0) : 64);
     float avg = 0.0f;
     for (int c0 = 0; c0 < n; c0 += 64) {
-        // 16 rows in flight per batch: one load at a time would expose the full HBM latency 2048 times per wave
-        for (int r0 = 0; r0 < nrows; r0 += 16) {
-            float v[16];
+        // the whole 64 x 64 tile in flight at once: sixteen 16-byte loads per lane (four rows of 64 samples per
+        // wave instruction), 16 KB per wave -- the kernel is a 4-byte-per-sample stream read whose only problem
+        // is memory-level parallelism (64-thread blocks, 9 per CU)
+        if ((n & 3) == 0 && (L & 3) == 0 && c0 + 64 <= n) {
+            float4 v[16];
+            const int sub = lane >> 4, col = 4 * (lane & 15);
 #pragma unroll
             for (int u = 0; u < 16; u++) {
-                const int r = (r0 + u) < nrows ? (r0 + u) : (nrows - 1);
+                const int r = (4 * u + sub) < nrows ? (4 * u + sub) : (nrows - 1);
                 const long long rb = __shfl(base, r, 64);
-                v[u] = (c0 + lane < n) ? d[rb + c0 + lane] : 0.0f;
+                v[u] = *reinterpret_cast<const float4 *>(d + rb + c0 + col);
             }
 #pragma unroll
-            for (int u = 0; u < 16; u++)
-                if (r0 + u < nrows) tile[r0 + u][lane] = v[u];
+            for (int u = 0; u < 16; u++) {
+                const int r = 4 * u + sub;
+                if (r < nrows) {
+                    tile[r][col] = v[u].x;
+                    tile[r][col + 1] = v[u].y;
+                    tile[r][col + 2] = v[u].z;
+                    tile[r][col + 3] = v[u].w;
+                }
+            }
+        } else {
+            for (int r0 = 0; r0 < nrows; r0 += 16) {
+                float v[16];
+#pragma unroll
+                for (int u = 0; u < 16; u++) {
+                    const int r = (r0 + u) < nrows ? (r0 + u) : (nrows - 1);
+                    const long long rb = __shfl(base, r, 64);
+                    v[u] = (c0 + lane < n) ? d[rb + c0 + lane] : 0.0f;
+                }
+#pragma unroll
+                for (int u = 0; u < 16; u++)
+                    if (r0 + u < nrows) tile[r0 + u][lane] = v[u];
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
