@@ -17,6 +17,7 @@
 // k_demod_out (-> int16 L,R), k_demod_state (history for the next call), k_demod_nco.
 #include "common.h"
 #include <math.h>
+#include <stdlib.h>
 #include <vector>
 
 namespace jsdr {
@@ -98,18 +99,17 @@ __device__ __forceinline__ float2 demod_mixed(const DemodConst &c, const float2 
 // windows overlap, so 28 LDS reads feed 8 outputs (3.5 per sample instead of 21), and I/Q ride in one packed
 // register pair: acc = acc + x*w is v_pk_mul_f32 + v_pk_add_f32, each half rounded separately exactly like the
 // reference's two scalar statements (:388-389).
+constexpr int DPER = DTILE / 256;  // 8 samples per thread and tile
+constexpr int DXS = DTILE + DHALO + (DTILE + DHALO) / 8 + 1;
+
+// tile j of frame f of stream s -> this thread's 8 detected samples dv[] (sam[s] after :441-462) and the running
+// maximum of their magnitudes; xs / last are the workgroup's LDS (two barriers inside, none after)
 template <bool F32IN>
-__global__ __launch_bounds__(256) void k_demod_front(DemodArgs a)
+__device__ __forceinline__ void demod_tile(const DemodArgs &a, const int s, const int f, const int j, float2 *xs, float2 *last,
+                                           float (&dv)[DPER], unsigned &mbits)
 {
-    constexpr int PER = DTILE / 256;  // 8
-    __shared__ float2 xs[DTILE + DHALO + (DTILE + DHALO) / 8 + 1];
-    __shared__ float2 last[256];
-    __shared__ unsigned red[4];
+    constexpr int PER = DPER;
     const int tid = threadIdx.x;
-    const int s = blockIdx.y;
-    const int tiles_per_frame = (a.n + DTILE - 1) / DTILE;
-    const int f = blockIdx.x / tiles_per_frame;
-    const int j = blockIdx.x - f * tiles_per_frame;
     const long long g0 = (long long)f * a.n + (long long)j * DTILE;
     const int len = (a.n - j * DTILE) < DTILE ? (a.n - j * DTILE) : DTILE;
     const int *raw = a.raw + (long long)s * a.stride_pairs;
@@ -207,9 +207,8 @@ __global__ __launch_bounds__(256) void k_demod_front(DemodArgs a)
         prev = demod_mixed(a.c, xs, a.nco, g0 - 1);
     else
         prev = a.lilq[s];
-    unsigned mbits = 0;  // max |d| as a bit pattern: non-negative floats order like unsigned ints, and any NaN
-                         // beats every number -- Math.max's NaN propagation (:463) for free
-    float dv[PER];
+    // max |d| travels as a bit pattern: non-negative floats order like unsigned ints, and any NaN beats every
+    // number -- Math.max's NaN propagation (:463) for free
 #pragma unroll
     for (int u = 0; u < PER; u++) {
         const v2f mm = m[u];
@@ -228,6 +227,42 @@ __global__ __launch_bounds__(256) void k_demod_front(DemodArgs a)
             mbits = bb > mbits ? bb : mbits;
         }
     }
+}
+
+__device__ __forceinline__ unsigned demod_block_max(unsigned mbits, unsigned *red)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const unsigned o = __shfl_xor(mbits, off, 64);
+        mbits = o > mbits ? o : mbits;
+    }
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mbits;
+    __syncthreads();
+    unsigned mx = red[0];
+    for (int w = 1; w < 4; w++) mx = red[w] > mx ? red[w] : mx;
+    return mx;
+}
+
+// AM (whose running mean needs the whole frame first) and frames longer than 5 tiles: one tile per workgroup, the
+// detected samples go to HBM as floats and k_demod_mean / k_demod_out finish the frame
+template <bool F32IN>
+__global__ __launch_bounds__(256) void k_demod_front(DemodArgs a)
+{
+    constexpr int PER = DPER;
+    __shared__ float2 xs[DXS];
+    __shared__ float2 last[256];
+    __shared__ unsigned red[4];
+    const int tid = threadIdx.x;
+    const int s = blockIdx.y;
+    const int tiles_per_frame = (a.n + DTILE - 1) / DTILE;
+    const int f = blockIdx.x / tiles_per_frame;
+    const int j = blockIdx.x - f * tiles_per_frame;
+    const long long g0 = (long long)f * a.n + (long long)j * DTILE;
+    const int len = (a.n - j * DTILE) < DTILE ? (a.n - j * DTILE) : DTILE;
+    const int t0 = tid * PER;
+    float dv[PER];
+    unsigned mbits = 0;
+    demod_tile<F32IN>(a, s, f, j, xs, last, dv, mbits);
     float *d = a.d + (long long)s * a.L + g0 + t0;
     if (t0 + PER <= len && (((long long)s * a.L + g0) & 3) == 0) {
         reinterpret_cast<float4 *>(d)[0] = make_float4(dv[0], dv[1], dv[2], dv[3]);
@@ -237,17 +272,66 @@ __global__ __launch_bounds__(256) void k_demod_front(DemodArgs a)
         for (int u = 0; u < PER; u++)
             if (t0 + u < len) d[u] = dv[u];
     }
+    const unsigned mx = demod_block_max(mbits, red);
+    if (tid == 0) atomicMax(&a.fmax_bits[(long long)s * a.nfr + f], mx);
+}
+
+__device__ __forceinline__ int demod_f2i(float v)  // Java (int) of a float
+{
+    if (v != v) return 0;
+    if (v >= 2147483648.0f) return 2147483647;
+    if (v <= -2147483648.0f) return (-2147483647 - 1);
+    return (int)v;
+}
+
+// Every mode but AM, frames of at most NT tiles: one workgroup per frame keeps the detected samples in registers,
+// takes the frame maximum itself and writes the int16 audio (:465-481) -- no float round trip through HBM and no
+// second pass (4 B in, 4 B out per sample).
+template <bool F32IN, int NT>
+__global__ __launch_bounds__(256) void k_demod_fused(DemodArgs a, int *__restrict__ out, long long out_stride_pairs,
+                                                     float *__restrict__ stats)
+{
+    constexpr int PER = DPER;
+    __shared__ float2 xs[DXS];
+    __shared__ float2 last[256];
+    __shared__ unsigned red[4];
+    const int tid = threadIdx.x;
+    const int s = blockIdx.y, f = blockIdx.x;
+    const int t0 = tid * PER;
+    float dv[NT][PER];
+    unsigned mbits = 0;
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const unsigned o = __shfl_xor(mbits, off, 64);
-        mbits = o > mbits ? o : mbits;
+    for (int j = 0; j < NT; j++) {
+        if (j) __syncthreads();  // the previous tile's LDS image is still being read
+        demod_tile<F32IN>(a, s, f, j, xs, last, dv[j], mbits);
     }
-    if ((tid & 63) == 0) red[tid >> 6] = mbits;
-    __syncthreads();
-    if (tid == 0) {
-        unsigned mx = red[0];
-        for (int w = 1; w < 4; w++) mx = red[w] > mx ? red[w] : mx;
-        atomicMax(&a.fmax_bits[(long long)s * a.nfr + f], mx);
+    const float mx = __uint_as_float(demod_block_max(mbits, red));
+    const float scale = a.c.doagc ? 1.0f / mx : 1.0f;
+    const long long F = (long long)s * a.nfr + f;
+    if (stats && tid == 0) {  // the reference's `max` / `avg` fields after the frame
+        stats[2 * F] = mx;
+        stats[2 * F + 1] = 0.0f;
+    }
+#pragma unroll
+    for (int j = 0; j < NT; j++) {
+        const int len = (a.n - j * DTILE) < DTILE ? (a.n - j * DTILE) : DTILE;
+        const long long g = (long long)f * a.n + (long long)j * DTILE + t0;
+        int *dst = out + (long long)s * out_stride_pairs + g;
+        int o[PER];
+#pragma unroll
+        for (int u = 0; u < PER; u++) {
+            const float x = dv[j][u] * scale;
+            const int sv = (int)(short)demod_f2i(x * 32767.0f);
+            o[u] = (sv & 0xffff) | (sv << 16);
+        }
+        if (t0 + PER <= len && ((((long long)s * out_stride_pairs + g) & 3) == 0)) {
+            reinterpret_cast<int4 *>(dst)[0] = make_int4(o[0], o[1], o[2], o[3]);
+            reinterpret_cast<int4 *>(dst)[1] = make_int4(o[4], o[5], o[6], o[7]);
+        } else {
+#pragma unroll
+            for (int u = 0; u < PER; u++)
+                if (t0 + u < len) dst[u] = o[u];
+        }
     }
 }
 
@@ -351,14 +435,6 @@ __global__ __launch_bounds__(64) void k_demod_mean(const float *__restrict__ d, 
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
     if (valid) favg[F] = avg;
-}
-
-__device__ __forceinline__ int demod_f2i(float v)  // Java (int) of a float
-{
-    if (v != v) return 0;
-    if (v >= 2147483648.0f) return 2147483647;
-    if (v <= -2147483648.0f) return (-2147483647 - 1);
-    return (int)v;
 }
 
 // :465-481: max -= avg (AM); sam = (AM ? sam - avg : sam) * (doagc ? 1.0f/max : 1); (short)(sam * 32767f) to L and R.
@@ -529,9 +605,29 @@ static int demod_run(jsdr_demod *h, const int16_t *raw_dev, const float *rawf_de
         hipLaunchKernelGGL(k_demod_nco, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, st, h->car_dev.p, (long long)L, h->nco.p);
         JSDR_LAUNCH_CHECK();
     }
-    JSDR_HIP_TRY(hipMemsetAsync(h->fmax.p, 0, sizeof(unsigned) * (size_t)S * nfr, st));
     const int tiles_per_frame = (h->n + DTILE - 1) / DTILE;
-    {
+    // every mode but AM, frames of up to 5 tiles (the reference's 9600-sample default included): one kernel from
+    // raw samples to int16 audio; JSDR_DEMOD_FUSED=0 keeps the three-kernel path for A/B runs
+    static const bool fused_ok = [] {
+        const char *e = getenv("JSDR_DEMOD_FUSED");
+        return !(e && e[0] == '0');
+    }();
+    const bool fused = fused_ok && h->mode != MODE_AM && tiles_per_frame <= 5;
+    if (fused) {
+        DemodProf ps(h, DK_FRONT, st);
+        int *outp = reinterpret_cast<int *>(audio_dev);
+        const long long osp = (long long)(audio_stride_i16 / 2);
+        const dim3 grid((unsigned)nfr, (unsigned)S);
+        switch (tiles_per_frame) {
+            case 1: hipLaunchKernelGGL((k_demod_fused<F32IN, 1>), grid, dim3(256), 0, st, a, outp, osp, h->stats.p); break;
+            case 2: hipLaunchKernelGGL((k_demod_fused<F32IN, 2>), grid, dim3(256), 0, st, a, outp, osp, h->stats.p); break;
+            case 3: hipLaunchKernelGGL((k_demod_fused<F32IN, 3>), grid, dim3(256), 0, st, a, outp, osp, h->stats.p); break;
+            case 4: hipLaunchKernelGGL((k_demod_fused<F32IN, 4>), grid, dim3(256), 0, st, a, outp, osp, h->stats.p); break;
+            default: hipLaunchKernelGGL((k_demod_fused<F32IN, 5>), grid, dim3(256), 0, st, a, outp, osp, h->stats.p); break;
+        }
+        JSDR_LAUNCH_CHECK();
+    } else {
+        JSDR_HIP_TRY(hipMemsetAsync(h->fmax.p, 0, sizeof(unsigned) * (size_t)S * nfr, st));
         DemodProf ps(h, DK_FRONT, st);
         hipLaunchKernelGGL(k_demod_front<F32IN>, dim3((unsigned)(tiles_per_frame * nfr), (unsigned)S), dim3(256), 0, st, a);
         JSDR_LAUNCH_CHECK();
@@ -550,7 +646,7 @@ static int demod_run(jsdr_demod *h, const int16_t *raw_dev, const float *rawf_de
                            nft, h->favg.p);
         JSDR_LAUNCH_CHECK();
     }
-    {
+    if (!fused) {
         DemodProf ps(h, DK_OUT, st);
         hipLaunchKernelGGL(k_demod_out, dim3((unsigned)((h->n + 1023) / 1024), (unsigned)nfr, (unsigned)S), dim3(256), 0, st, h->d.p, (long long)L,
                            h->n, nfr, h->mode, h->doagc, h->fmax.p, h->favg.p, reinterpret_cast<int *>(audio_dev),

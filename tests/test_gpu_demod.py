@@ -72,6 +72,8 @@ def test_demod_other_frame_sizes_rates_and_dc_correction():
     run_both(4, 1, 0, 1, n=4800, S=2, frames_per_call=[2], rate=48000, band=(-9000, 2000))
     run_both(2, 1, 1, 0, n=256, S=5, frames_per_call=[4, 4], rate=44100, band=(100, 4000))
     run_both(3, 1, 1, 1, n=2051, S=2, frames_per_call=[2, 2])            # frame that is not a multiple of anything
+    run_both(3, 1, 1, 1, n=19200, S=2, frames_per_call=[1, 1], rate=192000)  # > 5 tiles: the three-kernel path in an FM mode
+    run_both(1, 0, 1, 1, n=10240, S=1, frames_per_call=[2])               # exactly 5 full tiles, fused
 
 
 def test_demod_default_weights_are_zero_like_the_reference():
