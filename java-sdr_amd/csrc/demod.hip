@@ -104,7 +104,7 @@ constexpr int DXS = DTILE + DHALO + (DTILE + DHALO) / 8 + 1;
 
 // tile j of frame f of stream s -> this thread's 8 detected samples dv[] (sam[s] after :441-462) and the running
 // maximum of their magnitudes; xs / last are the workgroup's LDS (two barriers inside, none after)
-template <bool F32IN>
+template <bool F32IN, bool CHAINED>
 __device__ __forceinline__ void demod_tile(const DemodArgs &a, const int s, const int f, const int j, float2 *xs, float2 *last,
                                            float (&dv)[DPER], unsigned &mbits)
 {
@@ -115,36 +115,46 @@ __device__ __forceinline__ void demod_tile(const DemodArgs &a, const int s, cons
     const int *raw = a.raw + (long long)s * a.stride_pairs;
     const float2 *rawf = a.rawf + (long long)s * a.stride_pairs;
     const float2 *hist = a.hist + (long long)s * DHALO;
+    // FM detector across tiles of one workgroup: the previous tile's last sample, read before the staging barrier
+    // below lets anyone overwrite it
+    float2 carried = make_float2(0.0f, 0.0f);
+    if (CHAINED && tid == 0) carried = last[255];
     // xs[xpad8(i)] = x(g0 - 21 + i); beyond the tile's end: zeros (their outputs are never stored)
     if (g0 >= DHALO) {
         // every tile but the call's first: all nine loads of a thread are in flight before the first conversion /
         // LDS store (as a plain loop the compiler waits for each load in turn: nine memory latencies per tile)
+        // addressing: one uniform base per tile and a 32-bit offset per load, clamped inside the call (values
+        // beyond the tile's end are dropped below)
         constexpr int NLD = (DTILE + DHALO + 255) / 256;
-        const long long lastg = a.L - 1;
+        const long long room = a.L - 1 - (g0 - DHALO);
+        const unsigned relmax = (unsigned)(room < (long long)(DTILE + DHALO - 1) ? room : (long long)(DTILE + DHALO - 1));
+        const int *rb = raw + (g0 - DHALO);
+        const float2 *rbf = rawf + (g0 - DHALO);
         int w[NLD];
         float2 wf[NLD];
 #pragma unroll
         for (int q = 0; q < NLD; q++) {
-            long long g = g0 - DHALO + tid + 256 * q;
-            g = g > lastg ? lastg : g;  // beyond the tile's (and the call's) end: any valid address, the value is dropped
+            unsigned rel = (unsigned)(tid + 256 * q);
+            rel = rel < relmax ? rel : relmax;
             if (F32IN)
-                wf[q] = rawf[g];
+                wf[q] = rbf[rel];
             else
-                w[q] = raw[g];
+                w[q] = rb[rel];
         }
+        const bool full = len == DTILE;  // every tile of a frame but a ragged last one
 #pragma unroll
         for (int q = 0; q < NLD; q++) {
             const int i = tid + 256 * q;
-            if (i < DTILE + DHALO) {
-                float2 v = make_float2(0.0f, 0.0f);
-                if (i < len + DHALO) {
-                    if (F32IN)
-                        v = wf[q];
-                    else
-                        v = make_float2(i16_to_float_java(java_short_add((int)(short)(w[q] & 0xffff), a.ic)),
-                                        i16_to_float_java(java_short_add(w[q] >> 16, a.qc)));
-                }
-                xs[xpad8(i)] = v;
+            float2 v;
+            if (F32IN)
+                v = wf[q];
+            else
+                v = make_float2(i16_to_float_java(java_short_add((int)(short)(w[q] & 0xffff), a.ic)),
+                                i16_to_float_java(java_short_add(w[q] >> 16, a.qc)));
+            if (full) {
+                if (q < NLD - 1 || i < DTILE + DHALO) xs[xpad8(i)] = v;
+            } else if (i < DTILE + DHALO) {
+                xs[xpad8(i)] = (i < len + DHALO) ? v : make_float2(0.0f, 0.0f);
             }
         }
     } else {
@@ -192,21 +202,28 @@ __device__ __forceinline__ void demod_tile(const DemodArgs &a, const int s, cons
         }
 #pragma unroll
         for (int u = 0; u < PER; u++) {
+            // (x*c - y*s, x*s + y*c) as x*(c, s) + (-y, y)*(s, c): two packed products and one packed sum (x - y == x + (-y) exactly)
             const v2f v = m[u];
-            m[u] = (v2f){v.x * cs[u].x - v.y * cs[u].y, v.x * cs[u].y + v.y * cs[u].x};
+            const v2f c = (v2f){cs[u].x, cs[u].y};
+            const v2f ny = (v2f){-v.y, v.y};
+            m[u] = __builtin_shufflevector(v, v, 0, 0) * c + ny * __builtin_shufflevector(c, c, 1, 0);
         }
     }
     // the FM detector's previous sample: the neighbour thread's last one; thread 0 recomputes it from the halo,
     // or takes the carried state at the first sample of the call
-    last[tid] = make_float2(m[PER - 1].x, m[PER - 1].y);
-    __syncthreads();
-    float2 prev;
-    if (tid > 0)
-        prev = last[tid - 1];
-    else if (g0 > 0)
-        prev = demod_mixed(a.c, xs, a.nco, g0 - 1);
-    else
-        prev = a.lilq[s];
+    float2 prev = make_float2(0.0f, 0.0f);
+    if (a.c.mode == MODE_NFM || a.c.mode == MODE_WFM) {
+        last[tid] = make_float2(m[PER - 1].x, m[PER - 1].y);
+        __syncthreads();
+        if (tid > 0)
+            prev = last[tid - 1];
+        else if (CHAINED)
+            prev = carried;
+        else if (g0 > 0)
+            prev = demod_mixed(a.c, xs, a.nco, g0 - 1);
+        else
+            prev = a.lilq[s];
+    }
     // max |d| travels as a bit pattern: non-negative floats order like unsigned ints, and any NaN beats every
     // number -- Math.max's NaN propagation (:463) for free
 #pragma unroll
@@ -262,7 +279,7 @@ __global__ __launch_bounds__(256) void k_demod_front(DemodArgs a)
     const int t0 = tid * PER;
     float dv[PER];
     unsigned mbits = 0;
-    demod_tile<F32IN>(a, s, f, j, xs, last, dv, mbits);
+    demod_tile<F32IN, false>(a, s, f, j, xs, last, dv, mbits);
     float *d = a.d + (long long)s * a.L + g0 + t0;
     if (t0 + PER <= len && (((long long)s * a.L + g0) & 3) == 0) {
         reinterpret_cast<float4 *>(d)[0] = make_float4(dv[0], dv[1], dv[2], dv[3]);
@@ -276,13 +293,18 @@ __global__ __launch_bounds__(256) void k_demod_front(DemodArgs a)
     if (tid == 0) atomicMax(&a.fmax_bits[(long long)s * a.nfr + f], mx);
 }
 
-__device__ __forceinline__ int demod_f2i(float v)  // Java (int) of a float
+// Java's (int) of a float -- NaN -> 0, out of range saturates, else truncation -- is what v_cvt_i32_f32 does by
+// itself (C's (int) is undefined out of range, so the compiler may not assume it: spelled out, the three cases
+// cost five more instructions per sample)
+__device__ __forceinline__ int demod_f2i(float v)
 {
-    if (v != v) return 0;
-    if (v >= 2147483648.0f) return 2147483647;
-    if (v <= -2147483648.0f) return (-2147483647 - 1);
-    return (int)v;
+    int r;
+    asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(v));
+    return r;
 }
+
+// (short)(sam * 32767f) to both channels (:478-481): the low half of the int, twice
+__device__ __forceinline__ int demod_lr(float x) { const int sv = demod_f2i(x * 32767.0f); return (int)__builtin_amdgcn_perm((unsigned)sv, (unsigned)sv, 0x01000100u); }
 
 // Every mode but AM, frames of at most NT tiles: one workgroup per frame keeps the detected samples in registers,
 // takes the frame maximum itself and writes the int16 audio (:465-481) -- no float round trip through HBM and no
@@ -302,8 +324,12 @@ __global__ __launch_bounds__(256) void k_demod_fused(DemodArgs a, int *__restric
     unsigned mbits = 0;
 #pragma unroll
     for (int j = 0; j < NT; j++) {
-        if (j) __syncthreads();  // the previous tile's LDS image is still being read
-        demod_tile<F32IN>(a, s, f, j, xs, last, dv[j], mbits);
+        if (j) {
+            __syncthreads();  // the previous tile's LDS image is still being read
+            demod_tile<F32IN, true>(a, s, f, j, xs, last, dv[j], mbits);
+        } else {
+            demod_tile<F32IN, false>(a, s, f, j, xs, last, dv[j], mbits);
+        }
     }
     const float mx = __uint_as_float(demod_block_max(mbits, red));
     const float scale = a.c.doagc ? 1.0f / mx : 1.0f;
@@ -320,9 +346,7 @@ __global__ __launch_bounds__(256) void k_demod_fused(DemodArgs a, int *__restric
         int o[PER];
 #pragma unroll
         for (int u = 0; u < PER; u++) {
-            const float x = dv[j][u] * scale;
-            const int sv = (int)(short)demod_f2i(x * 32767.0f);
-            o[u] = (sv & 0xffff) | (sv << 16);
+            o[u] = demod_lr(dv[j][u] * scale);
         }
         if (t0 + PER <= len && ((((long long)s * out_stride_pairs + g) & 3) == 0)) {
             reinterpret_cast<int4 *>(dst)[0] = make_int4(o[0], o[1], o[2], o[3]);
@@ -473,9 +497,7 @@ __global__ __launch_bounds__(256) void k_demod_out(const float *__restrict__ d, 
     for (int u = 0; u < 4; u++) {
         float x = v[u];
         if (mode == MODE_AM) x = x - avg;
-        x = x * scale;
-        const int sv = (int)(short)demod_f2i(x * 32767.0f);
-        o[u] = (sv & 0xffff) | (sv << 16);
+        o[u] = demod_lr(x * scale);
     }
     if (vec) {
         *reinterpret_cast<int4 *>(dst) = make_int4(o[0], o[1], o[2], o[3]);

@@ -103,6 +103,24 @@ def test_demod_receive_float_frames_and_edge_values():
             assert same(mx, o.max) and same(av, o.avg)
 
 
+def test_demod_int_cast_saturation_nan_and_infinities():
+    """(short)(sam * 32767f) (:478-481) at the edges of Java's float -> int rule: NaN -> 0, +-inf and anything beyond
+    the int range saturate (then wrap to short), everything else truncates toward zero"""
+    n = 256
+    d = J.Demod(rate=48000, n=n, nstreams=1)
+    o = O.Demod(48000)
+    for mode in (1, 2):      # RAW: the fused kernel; AM: the three-kernel path (mean subtraction on top)
+        d.configure(mode, 0, 0, 0)
+        o.configure(mode, 0, 0, 0)
+        buf = np.zeros(2 * n, f32)
+        edge = [7.0e4, -7.0e4, np.inf, -np.inf, np.nan, 65535.9, -65536.1, 65538.0, -65538.5, 3.0e38, -3.0e38, 0.99999,
+                -0.99999, 1.0000001, -1.0000001, 2.5 / 32767, -2.5 / 32767, 1e-40, -0.0]
+        buf[0:2 * len(edge):2] = np.array(edge, f32)
+        got = d.receive(buf)
+        want = o.receive(buf)
+        assert np.array_equal(got, want), mode
+
+
 def test_demod_api_errors():
     with pytest.raises(J.JsdrError):
         J.Demod(rate=0)
