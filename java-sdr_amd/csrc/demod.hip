@@ -151,10 +151,12 @@ __device__ __forceinline__ void demod_tile(const DemodArgs &a, const int s, cons
             else
                 v = make_float2(i16_to_float_java(java_short_add((int)(short)(w[q] & 0xffff), a.ic)),
                                 i16_to_float_java(java_short_add(w[q] >> 16, a.qc)));
+            // xpad8(tid + 256 q) = xpad8(tid) + 288 q: one address register, constant offsets
+            float2 *slot = xs + (tid + (tid >> 3)) + 288 * q;
             if (full) {
-                if (q < NLD - 1 || i < DTILE + DHALO) xs[xpad8(i)] = v;
+                if (q < NLD - 1 || i < DTILE + DHALO) *slot = v;
             } else if (i < DTILE + DHALO) {
-                xs[xpad8(i)] = (i < len + DHALO) ? v : make_float2(0.0f, 0.0f);
+                *slot = (i < len + DHALO) ? v : make_float2(0.0f, 0.0f);
             }
         }
     } else {
@@ -168,7 +170,8 @@ __device__ __forceinline__ void demod_tile(const DemodArgs &a, const int s, cons
         v2f x[PER + 20];  // x[q] = input sample t0 - 20 + q
 #pragma unroll
         for (int q = 0; q < PER + 20; q++) {
-            const float2 v = xs[xpad8(t0 + 1 + q)];
+            // xpad8(8 tid + c) = 9 tid + c + (c >> 3)
+            const float2 v = xs[9 * tid + (1 + q) + ((1 + q) >> 3)];
             x[q] = (v2f){v.x, v.y};
         }
 #pragma unroll
@@ -181,7 +184,7 @@ __device__ __forceinline__ void demod_tile(const DemodArgs &a, const int s, cons
     } else {
 #pragma unroll
         for (int u = 0; u < PER; u++) {
-            const float2 v = xs[xpad8(t0 + DHALO + u)];
+            const float2 v = xs[9 * tid + (DHALO + u) + ((DHALO + u) >> 3)];
             m[u] = (v2f){v.x, v.y};
         }
     }
@@ -234,7 +237,10 @@ __device__ __forceinline__ void demod_tile(const DemodArgs &a, const int s, cons
         } else if (a.c.mode == MODE_RAW) {
             dv[u] = mm.x;
         } else if (a.c.mode == MODE_AM) {
-            dv[u] = (float)sqrt((double)(mm.x * mm.x + mm.y * mm.y));  // :449, literally (__fsqrt_rn is NOT correctly rounded)
+            // :449 (float)Math.sqrt((double)..): the correctly rounded double root of a float, rounded to float, IS the
+            // correctly rounded float root (53 >= 2*24 + 2 bits), which is what sqrtf compiles to here (v_sqrt_f32
+            // plus a one-ulp fix-up; __fsqrt_rn is NOT correctly rounded) -- all FP32, no v_rsq_f64 chain
+            dv[u] = __builtin_sqrtf(mm.x * mm.x + mm.y * mm.y);
         } else {
             dv[u] = ((prev.x * mm.y) - (prev.y * mm.x)) * a.c.fmgain;
             prev = make_float2(mm.x, mm.y);

@@ -114,7 +114,7 @@ def test_demod_int_cast_saturation_nan_and_infinities():
         o.configure(mode, 0, 0, 0)
         buf = np.zeros(2 * n, f32)
         edge = [7.0e4, -7.0e4, np.inf, -np.inf, np.nan, 65535.9, -65536.1, 65538.0, -65538.5, 3.0e38, -3.0e38, 0.99999,
-                -0.99999, 1.0000001, -1.0000001, 2.5 / 32767, -2.5 / 32767, 1e-40, -0.0]
+                -0.99999, 1.0000001, -1.0000001, 2.5 / 32767, -2.5 / 32767, 1e-40, -0.0, 1e-20, 3.3e-20, 7.7e-23, 1.1e19]
         buf[0:2 * len(edge):2] = np.array(edge, f32)
         got = d.receive(buf)
         want = o.receive(buf)
