@@ -527,12 +527,19 @@ struct jsdr_demod {
     float phi = 0.0f, car = 0.0f;
     DevBuf<float2> hist[2], lilq[2];
     int cur = 0;
-    DevBuf<float2> nco;
-    DevBuf<float> car_dev, d, favg, stats;
+    // carrier tables, double-buffered: call k fills set k&1 on the copy stream while call k-1's kernels still read
+    // the other one (no bubble between calls for the host's phase recurrence and its upload)
+    DevBuf<float2> nco[2];
+    DevBuf<float> car_dev[2];
+    float *car_pinned[2] = {nullptr, nullptr};
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_table[2] = {nullptr, nullptr}, ev_used[2] = {nullptr, nullptr};
+    bool used[2] = {false, false};
+    unsigned calls = 0;
+    DevBuf<float> d, favg, stats;
     DevBuf<unsigned> fmax;
     DevBuf<float> stage_in;  // one frame, receive_f32
     DevBuf<int> stage_out;
-    std::vector<float> car_host;
     int last_nfr = 0;
     // optional per-kernel HIP-event timing (bench.py's roofline leg), same contract as jsdr_bpsk_profile_*
     bool prof_on = false;
@@ -608,7 +615,8 @@ static int demod_run(jsdr_demod *h, const int16_t *raw_dev, const float *rawf_de
     a.qc = qc;
     a.hist = h->hist[h->cur].p;
     a.lilq = h->lilq[h->cur].p;
-    a.nco = h->nco.p;
+    const int set = (int)(h->calls++ & 1);
+    a.nco = h->nco[set].p;
     a.d = h->d.p;
     a.fmax_bits = h->fmax.p;
     memcpy(a.c.w, h->wfir, sizeof(a.c.w));
@@ -619,19 +627,31 @@ static int demod_run(jsdr_demod *h, const int16_t *raw_dev, const float *rawf_de
     a.c.doagc = h->doagc;
     if (h->dodwn) {
         // :427-429 in float, exactly as the reference steps it
-        h->car_host.resize((size_t)L);
+        if (h->used[set]) JSDR_HIP_TRY(hipEventSynchronize(h->ev_used[set]));  // the call before last has let go of this set
+        float *tab = h->car_pinned[set];
         float car = h->car;
         const float phi = h->phi, two_pi = (float)(2 * 3.14159265358979323846);
+        // a serial float recurrence, on the host; kept as a (well predicted) branch so that the dependent chain per
+        // sample is the one subtraction -- as a select it is subtract + add + blend, four times slower, and longer
+        // than the GPU takes for the whole batch
         for (int64_t g = 0; g < L; g++) {
-            h->car_host[(size_t)g] = car;
+            tab[g] = car;
             car -= phi;
-            if (car < 0.0f) car += two_pi;
+            if (__builtin_expect(car < 0.0f, 0)) {
+                asm volatile("" : "+x"(car));
+                car += two_pi;
+            }
         }
         h->car = car;
-        JSDR_HIP_TRY(hipMemcpyAsync(h->car_dev.p, h->car_host.data(), sizeof(float) * (size_t)L, hipMemcpyHostToDevice, st));
-        DemodProf ps(h, DK_NCO, st);
-        hipLaunchKernelGGL(k_demod_nco, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, st, h->car_dev.p, (long long)L, h->nco.p);
-        JSDR_LAUNCH_CHECK();
+        JSDR_HIP_TRY(hipMemcpyAsync(h->car_dev[set].p, tab, sizeof(float) * (size_t)L, hipMemcpyHostToDevice, h->copy_stream));
+        {
+            DemodProf ps(h, DK_NCO, h->copy_stream);
+            hipLaunchKernelGGL(k_demod_nco, dim3((unsigned)((L + 255) / 256)), dim3(256), 0, h->copy_stream, h->car_dev[set].p,
+                               (long long)L, h->nco[set].p);
+            JSDR_LAUNCH_CHECK();
+        }
+        JSDR_HIP_TRY(hipEventRecord(h->ev_table[set], h->copy_stream));
+        JSDR_HIP_TRY(hipStreamWaitEvent(st, h->ev_table[set], 0));
     }
     const int tiles_per_frame = (h->n + DTILE - 1) / DTILE;
     // every mode but AM, frames of up to 5 tiles (the reference's 9600-sample default included): one kernel from
@@ -645,7 +665,7 @@ static int demod_run(jsdr_demod *h, const int16_t *raw_dev, const float *rawf_de
         DemodProf ps(h, DK_FRONT, st);
         int *outp = reinterpret_cast<int *>(audio_dev);
         const long long osp = (long long)(audio_stride_i16 / 2);
-        const dim3 grid((unsigned)nfr, (unsigned)S);
+        const dim3 grid((unsigned)nfr, (unsigned)S);  // (streams fastest instead, for carrier-table locality: measured, no gain)
         switch (tiles_per_frame) {
             case 1: hipLaunchKernelGGL((k_demod_fused<F32IN, 1>), grid, dim3(256), 0, st, a, outp, osp, h->stats.p); break;
             case 2: hipLaunchKernelGGL((k_demod_fused<F32IN, 2>), grid, dim3(256), 0, st, a, outp, osp, h->stats.p); break;
@@ -681,6 +701,10 @@ static int demod_run(jsdr_demod *h, const int16_t *raw_dev, const float *rawf_de
                            (long long)(audio_stride_i16 / 2), h->stats.p);
         JSDR_LAUNCH_CHECK();
     }
+    if (h->dodwn) {
+        JSDR_HIP_TRY(hipEventRecord(h->ev_used[set], st));
+        h->used[set] = true;
+    }
     h->last_nfr = nfr;
     return JSDR_OK;
 }
@@ -709,7 +733,13 @@ int jsdr_demod_create(jsdr_demod **out, int rate, int nsamples_per_frame, int ns
     for (int k = 0; k < 2; k++)
         ok = ok && h->hist[k].alloc(S * DHALO) == JSDR_OK && h->lilq[k].alloc(S) == JSDR_OK && h->hist[k].zero() == JSDR_OK &&
              h->lilq[k].zero() == JSDR_OK;
-    ok = ok && h->nco.alloc(L + 8) == JSDR_OK && h->nco.zero() == JSDR_OK && h->car_dev.alloc(L) == JSDR_OK && h->d.alloc(S * L) == JSDR_OK &&
+    for (int k = 0; k < 2; k++)
+        ok = ok && h->nco[k].alloc(L + 8) == JSDR_OK && h->nco[k].zero() == JSDR_OK && h->car_dev[k].alloc(L) == JSDR_OK &&
+             hipHostMalloc(reinterpret_cast<void **>(&h->car_pinned[k]), sizeof(float) * L, hipHostMallocDefault) == hipSuccess &&
+             hipEventCreateWithFlags(&h->ev_table[k], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&h->ev_used[k], hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && h->d.alloc(S * L) == JSDR_OK &&
          h->favg.alloc(nf) == JSDR_OK && h->stats.alloc(2 * nf) == JSDR_OK && h->fmax.alloc(nf) == JSDR_OK &&
          h->stage_in.alloc(2 * (size_t)h->n) == JSDR_OK && h->stage_out.alloc((size_t)h->n) == JSDR_OK &&
          h->favg.zero() == JSDR_OK && hipDeviceSynchronize() == hipSuccess;
@@ -729,8 +759,14 @@ int jsdr_demod_destroy(jsdr_demod *h)
         h->hist[k].release();
         h->lilq[k].release();
     }
-    h->nco.release();
-    h->car_dev.release();
+    for (int k = 0; k < 2; k++) {
+        h->nco[k].release();
+        h->car_dev[k].release();
+        if (h->car_pinned[k]) (void)hipHostFree(h->car_pinned[k]);
+        if (h->ev_table[k]) (void)hipEventDestroy(h->ev_table[k]);
+        if (h->ev_used[k]) (void)hipEventDestroy(h->ev_used[k]);
+    }
+    if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     h->d.release();
     h->favg.release();
     h->stats.release();
