@@ -63,7 +63,7 @@ def parse():
     return ap.parse_args()
 
 
-def make_inputs(J, O, S, L, stream0):
+def make_inputs(J, S, L, stream0):
     """DBPSK streams stream0..stream0+S-1 on the device; returns (d_iq, payloads_dev, nframes)"""
     sps = RATE // 1200
     nfr = -(-L // (5200 * sps)) + 1
@@ -72,11 +72,11 @@ def make_inputs(J, O, S, L, stream0):
     J.fec_encode_dev(pay, S * nfr, d_sym)
     d_ds = J.DeviceBuffer(S * nfr * 5200)
     J.synth_diffsign(d_sym, nfr * 5200, S, d_ds)
-    ct, st = O.synth_tables(3000)
-    keys = np.array([O.mix64((SEED * 0x9E3779B1 + stream0 + s) ^ 0xA5A5A5A5) for s in range(S)], np.uint64)
+    ct, st = J.binding.synth_carrier_tables(3000)
+    keys = np.array([J.binding.synth_mix64((SEED * 0x9E3779B1 + stream0 + s) ^ 0xA5A5A5A5) for s in range(S)], np.uint64)
     d_iq = J.DeviceBuffer(S * L * 4)
     gain = int(round(1500.0 / 37837.0 * 32768.0))
-    J.synth_dbpsk(d_iq, 2 * L, S, 0, L, d_ds, nfr * 5200, sps, 0, O.phase_inc_u32(13200.0, RATE),
+    J.synth_dbpsk(d_iq, 2 * L, S, 0, L, d_ds, nfr * 5200, sps, 0, J.binding.synth_phase_inc_u32(13200.0, RATE),
                   J.DeviceBuffer.from_host(ct), J.DeviceBuffer.from_host(st), gain, J.DeviceBuffer.from_host(keys))
     J.binding.stream_sync(None)
     return d_iq, pay, nfr
@@ -103,9 +103,10 @@ def usable_cores():
     return max(1, min(n, int(os.environ.get("JSDR_CPU_THREADS", "64"))))
 
 
-def cpu_baseline(O, workload, L, seconds):
+def cpu_baseline(workload, L, seconds):
     """the oracle on the host cores: one stream per thread (ctypes releases the GIL), repeated until
-    ~`seconds` of wall time; same signal family, same frame size."""
+    ~`seconds` of wall time; same signal family, same frame size.  The only place bench.py touches oracle/."""
+    import oracle_lib as O
     cores = usable_cores()
     Lc = min(L, 1048576)
     streams = [O.make_dbpsk_stream(SEED, s, Lc)[0] for s in range(cores)]
@@ -190,7 +191,6 @@ def main():
             dist.init_process_group(backend)
     import java_sdr_amd as J
     from java_sdr_amd import sharding as SH
-    import oracle_lib as O  # input tables + cpu_baseline leg only
 
     if not J.have_gpu():
         raise SystemExit("bench.py: no HIP device (libjsdr_hip.so has no CPU fallback)")
@@ -205,7 +205,7 @@ def main():
     elif L % N_FFT:
         raise SystemExit("--samples must be a multiple of 2048")
     stream0, _ = SH.shard_streams(N * S, N, rank)  # contiguous shards: rank order == global stream order
-    d_iq, pay, nfr = make_inputs(J, O, S, L, stream0)
+    d_iq, pay, nfr = make_inputs(J, S, L, stream0)
     nframes = S * L // N_FFT
     fft = J.Fft(N_FFT, RATE) if a.workload in ("pipeline", "fft") else None
     d_psd = J.DeviceBuffer(nframes * (N_FFT + 2) * 4) if fft else None
@@ -365,7 +365,7 @@ def main():
             "validated": validated,
         }
         if N == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(O, a.workload if a.workload != "demod" else "demod:" + a.demod_mode, L, a.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(a.workload if a.workload != "demod" else "demod:" + a.demod_mode, L, a.cpu_seconds)
         print(json.dumps(out), flush=True)
     if N > 1:
         dist.barrier()

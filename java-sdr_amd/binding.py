@@ -544,6 +544,25 @@ def recordings_load(paths, channels, rate, first_frame, nframes, raw_dev, stream
 
 
 # ------------------------------------------------------------------ synthetic inputs
+def synth_mix64(z):
+    """splitmix64 finaliser: the counter hash of the synthetic-input generators (csrc/synth.hip)"""
+    m = 0xFFFFFFFFFFFFFFFF
+    z = (z + 0x9E3779B97F4A7C15) & m
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & m
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & m
+    return z ^ (z >> 31)
+
+
+def synth_carrier_tables(amp):
+    """1024-entry int16 cos / sin tables of amplitude amp (round half to even), the carrier of jsdr_synth_dbpsk / _tones"""
+    a = 2.0 * np.pi * np.arange(1024, dtype=np.float64) / 1024.0
+    return np.rint(amp * np.cos(a)).astype(np.int16), np.rint(amp * np.sin(a)).astype(np.int16)
+
+
+def synth_phase_inc_u32(freq_hz, rate):
+    return int(round(freq_hz / rate * 2 ** 32)) & 0xFFFFFFFF
+
+
 def synth_payloads(seed, stream0, nstreams, nframes, out_dev=None, stream=None):
     own = out_dev is None
     if own:

@@ -55,7 +55,7 @@ for step in "$@"; do
     bench_alone) JSDR_NO_OVERLAP=1 run bench_alone 300 python bench.py --workload bpsk --steps 5 --warmup 2 --no-cpu-baseline ;;
     bench_noov)  JSDR_NO_OVERLAP=1 run bench_noov 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline ;;
     bench_rd80)  JSDR_FRONT_RD=80 run bench_rd80 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline ;;
-    fec_bench)   run fec_bench 300 python tools/fec_bench.py ;;
+    fec_bench)   run fec_bench 300 python tests/tools/fec_bench.py ;;
     hbm)         run hbm_build 120 hipcc --offload-arch=gfx950 -O3 -o /tmp/mb_hbm tools/microbench_hbm.hip
                  run hbm 120 /tmp/mb_hbm ;;
     counters)    run counters 120 rocprofv3 -L ;;
@@ -75,7 +75,7 @@ for step in "$@"; do
     pmc_dm2)     rm -rf gpurun_out/pmc_dm2_$R
                  run pmc_dm2 600 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d gpurun_out/pmc_dm2_$R -- python3 bench.py --workload demod --demod-mode nfm --steps 2 --warmup 1 --no-cpu-baseline
                  python tools/pmc_summary.py gpurun_out/pmc_dm2_$R | tee gpurun_out/pmc_dm2_summary.txt ;;
-    dbg)         run dbg 300 python tools/dbg_fftmode.py ;;
+    dbg)         run dbg 300 python tests/tools/dbg_fftmode.py ;;
     fftm_bench)  run fftm_bench 300 python tools/fftm_bench.py ;;
     rate192)     JSDR_NO_OVERLAP=1 run rate192 300 python tools/rate_bench.py 192000 ;;
     rate48)      JSDR_NO_OVERLAP=1 run rate48 300 python tools/rate_bench.py 48000 ;;
@@ -84,8 +84,8 @@ for step in "$@"; do
     fft19200)    run fft19200 300 python tools/fft_n_bench.py 19200 ;;
     fft4800)     run fft4800 300 python tools/fft_n_bench.py 4800 ;;
     fftm_small)  FM_S=8 FM_NFR=20 run fftm_small 300 python tools/fftm_bench.py ;;
-    dbg_demod)   run dbg_demod 300 python tools/dbg_demod.py ;;
-    trig)        run trig 300 python tools/trig_stats.py ;;
+    dbg_demod)   run dbg_demod 300 python tests/tools/dbg_demod.py ;;
+    trig)        run trig 300 python tests/tools/trig_stats.py ;;
     bench_fft)   run bench_fft 300 python bench.py --workload fft --no-cpu-baseline ;;
     bench_fft_m16) JSDR_FFT_GRID_MULT=16 run bench_fft_m16 300 python bench.py --workload fft --no-cpu-baseline ;;
     bench_fft_m64) JSDR_FFT_GRID_MULT=64 run bench_fft_m64 300 python bench.py --workload fft --no-cpu-baseline ;;
