@@ -1,0 +1,12 @@
+#!/bin/bash
+# tools/sweep_env.sh VAR "v1 v2 ..." -- bench args...: one bench.py line per value of an environment knob
+var=$1; vals=$2; shift 3
+for v in $vals; do
+  env $var=$v python bench.py "$@" > gpurun_out/sweep_${var}_$v.log 2>&1 || { tail -3 gpurun_out/sweep_${var}_$v.log; exit 1; }
+  echo "$var=$v: $(python -c "
+import json
+for l in open('gpurun_out/sweep_${var}_$v.log'):
+    if l.startswith('{'):
+        d=json.loads(l); print(d['ms_per_step'], d['value'])
+")"
+done
