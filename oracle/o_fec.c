@@ -409,7 +409,7 @@ static void local_init_encoder(enc_t *e) /* :584-606 */
     sr = 0x7f;
     for (i = 0; i < 65; i++) {
         if ((sr & 64) != 0) e->reencode[ROWS * i] = 1;
-        sr = (sr << 1) | Partab[sr & SYNC_POLY];
+        sr = (int)((unsigned)sr << 1) | Partab[sr & SYNC_POLY]; /* Java's int shift wraps; C's signed shift may not */
     }
 }
 
