@@ -19,7 +19,7 @@
 
 namespace jsdr {
 
-constexpr int FM_T = 512;
+constexpr int FM_T = 768;
 constexpr int FM_NMAX = 9600;
 constexpr int FM_MAXPASS = 12;
 
