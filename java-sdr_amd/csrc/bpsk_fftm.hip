@@ -171,7 +171,20 @@ __global__ __launch_bounds__(FM_T) void k_front_fftm(FftmArgs aa)
     const int *__restrict__ raw = a.raw + (long long)s * a.stride_pairs;
     const float2 *__restrict__ rawf = a.rawf + (long long)s * a.stride_pairs;
     double2 *dm = a.dm + (long long)s * a.dm_stride;
+    // diagnostics (JSDR_FFT_PHASECLK=1): thread 0 of stream 0 accumulates the clock ticks of every phase
+    long long *clk = reinterpret_cast<long long *>(twL + aa.lds_tw);  // the 64 spare bytes behind the tables
+    long long tprev = 0;
+    const bool timing = a.phase_clk != nullptr && s == 0 && tid == 0;
+    if (timing)
+        for (int k = 0; k < 8; k++) clk[k] = 0;
+#define PHASE(k)                                     \
+    if (timing) {                                    \
+        const long long now_ = (long long)clock64(); \
+        clk[k] += now_ - tprev;                      \
+        tprev = now_;                                \
+    }
     __syncthreads();
+    if (timing) tprev = (long long)clock64();
 
     for (int f = 0; f < a.nframes; f++) {
         const long long t0 = (long long)f * n;  // call-relative index of the frame's first sample
@@ -190,7 +203,9 @@ __global__ __launch_bounds__(FM_T) void k_front_fftm(FftmArgs aa)
             X[t] = make_double2(di, dq);
         }
         __syncthreads();
+        PHASE(0)
         fm_forward(X, twL, aa, tid);  // :422-423
+        PHASE(1)
         // ---- |X| (:425-427) over the band the boxcar reads
         for (int i = pbase + tid; i < end - 24; i += FM_T) {
             const double2 v = X[i];
@@ -267,6 +282,7 @@ __global__ __launch_bounds__(FM_T) void k_front_fftm(FftmArgs aa)
             }
             if (centreBin < 102) centreBin = 102;
         }
+        PHASE(2)
         // ---- 204 bins around the centre to bin 0 of a zeroed array (:458), inverse transform (:459) as
         // conj o forward o conj; only real parts are read afterwards, so the closing conjugation is dropped
         double2 keep = make_double2(0.0, 0.0);
@@ -276,7 +292,9 @@ __global__ __launch_bounds__(FM_T) void k_front_fftm(FftmArgs aa)
         __syncthreads();
         if (tid < 204) X[tid] = make_double2(keep.x, -keep.y);
         __syncthreads();
+        PHASE(3)
         fm_forward(X, twL, aa, tid);
+        PHASE(4)
         // ---- RxDownSample(re, re) (:461-463, :470-492): outputs whose window ends inside this frame
         {
             long long jlo = (t0 - a.first_out + D - 1) / D;
@@ -302,12 +320,16 @@ __global__ __launch_bounds__(FM_T) void k_front_fftm(FftmArgs aa)
         __syncthreads();
         if (tid < 26) hist[tid] = hnew;
         __syncthreads();
+        PHASE(5)
     }
+#undef PHASE
     if (tid < 26) sp->hist[tid] = hist[tid];
     if (tid == 0) {
         sp->avePeakPower = avePeakPower;
         sp->aveCentreBin = aveCentreBin;
         sp->centreBin = centreBin;
+        if (timing)
+            for (int k = 0; k < 8; k++) a.phase_clk[k] = clk[k];
     }
 }
 

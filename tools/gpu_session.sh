@@ -81,6 +81,12 @@ for step in "$@"; do
     pmc_acq2)    rm -rf gpurun_out/pmc_acq2_$R
                  run pmc_acq2 600 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d gpurun_out/pmc_acq2_$R -- python3 bench.py --workload bpsk --fft-acquire --steps 2 --warmup 1 --no-cpu-baseline --no-validate
                  python tools/pmc_summary.py gpurun_out/pmc_acq2_$R | tee gpurun_out/pmc_acq2_summary.txt ;;
+    pmc_fm1)     rm -rf gpurun_out/pmc_fm1_$R
+                 run pmc_fm1 600 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --output-format csv -d gpurun_out/pmc_fm1_$R -- python3 tools/fftm_bench.py
+                 python tools/pmc_summary.py gpurun_out/pmc_fm1_$R | tee gpurun_out/pmc_fm1_summary.txt ;;
+    pmc_fm2)     rm -rf gpurun_out/pmc_fm2_$R
+                 run pmc_fm2 600 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d gpurun_out/pmc_fm2_$R -- python3 tools/fftm_bench.py
+                 python tools/pmc_summary.py gpurun_out/pmc_fm2_$R | tee gpurun_out/pmc_fm2_summary.txt ;;
     dbg)         run dbg 300 python tests/tools/dbg_fftmode.py ;;
     fftm_bench)  run fftm_bench 300 python tools/fftm_bench.py ;;
     rate192)     JSDR_NO_OVERLAP=1 run rate192 300 python tools/rate_bench.py 192000 ;;
