@@ -82,7 +82,7 @@ __device__ __forceinline__ void dft_r(double2 *v)
 
 // one Stockham pass, in place: every butterfly of the pass is in registers before the first store
 template <int R>
-__device__ __forceinline__ void fm_pass(double2 *X, const double2 *tw, int n, int P, unsigned pmagic, int tid)
+__device__ __attribute__((noinline)) void fm_pass(double2 *X, const double2 *tw, int n, int P, unsigned pmagic, int tid)
 {
     constexpr int ITERS = ((FM_NMAX / R) + FM_T - 1) / FM_T;
     const int nb = n / R;
@@ -114,14 +114,97 @@ __device__ __forceinline__ void fm_pass(double2 *X, const double2 *tw, int n, in
     __syncthreads();
 }
 
+// TWO consecutive Stockham passes (radix R1 at stride P, then R2 at stride P*R1) in one LDS round trip.  The R1*R2
+// points of a group are closed under both passes: group g = m0*P + k1 (k1 < P) takes the R2 first-pass butterflies
+// b1 = g + j2*(n/(R1 R2)) -- their outputs q1 feed the R1 second-pass butterflies b2 = m0*P*R1 + (k1 + q1*P), which
+// write z[m0*P*R1*R2 + k1 + q1*P + q2*P*R1].  Same operands, same tables, same operation order as fm_pass<R1>
+// followed by fm_pass<R2>: only the intermediate image stays in registers (an LDS store costs 13 cycles per wave
+// instruction, and the image is written once per pass).
+template <int R1, int R2>
+__device__ __attribute__((noinline)) void fm_pass2(double2 *X, const double2 *tw1, const double2 *tw2, int n, int P, unsigned pmagic,
+                                         int tid)
+{
+    constexpr int RR = R1 * R2;
+    constexpr int ITERS = ((FM_NMAX / RR) + FM_T - 1) / FM_T;
+    const int ng = n / RR, nb1 = n / R1;
+    double2 v[ITERS][R2][R1];
+#pragma unroll
+    for (int it = 0; it < ITERS; it++) {
+        const int g = it * FM_T + tid;
+        if (g < ng) {
+            const int k1 = (P == 1) ? 0 : g - (int)__umulhi((unsigned)g, pmagic) * P;
+#pragma unroll
+            for (int j2 = 0; j2 < R2; j2++) {
+                const int b1 = g + j2 * ng;
+#pragma unroll
+                for (int j1 = 0; j1 < R1; j1++) {
+                    v[it][j2][j1] = X[b1 + j1 * nb1];
+                    if (j1 >= 1 && P > 1) v[it][j2][j1] = cdmul(v[it][j2][j1], tw1[k1 * j1]);
+                }
+                dft_r<R1>(v[it][j2]);
+            }
+            __builtin_amdgcn_sched_barrier(0);  // the second stage's twiddles are fetched after the first stage's are dead
+#pragma unroll
+            for (int q1 = 0; q1 < R1; q1++) {
+                const int k2 = k1 + q1 * P;
+                double2 w[R2];
+#pragma unroll
+                for (int j2 = 0; j2 < R2; j2++) {
+                    w[j2] = v[it][j2][q1];
+                    if (j2 >= 1) w[j2] = cdmul(w[j2], tw2[k2 * j2]);
+                }
+                dft_r<R2>(w);
+#pragma unroll
+                for (int q2 = 0; q2 < R2; q2++) v[it][q2][q1] = w[q2];
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < ITERS; it++) {
+        const int g = it * FM_T + tid;
+        if (g < ng) {
+            const int k1 = (P == 1) ? 0 : g - (int)__umulhi((unsigned)g, pmagic) * P;
+            double2 *z = X + ((g - k1) * RR + k1);
+#pragma unroll
+            for (int q2 = 0; q2 < R2; q2++)
+#pragma unroll
+                for (int q1 = 0; q1 < R1; q1++) z[q1 * P + q2 * P * R1] = v[it][q2][q1];
+        }
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ const double2 *fm_table(const double2 *twL, const FftmArgs &a, int p, int P)
+{
+    // the narrow tables sit in LDS: a pass that starts with a round trip to L2 for its twiddles costs ~2 us,
+    // 14 times per frame, with nothing else to run on the CU
+    return (a.tw_off[p] + P * a.rad[p] <= a.lds_tw) ? twL + a.tw_off[p] : a.f.tw + a.tw_off[p];
+}
+
 __device__ __forceinline__ void fm_forward(double2 *X, const double2 *twL, const FftmArgs &a, int tid)
 {
     int P = 1;
-    for (int p = 0; p < a.np; p++) {
+    for (int p = 0; p < a.np;) {
         const int r = a.rad[p];
-        // the narrow tables sit in LDS: a pass that starts with a round trip to L2 for its twiddles costs ~2 us,
-        // 14 times per frame, with nothing else to run on the CU
-        const double2 *tw = (a.tw_off[p] + P * r <= a.lds_tw) ? twL + a.tw_off[p] : a.f.tw + a.tw_off[p];
+        const double2 *tw = fm_table(twL, a, p, P);
+        // after the first pass (whose stores would all hit one bank group as a pair), consecutive passes go in pairs
+        const int r2 = (p >= 1 && p + 1 < a.np) ? a.rad[p + 1] : 0;
+        const int pair = r * 8 + r2;
+        if (pair == 4 * 8 + 4 || pair == 4 * 8 + 2 || pair == 2 * 8 + 3 || pair == 3 * 8 + 5) {
+            const double2 *tw2 = fm_table(twL, a, p + 1, P * r);
+            if (pair == 4 * 8 + 4)
+                fm_pass2<4, 4>(X, tw, tw2, a.f.n, P, a.pmagic[p], tid);
+            else if (pair == 4 * 8 + 2)
+                fm_pass2<4, 2>(X, tw, tw2, a.f.n, P, a.pmagic[p], tid);
+            else if (pair == 2 * 8 + 3)
+                fm_pass2<2, 3>(X, tw, tw2, a.f.n, P, a.pmagic[p], tid);
+            else
+                fm_pass2<3, 5>(X, tw, tw2, a.f.n, P, a.pmagic[p], tid);
+            P *= r * r2;
+            p += 2;
+            continue;
+        }
         if (r == 4)
             fm_pass<4>(X, tw, a.f.n, P, a.pmagic[p], tid);
         else if (r == 2)
@@ -131,6 +214,7 @@ __device__ __forceinline__ void fm_forward(double2 *X, const double2 *twL, const
         else
             fm_pass<5>(X, tw, a.f.n, P, a.pmagic[p], tid);
         P *= r;
+        p += 1;
     }
 }
 
