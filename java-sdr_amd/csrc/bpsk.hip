@@ -1835,8 +1835,8 @@ int jsdr_bpsk_destroy(jsdr_bpsk *h)
     if (h->phase_clk.p) {
         static const char *const names_p2[8] = {"load+scatter", "forward FFT", "|X|", "boxcar+argmax", "centre-bin rule",
                                                 "gather/zero", "inverse FFT", "scale+RxDownSample"};
-        static const char *const names_mx[8] = {"load", "forward FFT", "|X| boxcar centre", "gather/zero/place", "inverse FFT",
-                                                "RxDownSample", "-", "-"};
+        static const char *const names_mx[8] = {"load", "forward FFT", "centre-bin rule", "gather/zero/place", "inverse FFT",
+                                                "RxDownSample", "|X|", "boxcar+argmax"};
         const char *const *names = h->fft_mixed ? names_mx : names_p2;
         long long c[8] = {0};
         if (hipDeviceSynchronize() == hipSuccess &&

@@ -218,6 +218,52 @@ __device__ __forceinline__ void fm_forward(double2 *X, const double2 *twL, const
     }
 }
 
+// Two adjacent 100-wide boxcar sums from the same 51 aligned 16-byte reads w[0..50] (w[0].x = P[i-50]):
+//   a0 = P[i-50] + ... + P[i+49],  a1 = P[i-49] + ... + P[i+50], each in ascending order (:433-437).
+// The window comes in chunks of 8 reads, the next chunk in flight while the current one is summed: as a plain loop
+// the compiler waits for every read before its four additions (fifty LDS latencies per pair); left alone with the
+// unrolled loop it hoists all 51 reads (204 registers, spilled).  Chunk C is a template parameter so that every
+// register index is a compile-time constant.
+template <int C>
+__device__ __forceinline__ void boxcar_chunk(const double2 *w, const double2 (&cur)[8], double &a0, double &a1, double &prev_y)
+{
+    constexpr int NCH = 7;  // 7 chunks of 8 cover w[0..50]
+    double2 nxt[8];
+    if constexpr (C + 1 < NCH) {
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            if ((C + 1) * 8 + u <= 50) nxt[u] = w[(C + 1) * 8 + u];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+        const int k = C * 8 + u;  // element w[k]
+        if (k <= 50) {
+            const double2 e = cur[u];
+            if (k >= 1) {
+                a0 += prev_y;
+                a1 += prev_y;
+            }
+            if (k < 50) a0 += e.x;
+            if (k >= 1) a1 += e.x;
+            prev_y = e.y;
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (C + 1 < NCH) boxcar_chunk<C + 1>(w, nxt, a0, a1, prev_y);
+}
+
+__device__ __forceinline__ void boxcar_pair(const double2 *w, double &a0, double &a1)
+{
+    double2 first[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) first[u] = w[u];
+    double prev_y = 0.0;
+    a0 = 0.0;
+    a1 = 0.0;
+    boxcar_chunk<0>(w, first, a0, a1, prev_y);
+}
+
 template <bool F32IN>
 __global__ __launch_bounds__(FM_T) void k_front_fftm(FftmArgs aa)
 {
@@ -272,48 +318,62 @@ __global__ __launch_bounds__(FM_T) void k_front_fftm(FftmArgs aa)
 
     for (int f = 0; f < a.nframes; f++) {
         const long long t0 = (long long)f * n;  // call-relative index of the frame's first sample
+        // opaque per frame: nothing derived from the thread index is loop invariant, or LLVM hoists every address
+        // of every phase out of the frame loop and spills them (the same trap as in k_front_fft)
+        int tf = tid;
+        asm volatile("" : "+v"(tf));
         // ---- frame -> LDS, natural order (:416-421)
-        for (int t = tid; t < n; t += FM_T) {
-            double di, dq;
-            if (F32IN) {
-                const float2 v = rawf[t0 + t];
-                di = (double)v.x;
-                dq = (double)v.y;
-            } else {
-                const int w = raw[t0 + t];
-                di = (double)i16_to_float_java(java_short_add((int)(short)(w & 0xffff), a.ic));
-                dq = (double)i16_to_float_java(java_short_add(w >> 16, a.qc));
+        {
+            // all of a thread's samples in flight before the first conversion (a load / convert / store loop pays the
+            // HBM latency once per sample: 13 times per frame)
+            constexpr int NLD = (FM_NMAX + FM_T - 1) / FM_T;
+            int w[NLD];
+            float2 wf[NLD];
+#pragma unroll
+            for (int q = 0; q < NLD; q++) {
+                int t = tf + q * FM_T;
+                t = t < n ? t : n - 1;
+                if (F32IN)
+                    wf[q] = rawf[t0 + t];
+                else
+                    w[q] = raw[t0 + t];
             }
-            X[t] = make_double2(di, dq);
+#pragma unroll
+            for (int q = 0; q < NLD; q++) {
+                const int t = tf + q * FM_T;
+                if (t < n) {
+                    double di, dq;
+                    if (F32IN) {
+                        di = (double)wf[q].x;
+                        dq = (double)wf[q].y;
+                    } else {
+                        di = (double)i16_to_float_java(java_short_add((int)(short)(w[q] & 0xffff), a.ic));
+                        dq = (double)i16_to_float_java(java_short_add(w[q] >> 16, a.qc));
+                    }
+                    X[t] = make_double2(di, dq);
+                }
+            }
         }
         __syncthreads();
         PHASE(0)
-        fm_forward(X, twL, aa, tid);  // :422-423
+        fm_forward(X, twL, aa, tf);  // :422-423
         PHASE(1)
         // ---- |X| (:425-427) over the band the boxcar reads
-        for (int i = pbase + tid; i < end - 24; i += FM_T) {
+        for (int i = pbase + tf; i < end - 24; i += FM_T) {
             const double2 v = X[i];
             P[i - pbase] = sqrt(v.x * v.x + v.y * v.y);
         }
         __syncthreads();
+        PHASE(6)
         // ---- 100-wide boxcar, summed j ascending for every i (:433-437); first maximum (:439-442).  A thread owns
         // the outputs i (even) and i+1: both windows come out of the same 51 aligned 16-byte reads.
         double bestv = 0.0;  // maxBin starts at 0.0, binPos at -1
         int besti = -1;
-        for (int i = beg + 74 + 2 * tid; i < end - 75; i += 2 * FM_T) {
+        for (int i = beg + 74 + 2 * tf; i < end - 75; i += 2 * FM_T) {
             const double2 *w = reinterpret_cast<const double2 *>(P + (i - 50 - pbase));
-            double a0 = 0.0, a1 = 0.0;
-            double2 cur = w[0];
-            a0 += cur.x;
-#pragma unroll 10
-            for (int k = 1; k <= 50; k++) {
-                const double2 nxt = w[k];
-                a0 += cur.y;
-                a1 += cur.y;
-                if (k < 50) a0 += nxt.x;
-                a1 += nxt.x;
-                cur = nxt;
-            }
+            double a0, a1;
+            boxcar_pair(w, a0, a1);
+            asm volatile("" : "+v"(a0), "+v"(a1));  // due here: sunk into the conditional uses below, the sums drag all 51 reads along
             if (i >= beg + 75) {
                 A[i - abase] = a0;
                 if (bestv < a0) {  // i ascends within a thread: strict '<' keeps the first maximum
@@ -343,6 +403,7 @@ __global__ __launch_bounds__(FM_T) void k_front_fftm(FftmArgs aa)
             redi[wave] = besti;
         }
         __syncthreads();
+        PHASE(7)
         // ---- centre-bin rule (:444-453), evaluated by every thread on the same values
         {
             double maxBin = 0.0;
@@ -370,39 +431,45 @@ __global__ __launch_bounds__(FM_T) void k_front_fftm(FftmArgs aa)
         // ---- 204 bins around the centre to bin 0 of a zeroed array (:458), inverse transform (:459) as
         // conj o forward o conj; only real parts are read afterwards, so the closing conjugation is dropped
         double2 keep = make_double2(0.0, 0.0);
-        if (tid < 204) keep = X[centreBin - 102 + tid];
+        if (tf < 204) keep = X[centreBin - 102 + tf];
         __syncthreads();
-        for (int i = tid; i < n; i += FM_T) X[i] = make_double2(0.0, -0.0);  // conj of the zeroed array: -0.0 imaginary parts
+        for (int i = tf; i < n; i += FM_T) X[i] = make_double2(0.0, -0.0);  // conj of the zeroed array: -0.0 imaginary parts
         __syncthreads();
-        if (tid < 204) X[tid] = make_double2(keep.x, -keep.y);
+        if (tf < 204) X[tf] = make_double2(keep.x, -keep.y);
         __syncthreads();
         PHASE(3)
-        fm_forward(X, twL, aa, tid);
+        fm_forward(X, twL, aa, tf);
         PHASE(4)
         // ---- RxDownSample(re, re) (:461-463, :470-492): outputs whose window ends inside this frame
         {
             long long jlo = (t0 - a.first_out + D - 1) / D;
             if (t0 <= a.first_out) jlo = 0;
-            for (long long j = jlo + tid;; j += FM_T) {
+            for (long long j = jlo + tf;; j += FM_T) {
                 const long long te = (long long)a.first_out + (long long)D * j;  // window end, call-relative
                 if (te >= t0 + n || j >= a.nds) break;
                 const double2 cs = a.vco_cs[j];
                 const int e = (int)(te - t0);  // 0..n-1 within the frame
                 double fi = 0.0;
+                if (e >= 26) {  // all but the first three windows of a frame: no history, constant offsets
+                    const double2 *w = X + e;
 #pragma unroll
-                for (int k = 0; k < 27; k++) {  // newest first (:479-483); re = X.x / n (:462)
-                    const int idx = e - k;
-                    const double v = (idx >= 0) ? X[idx].x * norm : hist[26 + idx];
-                    fi += v * taps[k];
+                    for (int k = 0; k < 27; k++) fi += (w[-k].x * norm) * taps[k];  // newest first (:479-483); re = X.x / n (:462)
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 27; k++) {
+                        const int idx = e - k;
+                        const double v = (idx >= 0) ? X[idx].x * norm : hist[26 + idx];
+                        fi += v * taps[k];
+                    }
                 }
                 const double o = fi * HOWARD;  // fi == fq: both rails get the same samples
                 dm[64 + j] = make_double2(o * cs.x, o * cs.y);  // :515-516
             }
         }
         double hnew = 0.0;
-        if (tid < 26) hnew = X[n - 26 + tid].x * norm;
+        if (tf < 26) hnew = X[n - 26 + tf].x * norm;
         __syncthreads();
-        if (tid < 26) hist[tid] = hnew;
+        if (tf < 26) hist[tf] = hnew;
         __syncthreads();
         PHASE(5)
     }
