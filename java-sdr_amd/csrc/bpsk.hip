@@ -45,15 +45,6 @@ static const float h_dm_half[33] = {
     -0.1244834076F, -0.1568500423F, -0.1553748911F, -0.1061032953F, -0.0015013786F, +0.1568500423F, +0.3572048240F,
     +0.5786381191F, +0.7940228249F, +0.9744923010F, +1.0945250059F, +1.1366117829F};
 
-// device-side copy with a static initialiser: indexed with compile-time constants in k_front, so the taps
-// fold into the instruction stream (14 distinct values) instead of occupying 54 SGPRs
-__constant__ const float kDsHalf[14] = {-6.103515625000e-004F, -1.220703125000e-004F, +2.380371093750e-003F,
-                                        +6.164550781250e-003F, +7.324218750000e-003F, +7.629394531250e-004F,
-                                        -1.464843750000e-002F, -3.112792968750e-002F, -3.225708007813e-002F,
-                                        -1.617431640625e-003F, +6.463623046875e-002F, +1.502380371094e-001F,
-                                        +2.231445312500e-001F, +2.518310546875e-001F};
-__device__ __forceinline__ double ds_tap(int n) { return (double)kDsHalf[n < 14 ? n : 26 - n]; }
-
 struct BpskConst {
     double ds_taps[32];   // [27] used
     double dm_taps[96];   // [65] used, zero beyond (edge steps of the register-blocked loops read past 64)

@@ -33,6 +33,62 @@ struct FftFrontArgs {
     long long *phase_clk;      // diagnostics: [8] cycle counts per phase of stream 0's workgroup, or null
 };
 
+// dsFilter (FUNcubeBPSKDemod.java:27-55, symmetric: first 14 of 27), device-side copy with a static initialiser:
+// indexed with compile-time constants in the front-end kernels, so the taps fold into the instruction stream (14
+// distinct values) instead of occupying 54 SGPRs or an LDS read per multiply
+static __constant__ const float kDsHalf[14] = {-6.103515625000e-004F, -1.220703125000e-004F, +2.380371093750e-003F,
+                                        +6.164550781250e-003F, +7.324218750000e-003F, +7.629394531250e-004F,
+                                        -1.464843750000e-002F, -3.112792968750e-002F, -3.225708007813e-002F,
+                                        -1.617431640625e-003F, +6.463623046875e-002F, +1.502380371094e-001F,
+                                        +2.231445312500e-001F, +2.518310546875e-001F};
+__device__ __forceinline__ double ds_tap(int n) { return (double)kDsHalf[n < 14 ? n : 26 - n]; }
+
+// Two adjacent 100-wide boxcar sums from the same 51 aligned 16-byte reads w[0..50] (w[0].x = P[i-50]):
+//   a0 = P[i-50] + ... + P[i+49],  a1 = P[i-49] + ... + P[i+50], each in ascending order (:433-437).
+// The window comes in chunks of 8 reads, the next chunk in flight while the current one is summed: as a plain loop
+// the compiler waits for every read before its four additions (fifty LDS latencies per pair); left alone with the
+// unrolled loop it hoists all 51 reads (204 registers, spilled).  Chunk C is a template parameter so that every
+// register index is a compile-time constant.
+template <int C>
+__device__ __forceinline__ void boxcar_chunk(const double2 *w, const double2 (&cur)[8], double &a0, double &a1, double &prev_y)
+{
+    constexpr int NCH = 7;  // 7 chunks of 8 cover w[0..50]
+    double2 nxt[8];
+    if constexpr (C + 1 < NCH) {
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            if ((C + 1) * 8 + u <= 50) nxt[u] = w[(C + 1) * 8 + u];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+        const int k = C * 8 + u;  // element w[k]
+        if (k <= 50) {
+            const double2 e = cur[u];
+            if (k >= 1) {
+                a0 += prev_y;
+                a1 += prev_y;
+            }
+            if (k < 50) a0 += e.x;
+            if (k >= 1) a1 += e.x;
+            prev_y = e.y;
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (C + 1 < NCH) boxcar_chunk<C + 1>(w, nxt, a0, a1, prev_y);
+}
+
+__device__ __forceinline__ void boxcar_pair(const double2 *w, double &a0, double &a1)
+{
+    double2 first[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) first[u] = w[u];
+    double prev_y = 0.0;
+    a0 = 0.0;
+    a1 = 0.0;
+    boxcar_chunk<0>(w, first, a0, a1, prev_y);
+}
+
 int launch_front_fft(const FftFrontArgs &a, int nstreams, hipStream_t st);
 // frames that are not a power of two (bpsk_fftm.hip): n = 2^a 3^b 5^c, 1024 < n <= 9600, n % 16 == 0
 bool fftm_supported(int n);

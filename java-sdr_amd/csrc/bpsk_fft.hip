@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256, (LOGN <= 11 ? 4 : (LOGN == 12 ? 2 : 1))) void 
     if (tid < 2 * kLdsTwiddleWing - 1) TsL[tid] = tsg[tid];
     FftFrontState *sp = &a.st[s];
     if (tid < 26) hist[tid] = sp->hist[tid];
-    if (tid < 27) taps[tid] = a.ds_taps[tid];
+    (void)taps;  // (the taps are compile-time constants now: ds_tap(); the slot stays for the layout)
     double avePeakPower = sp->avePeakPower, aveCentreBin = sp->aveCentreBin;
     int centreBin = sp->centreBin;
     // :399-402 -- float expressions widened to double
@@ -279,18 +279,9 @@ __global__ __launch_bounds__(256, (LOGN <= 11 ? 4 : (LOGN == 12 ? 2 : 1))) void 
             const int i = beg + 74 + 2 * (tid + 256 * b);  // beg is a multiple of 4: i - 50 is even
             if (i < end - 75) {
                 const double2 *w = reinterpret_cast<const double2 *>(P + i - 50);
-                double a0 = 0.0, a1 = 0.0;
-                double2 cur = w[0];
-                a0 += cur.x;
-#pragma unroll 10
-                for (int k = 1; k <= 50; k++) {
-                    const double2 nxt = w[k];
-                    a0 += cur.y;
-                    a1 += cur.y;
-                    if (k < 50) a0 += nxt.x;
-                    a1 += nxt.x;
-                    cur = nxt;
-                }
+                double a0, a1;
+                boxcar_pair(w, a0, a1);
+                asm volatile("" : "+v"(a0), "+v"(a1));  // due here: sunk into the conditional uses below, the sums drag all 51 reads along
                 if (i >= beg + 75) {
                     A[i] = a0;
                     if (bestv < a0) {  // i ascends within a thread: strict '<' keeps the first maximum
@@ -436,13 +427,13 @@ __global__ __launch_bounds__(256, (LOGN <= 11 ? 4 : (LOGN == 12 ? 2 : 1))) void 
                 double fi = 0.0;
                 if (e >= 26) {
 #pragma unroll
-                    for (int k = 0; k < 27; k++) fi += X[xpad(e - k)].x * taps[k];  // newest first (:479-483)
+                    for (int k = 0; k < 27; k++) fi += X[xpad(e - k)].x * ds_tap(k);  // newest first (:479-483)
                 } else {
 #pragma unroll
                     for (int k = 0; k < 27; k++) {
                         const int idx = e - k;
                         const double v = (idx >= 0) ? X[xpad(idx)].x : hist[26 + idx];
-                        fi += v * taps[k];
+                        fi += v * ds_tap(k);
                     }
                 }
                 const double o = fi * HOWARD;  // fi == fq: both rails get the same samples

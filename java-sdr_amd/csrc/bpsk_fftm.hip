@@ -218,52 +218,6 @@ __device__ __forceinline__ void fm_forward(double2 *X, const double2 *twL, const
     }
 }
 
-// Two adjacent 100-wide boxcar sums from the same 51 aligned 16-byte reads w[0..50] (w[0].x = P[i-50]):
-//   a0 = P[i-50] + ... + P[i+49],  a1 = P[i-49] + ... + P[i+50], each in ascending order (:433-437).
-// The window comes in chunks of 8 reads, the next chunk in flight while the current one is summed: as a plain loop
-// the compiler waits for every read before its four additions (fifty LDS latencies per pair); left alone with the
-// unrolled loop it hoists all 51 reads (204 registers, spilled).  Chunk C is a template parameter so that every
-// register index is a compile-time constant.
-template <int C>
-__device__ __forceinline__ void boxcar_chunk(const double2 *w, const double2 (&cur)[8], double &a0, double &a1, double &prev_y)
-{
-    constexpr int NCH = 7;  // 7 chunks of 8 cover w[0..50]
-    double2 nxt[8];
-    if constexpr (C + 1 < NCH) {
-#pragma unroll
-        for (int u = 0; u < 8; u++)
-            if ((C + 1) * 8 + u <= 50) nxt[u] = w[(C + 1) * 8 + u];
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int u = 0; u < 8; u++) {
-        const int k = C * 8 + u;  // element w[k]
-        if (k <= 50) {
-            const double2 e = cur[u];
-            if (k >= 1) {
-                a0 += prev_y;
-                a1 += prev_y;
-            }
-            if (k < 50) a0 += e.x;
-            if (k >= 1) a1 += e.x;
-            prev_y = e.y;
-        }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (C + 1 < NCH) boxcar_chunk<C + 1>(w, nxt, a0, a1, prev_y);
-}
-
-__device__ __forceinline__ void boxcar_pair(const double2 *w, double &a0, double &a1)
-{
-    double2 first[8];
-#pragma unroll
-    for (int u = 0; u < 8; u++) first[u] = w[u];
-    double prev_y = 0.0;
-    a0 = 0.0;
-    a1 = 0.0;
-    boxcar_chunk<0>(w, first, a0, a1, prev_y);
-}
-
 template <bool F32IN>
 __global__ __launch_bounds__(FM_T) void k_front_fftm(FftmArgs aa)
 {
@@ -289,7 +243,7 @@ __global__ __launch_bounds__(FM_T) void k_front_fftm(FftmArgs aa)
     const int abase = beg + 74;
     FftFrontState *sp = &a.st[s];
     if (tid < 26) hist[tid] = sp->hist[tid];
-    if (tid < 27) taps[tid] = a.ds_taps[tid];
+    (void)taps;  // (the taps are compile-time constants now: ds_tap(); the slot stays for the layout)
     double avePeakPower = sp->avePeakPower, aveCentreBin = sp->aveCentreBin;
     int centreBin = sp->centreBin;
     // :399-402 -- float expressions widened to double
@@ -453,13 +407,13 @@ __global__ __launch_bounds__(FM_T) void k_front_fftm(FftmArgs aa)
                 if (e >= 26) {  // all but the first three windows of a frame: no history, constant offsets
                     const double2 *w = X + e;
 #pragma unroll
-                    for (int k = 0; k < 27; k++) fi += (w[-k].x * norm) * taps[k];  // newest first (:479-483); re = X.x / n (:462)
+                    for (int k = 0; k < 27; k++) fi += (w[-k].x * norm) * ds_tap(k);  // newest first (:479-483); re = X.x / n (:462)
                 } else {
 #pragma unroll
                     for (int k = 0; k < 27; k++) {
                         const int idx = e - k;
                         const double v = (idx >= 0) ? X[idx].x * norm : hist[26 + idx];
-                        fi += v * taps[k];
+                        fi += v * ds_tap(k);
                     }
                 }
                 const double o = fi * HOWARD;  // fi == fq: both rails get the same samples
