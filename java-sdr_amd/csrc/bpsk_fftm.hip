@@ -226,8 +226,7 @@ __global__ __launch_bounds__(FM_T) void k_front_fftm(FftmArgs aa)
     const int n = a.n;
     double2 *X = reinterpret_cast<double2 *>(smem);      // [n]
     double *hist = reinterpret_cast<double *>(X + n);    // [32]
-    double *taps = hist + 32;                            // [32]
-    double *redv = taps + 32;                            // [16] per-wave best value
+    double *redv = hist + 32;                            // [16] per-wave best value
     int *redi = reinterpret_cast<int *>(redv + 16);      // [16] per-wave best index
     double2 *twL = reinterpret_cast<double2 *>(redi + 16);  // [lds_tw] twiddle tables of the first passes
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -243,7 +242,6 @@ __global__ __launch_bounds__(FM_T) void k_front_fftm(FftmArgs aa)
     const int abase = beg + 74;
     FftFrontState *sp = &a.st[s];
     if (tid < 26) hist[tid] = sp->hist[tid];
-    (void)taps;  // (the taps are compile-time constants now: ds_tap(); the slot stays for the layout)
     double avePeakPower = sp->avePeakPower, aveCentreBin = sp->aveCentreBin;
     int centreBin = sp->centreBin;
     // :399-402 -- float expressions widened to double
@@ -501,8 +499,8 @@ int launch_front_fftm(const FftFrontArgs &a, int np, const int *rad, const int *
     FftmArgs aa;
     aa.f = a;
     aa.np = np;
-    const size_t fixed = sizeof(double2) * (size_t)a.n + sizeof(double) * (32 + 32 + 16) + sizeof(int) * 16 + 64;
-    const size_t room = (size_t)160 * 1024 - fixed - 256;  // LDS left for twiddle tables
+    const size_t fixed = sizeof(double2) * (size_t)a.n + sizeof(double) * (32 + 16) + sizeof(int) * 16 + 64;
+    const size_t room = (size_t)160 * 1024 - fixed;  // LDS left for twiddle tables (at n = 9600: 596 entries, the first five passes')
     aa.lds_tw = 0;
     int P = 1;
     for (int p = 0; p < FM_MAXPASS; p++) {
