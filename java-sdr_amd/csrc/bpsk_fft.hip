@@ -417,6 +417,10 @@ __global__ __launch_bounds__(256, (LOGN <= 11 ? 4 : (LOGN == 12 ? 2 : 1))) void 
             fft_rest<true, LOGN, false>(X, TsL, tsg, tid, norm);  // leaves re/N in .x (:462)
         }
         PHASE(6)
+        // hist[26..51] (over the unused tap slots): the frame's first 26 samples, so that a window reaching back into the
+        // previous frame is one contiguous run too
+        if (tid < 26) hist[26 + tid] = X[xpad(tid)].x;
+        __syncthreads();
         // ---- RxDownSample(re, re) (:461-463, :470-492): outputs whose window ends inside this frame
 #pragma unroll
         for (int b = 0; b < JB; b++) {
@@ -429,12 +433,9 @@ __global__ __launch_bounds__(256, (LOGN <= 11 ? 4 : (LOGN == 12 ? 2 : 1))) void 
 #pragma unroll
                     for (int k = 0; k < 27; k++) fi += X[xpad(e - k)].x * ds_tap(k);  // newest first (:479-483)
                 } else {
+                    const double *w = hist + 26 + e;  // the first three windows of a frame: history, then the frame's head
 #pragma unroll
-                    for (int k = 0; k < 27; k++) {
-                        const int idx = e - k;
-                        const double v = (idx >= 0) ? X[xpad(idx)].x : hist[26 + idx];
-                        fi += v * ds_tap(k);
-                    }
+                    for (int k = 0; k < 27; k++) fi += w[-k] * ds_tap(k);
                 }
                 const double o = fi * HOWARD;  // fi == fq: both rails get the same samples
                 const double2 cs = (b == 0) ? cs0 : a.vco_cs[j];

@@ -225,7 +225,9 @@ __global__ __launch_bounds__(FM_T) void k_front_fftm(FftmArgs aa)
     const FftFrontArgs &a = aa.f;
     const int n = a.n;
     double2 *X = reinterpret_cast<double2 *>(smem);      // [n]
-    double *hist = reinterpret_cast<double *>(X + n);    // [32]
+    // [32]; during RxDownSample slots 26..51 (over the argmax scratch behind it, dead by then) hold the frame's first 26
+    // scaled samples, so that a window reaching back into the previous frame is one contiguous run as well
+    double *hist = reinterpret_cast<double *>(X + n);
     double *redv = hist + 32;                            // [16] per-wave best value
     int *redi = reinterpret_cast<int *>(redv + 16);      // [16] per-wave best index
     double2 *twL = reinterpret_cast<double2 *>(redi + 16);  // [lds_tw] twiddle tables of the first passes
@@ -392,6 +394,8 @@ __global__ __launch_bounds__(FM_T) void k_front_fftm(FftmArgs aa)
         PHASE(3)
         fm_forward(X, twL, aa, tf);
         PHASE(4)
+        if (tf < 26) hist[26 + tf] = X[tf].x * norm;
+        __syncthreads();
         // ---- RxDownSample(re, re) (:461-463, :470-492): outputs whose window ends inside this frame
         {
             long long jlo = (t0 - a.first_out + D - 1) / D;
@@ -407,12 +411,9 @@ __global__ __launch_bounds__(FM_T) void k_front_fftm(FftmArgs aa)
 #pragma unroll
                     for (int k = 0; k < 27; k++) fi += (w[-k].x * norm) * ds_tap(k);  // newest first (:479-483); re = X.x / n (:462)
                 } else {
+                    const double *w = hist + 26 + e;  // the first three windows of a frame: history, then the frame's head
 #pragma unroll
-                    for (int k = 0; k < 27; k++) {
-                        const int idx = e - k;
-                        const double v = (idx >= 0) ? X[idx].x * norm : hist[26 + idx];
-                        fi += v * ds_tap(k);
-                    }
+                    for (int k = 0; k < 27; k++) fi += w[-k] * ds_tap(k);
                 }
                 const double o = fi * HOWARD;  // fi == fq: both rails get the same samples
                 dm[64 + j] = make_double2(o * cs.x, o * cs.y);  // :515-516
