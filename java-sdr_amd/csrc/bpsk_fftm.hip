@@ -81,17 +81,22 @@ __device__ __forceinline__ void dft_r(double2 *v)
 }
 
 // one Stockham pass, in place: every butterfly of the pass is in registers before the first store
-template <int R>
-__device__ __attribute__((noinline)) void fm_pass(double2 *X, const double2 *tw, int n, int P, unsigned pmagic, int tid)
+// NN / PP: frame size and stride as compile-time constants for the two default frames (9600, 4800): every LDS offset
+// becomes an immediate, `b mod P` a mask or a constant multiply-high, and the butterfly count per thread is the
+// frame's, not the largest frame's.  0 = run-time values (any other supported n).
+template <int R, int NN = 0, int PP = 0>
+__device__ __attribute__((noinline)) void fm_pass(double2 *X, const double2 *tw, int n_rt, int P_rt, unsigned pmagic, int tid)
 {
-    constexpr int ITERS = ((FM_NMAX / R) + FM_T - 1) / FM_T;
+    constexpr int ITERS = (((NN ? NN : FM_NMAX) / R) + FM_T - 1) / FM_T;
+    const int n = NN ? NN : n_rt;
+    const int P = PP ? PP : P_rt;
     const int nb = n / R;
     double2 v[ITERS][R];
 #pragma unroll
     for (int it = 0; it < ITERS; it++) {
         const int b = it * FM_T + tid;
         if (b < nb) {
-            const int k = (P == 1) ? 0 : b - (int)__umulhi((unsigned)b, pmagic) * P;  // b % P without the division sequence
+            const int k = PP ? (b % PP) : (P == 1) ? 0 : b - (int)__umulhi((unsigned)b, pmagic) * P;  // b % P without the division sequence
 #pragma unroll
             for (int j = 0; j < R; j++) {
                 v[it][j] = X[b + j * nb];
@@ -105,7 +110,7 @@ __device__ __attribute__((noinline)) void fm_pass(double2 *X, const double2 *tw,
     for (int it = 0; it < ITERS; it++) {
         const int b = it * FM_T + tid;
         if (b < nb) {
-            const int k = (P == 1) ? 0 : b - (int)__umulhi((unsigned)b, pmagic) * P;  // (2^32/1 does not fit the magic)
+            const int k = PP ? (b % PP) : (P == 1) ? 0 : b - (int)__umulhi((unsigned)b, pmagic) * P;  // (2^32/1 does not fit the magic)
             const int j0 = (b - k) * R + k;
 #pragma unroll
             for (int q = 0; q < R; q++) X[j0 + q * P] = v[it][q];
@@ -120,19 +125,21 @@ __device__ __attribute__((noinline)) void fm_pass(double2 *X, const double2 *tw,
 // write z[m0*P*R1*R2 + k1 + q1*P + q2*P*R1].  Same operands, same tables, same operation order as fm_pass<R1>
 // followed by fm_pass<R2>: only the intermediate image stays in registers (an LDS store costs 13 cycles per wave
 // instruction, and the image is written once per pass).
-template <int R1, int R2>
-__device__ __attribute__((noinline)) void fm_pass2(double2 *X, const double2 *tw1, const double2 *tw2, int n, int P, unsigned pmagic,
-                                         int tid)
+template <int R1, int R2, int NN = 0, int PP = 0>
+__device__ __attribute__((noinline)) void fm_pass2(double2 *X, const double2 *tw1, const double2 *tw2, int n_rt, int P_rt,
+                                                   unsigned pmagic, int tid)
 {
     constexpr int RR = R1 * R2;
-    constexpr int ITERS = ((FM_NMAX / RR) + FM_T - 1) / FM_T;
+    constexpr int ITERS = (((NN ? NN : FM_NMAX) / RR) + FM_T - 1) / FM_T;
+    const int n = NN ? NN : n_rt;
+    const int P = PP ? PP : P_rt;
     const int ng = n / RR, nb1 = n / R1;
     double2 v[ITERS][R2][R1];
 #pragma unroll
     for (int it = 0; it < ITERS; it++) {
         const int g = it * FM_T + tid;
         if (g < ng) {
-            const int k1 = (P == 1) ? 0 : g - (int)__umulhi((unsigned)g, pmagic) * P;
+            const int k1 = PP ? (g % PP) : (P == 1) ? 0 : g - (int)__umulhi((unsigned)g, pmagic) * P;
 #pragma unroll
             for (int j2 = 0; j2 < R2; j2++) {
                 const int b1 = g + j2 * ng;
@@ -164,7 +171,7 @@ __device__ __attribute__((noinline)) void fm_pass2(double2 *X, const double2 *tw
     for (int it = 0; it < ITERS; it++) {
         const int g = it * FM_T + tid;
         if (g < ng) {
-            const int k1 = (P == 1) ? 0 : g - (int)__umulhi((unsigned)g, pmagic) * P;
+            const int k1 = PP ? (g % PP) : (P == 1) ? 0 : g - (int)__umulhi((unsigned)g, pmagic) * P;
             double2 *z = X + ((g - k1) * RR + k1);
 #pragma unroll
             for (int q2 = 0; q2 < R2; q2++)
@@ -184,6 +191,22 @@ __device__ __forceinline__ const double2 *fm_table(const double2 *twL, const Fft
 
 __device__ __forceinline__ void fm_forward(double2 *X, const double2 *twL, const FftmArgs &a, int tid)
 {
+    // the reference's two default frames: the plan is known (fftm_radices: 4,4,4,2,3,5,5 / 4,4,4,3,5,5)
+    if (a.f.n == 9600) {
+        fm_pass<4, 9600, 1>(X, fm_table(twL, a, 0, 1), 9600, 1, 0u, tid);
+        fm_pass2<4, 4, 9600, 4>(X, fm_table(twL, a, 1, 4), fm_table(twL, a, 2, 16), 9600, 4, 0u, tid);
+        fm_pass2<2, 3, 9600, 64>(X, fm_table(twL, a, 3, 64), fm_table(twL, a, 4, 128), 9600, 64, 0u, tid);
+        fm_pass<5, 9600, 384>(X, fm_table(twL, a, 5, 384), 9600, 384, 0u, tid);
+        fm_pass<5, 9600, 1920>(X, fm_table(twL, a, 6, 1920), 9600, 1920, 0u, tid);
+        return;
+    }
+    if (a.f.n == 4800) {
+        fm_pass<4, 4800, 1>(X, fm_table(twL, a, 0, 1), 4800, 1, 0u, tid);
+        fm_pass2<4, 4, 4800, 4>(X, fm_table(twL, a, 1, 4), fm_table(twL, a, 2, 16), 4800, 4, 0u, tid);
+        fm_pass2<3, 5, 4800, 64>(X, fm_table(twL, a, 3, 64), fm_table(twL, a, 4, 192), 4800, 64, 0u, tid);
+        fm_pass<5, 4800, 960>(X, fm_table(twL, a, 5, 960), 4800, 960, 0u, tid);
+        return;
+    }
     int P = 1;
     for (int p = 0; p < a.np;) {
         const int r = a.rad[p];

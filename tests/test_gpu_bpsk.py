@@ -264,6 +264,16 @@ def test_bpsk_fft_mode_at_the_reference_default_frames():
     same_state(d.state(), o.state())
 
 
+def test_bpsk_fft_mode_other_mixed_radix_frames():
+    """frames of 2^a 3^b 5^c samples other than the two defaults go through the run-time (unspecialised) Stockham passes
+    and pass pairs: 7680 = 4.4.4.4.2.3.5 -> [4][4,4][4,2][3,5], 1440 = 4.4.2.3.3.5 -> [4][4,2][3][3,5], 1200 = 4.4.3.5.5"""
+    for nsf in (7680, 1440, 1200):
+        n = nsf * 12
+        iq = O.make_dbpsk_stream(79, 0, n, carrier_hz=13100.0, noise_sigma=700.0)[0]
+        iq2 = O.make_dbpsk_stream(79, 1, n, carrier_hz=12650.0, noise_sigma=300.0)[0]
+        run_both([iq, iq2], n, [nsf * 5, nsf * 7], do_fft=1, blen=4 * nsf)
+
+
 def test_bpsk_fft_mode_negative_zero_spectrum_bins():
     """float frames of -0.0 (with a few impulses) leave -0.0 in spectrum bins: there a butterfly with a zero second
     operand does NOT return its first operand ((-0)+(+0) = +0), so the broadcast first inverse pass of
