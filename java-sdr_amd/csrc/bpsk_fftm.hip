@@ -182,6 +182,69 @@ __device__ __attribute__((noinline)) void fm_pass2(double2 *X, const double2 *tw
     __syncthreads();
 }
 
+// The first pass (radix 4, stride 1, no twiddles) of the default frames, fused with what produces its input: the
+// forward transform's straight from the frame's samples in global memory (x[b + j n/4], converted as :416-421), the
+// inverse's from the 204 gathered bins (only input 0 of the butterflies b < 204 is not the zeroed array's (0, -0)).
+// Same butterflies on the same operands as fm_pass<4>; what goes away is one LDS write of the whole image, one read
+// of it and two barriers per transform.
+template <int NN, bool F32IN>
+__device__ __attribute__((noinline)) void fm_first_from_raw(double2 *X, const int *raw, const float2 *rawf, int ic, int qc, int tid)
+{
+    constexpr int nb = NN / 4, ITERS = (nb + FM_T - 1) / FM_T;
+    int w[ITERS][4];
+    float2 wf[ITERS][4];
+#pragma unroll
+    for (int it = 0; it < ITERS; it++) {
+        int b = it * FM_T + tid;
+        b = b < nb ? b : nb - 1;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (F32IN)
+                wf[it][j] = rawf[b + j * nb];
+            else
+                w[it][j] = raw[b + j * nb];
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < ITERS; it++) {
+        const int b = it * FM_T + tid;
+        if (b < nb) {
+            double2 v[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (F32IN)
+                    v[j] = make_double2((double)wf[it][j].x, (double)wf[it][j].y);
+                else
+                    v[j] = make_double2((double)i16_to_float_java(java_short_add((int)(short)(w[it][j] & 0xffff), ic)),
+                                        (double)i16_to_float_java(java_short_add(w[it][j] >> 16, qc)));
+            }
+            dft_r<4>(v);
+#pragma unroll
+            for (int q = 0; q < 4; q++) X[4 * b + q] = v[q];
+        }
+    }
+    __syncthreads();
+}
+
+template <int NN>
+__device__ __attribute__((noinline)) void fm_first_from_bins(double2 *X, double2 in0, int tid)
+{
+    constexpr int nb = NN / 4, ITERS = (nb + FM_T - 1) / FM_T;
+    static_assert(FM_T >= 204, "butterfly b < 204 belongs to thread b");
+#pragma unroll
+    for (int it = 0; it < ITERS; it++) {
+        const int b = it * FM_T + tid;
+        if (b < nb) {
+            const double2 Z = make_double2(0.0, -0.0);  // conj of the zeroed array
+            double2 v[4] = {it == 0 ? in0 : Z, Z, Z, Z};
+            dft_r<4>(v);
+#pragma unroll
+            for (int q = 0; q < 4; q++) X[4 * b + q] = v[q];
+        }
+    }
+    __syncthreads();
+}
+
 __device__ __forceinline__ const double2 *fm_table(const double2 *twL, const FftmArgs &a, int p, int P)
 {
     // the narrow tables sit in LDS: a pass that starts with a round trip to L2 for its twiddles costs ~2 us,
@@ -189,11 +252,12 @@ __device__ __forceinline__ const double2 *fm_table(const double2 *twL, const Fft
     return (a.tw_off[p] + P * a.rad[p] <= a.lds_tw) ? twL + a.tw_off[p] : a.f.tw + a.tw_off[p];
 }
 
-__device__ __forceinline__ void fm_forward(double2 *X, const double2 *twL, const FftmArgs &a, int tid)
+// first_done: the caller has already run the first pass (fm_first_from_*, default frames only)
+__device__ __forceinline__ void fm_forward(double2 *X, const double2 *twL, const FftmArgs &a, int tid, bool first_done)
 {
     // the reference's two default frames: the plan is known (fftm_radices: 4,4,4,2,3,5,5 / 4,4,4,3,5,5)
     if (a.f.n == 9600) {
-        fm_pass<4, 9600, 1>(X, fm_table(twL, a, 0, 1), 9600, 1, 0u, tid);
+        if (!first_done) fm_pass<4, 9600, 1>(X, fm_table(twL, a, 0, 1), 9600, 1, 0u, tid);
         fm_pass2<4, 4, 9600, 4>(X, fm_table(twL, a, 1, 4), fm_table(twL, a, 2, 16), 9600, 4, 0u, tid);
         fm_pass2<2, 3, 9600, 64>(X, fm_table(twL, a, 3, 64), fm_table(twL, a, 4, 128), 9600, 64, 0u, tid);
         fm_pass<5, 9600, 384>(X, fm_table(twL, a, 5, 384), 9600, 384, 0u, tid);
@@ -201,7 +265,7 @@ __device__ __forceinline__ void fm_forward(double2 *X, const double2 *twL, const
         return;
     }
     if (a.f.n == 4800) {
-        fm_pass<4, 4800, 1>(X, fm_table(twL, a, 0, 1), 4800, 1, 0u, tid);
+        if (!first_done) fm_pass<4, 4800, 1>(X, fm_table(twL, a, 0, 1), 4800, 1, 0u, tid);
         fm_pass2<4, 4, 4800, 4>(X, fm_table(twL, a, 1, 4), fm_table(twL, a, 2, 16), 4800, 4, 0u, tid);
         fm_pass2<3, 5, 4800, 64>(X, fm_table(twL, a, 3, 64), fm_table(twL, a, 4, 192), 4800, 64, 0u, tid);
         fm_pass<5, 4800, 960>(X, fm_table(twL, a, 5, 960), 4800, 960, 0u, tid);
@@ -299,41 +363,48 @@ __global__ __launch_bounds__(FM_T) void k_front_fftm(FftmArgs aa)
         // of every phase out of the frame loop and spills them (the same trap as in k_front_fft)
         int tf = tid;
         asm volatile("" : "+v"(tf));
-        // ---- frame -> LDS, natural order (:416-421)
-        {
-            // all of a thread's samples in flight before the first conversion (a load / convert / store loop pays the
-            // HBM latency once per sample: 13 times per frame)
-            constexpr int NLD = (FM_NMAX + FM_T - 1) / FM_T;
-            int w[NLD];
-            float2 wf[NLD];
+        const bool fused_first = (n == 9600 || n == 4800);
+        if (n == 9600) {
+            fm_first_from_raw<9600, F32IN>(X, raw + t0, rawf + t0, a.ic, a.qc, tf);
+        } else if (n == 4800) {
+            fm_first_from_raw<4800, F32IN>(X, raw + t0, rawf + t0, a.ic, a.qc, tf);
+        } else {
+            // ---- frame -> LDS, natural order (:416-421)
+            {
+                // all of a thread's samples in flight before the first conversion (a load / convert / store loop pays the
+                // HBM latency once per sample: 13 times per frame)
+                constexpr int NLD = (FM_NMAX + FM_T - 1) / FM_T;
+                int w[NLD];
+                float2 wf[NLD];
 #pragma unroll
-            for (int q = 0; q < NLD; q++) {
-                int t = tf + q * FM_T;
-                t = t < n ? t : n - 1;
-                if (F32IN)
-                    wf[q] = rawf[t0 + t];
-                else
-                    w[q] = raw[t0 + t];
-            }
+                for (int q = 0; q < NLD; q++) {
+                    int t = tf + q * FM_T;
+                    t = t < n ? t : n - 1;
+                    if (F32IN)
+                        wf[q] = rawf[t0 + t];
+                    else
+                        w[q] = raw[t0 + t];
+                }
 #pragma unroll
-            for (int q = 0; q < NLD; q++) {
-                const int t = tf + q * FM_T;
-                if (t < n) {
-                    double di, dq;
-                    if (F32IN) {
-                        di = (double)wf[q].x;
-                        dq = (double)wf[q].y;
-                    } else {
-                        di = (double)i16_to_float_java(java_short_add((int)(short)(w[q] & 0xffff), a.ic));
-                        dq = (double)i16_to_float_java(java_short_add(w[q] >> 16, a.qc));
+                for (int q = 0; q < NLD; q++) {
+                    const int t = tf + q * FM_T;
+                    if (t < n) {
+                        double di, dq;
+                        if (F32IN) {
+                            di = (double)wf[q].x;
+                            dq = (double)wf[q].y;
+                        } else {
+                            di = (double)i16_to_float_java(java_short_add((int)(short)(w[q] & 0xffff), a.ic));
+                            dq = (double)i16_to_float_java(java_short_add(w[q] >> 16, a.qc));
+                        }
+                        X[t] = make_double2(di, dq);
                     }
-                    X[t] = make_double2(di, dq);
                 }
             }
+            __syncthreads();
         }
-        __syncthreads();
         PHASE(0)
-        fm_forward(X, twL, aa, tf);  // :422-423
+        fm_forward(X, twL, aa, tf, fused_first);  // :422-423
         PHASE(1)
         // ---- |X| (:425-427) over the band the boxcar reads
         for (int i = pbase + tf; i < end - 24; i += FM_T) {
@@ -410,12 +481,20 @@ __global__ __launch_bounds__(FM_T) void k_front_fftm(FftmArgs aa)
         double2 keep = make_double2(0.0, 0.0);
         if (tf < 204) keep = X[centreBin - 102 + tf];
         __syncthreads();
-        for (int i = tf; i < n; i += FM_T) X[i] = make_double2(0.0, -0.0);  // conj of the zeroed array: -0.0 imaginary parts
-        __syncthreads();
-        if (tf < 204) X[tf] = make_double2(keep.x, -keep.y);
-        __syncthreads();
+        if (fused_first) {
+            const double2 in0 = (tf < 204) ? make_double2(keep.x, -keep.y) : make_double2(0.0, -0.0);
+            if (n == 9600)
+                fm_first_from_bins<9600>(X, in0, tf);
+            else
+                fm_first_from_bins<4800>(X, in0, tf);
+        } else {
+            for (int i = tf; i < n; i += FM_T) X[i] = make_double2(0.0, -0.0);  // conj of the zeroed array: -0.0 imaginary parts
+            __syncthreads();
+            if (tf < 204) X[tf] = make_double2(keep.x, -keep.y);
+            __syncthreads();
+        }
         PHASE(3)
-        fm_forward(X, twL, aa, tf);
+        fm_forward(X, twL, aa, tf, fused_first);
         PHASE(4)
         if (tf < 26) hist[26 + tf] = X[tf].x * norm;
         __syncthreads();
