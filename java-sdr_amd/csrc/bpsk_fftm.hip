@@ -182,6 +182,36 @@ __device__ __attribute__((noinline)) void fm_pass2(double2 *X, const double2 *tw
     __syncthreads();
 }
 
+// The first pass stores X[4b + q]: lane stride 4 slots, so the 8 lanes of a 16-byte-store group share two bank groups
+// (4-way conflict, 32 LDS cycles per wave store instead of 8).  Rotating which output a lane stores in which
+// instruction -- output (i + (lane >> 1)) & 3 in instruction i -- puts the 8 lanes on 8 different bank groups; the
+// rotation is two conditional-move stages over the four values.
+__device__ __forceinline__ void fm_store4_rotated(double2 *X, int b, const double2 (&v)[4], int tid)
+{
+    const int r = (tid >> 1) & 3;
+    double2 w[4], t[4], u[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        w[i] = v[i];
+        // fresh values: LLVM otherwise turns "select of array elements" into a dynamically indexed private array (scratch)
+        asm volatile("" : "+v"(w[i].x), "+v"(w[i].y));
+    }
+    // (component by component on values: `c ? a[i] : a[j]` on the structs is an lvalue select, i.e. an address select)
+    const bool c1 = (r & 1) != 0, c2 = (r & 2) != 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const double ax = w[(i + 1) & 3].x, ay = w[(i + 1) & 3].y, bx = w[i].x, by = w[i].y;
+        t[i] = make_double2(c1 ? ax : bx, c1 ? ay : by);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const double ax = t[(i + 2) & 3].x, ay = t[(i + 2) & 3].y, bx = t[i].x, by = t[i].y;
+        u[i] = make_double2(c2 ? ax : bx, c2 ? ay : by);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) X[4 * b + ((i + r) & 3)] = u[i];
+}
+
 // The first pass (radix 4, stride 1, no twiddles) of the default frames, fused with what produces its input: the
 // forward transform's straight from the frame's samples in global memory (x[b + j n/4], converted as :416-421), the
 // inverse's from the 204 gathered bins (only input 0 of the butterflies b < 204 is not the zeroed array's (0, -0)).
@@ -219,8 +249,7 @@ __device__ __attribute__((noinline)) void fm_first_from_raw(double2 *X, const in
                                         (double)i16_to_float_java(java_short_add(w[it][j] >> 16, qc)));
             }
             dft_r<4>(v);
-#pragma unroll
-            for (int q = 0; q < 4; q++) X[4 * b + q] = v[q];
+            fm_store4_rotated(X, b, v, tid);
         }
     }
     __syncthreads();
@@ -238,8 +267,7 @@ __device__ __attribute__((noinline)) void fm_first_from_bins(double2 *X, double2
             const double2 Z = make_double2(0.0, -0.0);  // conj of the zeroed array
             double2 v[4] = {it == 0 ? in0 : Z, Z, Z, Z};
             dft_r<4>(v);
-#pragma unroll
-            for (int q = 0; q < 4; q++) X[4 * b + q] = v[q];
+            fm_store4_rotated(X, b, v, tid);
         }
     }
     __syncthreads();
