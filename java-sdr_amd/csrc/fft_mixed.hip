@@ -192,11 +192,18 @@ __global__ __launch_bounds__(T) void k_fft_mixed(FftArgs a)
         Best best;
         best.v = -3.402823466e+38f;
         best.k = 0x7fffffff;
-        mixed_pass<N, T, IN, OUT, R0, 1, true, false>(a, frame, tid, buf, tw, best);
-        mixed_pass<N, T, IN, OUT, R1, R0, false, false>(a, frame, tid, buf, tw + O2, best);
-        mixed_pass<N, T, IN, OUT, R2, R0 * R1, false, false>(a, frame, tid, buf, tw + O3, best);
-        mixed_pass<N, T, IN, OUT, R3, R0 * R1 * R2, false, false>(a, frame, tid, buf, tw + O4, best);
-        mixed_pass<N, T, IN, OUT, R4, R0 * R1 * R2 * R3, false, true>(a, frame, tid, buf, tw + O5, best);
+        // n = 4800: opaque per frame, so that nothing derived from the thread index is loop invariant -- LLVM otherwise
+        // hoists the LDS addresses of all five passes out of the frame loop (158 VGPRs instead of 58) and a CU holds one
+        // workgroup less (4.8 -> 4.05 ms per 2^30 samples).  n = 9600 is limited to one workgroup per CU by its LDS image
+        // anyway: there the hoisted addresses are free registers and save per-frame arithmetic (4.0 vs 4.7 ms;
+        // 1024-thread workgroups: 4.55 ms opaque, 11 ms with the hoisted addresses spilled under the 128-VGPR cap).
+        int tf = tid;
+        if constexpr (N <= 4800) asm volatile("" : "+v"(tf));
+        mixed_pass<N, T, IN, OUT, R0, 1, true, false>(a, frame, tf, buf, tw, best);
+        mixed_pass<N, T, IN, OUT, R1, R0, false, false>(a, frame, tf, buf, tw + O2, best);
+        mixed_pass<N, T, IN, OUT, R2, R0 * R1, false, false>(a, frame, tf, buf, tw + O3, best);
+        mixed_pass<N, T, IN, OUT, R3, R0 * R1 * R2, false, false>(a, frame, tf, buf, tw + O4, best);
+        mixed_pass<N, T, IN, OUT, R4, R0 * R1 * R2 * R3, false, true>(a, frame, tf, buf, tw + O5, best);
         if constexpr (OUT == OUT_PSD) {
             float bestv = best.v;
             int bestk = best.k;
