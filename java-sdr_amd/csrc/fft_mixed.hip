@@ -60,6 +60,19 @@ __device__ __forceinline__ void dft_any(float2 *x)
     else dft_reg<R>(x);
 }
 
+// LDS image: n = 9600 must leave room for a SECOND workgroup on the CU (one workgroup per CU marches through its
+// load / compute / barrier / store phases alone, and nothing fills the gaps): one pad slot per 32 elements instead of
+// per 16 (the first pass's stride-16 stores become 2-way conflicts instead of none) and only the narrow passes'
+// twiddle tables in LDS -- the wide ones (stride >= 640: 30 KB) are read through L1/L2, one coalesced read per
+// butterfly -- make it 81.2 KB per workgroup.
+template <int N>
+__device__ __forceinline__ int mpad(int idx)
+{
+    return N == 9600 ? idx + (idx >> 5) : idx + (idx >> 4);
+}
+constexpr int mixed_frame_elems(int n) { return n == 9600 ? n + (n >> 5) + 1 : n + (n >> 4) + 1; }
+constexpr int mixed_lds_passes(int n) { return n == 9600 ? 3 : 5; }  // passes whose tables are copied to LDS (pass 1 has none)
+
 constexpr bool mtw_direct(int P, int R) { return P * R <= 512; }
 constexpr int mtw_size(int P, int R) { return (P <= 1 || R <= 1) ? 0 : (mtw_direct(P, R) ? P * R : P); }
 
@@ -132,7 +145,7 @@ __device__ __forceinline__ void mixed_pass(const FftArgs &a, long long frame, in
         if (b < NB) {
             if constexpr (!FIRST) {
 #pragma unroll
-                for (int r = 0; r < R; r++) v[it][r] = buf[lds_pad(b + r * NB)];
+                for (int r = 0; r < R; r++) v[it][r] = buf[mpad<N>(b + r * NB)];
             }
             mixed_twiddles_apply<R, P>(v[it], b % P, tab);
             dft_any<R>(v[it]);
@@ -147,7 +160,7 @@ __device__ __forceinline__ void mixed_pass(const FftArgs &a, long long frame, in
             const int j0 = (b - k) * R + k;
             if constexpr (!LAST) {
 #pragma unroll
-                for (int r = 0; r < R; r++) buf[lds_pad(j0 + r * P)] = v[it][out_slot<R>(r)];
+                for (int r = 0; r < R; r++) buf[mpad<N>(j0 + r * P)] = v[it][out_slot<R>(r)];
             } else if constexpr (OUT == OUT_SPEC) {
                 float2 *dst = reinterpret_cast<float2 *>(a.out) + frame * N;
 #pragma unroll
@@ -174,19 +187,22 @@ __device__ __forceinline__ void mixed_pass(const FftArgs &a, long long frame, in
 }
 
 template <int N, int T, int IN, int OUT, int R0, int R1, int R2, int R3, int R4>
-__global__ __launch_bounds__(T) void k_fft_mixed(FftArgs a)
+__global__ __launch_bounds__(T, (N == 9600 ? 2 : 1)) void k_fft_mixed(FftArgs a)
 {
     static_assert(R0 * R1 * R2 * R3 * R4 == N, "radix plan must multiply to N");
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int O2 = 0, O3 = O2 + mtw_size(R0, R1), O4 = O3 + mtw_size(R0 * R1, R2),
                   O5 = O4 + mtw_size(R0 * R1 * R2, R3), TWN = O5 + mtw_size(R0 * R1 * R2 * R3, R4);
+    constexpr int TWL = mixed_lds_passes(N) >= 5 ? TWN : O4;  // table entries kept in LDS
     float2 *tw = reinterpret_cast<float2 *>(smem);
-    float2 *buf = tw + TWN;
+    float2 *buf = tw + TWL;
     constexpr int NW = (T + 63) / 64;
-    float *red_val = reinterpret_cast<float *>(buf + lds_frame_elems(N));
+    float *red_val = reinterpret_cast<float *>(buf + mixed_frame_elems(N));
     int *red_idx = reinterpret_cast<int *>(red_val + NW);
     const int tid = threadIdx.x;
-    for (int i = tid; i < TWN; i += T) tw[i] = a.tw[i];
+    for (int i = tid; i < TWL; i += T) tw[i] = a.tw[i];
+    const float2 *tw4 = (TWL == TWN) ? tw + O4 : a.tw + O4;
+    const float2 *tw5 = (TWL == TWN) ? tw + O5 : a.tw + O5;
     __syncthreads();
     for (long long frame = blockIdx.x; frame < a.nframes; frame += gridDim.x) {
         Best best;
@@ -198,12 +214,12 @@ __global__ __launch_bounds__(T) void k_fft_mixed(FftArgs a)
         // anyway: there the hoisted addresses are free registers and save per-frame arithmetic (4.0 vs 4.7 ms;
         // 1024-thread workgroups: 4.55 ms opaque, 11 ms with the hoisted addresses spilled under the 128-VGPR cap).
         int tf = tid;
-        if constexpr (N <= 4800) asm volatile("" : "+v"(tf));
+        if constexpr (N <= 9600) asm volatile("" : "+v"(tf));
         mixed_pass<N, T, IN, OUT, R0, 1, true, false>(a, frame, tf, buf, tw, best);
         mixed_pass<N, T, IN, OUT, R1, R0, false, false>(a, frame, tf, buf, tw + O2, best);
         mixed_pass<N, T, IN, OUT, R2, R0 * R1, false, false>(a, frame, tf, buf, tw + O3, best);
-        mixed_pass<N, T, IN, OUT, R3, R0 * R1 * R2, false, false>(a, frame, tf, buf, tw + O4, best);
-        mixed_pass<N, T, IN, OUT, R4, R0 * R1 * R2 * R3, false, true>(a, frame, tf, buf, tw + O5, best);
+        mixed_pass<N, T, IN, OUT, R3, R0 * R1 * R2, false, false>(a, frame, tf, buf, tw4, best);
+        mixed_pass<N, T, IN, OUT, R4, R0 * R1 * R2 * R3, false, true>(a, frame, tf, buf, tw5, best);
         if constexpr (OUT == OUT_PSD) {
             float bestv = best.v;
             int bestk = best.k;
@@ -303,7 +319,12 @@ bool mixed_plan(int n, MixedPlan &p)
         P *= p.radix[i];
     }
     const int nw = (p.threads + 63) / 64;
-    p.lds_bytes = sizeof(float2) * ((size_t)p.tw_count + lds_frame_elems(n)) + (sizeof(float) + sizeof(int)) * nw + 16;
+    int lds_tw = 0, Pl = p.radix[0];
+    for (int i = 1; i < p.nrad && i < mixed_lds_passes(n); i++) {
+        lds_tw += mtw_size(Pl, p.radix[i]);
+        Pl *= p.radix[i];
+    }
+    p.lds_bytes = sizeof(float2) * ((size_t)lds_tw + mixed_frame_elems(n)) + (sizeof(float) + sizeof(int)) * nw + 16;
     return true;
 }
 
