@@ -208,10 +208,10 @@ __global__ __launch_bounds__(T, (N == 9600 ? 2 : 1)) void k_fft_mixed(FftArgs a)
         Best best;
         best.v = -3.402823466e+38f;
         best.k = 0x7fffffff;
-        // n = 4800: opaque per frame, so that nothing derived from the thread index is loop invariant -- LLVM otherwise
+        // opaque per frame, so that nothing derived from the thread index is loop invariant -- LLVM otherwise
         // hoists the LDS addresses of all five passes out of the frame loop (158 VGPRs instead of 58) and a CU holds one
-        // workgroup less (4.8 -> 4.05 ms per 2^30 samples).  n = 9600 is limited to one workgroup per CU by its LDS image
-        // anyway: there the hoisted addresses are free registers and save per-frame arithmetic (4.0 vs 4.7 ms;
+        // workgroup less (4.8 -> 4.05 ms per 2^30 samples).  n = 9600: 256 VGPRs + 60 B scratch -> 94, which the second
+        // workgroup per CU needs (alone on a CU the hoisted addresses were free and saved arithmetic: 4.0 vs 4.7 ms;
         // 1024-thread workgroups: 4.55 ms opaque, 11 ms with the hoisted addresses spilled under the 128-VGPR cap).
         int tf = tid;
         if constexpr (N <= 9600) asm volatile("" : "+v"(tf));
