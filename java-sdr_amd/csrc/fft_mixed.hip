@@ -68,10 +68,11 @@ __device__ __forceinline__ void dft_any(float2 *x)
 template <int N>
 __device__ __forceinline__ int mpad(int idx)
 {
-    return N == 9600 ? idx + (idx >> 5) : idx + (idx >> 4);
+    return (N == 9600 || N == 4800) ? idx + (idx >> 5) : idx + (idx >> 4);
 }
-constexpr int mixed_frame_elems(int n) { return n == 9600 ? n + (n >> 5) + 1 : n + (n >> 4) + 1; }
-constexpr int mixed_lds_passes(int n) { return n == 9600 ? 3 : 5; }  // passes whose tables are copied to LDS (pass 1 has none)
+constexpr int mixed_frame_elems(int n) { return (n == 9600 || n == 4800) ? n + (n >> 5) + 1 : n + (n >> 4) + 1; }
+// passes whose tables are copied to LDS (pass 1 has none); n = 4800: 59 -> 40 KB, four workgroups per CU instead of two
+constexpr int mixed_lds_passes(int n) { return n == 4800 ? 2 : 3; }
 
 constexpr bool mtw_direct(int P, int R) { return P * R <= 512; }
 constexpr int mtw_size(int P, int R) { return (P <= 1 || R <= 1) ? 0 : (mtw_direct(P, R) ? P * R : P); }
@@ -187,13 +188,13 @@ __device__ __forceinline__ void mixed_pass(const FftArgs &a, long long frame, in
 }
 
 template <int N, int T, int IN, int OUT, int R0, int R1, int R2, int R3, int R4>
-__global__ __launch_bounds__(T, (N == 9600 ? 2 : 1)) void k_fft_mixed(FftArgs a)
+__global__ __launch_bounds__(T, (N == 9600 ? 2 : 4)) void k_fft_mixed(FftArgs a)
 {
     static_assert(R0 * R1 * R2 * R3 * R4 == N, "radix plan must multiply to N");
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int O2 = 0, O3 = O2 + mtw_size(R0, R1), O4 = O3 + mtw_size(R0 * R1, R2),
                   O5 = O4 + mtw_size(R0 * R1 * R2, R3), TWN = O5 + mtw_size(R0 * R1 * R2 * R3, R4);
-    constexpr int TWL = mixed_lds_passes(N) >= 5 ? TWN : O4;  // table entries kept in LDS
+    constexpr int TWL = mixed_lds_passes(N) >= 5 ? TWN : (mixed_lds_passes(N) == 3 ? O4 : O3);  // table entries kept in LDS
     float2 *tw = reinterpret_cast<float2 *>(smem);
     float2 *buf = tw + TWL;
     constexpr int NW = (T + 63) / 64;
@@ -201,6 +202,7 @@ __global__ __launch_bounds__(T, (N == 9600 ? 2 : 1)) void k_fft_mixed(FftArgs a)
     int *red_idx = reinterpret_cast<int *>(red_val + NW);
     const int tid = threadIdx.x;
     for (int i = tid; i < TWL; i += T) tw[i] = a.tw[i];
+    const float2 *tw3 = (TWL > O3) ? tw + O3 : a.tw + O3;
     const float2 *tw4 = (TWL == TWN) ? tw + O4 : a.tw + O4;
     const float2 *tw5 = (TWL == TWN) ? tw + O5 : a.tw + O5;
     __syncthreads();
@@ -217,7 +219,7 @@ __global__ __launch_bounds__(T, (N == 9600 ? 2 : 1)) void k_fft_mixed(FftArgs a)
         if constexpr (N <= 9600) asm volatile("" : "+v"(tf));
         mixed_pass<N, T, IN, OUT, R0, 1, true, false>(a, frame, tf, buf, tw, best);
         mixed_pass<N, T, IN, OUT, R1, R0, false, false>(a, frame, tf, buf, tw + O2, best);
-        mixed_pass<N, T, IN, OUT, R2, R0 * R1, false, false>(a, frame, tf, buf, tw + O3, best);
+        mixed_pass<N, T, IN, OUT, R2, R0 * R1, false, false>(a, frame, tf, buf, tw3, best);
         mixed_pass<N, T, IN, OUT, R3, R0 * R1 * R2, false, false>(a, frame, tf, buf, tw4, best);
         mixed_pass<N, T, IN, OUT, R4, R0 * R1 * R2 * R3, false, true>(a, frame, tf, buf, tw5, best);
         if constexpr (OUT == OUT_PSD) {
