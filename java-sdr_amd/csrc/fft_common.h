@@ -157,7 +157,6 @@ bool mixed_plan(int n, MixedPlan &p);
 void mixed_twiddles(const MixedPlan &p, float2 *out);
 int mixed_launch(const MixedPlan &p, const FftArgs &a, int in_kind, int out_kind, int grid, hipStream_t st);
 // split2 plans: half-size spectra of `nframes` frames into tmp [2*nframes][n/2], then the combine pass
-int mixed_launch_split2(const MixedPlan &p, const FftArgs &a, int in_kind, int out_kind, int num_cu, float2 *tmp,
-                        long long tmp_frames, hipStream_t st);
+int mixed_launch_split2(const MixedPlan &p, const FftArgs &a, int in_kind, int out_kind, int num_cu, hipStream_t st);
 
 }  // namespace jsdr

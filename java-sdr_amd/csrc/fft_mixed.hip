@@ -8,6 +8,7 @@
 // Parity: 1e-5 of the frame peak against the exact DFT (JTransforms' rounding is unknowable).
 #include "fft_common.h"
 #include <math.h>
+#include <stdlib.h>
 #include <vector>
 
 namespace jsdr {
@@ -263,6 +264,124 @@ __global__ __launch_bounds__(T, (N == 9600 ? 2 : 4)) void k_fft_mixed(FftArgs a)
     }
 }
 
+// n = 19200 (192 kHz): the frame does not fit one workgroup's LDS as one transform, but its two halves do --
+// X[k] = E[k] + W^k O[k], X[k+n/2] = E[k] - W^k O[k] with E, O the 9600-point transforms of the even / odd samples.
+// One workgroup runs both half transforms back to back, each into its own LDS image (2 x 79 KB), and combines them
+// from LDS with the PSD epilogue: 4 B in, 4 B out per sample, where the former two-kernel form moved the half
+// spectra through HBM (three times the traffic).
+template <int T, int IN, int OUT>
+__global__ __launch_bounds__(T) void k_fft_mixed_dual(FftArgs a, const float2 *__restrict__ wcomb)
+{
+    constexpr int N = 9600, R0 = 16, R1 = 8, R2 = 5, R3 = 5, R4 = 3, N2 = 2 * N;
+    extern __shared__ __align__(16) unsigned char smem[];
+    constexpr int O2 = 0, O3 = O2 + mtw_size(R0, R1), O4 = O3 + mtw_size(R0 * R1, R2),
+                  O5 = O4 + mtw_size(R0 * R1 * R2, R3);
+    constexpr int TWL = O4;
+    float2 *tw = reinterpret_cast<float2 *>(smem);
+    float2 *bufE = tw + TWL;
+    float2 *bufO = bufE + mixed_frame_elems(N);
+    constexpr int NW = (T + 63) / 64;
+    float *red_val = reinterpret_cast<float *>(bufO + mixed_frame_elems(N));
+    int *red_idx = reinterpret_cast<int *>(red_val + NW);
+    const int tid = threadIdx.x;
+    for (int i = tid; i < TWL; i += T) tw[i] = a.tw[i];
+    const float2 *tw4 = a.tw + O4, *tw5 = a.tw + O5;
+    __syncthreads();
+    for (long long frame = blockIdx.x; frame < a.nframes; frame += gridDim.x) {
+        Best best;
+        best.v = -3.402823466e+38f;
+        best.k = 0x7fffffff;
+        int tf = tid;
+        asm volatile("" : "+v"(tf));  // (see k_fft_mixed)
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            float2 *buf = h ? bufO : bufE;
+            const long long hf = 2 * frame + h;  // a.split addressing: even / odd samples of frame `frame`
+            int th = tf;
+            asm volatile("" : "+v"(th));  // (and per half: shared between the halves, the addresses live through ten passes)
+            mixed_pass<N, T, IN, OUT_SPEC, R0, 1, true, false>(a, hf, th, buf, tw, best);
+            mixed_pass<N, T, IN, OUT_SPEC, R1, R0, false, false>(a, hf, th, buf, tw + O2, best);
+            mixed_pass<N, T, IN, OUT_SPEC, R2, R0 * R1, false, false>(a, hf, th, buf, tw + O3, best);
+            mixed_pass<N, T, IN, OUT_SPEC, R3, R0 * R1 * R2, false, false>(a, hf, th, buf, tw4, best);
+            mixed_pass<N, T, IN, OUT_SPEC, R4, R0 * R1 * R2 * R3, false, false>(a, hf, th, buf, tw5, best);  // spectrum stays in LDS
+        }
+        constexpr int ITERS = (N + T - 1) / T;
+        float2 wk[ITERS];
+#pragma unroll
+        for (int it = 0; it < ITERS; it++) {  // the combine twiddles of this thread's bins, in flight together
+            const int k = it * T + tf;
+            wk[it] = wcomb[k < N ? k : N - 1];
+        }
+#pragma unroll
+        for (int it = 0; it < ITERS; it++) {
+            const int k = it * T + tf;
+            if (k < N) {
+                const float2 e = bufE[mpad<N>(k)];
+                const float2 t = cmul(bufO[mpad<N>(k)], wk[it]);
+                const float2 x0 = cadd(e, t), x1 = csub(e, t);
+                if constexpr (OUT == OUT_SPEC) {
+                    float2 *dst = reinterpret_cast<float2 *>(a.out) + frame * N2;
+                    dst[k] = x0;
+                    dst[k + N] = x1;
+                } else {
+                    const float cf = (2.0f / (float)N2) * (2.0f / (float)N2);
+                    float *dst = a.out + frame * (N2 + 2);
+                    const float d0 = 3.0102999566398120f * __log2f((x0.x * x0.x + x0.y * x0.y) * cf);  // fft.java:207
+                    const float d1 = 3.0102999566398120f * __log2f((x1.x * x1.x + x1.y * x1.y) * cf);
+                    dst[k] = d0;
+                    dst[k + N] = d1;
+                    if (d0 > best.v || (d0 == best.v && k < best.k)) {
+                        best.v = d0;
+                        best.k = k;
+                    }
+                    if (d1 > best.v || (d1 == best.v && k + N < best.k)) {
+                        best.v = d1;
+                        best.k = k + N;
+                    }
+                }
+            }
+        }
+        if constexpr (OUT == OUT_PSD) {
+            float bestv = best.v;
+            int bestk = best.k;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const float ov = __shfl_xor(bestv, off, 64);
+                const int ok = __shfl_xor(bestk, off, 64);
+                if (ov > bestv || (ov == bestv && ok < bestk)) {
+                    bestv = ov;
+                    bestk = ok;
+                }
+            }
+            if ((tid & 63) == 0) {
+                red_val[tid >> 6] = bestv;
+                red_idx[tid >> 6] = bestk;
+            }
+            __syncthreads();
+            if (tid == 0) {
+                for (int wv = 1; wv < NW; wv++) {
+                    const float ov = red_val[wv];
+                    const int ok = red_idx[wv];
+                    if (ov > bestv || (ov == bestv && ok < bestk)) {
+                        bestv = ov;
+                        bestk = ok;
+                    }
+                }
+                // fft.java:201-224
+                int p = (bestv > -3.402823466e+38f) ? 2 * bestk : -1;
+                const float m = (p >= 0) ? bestv : -3.402823466e+38f;
+                const int datlen = 2 * N2;
+                if (p >= datlen / 2) p -= datlen;
+                const int hz = (int)((unsigned)p * (unsigned)a.rate) / datlen;
+                float *dst = a.out + frame * (N2 + 2);
+                dst[N2] = (float)hz;
+                dst[N2 + 1] = m;
+            }
+        }
+        __syncthreads();  // the images are rewritten by the next frame's first passes
+    }
+}
+
 template <int N, int T, int R0, int R1, int R2, int R3, int R4>
 static int mixed_launch_t(const MixedPlan &p, const FftArgs &a, int in_kind, int out_kind, int grid, hipStream_t st)
 {
@@ -363,117 +482,33 @@ void mixed_twiddles(const MixedPlan &p, float2 *out)
     }
 }
 
-// radix-2 combine of the even / odd half spectra (one 256-thread workgroup per frame) + the PSD epilogue of
-// fft.receive (fft.java:201-227) or the plain spectrum
-template <int OUT>
-__global__ __launch_bounds__(256) void k_fft_combine2(const float2 *__restrict__ tmp, const float2 *__restrict__ w, int half,
-                                                      long long nframes, int rate, float *__restrict__ out)
+int mixed_launch_split2(const MixedPlan &p, const FftArgs &a, int in_kind, int out_kind, int num_cu, hipStream_t st)
 {
-    __shared__ float red_val[4];
-    __shared__ int red_idx[4];
-    const int tid = threadIdx.x;
-    const int N = 2 * half;
-    for (long long frame = blockIdx.x; frame < nframes; frame += gridDim.x) {
-        const float2 *E = tmp + (2 * frame) * half, *O = E + half;
-        Best best;
-        best.v = -3.402823466e+38f;
-        best.k = 0x7fffffff;
-        for (int k = tid; k < half; k += 256) {
-            const float2 e = E[k];
-            const float2 t = cmul(O[k], w[k]);
-            const float2 x0 = cadd(e, t), x1 = csub(e, t);
-            if constexpr (OUT == OUT_SPEC) {
-                float2 *dst = reinterpret_cast<float2 *>(out) + frame * N;
-                dst[k] = x0;
-                dst[k + half] = x1;
-            } else {
-                const float cf = (2.0f / (float)N) * (2.0f / (float)N);
-                float *dst = out + frame * (N + 2);
-                const float d0 = 3.0102999566398120f * __log2f((x0.x * x0.x + x0.y * x0.y) * cf);  // fft.java:207
-                const float d1 = 3.0102999566398120f * __log2f((x1.x * x1.x + x1.y * x1.y) * cf);
-                dst[k] = d0;
-                dst[k + half] = d1;
-                if (d0 > best.v || (d0 == best.v && k < best.k)) {
-                    best.v = d0;
-                    best.k = k;
-                }
-                if (d1 > best.v || (d1 == best.v && k + half < best.k)) {
-                    best.v = d1;
-                    best.k = k + half;
-                }
-            }
+    JSDR_REQUIRE(p.n == 19200, "fft: no two-half plan for n=%d", p.n);
+    constexpr int T = 512, N = 9600;
+    constexpr int O4 = mtw_size(16, 8) + mtw_size(16 * 8, 5);
+    const size_t lds = sizeof(float2) * ((size_t)O4 + 2 * (size_t)mixed_frame_elems(N)) + (sizeof(float) + sizeof(int)) * ((T + 63) / 64) + 16;
+    FftArgs h = a;
+    h.split = 1;  // half transform hf reads the even (hf even) / odd samples of frame hf >> 1
+    const float2 *wcomb = a.tw + p.half_tw_count;
+    static const int mgrid = [] { const char *e = getenv("JSDR_MIXED_GRID"); return e ? atoi(e) : 16; }();
+    const long long cap = (long long)num_cu * mgrid;
+    const unsigned grid = (unsigned)(a.nframes < cap ? a.nframes : cap);
+    auto go = [&](auto kern) -> int {
+        static bool attr_done = false;
+        if (!attr_done) {
+            JSDR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_done = true;
         }
-        if constexpr (OUT == OUT_PSD) {
-            float bestv = best.v;
-            int bestk = best.k;
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) {
-                const float ov = __shfl_xor(bestv, off, 64);
-                const int ok = __shfl_xor(bestk, off, 64);
-                if (ov > bestv || (ov == bestv && ok < bestk)) {
-                    bestv = ov;
-                    bestk = ok;
-                }
-            }
-            if ((tid & 63) == 0) {
-                red_val[tid >> 6] = bestv;
-                red_idx[tid >> 6] = bestk;
-            }
-            __syncthreads();
-            if (tid == 0) {
-                for (int wv = 1; wv < 4; wv++) {
-                    const float ov = red_val[wv];
-                    const int ok = red_idx[wv];
-                    if (ov > bestv || (ov == bestv && ok < bestk)) {
-                        bestv = ov;
-                        bestk = ok;
-                    }
-                }
-                // fft.java:201-224
-                int p = (bestv > -3.402823466e+38f) ? 2 * bestk : -1;
-                const float m = (p >= 0) ? bestv : -3.402823466e+38f;
-                const int datlen = 2 * N;
-                if (p >= datlen / 2) p -= datlen;
-                const int hz = (int)((unsigned)p * (unsigned)rate) / datlen;
-                float *dst = out + frame * (N + 2);
-                dst[N] = (float)hz;
-                dst[N + 1] = m;
-            }
-            __syncthreads();
-        }
-    }
-}
-
-int mixed_launch_split2(const MixedPlan &p, const FftArgs &a, int in_kind, int out_kind, int num_cu, float2 *tmp,
-                        long long tmp_frames, hipStream_t st)
-{
-    MixedPlan hp;
-    if (!mixed_plan(p.n / 2, hp)) {
-        set_error("fft: no half plan for n=%d", p.n);
-        return JSDR_ERR;
-    }
-    const int half = p.n / 2;
-    const size_t in_elem = (in_kind == IN_I16) ? sizeof(int) : sizeof(float2);
-    for (long long f0 = 0; f0 < a.nframes; f0 += tmp_frames) {
-        const long long nf = (a.nframes - f0) < tmp_frames ? (a.nframes - f0) : tmp_frames;
-        FftArgs h = a;
-        h.in = static_cast<const unsigned char *>(a.in) + (size_t)f0 * (size_t)p.n * in_elem;
-        h.out = reinterpret_cast<float *>(tmp);
-        h.nframes = 2 * nf;
-        h.split = 1;
-        const long long cap = (long long)num_cu * 2;
-        if (mixed_launch(hp, h, in_kind, OUT_SPEC, (int)(h.nframes < cap ? h.nframes : cap), st) != JSDR_OK) return JSDR_ERR;
-        const long long gcap = (long long)num_cu * 8;
-        const unsigned grid = (unsigned)(nf < gcap ? nf : gcap);
-        if (out_kind == OUT_PSD)
-            hipLaunchKernelGGL(k_fft_combine2<OUT_PSD>, dim3(grid), dim3(256), 0, st, tmp, a.tw + p.half_tw_count, half, nf, a.rate,
-                               a.out + (size_t)f0 * ((size_t)p.n + 2));
-        else
-            hipLaunchKernelGGL(k_fft_combine2<OUT_SPEC>, dim3(grid), dim3(256), 0, st, tmp, a.tw + p.half_tw_count, half, nf,
-                               a.rate, a.out + (size_t)f0 * 2 * (size_t)p.n);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(T), lds, st, h, wcomb);
         JSDR_LAUNCH_CHECK();
-    }
-    return JSDR_OK;
+        return JSDR_OK;
+    };
+    if (in_kind == IN_I16 && out_kind == OUT_PSD) return go(k_fft_mixed_dual<T, IN_I16, OUT_PSD>);
+    if (in_kind == IN_F32 && out_kind == OUT_PSD) return go(k_fft_mixed_dual<T, IN_F32, OUT_PSD>);
+    if (in_kind == IN_F32 && out_kind == OUT_SPEC) return go(k_fft_mixed_dual<T, IN_F32, OUT_SPEC>);
+    if (in_kind == IN_I16 && out_kind == OUT_SPEC) return go(k_fft_mixed_dual<T, IN_I16, OUT_SPEC>);
+    JSDR_REQUIRE(false, "fft: no kernel for in=%d out=%d", in_kind, out_kind);
 }
 
 int mixed_launch(const MixedPlan &p, const FftArgs &a, int in_kind, int out_kind, int grid, hipStream_t st)

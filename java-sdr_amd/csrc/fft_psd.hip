@@ -326,8 +326,6 @@ struct jsdr_fft {
     int num_cu = 256;
     bool mixed = false;  // non power-of-two frame: fft_mixed.hip
     MixedPlan mplan;
-    DevBuf<float2> split_tmp;  // split2 plans: half spectra of a chunk of frames
-    long long split_frames = 0;
 };
 
 static int fft_run(jsdr_fft *h, const void *in_dev, int in_kind, int out_kind, long long nframes, int ic, int qc,
@@ -347,7 +345,7 @@ static int fft_run(jsdr_fft *h, const void *in_dev, int in_kind, int out_kind, l
         a.ic = ic;
         a.qc = qc;
         if (h->mplan.split2)
-            return mixed_launch_split2(h->mplan, a, in_kind, out_kind, h->num_cu, h->split_tmp.p, h->split_frames, s);
+            return mixed_launch_split2(h->mplan, a, in_kind, out_kind, h->num_cu, s);
         static const int mgrid = [] { const char *e = getenv("JSDR_MIXED_GRID"); return e ? atoi(e) : 16; }();  // workgroups per CU: shorter workgroups balance the tail (2: 3.84, 16: 3.56 ms at n = 9600)
         long long cap = (long long)h->num_cu * mgrid;
         return mixed_launch(h->mplan, a, in_kind, out_kind, (int)(nframes < cap ? nframes : cap), s);
@@ -411,13 +409,6 @@ int jsdr_fft_create(jsdr_fft **out, int n, int rate)
             jsdr_fft_destroy(h);
             return JSDR_ERR;
         }
-        if (mp.split2) {
-            h->split_frames = 2048;  // 2048 x 19200 x 8 B = 315 MB of half spectra per chunk
-            if (h->split_tmp.alloc((size_t)h->split_frames * (size_t)n) != JSDR_OK) {
-                jsdr_fft_destroy(h);
-                return JSDR_ERR;
-            }
-        }
         *out = h;
         return JSDR_OK;
     }
@@ -470,7 +461,6 @@ int jsdr_fft_destroy(jsdr_fft *h)
     h->tw.release();
     h->in_stage.release();
     h->out_stage.release();
-    h->split_tmp.release();
     delete h;
     return JSDR_OK;
 }
