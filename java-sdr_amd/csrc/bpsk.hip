@@ -874,20 +874,30 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs a)
             // registers only (an LDS read per step would put ~100 cycles of latency on every link of the chain)
             double xs[64];
 #pragma unroll
-            for (int p = 0; p < 64; p++) xs[p] = enL[p * 8 + idx];
-            // only the first and the last period of a call can be partial
-            const int pfirst = (glane < g_first) ? 1 : 0;  // period 0 of the chunk lacks this lane's sample
-            double es[64];
+            for (int p = 0; p < 64; p++) xs[p] = enL[p * 8 + idx] * Sc;  // the products are off the chain
+            // (pinned: left to itself the compiler sinks the reads back into the chain, one LDS wait per two steps)
 #pragma unroll
-            for (int p = 0; p < 64; p++) {
-                const double ne = (e * Kc) + (xs[p] * Sc);  // :535 / :538
-                const bool ok = lane_on && (p >= pfirst) && (glane + 8 * p < g_end);
-                if (ok) e = ne;
-                es[p] = e;
-            }
-            if (lane_iir) {
+            for (int p = 0; p < 64; p++) asm volatile("" : "+v"(xs[p]));
+            // only the first and the last period of a call can be partial; everywhere else, with the peak position
+            // settled (the locked demodulator), a link of the chain is one multiply and one add.  The energies go to
+            // LDS as they fall out (stores are not on the chain; a register copy of all 64 would double the kernel's
+            // footprint beside the kernels it overlaps with).
+            const bool interior = (8 * MB >= g_first) && (8 * (MB + 64) <= g_end);  // uniform
+            if (interior && spec) {
 #pragma unroll
-                for (int p = 0; p < 64; p++) eL[p][lane] = es[p];
+                for (int p = 0; p < 64; p++) {
+                    e = (e * Kc) + xs[p];  // :535 / :538 (lanes above 8 fold numbers nobody reads)
+                    if (lane_iir) eL[p][lane] = e;
+                }
+            } else {
+                const int pfirst = (glane < g_first) ? 1 : 0;  // period 0 of the chunk lacks this lane's sample
+#pragma unroll
+                for (int p = 0; p < 64; p++) {
+                    const double ne = (e * Kc) + xs[p];
+                    const bool ok = lane_on && (p >= pfirst) && (glane + 8 * p < g_end);
+                    if (ok) e = ne;
+                    if (lane_iir) eL[p][lane] = e;
+                }
             }
         }
         JSDR_WAVE_SYNC();
