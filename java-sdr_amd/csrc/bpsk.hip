@@ -861,6 +861,7 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs a)
         JSDR_WAVE_SYNC();
         if (MB + 64 <= M_last) fetch(MB + 64);
         const int nper = (int)((M_last - MB + 1) < 64 ? (M_last - MB + 1) : 64);
+        const bool interior = (8 * MB >= g_first) && (8 * (MB + 64) <= g_end);  // every sample of all 64 periods is in range (uniform)
         // ---------------- serial IIRs, speculating that the peak position stays at v
         const int v = peakPos;
         const bool spec = (newPeak == peakPos);
@@ -882,12 +883,15 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs a)
             // settled (the locked demodulator), a link of the chain is one multiply and one add.  The energies go to
             // LDS as they fall out (stores are not on the chain; a register copy of all 64 would double the kernel's
             // footprint beside the kernels it overlaps with).
-            const bool interior = (8 * MB >= g_first) && (8 * (MB + 64) <= g_end);  // uniform
             if (interior && spec) {
+                // lanes 0..8 only, under ONE exec mask for the whole chain (a mask per store costs an exec write and its
+                // hazard on every link); lane 8 (dmEnergyOut) stores into the rows' pad column, which nobody reads
+                if (lane <= 8) {
 #pragma unroll
-                for (int p = 0; p < 64; p++) {
-                    e = (e * Kc) + xs[p];  // :535 / :538 (lanes above 8 fold numbers nobody reads)
-                    if (lane_iir) eL[p][lane] = e;
+                    for (int p = 0; p < 64; p++) {
+                        e = (e * Kc) + xs[p];  // :535 / :538
+                        eL[p][lane] = e;
+                    }
                 }
             } else {
                 const int pfirst = (glane < g_first) ? 1 : 0;  // period 0 of the chunk lacks this lane's sample
@@ -921,72 +925,78 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs a)
         bool replay = false;
         const bool bad = (np >= 0) && (np != v);
         const bool held = spec && (__ballot(bad) == 0ull);
-        if (held) {
-            if (lane < nper) {
-                const long long g = 8 * (MB + lane) + v;
-                maskL[lane] = (g >= g_first && g < g_end) ? (unsigned char)(1 << v) : (unsigned char)0;
-            }
-            // peakPos stays v; every measured peak was v, so newPeak stays v as well
-        } else {
-            // The peak moved (acquisition, fades, frame seams of the FFT-acquire mode).  The peakPos/newPeak
-            // machine of :537,:577-579,:592 is integer only -- its inputs are the per-period argmax values np,
-            // which do not depend on dmEnergyOut -- so it runs as scalar code over the periods, one mask per
-            // period; dmEnergyOut is then redone from its saved value along the decision list further down.
-            int mymask_r = 0;
-            for (int p = 0; p < nper; p++) {
-                const long long gbase = 8 * (MB + p);
-                const int cfirst = (gbase < g_first) ? (int)(g_first - gbase) : 0;
-                const int clast = (gbase + 7 >= g_end) ? (int)(g_end - 1 - gbase) : 7;
-                int mask = 0;
-                if (peakPos == newPeak) {  // nothing can change inside the period
-                    if (peakPos >= cfirst && peakPos <= clast) mask = 1 << peakPos;
-                } else {
-                    for (int c = cfirst; c <= clast; c++) {
-                        if (c == peakPos) mask |= 1 << c;                          // decision point (:537)
-                        if (c == ((peakPos + 4) & 7)) peakPos = newPeak;           // dmHalfTable (:500,:577-578)
-                    }
+        // A locked stream away from the call's edges: every period has its one decision at bit position v, in period
+        // order -- the decision list is known without the mask / prefix-sum / list round trips through LDS.
+        const bool fastd = held && interior;
+        int nd = 64;
+        if (!fastd) {
+            if (held) {
+                if (lane < nper) {
+                    const long long g = 8 * (MB + lane) + v;
+                    maskL[lane] = (g >= g_first && g < g_end) ? (unsigned char)(1 << v) : (unsigned char)0;
                 }
-                if (lane == p) mymask_r = mask;
-                if (clast == 7) newPeak = __builtin_amdgcn_readlane(np, p);
+                // peakPos stays v; every measured peak was v, so newPeak stays v as well
+            } else {
+                // The peak moved (acquisition, fades, frame seams of the FFT-acquire mode).  The peakPos/newPeak
+                // machine of :537,:577-579,:592 is integer only -- its inputs are the per-period argmax values np,
+                // which do not depend on dmEnergyOut -- so it runs as scalar code over the periods, one mask per
+                // period; dmEnergyOut is then redone from its saved value along the decision list further down.
+                int mymask_r = 0;
+                for (int p = 0; p < nper; p++) {
+                    const long long gbase = 8 * (MB + p);
+                    const int cfirst = (gbase < g_first) ? (int)(g_first - gbase) : 0;
+                    const int clast = (gbase + 7 >= g_end) ? (int)(g_end - 1 - gbase) : 7;
+                    int mask = 0;
+                    if (peakPos == newPeak) {  // nothing can change inside the period
+                        if (peakPos >= cfirst && peakPos <= clast) mask = 1 << peakPos;
+                    } else {
+                        for (int c = cfirst; c <= clast; c++) {
+                            if (c == peakPos) mask |= 1 << c;                          // decision point (:537)
+                            if (c == ((peakPos + 4) & 7)) peakPos = newPeak;           // dmHalfTable (:500,:577-578)
+                        }
+                    }
+                    if (lane == p) mymask_r = mask;
+                    if (clast == 7) newPeak = __builtin_amdgcn_readlane(np, p);
+                }
+                if (lane < 64) maskL[lane] = (unsigned char)mymask_r;
+                replay = true;
             }
-            if (lane < 64) maskL[lane] = (unsigned char)mymask_r;
-            replay = true;
-        }
-        JSDR_WAVE_SYNC();
-        // ---------------- decision list of the chunk, in time order
-        const int mymask = (lane < nper) ? (int)maskL[lane] : 0;
-        const int mycnt = __popc(mymask);
-        int pre_sum = mycnt;  // inclusive prefix sum over lanes
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            int o = __shfl_up(pre_sum, off, 64);
-            if (lane >= off) pre_sum += o;
-        }
-        const int nd = __shfl(pre_sum, 63, 64);
-        {
-            int pos = pre_sum - mycnt;
-            int m = mymask;
-            while (m) {
-                int c = __ffs(m) - 1;
-                m &= m - 1;
-                declist[pos++] = (short)(lane * 8 + c);
+            JSDR_WAVE_SYNC();
+            // ---------------- decision list of the chunk, in time order
+            const int mymask = (lane < nper) ? (int)maskL[lane] : 0;
+            const int mycnt = __popc(mymask);
+            int pre_sum = mycnt;  // inclusive prefix sum over lanes
+    #pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                int o = __shfl_up(pre_sum, off, 64);
+                if (lane >= off) pre_sum += o;
             }
-        }
-        JSDR_WAVE_SYNC();
-        if (replay) {
-            // dmEnergyOut (:538) over the decisions in time order: the products x*S2 lane-parallel, the chain
-            // e = e*K2 + (x*S2) on broadcast values, in the reference's operation order
-            double xa = 0.0, xb = 0.0;
-            if (lane < nd) xa = enL[declist[lane]] * S2;
-            if (lane + 64 < nd) xb = enL[declist[lane + 64]] * S2;
-            double eo = __shfl(e_in, 8, 64);
-            for (int d = 0; d < nd; d++) {  // d is uniform: v_readlane, no LDS round trip on the chain
-                const double xs = (d < 64) ? xa : xb;
-                const int lo = __builtin_amdgcn_readlane(__double2loint(xs), d & 63);
-                const int hi = __builtin_amdgcn_readlane(__double2hiint(xs), d & 63);
-                eo = (eo * K2) + __hiloint2double(hi, lo);
+            nd = __shfl(pre_sum, 63, 64);
+            {
+                int pos = pre_sum - mycnt;
+                int m = mymask;
+                while (m) {
+                    int c = __ffs(m) - 1;
+                    m &= m - 1;
+                    declist[pos++] = (short)(lane * 8 + c);
+                }
             }
-            if (lane == 8) e = eo;
+            JSDR_WAVE_SYNC();
+            if (replay) {
+                // dmEnergyOut (:538) over the decisions in time order: the products x*S2 lane-parallel, the chain
+                // e = e*K2 + (x*S2) on broadcast values, in the reference's operation order
+                double xa = 0.0, xb = 0.0;
+                if (lane < nd) xa = enL[declist[lane]] * S2;
+                if (lane + 64 < nd) xb = enL[declist[lane + 64]] * S2;
+                double eo = __shfl(e_in, 8, 64);
+                for (int d = 0; d < nd; d++) {  // d is uniform: v_readlane, no LDS round trip on the chain
+                    const double xs = (d < 64) ? xa : xb;
+                    const int lo = __builtin_amdgcn_readlane(__double2loint(xs), d & 63);
+                    const int hi = __builtin_amdgcn_readlane(__double2hiint(xs), d & 63);
+                    eo = (eo * K2) + __hiloint2double(hi, lo);
+                }
+                if (lane == 8) e = eo;
+            }
         }
         // ---------------- parallel: differential detector per decision (:539-545)
         for (int d0 = 0; d0 < nd; d0 += 64) {
@@ -994,8 +1004,8 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs a)
             const bool have = d < nd;
             double2 cur = make_double2(0.0, 0.0), prv = make_double2(lastI, lastQ);
             if (have) {
-                cur = yL[declist[d]];
-                if (d > 0) prv = yL[declist[d - 1]];
+                cur = yL[fastd ? 8 * d + v : (int)declist[d]];
+                if (d > 0) prv = yL[fastd ? 8 * (d - 1) + v : (int)declist[d - 1]];
             }
             const double di = -((prv.x * cur.x) + (prv.y * cur.y));
             const double dq = (prv.x * cur.y) - (prv.y * cur.x);
