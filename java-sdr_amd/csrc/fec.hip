@@ -303,6 +303,16 @@ __device__ __forceinline__ int rs_correct_lane(unsigned char *data, const int *s
     return count;
 }
 
+// Position of the decision word of trellis step k in the GLOBAL scratch (k_fec_bpsk): the parallel chain-back has
+// lane j read the words of bit i = 40 j + c at the same moment, so the words are stored c-major (row c = i % 40, column
+// i / 40): one coalesced 512-byte load per step instead of 64 scattered ones.  The forward pass pays with a scattered
+// store per 64 steps (nobody waits for stores).  Steps k < 6 carry no output bit and park behind the table.
+__device__ __forceinline__ int dec_gpos(int k)
+{
+    const int i = k - 6;
+    return i < 0 ? 40 * 64 + k : (i % 40) * 64 + i / 40;
+}
+
 // FECDecode (:703-852) on L.raw; payload to L.data only on success (as the reference leaves
 // RSdecdata untouched on failure).  Returns -1 or the channel error count (wave-uniform).
 template <int DECW>
@@ -345,8 +355,8 @@ __device__ __forceinline__ int fec_decode_wave(FecLdsT<DECW> &L, int lane, unsig
                     const bool mine = lane == slot;
                     dlo = mine ? (unsigned)mask : dlo;
                     dhi = mine ? (unsigned)(mask >> 32) : dhi;
-                    if (slot == 63 || k == NBITS - 1)  // one coalesced 512-byte store per 64 trellis steps
-                        decg[(k & ~63) + lane] = ((unsigned long long)dhi << 32) | dlo;
+                    if ((slot == 63 || k == NBITS - 1) && (k & ~63) + lane < NBITS)  // one store per 64 trellis steps
+                        decg[dec_gpos((k & ~63) + lane)] = ((unsigned long long)dhi << 32) | dlo;
                 } else {
                     if (lane == 0) L.dec[k0 + kk] = mask;
                 }
@@ -369,7 +379,7 @@ __device__ __forceinline__ int fec_decode_wave(FecLdsT<DECW> &L, int lane, unsig
             const int my = hi - lane;
             if (hi < 0 || my < 0) return 0ull;
             if constexpr (DEC_GLOBAL)
-                return __hip_atomic_load(&decg[my + 6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return __hip_atomic_load(&decg[dec_gpos(my + 6)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             else
                 return L.dec[my + 6];
         };
@@ -377,8 +387,53 @@ __device__ __forceinline__ int fec_decode_wave(FecLdsT<DECW> &L, int lane, unsig
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // the decision stores have reached L2
             __builtin_amdgcn_wave_barrier();
         }
-        unsigned long long wnext = fetch(NBITS - 7);
-        for (int hi_i = NBITS - 7; hi_i >= 0; hi_i -= 64) {
+        // The chain-back is one dependent step per bit (2560 links of ~140 cycles).  Survivor paths merge within a few
+        // constraint lengths, so every lane traces ITS OWN 40 bits (5 bytes) after a warm-up of WARM steps from an
+        // arbitrary state above its segment, all 64 lanes in lock-step: 104 steps instead of 2560.  The result is
+        // accepted only if the segments chain up exactly -- lane j enters its segment in the state lane j+1 left its own
+        // (lane 63 starts in the true state 0), which by induction makes every lane's path the reference's path;
+        // otherwise (paths that did not merge: garbage frames) the serial chain-back below runs as before.
+        bool par_ok = false;
+        {
+            constexpr int SEG = 40, WARM = 64, LAST = NBITS - 7;  // bits 0..LAST
+            static_assert(64 * SEG == LAST + 1, "64 lanes x 40 bits");
+            const int seg_lo = SEG * lane;
+            int st = 0, top = 0;
+            unsigned long long bits = 0;  // bit (i - seg_lo) of the segment
+            for (int t0 = 0; t0 < SEG + WARM; t0 += 8) {
+                unsigned long long w[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {  // the eight words in flight together: they do not depend on the state
+                    const int i = seg_lo + SEG - 1 + WARM - (t0 + u);
+                    const int ic = i > LAST ? LAST : i;
+                    if constexpr (DEC_GLOBAL)
+                        w[u] = __hip_atomic_load(&decg[dec_gpos(ic + 6)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    else
+                        w[u] = L.dec[ic + 6];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int i = seg_lo + SEG - 1 + WARM - (t0 + u);
+                    if (i == seg_lo + SEG - 1) top = st;
+                    if (i <= LAST) {
+                        const unsigned word = (st >> 5) ? (unsigned)(w[u] >> 32) : (unsigned)w[u];
+                        const unsigned bit = (word >> (st & 31)) & 1u;
+                        st = (int)(((unsigned)st | (bit << 6)) >> 1);
+                        if (i <= seg_lo + SEG - 1) bits |= (unsigned long long)bit << (i - seg_lo);
+                    }
+                }
+            }
+            const int above = __shfl_down(st, 1, 64);  // the state in which lane j+1 left its segment
+            const bool good = (lane == 63) ? (top == 0) : (top == above);
+            par_ok = __ballot(!good) == 0ull;
+            if (par_ok) {
+#pragma unroll
+                for (int b = 0; b < SEG / 8; b++)  // bit i sits at 0x80 >> (i & 7) of byte i >> 3 (:270-273)
+                    L.vit[(seg_lo >> 3) + b] = (unsigned char)(__brev((unsigned)((bits >> (8 * b)) & 0xffu)) >> 24);
+            }
+        }
+        unsigned long long wnext = par_ok ? 0ull : fetch(NBITS - 7);
+        for (int hi_i = par_ok ? -1 : NBITS - 7; hi_i >= 0; hi_i -= 64) {
             // this chunk covers i = hi_i .. max(hi_i-63,0); step index k = i + 6
             unsigned long long w = wnext;
             wnext = fetch(hi_i - 64);
