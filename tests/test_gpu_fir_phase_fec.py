@@ -97,6 +97,33 @@ def test_fec_decode_roundtrip_errors_and_failure():
     assert (rc[:4] == [0, 1, 17, 150]).all() and rc[7] == -1
 
 
+def test_fec_decode_chain_back_paths_across_the_noise_range():
+    """the chain-back runs lane-parallel (40 bits per lane after a warm-up) and is accepted only if the segments chain
+    up; blocks from clean to far beyond the correction limit -- and soft garbage -- take both that and the serial path"""
+    rng = np.random.default_rng(11)
+    raws = []
+    for e in range(0, 960, 20):
+        data = rng.integers(0, 256, 256, dtype=np.uint8)
+        soft = np.where(O.fec_encode(data) == 1, 0xC0, 0x40).astype(np.uint8)
+        if e:
+            idx = rng.choice(5200, e, replace=False)
+            soft[idx] = rng.integers(0, 256, e, dtype=np.uint8)  # erasure-like and inverted symbols of any strength
+        raws.append(soft)
+    for _ in range(8):
+        raws.append(rng.integers(0, 256, 5200, dtype=np.uint8))
+    rc, out = J.fec_decode_batch(np.stack(raws))
+    ok = fail = 0
+    for i, soft in enumerate(raws):
+        wrc, wout = O.fec_decode(soft)
+        assert rc[i] == wrc, i
+        if wrc >= 0:
+            assert np.array_equal(out[i], wout), i
+            ok += 1
+        else:
+            fail += 1
+    assert ok >= 10 and fail >= 8
+
+
 def test_fec_decode_byte_errors_exercise_berlekamp_massey():
     """Corrupt whole interleaver rows so that the Viterbi decoder emits byte errors and the RS stage has to
     locate and fix them (count > 0 path of decode_rs_8); must stay bit-identical to the oracle."""
