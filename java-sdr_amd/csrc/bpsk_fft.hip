@@ -260,12 +260,17 @@ __global__ __launch_bounds__(256, (LOGN <= 11 ? 4 : (LOGN == 12 ? 2 : 1))) void 
         PHASE(0)
         fft_rest<false, LOGN, false>(X, TsL, tsg, tid, norm);
         PHASE(1)
-        // ---- |X| (:425-427)
+        // ---- |X| (:425-427), for the bins the boxcar reads: [beg+24, end-24) -- a quarter band, not the N/2 bins the
+        // reference fills (the double-precision root is ~28 instructions a bin)
+        constexpr int NBAND = N / 4 - 48;
 #pragma unroll
-        for (int i0 = 0; i0 < N / 2; i0 += 256) {
-            const int i = i0 + tid;
-            const double2 v = X[xpad(i)];
-            P[i] = sqrt(v.x * v.x + v.y * v.y);
+        for (int i0 = 0; i0 < NBAND; i0 += 256) {
+            const int r = i0 + tid;
+            if (NBAND % 256 == 0 || r < NBAND) {
+                const int i = beg + 24 + r;
+                const double2 v = X[xpad(i)];
+                P[i] = sqrt(v.x * v.x + v.y * v.y);
+            }
         }
         __syncthreads();
         PHASE(2)
