@@ -1,0 +1,128 @@
+"""GPU parity against fixtures that do NOT come from the C oracle.
+
+tests/golden/reference_fixtures.npz is the output of the pure-Python restatement of the Java text
+(tests/golden/java_restatement.py, run in the build container): slicer bits, counters, every scalar state double,
+(fi,fq) trace, FECDecode return codes and bytes.  The HIP path, through the C ABI, must reproduce all of it bit
+for bit.  Also here: the BASELINE config-5 per-GPU shard shape (1024 streams x 2^20 samples) on the device.
+"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import java_sdr_amd as J
+import oracle_lib as O
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+from fixture_cases import FEC_CASES, STREAMS, stream_input  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+FX = np.load(os.path.join(HERE, "golden", "reference_fixtures.npz"))
+CN = ("cntRaw", "cntDS", "cntBit", "cntFEC", "cntDec", "dmErrBits", "dmCorr", "dmMaxCorr", "decodeOK")
+KEEP = [0, 1, 2, 3, 4, 5] + list(range(8, 18))
+
+
+def _check_stream(name, chunks, variant=None):
+    p = STREAMS[name]
+    raw = stream_input(name)
+    k = "s_" + name + "_"
+    assert hashlib.sha256(raw.tobytes()).digest() == FX[k + "sha256"].tobytes()
+    kw = {} if variant is None else {"variant": variant}
+    d = J.Bpsk(rate=p["rate"], blen=8192, tuning=p["tuning"], nstreams=1, max_batch_samples=max(chunks), **kw)
+    d_iq = J.DeviceBuffer.from_host(raw)
+    bits, trace, fec = [], [], []
+    pos = 0
+    for L in chunks:
+        d.batch_i16(d_iq.ptr + 4 * pos, 2 * p["n"], L, p["ic"], p["qc"])
+        bits.append(d.bits(0).copy())
+        trace.append(d.trace(0).copy())
+        fec.extend(d.fec_results(0))
+        pos += L
+    assert pos == p["n"]
+    c = d.counters(0)
+    assert [c[n] for n in CN] == [int(v) for v in FX[k + "counters"][:9]]
+    assert np.array_equal(np.concatenate(bits), FX[k + "bits"])
+    assert [r[0] for r in fec] == [int(v) for v in FX[k + "fec_rc"]]
+    for r, want in zip(fec, FX[k + "fec_data"]):
+        assert np.array_equal(r[2], want)
+    assert np.array_equal(d.decoded(0), FX[k + "decoded"])
+    if variant in (None, "exact"):  # the exact-order FP64 variant reproduces the doubles as well
+        assert d.state(0)[KEEP].tobytes() == FX[k + "state"][KEEP].tobytes()
+        assert np.concatenate(trace)[:2048].tobytes() == FX[k + "trace"].tobytes()
+    return d
+
+
+@pytest.mark.parametrize("name", list(STREAMS))
+def test_hip_demodulator_equals_python_restatement_one_batch(name):
+    _check_stream(name, [STREAMS[name]["n"]])
+
+
+@pytest.mark.parametrize("name", ["sine", "clean", "r48k_dc", "r192k"])
+def test_hip_demodulator_equals_python_restatement_frame_cadence_and_ragged(name):
+    n = STREAMS[name]["n"]
+    if name == "sine":
+        _check_stream(name, [2048, 2048])
+    else:
+        _check_stream(name, [2048] * 8 + [77, 1, 4099, n - 2048 * 8 - 77 - 1 - 4099 - 65536, 65536])
+
+
+def test_hip_encoder_equals_python_restatement():
+    assert np.array_equal(J.fec_encode(FX["f_payload"]), FX["f_symbols"])
+
+
+@pytest.mark.parametrize("name", FEC_CASES)
+def test_hip_fecdecode_equals_python_restatement(name):
+    rc, out = J.fec_decode(FX["f_" + name + "_in"], out_init=np.full(256, 0xEE, np.uint8))
+    assert rc == int(FX["f_" + name + "_rc"][0])
+    assert np.array_equal(out, FX["f_" + name + "_out"])
+
+
+def test_hip_fecdecode_batch_equals_python_restatement():
+    raws = np.stack([FX["f_" + n + "_in"] for n in FEC_CASES] * 5)
+    rcs, outs = J.fec_decode_batch(raws)
+    for i, n in enumerate(FEC_CASES * 5):
+        assert rcs[i] == int(FX["f_" + n + "_rc"][0])
+        if rcs[i] >= 0:
+            assert np.array_equal(outs[i], FX["f_" + n + "_out"])
+
+
+def test_config5_shard_shape_1024_streams_by_2pow20_samples():
+    """BASELINE config 5's per-GPU shard: 1024 streams x 1,048,576 int16 IQ samples (4 GiB) resident on the device.
+    Every stream must return the payloads it was sent (encode -> modulate -> demodulate -> decode), and eight
+    sampled streams must match the oracle's bits, counters and FEC bytes."""
+    S, L, sps, nfr, seed = 1024, 1048576, 80, 3, 20020109
+    pay = J.synth_payloads(seed, 0, S, nfr)
+    d_sym = J.DeviceBuffer(S * nfr * 5200)
+    J.fec_encode_dev(pay, S * nfr, d_sym)
+    d_ds = J.DeviceBuffer(S * nfr * 5200)
+    J.synth_diffsign(d_sym, nfr * 5200, S, d_ds)
+    ct, st = O.synth_tables(3000)
+    keys = np.array([O.mix64((seed * 0x9E3779B1 + s) ^ 0xA5A5A5A5) for s in range(S)], np.uint64)
+    d_iq = J.DeviceBuffer(S * L * 4)
+    gain = int(round(1500.0 / 37837.0 * 32768.0))
+    J.synth_dbpsk(d_iq, 2 * L, S, 0, L, d_ds, nfr * 5200, sps, 0, O.phase_inc_u32(13200.0, 96000),
+                  J.DeviceBuffer.from_host(ct), J.DeviceBuffer.from_host(st), gain, J.DeviceBuffer.from_host(keys))
+    d = J.Bpsk(nstreams=S, max_batch_samples=L)
+    d.batch_i16(d_iq, 2 * L, L)
+    payloads = pay.to_host(np.uint8).reshape(S, nfr, 256)
+    info = d.slot_info()
+    slots = J.DeviceBuffer(S * info["slot_bytes"])
+    d.pack_slots(slots)
+    blob = slots.to_host(np.uint8).reshape(S, info["slot_bytes"])
+    for s in range(S):
+        u = J.unpack_slot(blob[s], info)
+        assert len(u["fec"]) == 2, (s, len(u["fec"]))
+        for k2, (rc, _, data) in enumerate(u["fec"]):
+            assert rc >= 0 and np.array_equal(data, payloads[s, k2]), (s, k2, rc)
+    for s in (0, 1, 127, 128, 511, 512, 777, 1023):
+        iq = d_iq.to_host(np.int16, count=2 * L, offset_bytes=4 * L * s)
+        o = O.Bpsk()
+        o.receive_i16(iq)
+        assert np.array_equal(d.bits(s), o.bits()), s
+        c, oc = d.counters(s), o.counters()
+        assert [c[n] for n in CN] == [oc[n] for n in CN], s
+        for (rc, _, data), (orc, _, odata) in zip(d.fec_results(s), o.fec_results()):
+            assert rc == orc and np.array_equal(data, odata)
