@@ -6,9 +6,10 @@
 //     in a VGPR; the two predecessors (s>>1, (s>>1)+32) arrive by cross-lane reads; the 64 decisions of a
 //     step are one __ballot -- the same 64 bits the reference packs into its two `long pp[]` words per step
 //     (FECDecoder.java:229-255) -- kept in LDS for the chain-back.
-//   * RS(255,223) x2: the 2 x 32 syndromes are the 64 lanes (Horner over the 160 non-padding columns);
-//     Berlekamp-Massey / Chien / Forney only run when a syndrome is non-zero, one lane per codeword,
-//     restating :387-511 verbatim.
+//   * RS(255,223) x2: the 2 x 32 syndromes are the 64 lanes (Horner over the 160 non-padding columns); when a
+//     syndrome is non-zero the two code words are corrected on the two half-waves, 32 lanes each: Berlekamp-
+//     Massey with the polynomials spread over the lanes, Chien search as ballots over the 255 field elements,
+//     Forney with one root per lane (rs_correct_halfwave; same results as :387-511).
 //   * re-encode: the two RS parity LFSRs run on the two half-waves (lane = register position), the
 //     convolutional encoder + interleaver is parallel over the 2566 bits.
 #include "bpsk_fec.h"
@@ -203,104 +204,163 @@ __device__ __forceinline__ void fec_encode_wave(FecLdsT<DECW> &L, const unsigned
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// decode_rs_8 (:325-519) after the syndromes: one lane per code word, verbatim control flow.
-// s[] in index form.  Returns the number of corrected symbols or -1.
-// The work arrays live in LDS (`w`, 272 shorts per code word), not in private memory: a kernel with scratch
-// makes the runtime size a scratch arena for every dispatch, which costs more than the decode itself.
-__device__ __forceinline__ int rs_correct_lane(unsigned char *data, const int *s_in, const unsigned char *alpha_to,
-                                            const unsigned char *index_of, short *w)
+// ---------------------------------------------------------------------------------------------- RS correction
+// Errors-only RS(255,223) correction of the block's two code words, ONE HALF-WAVE PER CODE WORD, after the
+// syndromes (which are already lane-parallel).  Same results as decode_rs_8 (FECDecoder.java:387-511) -- the
+// number of corrected symbols, or -1 when the locator's degree and its root count differ (:474) or an error
+// value is undefined (:503) -- but organised for 32 lanes instead of one:
+//   locator   : Berlekamp-Massey with the polynomials spread over the lanes.  Lane q keeps the coefficient
+//               Lambda_{q+1} (Lambda_0 is 1 throughout) and B_q; a step is one GF multiply per lane, a 5-level
+//               xor-reduction for the discrepancy, and neighbour shuffles for x.B(x) and B <- Lambda / Delta.
+//   roots     : Chien search with the 255 field elements dealt over the lanes, 8 rounds; a ballot per round gives
+//               the roots in increasing order, a prefix popcount their slot in the root list.
+//   evaluator : Omega = S . Lambda mod x^32, one coefficient per lane.
+//   values    : Forney with one root per lane: numerator, formal derivative, and the byte patched in place.
+// The data-dependent trip counts (deg Lambda, deg Omega, root count) of the two code words differ, so both
+// half-waves run the wave-uniform maximum under a per-lane guard.
+#define FEC_WAVE_SYNC()                                        \
+    do {                                                       \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+        __builtin_amdgcn_wave_barrier();                       \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+    } while (0)
+
+struct RsWork {            // per code word, in LDS; index form (A0 = the zero element) unless noted
+    short lam[NROOTS + 2]; // locator coefficients 0..32
+    short omg[NROOTS];     // evaluator coefficients
+    short root[NROOTS];    // exponents i with Lambda(alpha^i) = 0, ascending
+    short loc[NROOTS];     // the code word positions they stand for
+};
+static_assert(sizeof(RsWork) <= 272 * sizeof(short), "RsWork must fit the per-code-word slice of the dead decision area");
+
+__device__ __forceinline__ int xor_reduce32(int v)  // over the 32 lanes of a half-wave
 {
-    short *lambda = w, *s = w + 34, *b = w + 68, *t = w + 102, *omega = w + 136;
-    short *root = w + 170, *reg = w + 204, *loc = w + 238;
-    int deg_lambda, el, deg_omega, i, j, r, k, q, tmp, num1, num2, den, discr_r, count;
-    for (i = 0; i < NROOTS; i++) s[i] = (short)s_in[i];
-    for (i = 0; i <= NROOTS; i++) {
-        lambda[i] = 0;
-        t[i] = 0;
-        omega[i] = 0;
-        reg[i] = 0;
-    }
-    lambda[0] = 1;
-    for (i = 0; i < NROOTS + 1; i++) b[i] = index_of[lambda[i]];
-    r = 0;
-    el = 0;
-    while (++r <= NROOTS) {
-        discr_r = 0;
-        for (i = 0; i < r; i++) {
-            if ((lambda[i] != 0) && (s[r - i - 1] != A0))
-                discr_r ^= alpha_to[gf_mod255(index_of[lambda[i]] + s[r - i - 1])];
+#pragma unroll
+    for (int off = 16; off >= 1; off >>= 1) v ^= __shfl_xor(v, off, 64);
+    return v;
+}
+
+// cw: the code word of this half-wave (255 bytes, LDS); syn: its 32 syndromes, index form (LDS); W: its work area.
+// q = lane & 31.  Returns the half-wave-uniform result.
+__device__ __forceinline__ int rs_correct_halfwave(unsigned char *cw, const int *syn, const unsigned char *alpha_to,
+                                                   const unsigned char *index_of, RsWork *W, int lane)
+{
+    const int q = lane & 31, base = lane & 32;
+    // ---- locator
+    int lam = 0;                    // Lambda_{q+1}, polynomial form
+    int bq = (q == 0) ? 0 : A0;     // B_q, index form; B(x) = 1 to start with
+    int el = 0;
+    for (int r = 1; r <= NROOTS; r++) {
+        int term = 0;
+        if (q <= r - 2 && lam != 0) {
+            const int sx = syn[r - 2 - q];
+            if (sx != A0) term = alpha_to[gf_mod255((int)index_of[lam] + sx)];
         }
-        discr_r = index_of[discr_r];
-        if (discr_r == A0) {
-            for (i = NROOTS; i > 0; i--) b[i] = b[i - 1];
-            b[0] = A0;
+        const int s0 = syn[r - 1];
+        const int delta = xor_reduce32(term) ^ (s0 != A0 ? (int)alpha_to[s0] : 0);
+        const int up_b = __shfl(bq, base + ((q + 31) & 31), 64);    // B_{q-1}
+        const int up_l = __shfl(lam, base + ((q + 31) & 31), 64);   // Lambda_q
+        const int shifted = (q == 0) ? A0 : up_b;                   // coefficient q of x.B(x)
+        if (delta == 0) {
+            bq = shifted;
         } else {
-            t[0] = lambda[0];
-            for (i = 0; i < NROOTS; i++) {
-                if (b[i] != A0)
-                    t[i + 1] = lambda[i + 1] ^ alpha_to[gf_mod255(discr_r + b[i])];
-                else
-                    t[i + 1] = lambda[i + 1];
-            }
+            const int dx = index_of[delta];
+            const int next = lam ^ (bq != A0 ? (int)alpha_to[gf_mod255(dx + bq)] : 0);
             if (2 * el <= r - 1) {
                 el = r - el;
-                for (i = 0; i <= NROOTS; i++)
-                    b[i] = (lambda[i] == 0) ? A0 : gf_mod255(index_of[lambda[i]] - discr_r + NN);
+                const int lq = (q == 0) ? 1 : up_l;  // coefficient q of the outgoing Lambda
+                bq = (lq == 0) ? A0 : gf_mod255((int)index_of[lq] - dx + NN);
             } else {
-                for (i = NROOTS; i > 0; i--) b[i] = b[i - 1];
-                b[0] = A0;
+                bq = shifted;
             }
-            for (i = 0; i <= NROOTS; i++) lambda[i] = t[i];
+            lam = next;
         }
     }
-    deg_lambda = 0;
-    for (i = 0; i < NROOTS + 1; i++) {
-        lambda[i] = index_of[lambda[i]];
-        if (lambda[i] != A0) deg_lambda = i;
-    }
-    for (i = 1; i <= NROOTS; i++) reg[i] = lambda[i];
-    count = 0;
-    for (i = 1, k = IPRIM - 1; i <= NN; i++, k = gf_mod255(k + IPRIM)) {
-        q = 1;
-        for (j = deg_lambda; j > 0; j--) {
-            if (reg[j] != A0) {
-                reg[j] = gf_mod255(reg[j] + j);
-                q ^= alpha_to[reg[j]];
+    const unsigned nzl = (unsigned)(__ballot(lam != 0) >> base);
+    const int deg = nzl ? 32 - __clz(nzl) : 0;
+    W->lam[q + 1] = index_of[lam];
+    if (q == 0) W->lam[0] = 0;
+    FEC_WAVE_SYNC();
+    const int deg_other = __shfl(deg, base ^ 32, 64);
+    const int deg_max = deg > deg_other ? deg : deg_other;
+    // ---- roots: element alpha^i, i = q+1+32k
+    int count = 0;
+    for (int k = 0; k < 8; k++) {
+        const int i = q + 1 + 32 * k;
+        int v = 1;
+        int e = 0;  // i*j mod 255, stepped
+        for (int j = 1; j <= deg_max; j++) {
+            e += i;
+            if (e >= 255) e -= 255;
+            const int lj = W->lam[j];
+            if (j <= deg && lj != A0) v ^= alpha_to[gf_mod255(lj + e)];
+        }
+        const bool hit = (i <= NN) && (v == 0);
+        const unsigned m = (unsigned)(__ballot(hit) >> base);
+        if (hit) {
+            const int slot = count + __popc(m & ((1u << q) - 1u));
+            if (slot < NROOTS) {
+                W->root[slot] = (short)i;
+                W->loc[slot] = (short)gf_mod255(IPRIM * i - 1);
             }
         }
-        if (q != 0) continue;
-        root[count] = i;
-        loc[count] = k;
-        if (++count == deg_lambda) break;
+        count += __popc(m);
     }
-    if (deg_lambda != count) return -1;
-    deg_omega = 0;
-    for (i = 0; i < NROOTS; i++) {
-        tmp = 0;
-        j = (deg_lambda < i) ? deg_lambda : i;
-        for (; j >= 0; j--) {
-            if ((s[i - j] != A0) && (lambda[j] != A0)) tmp ^= alpha_to[gf_mod255(s[i - j] + lambda[j])];
+    FEC_WAVE_SYNC();
+    const bool miss = count != deg;  // uniform per half-wave
+    // ---- evaluator: Omega_q = sum_j S_{q-j} Lambda_j, j <= min(deg, q)
+    int om = 0;
+    {
+        const int top = deg < q ? deg : q;
+        for (int j = 0; j <= deg_max && j <= 31; j++) {
+            if (j <= top) {
+                const int sx = syn[q - j], lj = W->lam[j];
+                if (sx != A0 && lj != A0) om ^= alpha_to[gf_mod255(sx + lj)];
+            }
         }
-        if (tmp != 0) deg_omega = i;
-        omega[i] = index_of[tmp];
     }
-    omega[NROOTS] = A0;
-    for (j = count - 1; j >= 0; j--) {
-        num1 = 0;
-        for (i = deg_omega; i >= 0; i--) {
-            if (omega[i] != A0) num1 ^= alpha_to[gf_mod255(omega[i] + i * root[j])];
+    W->omg[q] = index_of[om];
+    const unsigned nzo = (unsigned)(__ballot(om != 0) >> base);
+    const int dego = nzo ? 31 - __clz(nzo) : 0;
+    FEC_WAVE_SYNC();
+    // ---- error values, one root per lane
+    bool undefined = false;
+    int patch = 0, where = 0;
+    const bool mine = !miss && q < count;
+    {
+        const int rt = mine ? (int)W->root[q] : 0;
+        const int dego_other = __shfl(dego, base ^ 32, 64);
+        const int n1 = dego > dego_other ? dego : dego_other;
+        int num = 0, e = 0;  // e = i*rt mod 255
+        for (int i = 0; i <= n1; i++) {
+            const int oi = W->omg[i];
+            if (i <= dego && oi != A0) num ^= alpha_to[gf_mod255(oi + e)];
+            e += rt;
+            if (e >= 255) e -= 255;
         }
-        num2 = alpha_to[gf_mod255(root[j] * (FCR - 1) + NN)];
-        den = 0;
-        int top = deg_lambda < NROOTS - 1 ? deg_lambda : NROOTS - 1;
-        for (i = top & ~1; i >= 0; i -= 2) {
-            if (lambda[i + 1] != A0) den ^= alpha_to[gf_mod255(lambda[i + 1] + i * root[j])];
+        int den = 0;
+        const int dtop = (deg < NROOTS - 1 ? deg : NROOTS - 1) & ~1;
+        const int dtop_max = (deg_max < NROOTS - 1 ? deg_max : NROOTS - 1) & ~1;
+        const int r2 = gf_mod255(2 * rt);
+        e = 0;  // i*rt mod 255 for even i
+        for (int i = 0; i <= dtop_max; i += 2) {
+            const int l1 = W->lam[i + 1];
+            if (i <= dtop && l1 != A0) den ^= alpha_to[gf_mod255(l1 + e)];
+            e += r2;
+            if (e >= 255) e -= 255;
         }
-        if (den == 0) return -1;
-        if (num1 != 0)
-            data[loc[j]] ^= alpha_to[gf_mod255(index_of[num1] + index_of[num2] + NN - index_of[den])];
+        if (mine) {
+            undefined = den == 0;
+            if (!undefined && num != 0) {
+                const int scale = alpha_to[gf_mod255(rt * (FCR - 1) + NN)];
+                patch = alpha_to[gf_mod255((int)index_of[num] + (int)index_of[scale] + NN - (int)index_of[den])];
+                where = W->loc[q];
+            }
+        }
     }
-    return count;
+    const bool fail = miss || ((unsigned)(__ballot(undefined) >> base) != 0u);
+    if (!fail && patch != 0) cw[where] ^= (unsigned char)patch;
+    return fail ? -1 : count;
 }
 
 // Position of the decision word of trellis step k in the GLOBAL scratch (k_fec_bpsk): the parallel chain-back has
@@ -484,14 +544,14 @@ __device__ __forceinline__ int fec_decode_wave(FecLdsT<DECW> &L, int lane, unsig
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     int rserr = 0;
-    bool need0 = (nz & 0xffffffffull) != 0, need1 = (nz >> 32) != 0;
-    if ((lane == 0 && need0) || (lane == 32 && need1))
-        rserr = rs_correct_lane(L.rs[blk], sidx + blk * 32, L.alpha_to, L.index_of,
-                                reinterpret_cast<short *>(&L.dec[0]) + blk * 272);  // decisions are dead by now
+    if (nz != 0ull) {  // a code word with all-zero syndromes is left alone and counts 0 corrections (:351-358)
+        const bool need = ((nz >> (lane & 32)) & 0xffffffffull) != 0ull;
+        const int r = rs_correct_halfwave(L.rs[blk], sidx + blk * 32, L.alpha_to, L.index_of,
+                                          reinterpret_cast<RsWork *>(reinterpret_cast<short *>(&L.dec[0]) + blk * 272), lane);
+        rserr = need ? r : 0;  // decisions are dead by now: their LDS holds the work areas
+    }
     int e0 = __shfl(rserr, 0, 64), e1 = __shfl(rserr, 32, 64);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    FEC_WAVE_SYNC();
     if (e0 == -1 || e1 == -1) return -1;  // :821-824
     for (int j = lane; j < 256; j += 64) L.data[j] = L.rs[j & 1][RSPAD + (j >> 1)];  // :783-787
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

@@ -13,6 +13,7 @@ import numpy as np
 import pytest
 
 import java_sdr_amd as J
+from java_sdr_amd import sharding as SH
 import oracle_lib as O
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -113,7 +114,7 @@ def test_config5_shard_shape_1024_streams_by_2pow20_samples():
     d.pack_slots(slots)
     blob = slots.to_host(np.uint8).reshape(S, info["slot_bytes"])
     for s in range(S):
-        u = J.unpack_slot(blob[s], info)
+        u = SH.unpack_slot(blob[s], info)
         assert len(u["fec"]) == 2, (s, len(u["fec"]))
         for k2, (rc, _, data) in enumerate(u["fec"]):
             assert rc >= 0 and np.array_equal(data, payloads[s, k2]), (s, k2, rc)
