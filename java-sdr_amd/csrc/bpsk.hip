@@ -643,7 +643,9 @@ struct MatchedArgs {
     long long tile0;     // global index of the first block of tile 0 (== 64 mod 65, <= g_first)
 };
 
-template <int R>
+// FAST: one fused multiply-add per tap instead of the reference's separately rounded product and sum (the
+// margin-certified variant); the exact-order form is the default everywhere.
+template <int R, bool FAST = false>
 __device__ __forceinline__ void matched_block(const double2 *xl /* &X[s0] of this lane */, int u0, double (&ai)[R],
                                               double (&aq)[R])
 {
@@ -660,8 +662,13 @@ __device__ __forceinline__ void matched_block(const double2 *xl /* &X[s0] of thi
 #pragma unroll
         for (int r = 0; r < R; r++) {
             double t = f[u0 + i + r];
-            ai[r] += v.x * t;
-            aq[r] += v.y * t;
+            if constexpr (FAST) {
+                ai[r] = __builtin_fma(v.x, t, ai[r]);
+                aq[r] = __builtin_fma(v.y, t, aq[r]);
+            } else {
+                ai[r] += v.x * t;
+                aq[r] += v.y * t;
+            }
         }
     }
     // phase 1 tail: outputs drop out from the top (age would exceed 64)
@@ -672,8 +679,13 @@ __device__ __forceinline__ void matched_block(const double2 *xl /* &X[s0] of thi
 #pragma unroll
         for (int r = 0; r < R - 1 - q; r++) {
             double t = f[u0 + i + r];
-            ai[r] += v.x * t;
-            aq[r] += v.y * t;
+            if constexpr (FAST) {
+                ai[r] = __builtin_fma(v.x, t, ai[r]);
+                aq[r] = __builtin_fma(v.y, t, aq[r]);
+            } else {
+                ai[r] += v.x * t;
+                aq[r] += v.y * t;
+            }
         }
     }
     // phase 2 head: s = s0 + u0 + R-1-q, only outputs with u >= s-s0 take part, age = u-(s-s0)
@@ -683,8 +695,13 @@ __device__ __forceinline__ void matched_block(const double2 *xl /* &X[s0] of thi
 #pragma unroll
         for (int r = R - 1 - q; r < R; r++) {
             double t = f[r - (R - 1 - q)];
-            ai[r] += v.x * t;
-            aq[r] += v.y * t;
+            if constexpr (FAST) {
+                ai[r] = __builtin_fma(v.x, t, ai[r]);
+                aq[r] = __builtin_fma(v.y, t, aq[r]);
+            } else {
+                ai[r] += v.x * t;
+                aq[r] += v.y * t;
+            }
         }
     }
     // phase 2 main: s = s0 + u0 - m, m = 0..u0-1, age = r + m
@@ -693,8 +710,13 @@ __device__ __forceinline__ void matched_block(const double2 *xl /* &X[s0] of thi
 #pragma unroll
         for (int r = 0; r < R; r++) {
             double t = f[r + m];
-            ai[r] += v.x * t;
-            aq[r] += v.y * t;
+            if constexpr (FAST) {
+                ai[r] = __builtin_fma(v.x, t, ai[r]);
+                aq[r] = __builtin_fma(v.y, t, aq[r]);
+            } else {
+                ai[r] += v.x * t;
+                aq[r] += v.y * t;
+            }
         }
     }
 }
@@ -763,6 +785,231 @@ __global__ __launch_bounds__(64) void k_dm_history(double2 *dm, long long dm_str
     __builtin_amdgcn_wave_barrier();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     p[threadIdx.x] = v;
+}
+
+// ------------------------------------------------------------------------------------------- k_fm
+// Front end and matched filter in ONE kernel: int16 IQ -> tuner mix -> 27-tap /D low-pass -> x HOWARD -> VCO mix
+// (k_front_reg's arithmetic) -> 65-tap matched filter in ring-slot order (k_matched's) -> y = (fi,fq).  The VCO-mixed
+// 9600 Hz samples of a tile never leave the CU: the front half writes them into the LDS image the matched filter
+// reads (16 B per 9600 Hz sample that used to go to HBM and come back: 3.4 GB per 1024 x 2^20 batch), and the
+// 1 B/sample tuner-index stream is gone as well -- the tuner table index is periodic in the sample number (an
+// exact 8-cycle at 12 kHz / 96 kHz; the host verifies the period over every sample of the call), so the (cos, sin)
+// pair of window sample m sits at a COMPILE-TIME offset from a tile-uniform base in an unwrapped table: scalar
+// loads, SGPR operands, no per-sample index arithmetic and no LDS lookups.
+//
+//   tile   : NB = 62 blocks of 65 outputs (k_matched's lane = block mapping) + 64 samples of halo = 4094 VCO-mixed
+//            samples = 65.5 KB of LDS; 512 threads; two workgroups per CU.
+//   front  : 1024 jobs of R = 4 outputs (two rounds of 512 threads, 99.9 % of the lanes busy); a lane reads ITS
+//            OWN 57-sample window with 4-byte aligned 16-byte loads, newest quad first, converts I and Q of a
+//            sample together (packed FP32: the same IEEE operations as the scalar form, two per instruction) and
+//            walks newest -> oldest with the R accumulator pairs in registers (:479-483).  The halo is recomputed
+//            (1.6 %); before the call's first sample it comes from the 64 samples the previous call saved.
+//   matched: as k_matched, from the LDS image.
+// Every floating-point operation and its order are those of k_front_reg + k_matched (FAST = false), so (fi,fq)
+// stay bit-identical to the reference.  Used when the input is int16, the tuner schedule is periodic with a period
+// that divides the lane span (or the tuner is off, tuning <= 0); everything else takes the three-kernel path.
+enum { FM_NB = 62, FM_NT = 64 + 65 * FM_NB, FM_THREADS = 512, FM_TABLE_SLACK = 128 };
+
+struct FmArgs {
+    const int *raw;             // int16 pairs as dwords, [S][stride]
+    long long stride_pairs;
+    int nsamples;               // L
+    int ic, qc;
+    const int2 *hist;           // [S][32]: the 26 inputs before this call, DC-corrected int16 pairs in .x
+    const double2 *tcs;         // unwrapped tuner table: entry e = (cos, sin) for samples n with (n + 26) mod P == e mod P
+    int tper;                   // P (1 when the tuner is off)
+    const unsigned char *kvco;  // [nds] VCO table index per decimated sample
+    const double *sincos;       // cos[256], sin[256]
+    const double2 *dmh_old;     // [S][64] the 64 VCO-mixed samples before this call
+    double2 *dmh_new;           // [S][64] the last 64 of this call
+    double2 *y;                 // [S][y_stride]
+    long long y_stride;
+    int nds;
+    long long g_first;          // global 9600 Hz index of this call's output 0
+    long long tile0;            // global index of tile 0's first block (== 64 mod 65, <= g_first)
+    int first_out;              // input index whose arrival completes output 0
+};
+
+__device__ __forceinline__ void fm_convert(int w, int ic, int qc, bool dc, double &di, double &dq)
+{
+    int si = (int)(short)(w & 0xffff), sq = w >> 16;
+    if (dc) {
+        si = java_short_add(si, ic);
+        sq = java_short_add(sq, qc);
+    }
+    // (float)s / 32767f for I and Q at once: q = fma(a, rh, a * rl) (common.h) on the native two-float vector --
+    // v_pk_mul_f32 + v_pk_fma_f32 round each half exactly as the scalar instructions do
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    const v2f a = {(float)si, (float)sq};
+    const v2f rh = {0x1.0002p-15f, 0x1.0002p-15f}, rl = {0x1.0002p-45f, 0x1.0002p-45f};
+    const v2f q = __builtin_elementwise_fma(a, rh, a * rl);
+    di = (double)q.x;
+    dq = (double)q.y;
+}
+
+template <int D, int R, bool MIX, bool DC, bool FAST>
+__global__ __launch_bounds__(FM_THREADS, 2) void k_fm(FmArgs a)
+{
+    constexpr int RD = D * R, NS = RD - D + 27, NSQ = (NS + 3) / 4;
+    constexpr int JOBS = (FM_NT + R - 1) / R, ROUNDS = (JOBS + FM_THREADS - 1) / FM_THREADS;
+    extern __shared__ __align__(16) unsigned char smem[];
+    double2 *X = reinterpret_cast<double2 *>(smem);                    // [FM_NT]: X[t] = sample G - 64 + t
+    double *sc = reinterpret_cast<double *>(smem + FM_NT * sizeof(double2));  // [512]
+    for (int i = threadIdx.x; i < 512; i += FM_THREADS) sc[i] = a.sincos[i];
+    const int s = blockIdx.y;
+    const long long G = a.tile0 + (long long)(65 * FM_NB) * blockIdx.x;
+    const int jrel0 = (int)(G - 64 - a.g_first);  // call-relative output index of X[0] (negative in the first tile)
+    const int *raw = a.raw + (long long)s * a.stride_pairs;
+    const int2 *hist = a.hist + (long long)s * 32;
+    const double2 *dmh_old = a.dmh_old + (long long)s * 64;
+    const int Lm1 = a.nsamples - 1, nds = a.nds, P = a.tper;
+    const double HOWARD = 0.9 * 32768.0;  // :469
+    // tile-uniform base into the unwrapped tuner table: window sample m of ANY job of this tile uses entry e0 + m
+    // (the lane span RD is a multiple of the period)
+    int e0 = 0;
+    if constexpr (MIX) {
+        const long long v = (long long)a.first_out + (long long)D * jrel0;
+        e0 = (int)(((v % P) + P) % P);
+    }
+    // constant address space: the table is read-only for the launch, and only loads the compiler may assume invariant
+    // become scalar loads (a plain global pointer in a kernel that also stores gives 57 vector loads per job)
+    typedef const __attribute__((address_space(4))) double2 *const_tab_t;
+    const_tab_t tb = (const_tab_t)(a.tcs + e0);
+    __syncthreads();  // sin/cos table
+    // ================================================================================ front half
+#pragma unroll 1
+    for (int round = 0; round < ROUNDS; round++) {
+        const int job = threadIdx.x + FM_THREADS * round;
+        const int t0 = R * job;
+        if (t0 >= FM_NT) break;
+        const int j0 = jrel0 + t0;                   // first output of the job, call relative
+        const int n0 = a.first_out + D * j0 - 26;    // its window's first sample
+        const bool inside = j0 >= 0 && j0 + R <= nds && t0 + R <= FM_NT && n0 >= 0 && n0 + 4 * NSQ - 1 <= Lm1;
+        if (inside) {
+            int4 W[NSQ];
+#pragma unroll
+            for (int q = NSQ - 1; q >= 0; q--) W[q] = *reinterpret_cast<const int4 *>(raw + n0 + 4 * q);
+            double ai[R], aq[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                ai[r] = 0.0;
+                aq[r] = 0.0;
+            }
+#pragma unroll
+            for (int q = NSQ - 1; q >= 0; q--) {
+                const int4 w4 = W[q];
+#pragma unroll
+                for (int t = 3; t >= 0; t--) {
+                    const int m = 4 * q + t;
+                    if (m < NS) {
+                        const int w = (t == 0) ? w4.x : (t == 1) ? w4.y : (t == 2) ? w4.z : w4.w;
+                        double di, dq;
+                        fm_convert(w, a.ic, a.qc, DC, di, dq);
+                        if constexpr (MIX) {  // :388-390 component-wise, not a complex multiply
+                            const double2 cs = tb[m];
+                            di = di * cs.x;
+                            dq = dq * cs.y;
+                        }
+#pragma unroll
+                        for (int r = 0; r < R; r++) {
+                            if (m >= D * r && m <= D * r + 26) {  // age D*r+26-m in the window of output r
+                                const double tp = ds_tap(D * r + 26 - m);
+                                if constexpr (FAST) {
+                                    ai[r] = __builtin_fma(di, tp, ai[r]);
+                                    aq[r] = __builtin_fma(dq, tp, aq[r]);
+                                } else {
+                                    ai[r] += di * tp;
+                                    aq[r] += dq * tp;
+                                }
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < R; r++) asm volatile("" : "+v"(ai[r]), "+v"(aq[r])::"memory");  // sums are due here
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int r = 0; r < R; r++) {  // x HOWARD_FUDGE_FACTOR (:486), VCO mix (:515-516)
+                const double oi = ai[r] * HOWARD, oq = aq[r] * HOWARD;
+                const int kv = a.kvco[j0 + r];
+                X[t0 + r] = make_double2(oi * sc[kv], oq * sc[256 + kv]);
+            }
+        } else {
+            // the call's edges (history before sample 0, the halo before output 0, the end of the data): one output
+            // at a time, run-time indices; a handful of jobs per stream and call
+#pragma unroll 1
+            for (int r = 0; r < R; r++) {
+                const int t = t0 + r, j = j0 + r;
+                if (t >= FM_NT) break;
+                double2 val = make_double2(0.0, 0.0);
+                if (j >= -64 && j < 0) {
+                    val = dmh_old[64 + j];
+                } else if (j >= 0 && j < nds) {
+                    double fi = 0.0, fq = 0.0;
+#pragma unroll 1
+                    for (int age = 0; age < 27; age++) {
+                        const int n = a.first_out + D * j - age;  // >= -26
+                        double di, dq;
+                        if (n >= 0) fm_convert(raw[n], a.ic, a.qc, DC, di, dq);
+                        else fm_convert(hist[26 + n].x, 0, 0, false, di, dq);  // stored corrected
+                        if constexpr (MIX) {
+                            const double2 cs = a.tcs[(n + 26) % P];
+                            di = di * cs.x;
+                            dq = dq * cs.y;
+                        }
+                        const double tp = c_bpsk.ds_taps[age];
+                        if constexpr (FAST) {
+                            fi = __builtin_fma(di, tp, fi);
+                            fq = __builtin_fma(dq, tp, fq);
+                        } else {
+                            fi += di * tp;
+                            fq += dq * tp;
+                        }
+                    }
+                    const double oi = fi * HOWARD, oq = fq * HOWARD;
+                    const int kv = a.kvco[j];
+                    val = make_double2(oi * sc[kv], oq * sc[256 + kv]);
+                }
+                X[t] = val;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- the call's last 64 VCO-mixed samples are the next call's halo; every sample is owned by one tile
+    if (jrel0 + FM_NT > nds - 64) {  // uniform
+        double2 *dmh_new = a.dmh_new + (long long)s * 64;
+        for (int t = 64 + threadIdx.x; t < FM_NT; t += FM_THREADS) {
+            const int j = jrel0 + t;
+            if (j >= nds - 64 && j < nds && j >= 0) dmh_new[j - (nds - 64)] = X[t];
+        }
+        if (blockIdx.x == 0 && nds < 64 && (int)threadIdx.x < 64 - nds) dmh_new[threadIdx.x] = dmh_old[threadIdx.x + nds];
+    }
+    // ================================================================================ matched filter
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int blk = lane < FM_NB ? lane : FM_NB - 1;  // lanes 62, 63 shadow block 61 and store nothing
+    const double2 *xl = X + 64 + 65 * blk;            // &X[s0]
+    const int rel0 = jrel0 + 64 + 65 * blk;           // call-relative index of s0
+    double2 *y = a.y + (long long)s * a.y_stride;
+    if (wave == 0) {
+        double ai[9], aq[9];
+        matched_block<9, FAST>(xl, 0, ai, aq);
+#pragma unroll
+        for (int r = 0; r < 9; r++) {
+            const int rel = rel0 + r;
+            if (lane < FM_NB && rel >= 0 && rel < nds) y[rel] = make_double2(ai[r], aq[r]);
+        }
+    } else {
+        const int u0 = 9 + 8 * (wave - 1);
+        double ai[8], aq[8];
+        matched_block<8, FAST>(xl, u0, ai, aq);
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int rel = rel0 + u0 + r;
+            if (lane < FM_NB && rel >= 0 && rel < nds) y[rel] = make_double2(ai[r], aq[r]);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------- k_tail
@@ -1162,6 +1409,16 @@ struct jsdr_bpsk {
     int hist_cur = 0;
     DevBuf<double2> dm, y[2];  // y is double-buffered: the tail of call k overlaps the front end of call k+1
     int y_cur = 0;
+    // fused front end + matched filter (k_fm): the 64-sample halo lives in its own double buffer, the tuner table is
+    // an unwrapped periodic (cos, sin) table
+    DevBuf<double2> dmh[2], tcs;
+    int dmh_cur = 0;
+    bool halo_in_dmh = false;      // where the last call left the 64 VCO-mixed history samples (dm[s][0..63] or dmh)
+    bool use_fm = true;            // JSDR_FM=0: always the three-kernel path
+    int variant = 0;               // 0 exact-order FP64, 1 fast (FMA-contracted FP64, margin-certified decisions)
+    int c_tper = 0;                // period of the cached tuner schedule (0: not periodic with a period <= 256)
+    bool ktu_uploaded = false;     // the device copy of the per-sample tuner index table matches the cached schedule
+    std::vector<double2> h_tcs;
     hipStream_t tail_stream = nullptr;   // non-blocking side stream for the latency-bound 9600 Hz tail + FEC
     hipEvent_t ev_matched = nullptr;     // caller stream -> tail stream: (fi,fq) of this call are complete
     hipEvent_t ev_tail_done[2] = {nullptr, nullptr};  // tail stream -> caller stream: y[i] may be overwritten
@@ -1202,9 +1459,9 @@ struct jsdr_bpsk {
     std::vector<hipEvent_t> prof_pool;
 };
 
-enum { PK_FRONT = 0, PK_HIST, PK_MATCHED, PK_DMHIST, PK_TAIL, PK_SYNC, PK_SYNCFIN, PK_FEC, PK_COUNT };
+enum { PK_FRONT = 0, PK_HIST, PK_MATCHED, PK_DMHIST, PK_TAIL, PK_SYNC, PK_SYNCFIN, PK_FEC, PK_FM, PK_COUNT };
 static const char *const kProfNames[PK_COUNT] = {"k_front", "k_hist_in", "k_matched", "k_dm_history",
-                                                 "k_tail", "k_sync", "k_sync_fin", "k_fec_bpsk"};
+                                                 "k_tail", "k_sync", "k_sync_fin", "k_fec_bpsk", "k_fm"};
 
 static hipEvent_t prof_event(jsdr_bpsk *h)
 {
@@ -1297,6 +1554,31 @@ static long long build_schedule(jsdr_bpsk *h, long long L)
     h->c_nds = (long long)h->h_kvco.size();
     memcpy(h->h_khist, h->h_ktu.data() + L, 26);
     h->cache_valid = false;  // device copy refreshed by the caller
+    // Is the tuner index periodic in the sample number?  (An exact 8-cycle at 12 kHz / 96 kHz.)  Candidate from the
+    // head of the table, then verified over EVERY sample of the call, history included -- at the start of a stream
+    // the 26 history samples are zeros, whose table entry does not matter.
+    h->c_tper = 0;
+    if (!h->do_fft && h->mix == 1) {
+        const unsigned char *k = h->h_ktu.data() + (h->n_in == 0 ? 26 : 0);
+        const long long len = L + (h->n_in == 0 ? 0 : 26);
+        const long long head = len < 1024 ? len : 1024;
+        for (int p = 1; p <= 256 && p < len; p++) {
+            if (memcmp(k, k + p, (size_t)(head - p)) != 0) continue;
+            if (memcmp(k, k + p, (size_t)(len - p)) == 0) {
+                h->c_tper = p;
+                // unwrapped table: entry e <-> samples n with (n + 26) mod p == e mod p
+                const long long off = (h->n_in == 0 ? 26 : 0);  // k[i] is the index of sample n = i + off - 26
+                h->h_tcs.resize((size_t)p + FM_TABLE_SLACK);
+                for (int e = 0; e < p + FM_TABLE_SLACK; e++) {
+                    // smallest i >= 0 with (i + off) mod p == e mod p
+                    const int i = (int)(((e - off) % p + p) % p);
+                    const int kk = k[i];
+                    h->h_tcs[(size_t)e] = make_double2(h->h_sincos[kk], h->h_sincos[256 + kk]);
+                }
+            }
+            break;
+        }
+    }
     return h->c_nds;
 }
 
@@ -1451,6 +1733,48 @@ static void launch_front(const FrontArgs &fa, int nstreams, long long nds, hipSt
     }
 }
 
+
+template <int D, int R>
+static int launch_fm_t(const FmArgs &a, bool mix, bool dc, bool fast, int nstreams, hipStream_t st)
+{
+    const size_t lds = (size_t)FM_NT * sizeof(double2) + 512 * sizeof(double);
+    const long long span = 65LL * FM_NB;
+    const long long ntiles = (a.g_first + a.nds - a.tile0 + span - 1) / span;
+    const dim3 grid((unsigned)ntiles, (unsigned)nstreams), block(FM_THREADS);
+#define JSDR_FM_LAUNCH(MIX, DC, FAST)                                                                           \
+    do {                                                                                                        \
+        static bool attr_done = false;                                                                          \
+        if (!attr_done) {                                                                                       \
+            JSDR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fm<D, R, MIX, DC, FAST>),         \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));            \
+            attr_done = true;                                                                                   \
+        }                                                                                                       \
+        hipLaunchKernelGGL((k_fm<D, R, MIX, DC, FAST>), grid, block, lds, st, a);                               \
+    } while (0)
+    if (fast) {
+        if (mix) { if (dc) JSDR_FM_LAUNCH(true, true, true); else JSDR_FM_LAUNCH(true, false, true); }
+        else { if (dc) JSDR_FM_LAUNCH(false, true, true); else JSDR_FM_LAUNCH(false, false, true); }
+    } else {
+        if (mix) { if (dc) JSDR_FM_LAUNCH(true, true, false); else JSDR_FM_LAUNCH(true, false, false); }
+        else { if (dc) JSDR_FM_LAUNCH(false, true, false); else JSDR_FM_LAUNCH(false, false, false); }
+    }
+#undef JSDR_FM_LAUNCH
+    JSDR_LAUNCH_CHECK();
+    return JSDR_OK;
+}
+
+static int launch_fm(const FmArgs &a, int decim, bool mix, bool dc, bool fast, int nstreams, hipStream_t st)
+{
+    switch (decim) {
+        case 4: return launch_fm_t<4, 5>(a, mix, dc, fast, nstreams, st);
+        case 5: return launch_fm_t<5, 4>(a, mix, dc, fast, nstreams, st);
+        case 10: return launch_fm_t<10, 4>(a, mix, dc, fast, nstreams, st);
+        case 20: return launch_fm_t<20, 4>(a, mix, dc, fast, nstreams, st);
+    }
+    set_error("bpsk: unsupported decimation %d", decim);
+    return JSDR_ERR;
+}
+
 static int sync_last(jsdr_bpsk *h);
 
 static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev, long long stride_i16, long long L,
@@ -1467,11 +1791,21 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
     const long long nds = build_schedule(h, L);
     JSDR_REQUIRE(nds <= h->max_ds, "bpsk: internal: %lld decimated samples exceed capacity %lld", nds, h->max_ds);
     JSDR_REQUIRE(h->do_fft || h->mix >= 0, "bpsk: tuner phase changes sign inside a call (unsupported)");
+    // fused path (k_fm): int16 input, a tuner schedule that is periodic with a period dividing the lane span (or
+    // no tuner at all), 32-bit sample indices
+    const int fm_rd = h->decim == 4 ? 20 : h->decim * 4;  // D * R of the k_fm instantiation
+    const bool fm_ok = h->use_fm && !h->do_fft && raw_dev && !rawf_dev && nds > 0 && L <= 0x3fffffffLL &&
+                       (h->mix == 0 || (h->mix == 1 && h->c_tper > 0 && fm_rd % h->c_tper == 0));
     // the byte table is shifted by 0..3 so that ktu[26 + first_out] is dword aligned (k_front_dma's dword DMA)
     const int kshift = (4 - (first_out & 3)) & 3;  // element 26+lo = first_out + D*j0, and D*j0 is a multiple of 4
-    if (!h->cache_valid || kshift != h->c_kshift) {
+    const bool fresh = !h->cache_valid;
+    if (fresh) h->ktu_uploaded = false;
+    if (!fm_ok && (!h->ktu_uploaded || kshift != h->c_kshift)) {
         h->c_kshift = kshift;
         JSDR_HIP_TRY(hipMemcpyAsync(h->ktu.p + kshift, h->h_ktu.data(), (size_t)L + 26, hipMemcpyHostToDevice, st));
+        h->ktu_uploaded = true;
+    }
+    if (fresh) {
         if (nds > 0)
             JSDR_HIP_TRY(hipMemcpyAsync(h->kvco.p, h->h_kvco.data(), (size_t)nds, hipMemcpyHostToDevice, st));
         if (nds > 0 && h->do_fft) {
@@ -1480,9 +1814,21 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
                 h->h_vco_cs[(size_t)j] = make_double2(h->h_sincos[h->h_kvco[(size_t)j]], h->h_sincos[256 + h->h_kvco[(size_t)j]]);
             JSDR_HIP_TRY(hipMemcpyAsync(h->vco_cs.p, h->h_vco_cs.data(), sizeof(double2) * (size_t)nds, hipMemcpyHostToDevice, st));
         }
+        if (h->c_tper > 0)
+            JSDR_HIP_TRY(hipMemcpyAsync(h->tcs.p, h->h_tcs.data(), sizeof(double2) * h->h_tcs.size(), hipMemcpyHostToDevice, st));
         // the host vectors must stay untouched until the copies ran; pageable memcpyAsync stages
         // synchronously, so they are safe to reuse on return
         h->cache_valid = true;
+    }
+    // the 64-sample halo of VCO-mixed samples lives where the previous call's path left it
+    if (nds > 0 && !h->do_fft && fm_ok != h->halo_in_dmh) {
+        if (fm_ok)
+            JSDR_HIP_TRY(hipMemcpy2DAsync(h->dmh[h->dmh_cur].p, 64 * sizeof(double2), h->dm.p, (size_t)h->dm_stride * sizeof(double2),
+                                          64 * sizeof(double2), (size_t)h->nstreams, hipMemcpyDeviceToDevice, st));
+        else
+            JSDR_HIP_TRY(hipMemcpy2DAsync(h->dm.p, (size_t)h->dm_stride * sizeof(double2), h->dmh[h->dmh_cur].p, 64 * sizeof(double2),
+                                          64 * sizeof(double2), (size_t)h->nstreams, hipMemcpyDeviceToDevice, st));
+        h->halo_in_dmh = fm_ok;
     }
     const int S = h->nstreams;
     FrontArgs fa;
@@ -1526,6 +1872,34 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
         ProfScope ps(h, PK_FRONT, st);
         if ((h->fft_mixed ? launch_front_fftm(xa, h->fm_np, h->fm_rad, h->fm_off, S, st) : launch_front_fft(xa, S, st)) != JSDR_OK)
             return JSDR_ERR;
+    } else if (nds > 0 && fm_ok) {
+        // wait for the tail that last read y[y_cur] (two calls ago) before the fused kernel overwrites it
+        if (h->overlap && h->tail_pending[h->y_cur]) {
+            JSDR_HIP_TRY(hipStreamWaitEvent(st, h->ev_tail_done[h->y_cur], 0));
+            h->tail_pending[h->y_cur] = false;
+        }
+        FmArgs ma;
+        ma.raw = fa.raw;
+        ma.stride_pairs = fa.stride_pairs;
+        ma.nsamples = (int)L;
+        ma.ic = ic;
+        ma.qc = qc;
+        ma.hist = fa.hist;
+        ma.tcs = h->tcs.p;
+        ma.tper = h->mix ? h->c_tper : 1;
+        ma.kvco = h->kvco.p;
+        ma.sincos = h->sincos.p;
+        ma.dmh_old = h->dmh[h->dmh_cur].p;
+        ma.dmh_new = h->dmh[h->dmh_cur ^ 1].p;
+        ma.y = h->y[h->y_cur].p;
+        ma.y_stride = h->y_stride;
+        ma.nds = (int)nds;
+        ma.g_first = g_first;
+        ma.tile0 = g_first - (((g_first - 64) % 65 + 65) % 65);
+        ma.first_out = first_out;
+        ProfScope ps(h, PK_FM, st);
+        if (launch_fm(ma, h->decim, h->mix != 0, (ic != 0) || (qc != 0), h->variant != 0, S, st) != JSDR_OK) return JSDR_ERR;
+        h->dmh_cur ^= 1;
     } else if (nds > 0) {
         ProfScope ps(h, PK_FRONT, st);
         switch (h->decim) {
@@ -1571,7 +1945,7 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
         JSDR_HIP_TRY(hipStreamWaitEvent(st, h->ev_tail_done[yb], 0));
         h->tail_pending[yb] = false;
     }
-    if (nds > 0) {
+    if (nds > 0 && !(fm_ok && !h->do_fft)) {
         MatchedArgs ma;
         ma.dm = h->dm.p;
         ma.dm_stride = h->dm_stride;
@@ -1715,6 +2089,7 @@ int jsdr_bpsk_create(jsdr_bpsk **out, int rate, int nsamples_per_frame, int tuni
     if (const char *e = getenv("JSDR_FRONT_RD")) h->front_rd = atoi(e) == 80 ? 80 : 40;
     if (const char *e = getenv("JSDR_NO_OVERLAP")) h->overlap = atoi(e) == 0;
     if (const char *e = getenv("JSDR_FRONT_DMA")) h->front_dma = atoi(e) != 0;
+    if (const char *e = getenv("JSDR_FM")) h->use_fm = atoi(e) != 0;
     const size_t S = (size_t)nstreams;
     h->dm_stride = 64 + h->max_ds + 64;
     h->y_stride = h->max_ds;
@@ -1731,6 +2106,7 @@ int jsdr_bpsk_create(jsdr_bpsk **out, int rate, int nsamples_per_frame, int tuni
               h->cnt_dec.alloc(S) == JSDR_OK && h->corr.alloc(S * (size_t)h->max_bits) == JSDR_OK &&
               h->fec_data.alloc(S * MAX_TRIG * 256) == JSDR_OK && h->decoded.alloc(S * 256) == JSDR_OK &&
               h->stage_raw.alloc((size_t)nsamples_per_frame * 2) == JSDR_OK && h->ds_taps_dev.alloc(32) == JSDR_OK &&
+              h->dmh[0].alloc(S * 64) == JSDR_OK && h->dmh[1].alloc(S * 64) == JSDR_OK && h->tcs.alloc(256 + FM_TABLE_SLACK) == JSDR_OK &&
               (!do_fft || (h->fft_state.alloc(S) == JSDR_OK && h->fft_tw.alloc(fft_pow2 ? (size_t)nsamples_per_frame : (size_t)32768) == JSDR_OK &&
                             h->vco_cs.alloc((size_t)h->max_ds) == JSDR_OK));
     if (!ok) {
@@ -1792,6 +2168,7 @@ int jsdr_bpsk_create(jsdr_bpsk **out, int rate, int nsamples_per_frame, int tuni
               hipMemcpyToSymbol(HIP_SYMBOL(c_bpsk), &bc, sizeof(bc)) == hipSuccess &&
               hipMemcpy(h->tail.p, ts.data(), sizeof(TailState) * S, hipMemcpyHostToDevice) == hipSuccess &&
               h->hist_in[0].zero() == JSDR_OK && h->hist_in[1].zero() == JSDR_OK && h->dm.zero() == JSDR_OK &&
+              h->dmh[0].zero() == JSDR_OK && h->dmh[1].zero() == JSDR_OK && h->tcs.zero() == JSDR_OK &&
               h->bitlog[0].zero() == JSDR_OK && h->bitlog[1].zero() == JSDR_OK && h->decoded.zero() == JSDR_OK &&
               h->nbits.zero() == JSDR_OK && h->trig_count.zero() == JSDR_OK && h->fec_last.zero() == JSDR_OK &&
               h->cnt_dec.zero() == JSDR_OK && h->y[0].zero() == JSDR_OK && h->y[1].zero() == JSDR_OK &&
@@ -1817,6 +2194,9 @@ int jsdr_bpsk_destroy(jsdr_bpsk *h)
     h->hist_in[0].release();
     h->hist_in[1].release();
     h->dm.release();
+    h->dmh[0].release();
+    h->dmh[1].release();
+    h->tcs.release();
     h->y[0].release();
     h->y[1].release();
     if (h->tail_stream) {
