@@ -7,9 +7,11 @@ One STEP = one pass of the hot path over one HBM-resident batch of synthetic inp
     S streams x L int16 IQ samples (96 kHz FUNcube-style DBPSK carrying valid FEC frames, generated on
     the device) -> fft.java waterfall PSD of every 2048-sample frame  +  FUNcubeBPSKDemod (tuner, 27-tap
     /10, VCO, 65-tap matched filter, slicer, sync correlation) + FECDecoder of every synchronised frame.
-N > 1: one rank per GPU (torch.distributed, backend nccl == RCCL), streams are sharded S per rank (weak
-scaling: BASELINE config 5 is 8 x 1024 streams), and every step ends with one all-gather of the fixed-size
-per-stream result slots over xGMI.  value = samples processed by all ranks / max-over-ranks time.
+N > 1: one rank per GPU (torch.distributed, backend nccl == RCCL).  Default = BASELINE config 5 as SURVEY.md 8d
+defines it: --total-streams 8192 FIXED and sharded contiguously over the ranks (8192 / N streams per rank,
+"scaling": "strong"; the N=1 line runs all 8192 streams, 32 GiB of IQ, on one GPU).  --streams S gives S streams
+per rank instead ("scaling": "weak").  Every step ends with one all-gather of the fixed-size per-stream result
+slots over xGMI.  value = samples processed by all ranks / max-over-ranks time.
 
 The JSON line also carries
     roofline     : dominant kernel (HIP events recorded on the launch stream inside the timed region)
@@ -47,7 +49,13 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="pipeline", choices=["pipeline", "fft", "bpsk", "demod"])
-    ap.add_argument("--streams", type=int, default=1024, help="streams per GPU")
+    ap.add_argument("--total-streams", type=int, default=8192,
+                    help="streams of the whole job, sharded over the GPUs (strong scaling, BASELINE config 5)")
+    ap.add_argument("--streams", type=int, default=0, help="streams PER GPU (weak scaling) instead of --total-streams")
+    ap.add_argument("--variant", default="exact", choices=["exact", "fast"],
+                    help="demodulator arithmetic: exact-order FP64 (default) or FMA-contracted FP64 with margin-certified decisions")
+    ap.add_argument("--serial-psd", action="store_true",
+                    help="PSD kernel on the demodulator's stream (one after the other) instead of a stream of its own")
     ap.add_argument("--samples", type=int, default=1048576, help="IQ samples per stream per step")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -166,8 +174,44 @@ def cpu_baseline(workload, L, seconds):
                       f"{dt:.1f} s wall; single-thread {Lc / t1 / 1e6:.2f} Msamples/s"}
 
 
+def workload_text(a):
+    mode = "FFT-acquire mode (bpsk-dofft)" if a.fft_acquire else "tune mode"
+    return {"pipeline": f"fft.java PSD of every 2048-sample frame + FUNcubeBPSKDemod ({mode}) + FECDecoder, same HBM-resident IQ",
+            "fft": "batched 2048-pt waterfall FFT+PSD (BASELINE config 2)",
+            "bpsk": f"FUNcubeBPSKDemod {mode} + FECDecoder (BASELINE config 4), {a.bpsk_frame}-sample frames",
+            "demod": f"demod.java {a.demod_mode.upper()} chain (8f next-3): 21-tap complex FIR + NCO + detector + AGC -> "
+                     "int16 stereo, 2048-sample frames"}[a.workload]
+
+
+def variant_text(a):
+    if a.workload == "fft":
+        return "float32 Stockham FFT + PSD (1e-5 of frame peak)"
+    if a.workload == "demod":
+        return "exact-order float32 (bit-exact int16 audio)"
+    front = "FFT-acquire front end" if a.fft_acquire else "tuner front end"
+    if a.variant == "fast":
+        return f"FMA-contracted FP64, every slicer decision margin-certified or recomputed in exact order (bit-exact bits/bytes), {front}"
+    return f"exact-order FP64 (bit-exact bits/bytes and doubles), {front}"
+
+
+def stream_text(a, psd_own_stream):
+    if a.workload == "pipeline":
+        return "PSD on its own HIP stream beside the demodulator; tail/sync/FEC on the handle's side stream" if psd_own_stream \
+            else "PSD then demodulator on one stream; tail/sync/FEC on the handle's side stream"
+    return "tail/sync/FEC on the handle's side stream" if a.workload == "bpsk" else "one stream"
+
+
+def backend_text():
+    b = os.environ.get("JSDR_BENCH_BACKEND", "nccl")
+    same = os.environ.get("JSDR_BENCH_SAME_DEVICE", "0") == "1"
+    return ("RCCL" if b == "nccl" else b) + (", rehearsal: all ranks on device 0" if same else "")
+
+
 def main():
     a = parse()
+    knobs = sorted(k for k in os.environ if k.startswith("JSDR_EXPERIMENT_"))
+    if knobs:
+        raise SystemExit(f"bench.py: {', '.join(knobs)} set -- experiment knobs make the product skip work; refusing to measure")
     N = a.gpus
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -197,7 +241,13 @@ def main():
     if J.lib().jsdr_set_device((0 if os.environ.get("JSDR_BENCH_SAME_DEVICE", "0") == "1" else local_rank) if N > 1 else 0) != 0:
         raise SystemExit(J.lib().jsdr_last_error())
 
-    S, L = a.streams, a.samples
+    if a.streams > 0:
+        S, scaling = a.streams, "weak"
+    else:
+        if a.total_streams % N:
+            raise SystemExit(f"--total-streams {a.total_streams} is not a multiple of --gpus {N}")
+        S, scaling = a.total_streams // N, "strong"
+    L = a.samples
     if a.bpsk_frame != N_FFT:
         if a.workload != "bpsk":
             raise SystemExit("--bpsk-frame needs --workload bpsk")
@@ -209,8 +259,11 @@ def main():
     nframes = S * L // N_FFT
     fft = J.Fft(N_FFT, RATE) if a.workload in ("pipeline", "fft") else None
     d_psd = J.DeviceBuffer(nframes * (N_FFT + 2) * 4) if fft else None
-    dem = J.Bpsk(rate=RATE, blen=4 * a.bpsk_frame, tuning=12000, do_fft=int(a.fft_acquire), nstreams=S, max_batch_samples=L) \
-        if a.workload in ("pipeline", "bpsk") else None
+    dem = J.Bpsk(rate=RATE, blen=4 * a.bpsk_frame, tuning=12000, do_fft=int(a.fft_acquire), nstreams=S, max_batch_samples=L,
+                 variant=a.variant) if a.workload in ("pipeline", "bpsk") else None
+    # the PSD kernel is HBM-bound, the demodulator FP64-issue bound: on streams of their own they share the CUs
+    psd_stream = J.Stream() if (fft is not None and dem is not None and not a.serial_psd) else None
+    ps = psd_stream.ptr if psd_stream else None
     amfm = d_audio = None
     if a.workload == "demod":
         amfm = J.Demod(rate=RATE, n=N_FFT, nstreams=S, max_batch_samples=L)
@@ -234,16 +287,16 @@ def main():
     def step(i, timed):
         if fft is not None:
             if timed:
-                fft_timer[i].start(None)
-            fft.batch_i16(d_iq, nframes, d_psd)
+                fft_timer[i].start(ps)
+            fft.batch_i16(d_iq, nframes, d_psd, stream=ps)
             if timed:
-                fft_timer[i].stop(None)
+                fft_timer[i].stop(ps)
             if wf:
                 if timed:
-                    wf_timer[i].start(None)
-                J.waterfall_lines_dev(d_psd, nframes, N_FFT, wf, d_pix)
+                    wf_timer[i].start(ps)
+                J.waterfall_lines_dev(d_psd, nframes, N_FFT, wf, d_pix, stream=ps)
                 if timed:
-                    wf_timer[i].stop(None)
+                    wf_timer[i].stop(ps)
         if amfm is not None:
             amfm.batch_i16(d_iq, 2 * L, L, d_audio, 2 * L)
         if dem is not None:
@@ -254,6 +307,8 @@ def main():
                     dist.all_gather_into_tensor(gathered, slots)  # == sharding.all_gather_slots, reused buffer
 
     def sync():
+        if psd_stream is not None:
+            psd_stream.sync()
         if dem is not None:
             dem.sync()  # the tail / FEC of the last step run on the handle's side stream
         if N > 1:
@@ -298,12 +353,13 @@ def main():
             if cnt:
                 kern[name] = (ms, cnt, BYTES_PER_SAMPLE["demod"])
     if dem is not None:
+        front_name = dem.front_kernel_name()  # which front-end kernel ran: k_front_reg / k_front_fft / k_front_fftm / ...
         for name, (ms, cnt) in dem.profile_read().items():
             if cnt:
-                kern[name] = (ms, cnt, BYTES_PER_SAMPLE["bpsk"])
+                kern[front_name if name == "k_front" else name] = (ms, cnt, BYTES_PER_SAMPLE["bpsk"])
     # the dominant kernel is taken on the critical path: the tail / sync / FEC kernels run on the handle's side
     # stream under the next step's throughput kernels (their times are listed, they do not bound the step)
-    SIDE = ("k_tail", "k_sync", "k_sync_fin", "k_fec_bpsk")
+    SIDE = ("k_tail", "k_sync", "k_sync_fin", "k_fec_bpsk", "k_fec_fin")
     main = {k: v for k, v in kern.items() if k not in SIDE or a.fft_acquire}
     dom = max(main, key=lambda k: main[k][0])
     dom_ms = kern[dom][0] / kern[dom][1]
@@ -313,7 +369,9 @@ def main():
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
         try:
-            traffic = json.load(open(pmc)).get(dom, {}).get("hbm_bytes_per_launch")
+            tab = json.load(open(pmc))
+            per = tab.get(dom, {}).get("hbm_bytes_per_launch")  # measured at tab["_samples_per_launch"] samples a launch
+            traffic = int(per * (S * L) / tab.get("_samples_per_launch", 1024 * 1048576)) if per else None
         except Exception:
             traffic = None
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -326,14 +384,29 @@ def main():
     # (FFT-acquire mode is not validated by payload: the reference's block-wise FFT filter puts a seam into the
     #  signal every frame, and at 2048-sample frames its own demodulator -- the oracle bit for bit, see
     #  tests/test_gpu_bpsk.py -- rarely brings a 5200-bit FEC block through; parity for that mode is the tests')
+    cert = None
     if dem is not None and not a.no_validate and not (a.fft_acquire and a.bpsk_frame != 9600):
         payloads = pay.to_host(np.uint8).reshape(S, nfr, 256)
-        ok = True
-        for s in sorted(set([0, S // 2, S - 1])):
-            fr = dem.fec_results(s)
-            ok = ok and len(fr) >= 1 and all(r[0] >= 0 for r in fr)
-            ok = ok and all(any(np.array_equal(r[2], payloads[s, f]) for f in range(nfr)) for r in fr)
+        info = dem.slot_info()
+        vslots = J.DeviceBuffer(S * info["slot_bytes"])
+        dem.pack_slots(vslots)
+        blob = vslots.to_host(np.uint8).reshape(S, info["slot_bytes"])
+        # EVERY stream of this rank: at least one FEC frame decoded, and every decoded frame equals a payload that was
+        # sent (a sync hit on the seam where the step's input repeats may fail to decode: rc = -1, as in the reference)
+        n_none = n_wrong = n_failed = 0
+        for s in range(S):
+            fr = SH.unpack_slot(blob[s], info)["fec"]
+            good = [r for r in fr if r[0] >= 0]
+            n_failed += len(fr) - len(good)
+            n_none += 0 if good else 1
+            n_wrong += sum(0 if any(np.array_equal(r[2], payloads[s, f]) for f in range(nfr)) else 1 for r in good)
+        ok = n_none == 0 and n_wrong == 0
+        if not ok or n_failed:
+            print(f"[bench] validation rank {rank}: {n_none} streams without a decoded frame, {n_wrong} decoded frames that "
+                  f"match no sent payload, {n_failed} sync hits whose FEC decode failed (of {S} streams)", file=sys.stderr)
         validated = bool(ok)
+    if dem is not None and a.variant == "fast":
+        cert = dem.cert_stats()
 
     if rank == 0:
         total = float(N) * S * L * a.steps
@@ -346,24 +419,21 @@ def main():
             "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
-            "dtype": "f64" if a.workload in ("pipeline", "bpsk") else "f32",
+            "dtype": "f64" if a.workload in ("pipeline", "bpsk") else "f32",  # the arithmetic type of the dominant path
             "data": "synthetic",
-            "config": {"workload": {"pipeline": "fft.java PSD of every 2048-sample frame + FUNcubeBPSKDemod "
-                                                "(tune mode) + FECDecoder, same HBM-resident IQ",
-                                    "fft": "batched 2048-pt waterfall FFT+PSD (BASELINE config 2)",
-                                    "bpsk": "FUNcubeBPSKDemod tune mode + FECDecoder (BASELINE config 4)",
-                                    "demod": f"demod.java {a.demod_mode.upper()} chain (8f next-3): 21-tap complex FIR + NCO "
-                                             "+ detector + AGC -> int16 stereo, 2048-sample frames"}[a.workload],
-                       "streams_per_gpu": S, "samples_per_stream": L, "rate_hz": RATE, "frame": a.bpsk_frame if a.workload == "bpsk" else N_FFT,
-                       "input_bytes_per_gpu": S * L * 4, "variant": ("exact-order float32 (bit-exact int16 audio)" if a.workload == "demod" else
-                                   "exact-order FP64 (bit-exact bits/bytes)" + (", FFT-acquire front end" if a.fft_acquire else ", tune mode")),
-                       "parallelism": f"streams sharded over {N} GPU(s)" + (", RCCL all-gather of result slots" if N > 1 else "")},
+            "config": {"workload": workload_text(a), "streams_per_gpu": S, "total_streams": N * S, "samples_per_stream": L,
+                       "rate_hz": RATE, "frame": a.bpsk_frame if a.workload == "bpsk" else N_FFT, "input_bytes_per_gpu": S * L * 4,
+                       "variant": variant_text(a), "streams": stream_text(a, psd_stream is not None),
+                       "parallelism": f"{N * S} streams sharded contiguously over {N} GPU(s)" +
+                                      (f", one all-gather of result slots per step ({backend_text()})" if N > 1 else "")},
             "roofline": roofline,
             "hbm_read_roofline_frac": round(total / dt * 4.0 / (N * HBM_PEAK_GBS * 1e9), 4),
             "validated": validated,
         }
+        if cert is not None:
+            out["certification"] = cert
         if N == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.workload if a.workload != "demod" else "demod:" + a.demod_mode, L, a.cpu_seconds)
         print(json.dumps(out), flush=True)

@@ -42,6 +42,10 @@ int jsdr_free(void *dev);
 int jsdr_memset(void *dev, int value, size_t bytes);
 int jsdr_memcpy_h2d(void *dev, const void *host, size_t bytes);
 int jsdr_memcpy_d2h(void *host, const void *dev, size_t bytes);
+/* a non-blocking HIP stream for the `stream` argument of the batch calls (independent handles on different streams
+ * run concurrently: the HBM-bound PSD kernel beside the FP64-bound demodulator) */
+int jsdr_stream_create(void **stream);
+int jsdr_stream_destroy(void *stream);
 int jsdr_stream_sync(void *stream);
 /* HIP-event timing on `stream` (what bench.py brackets kernels with) */
 int jsdr_timer_create(void **timer);
@@ -109,6 +113,12 @@ typedef struct jsdr_bpsk jsdr_bpsk;
 int jsdr_bpsk_create(jsdr_bpsk **h, int rate, int nsamples_per_frame, int tuning_hz, int do_fft,
                      int do_up, int nstreams, int64_t max_batch_samples);
 int jsdr_bpsk_destroy(jsdr_bpsk *h);
+/* arithmetic of the demodulator (before the first sample): EXACT = every double product and sum rounded separately in
+ * the reference's order (bits, bytes AND doubles identical to the Java arithmetic); FAST = fused multiply-adds in the
+ * two FIR stages, every slicer decision certified by a proven error margin or recomputed in exact order (bits and
+ * bytes identical, doubles within 1e-12 relative).                                                          */
+enum { JSDR_VARIANT_EXACT = 0, JSDR_VARIANT_FAST = 1 };
+int jsdr_bpsk_set_variant(jsdr_bpsk *h, int variant);
 /* receive(float[]) / raw form for stream 0 of a 1-stream handle (:357-364) */
 int jsdr_bpsk_receive_f32(jsdr_bpsk *h, const float *iq_host);
 int jsdr_bpsk_receive_i16(jsdr_bpsk *h, const int16_t *raw_host, int ic, int qc);
@@ -138,6 +148,7 @@ int jsdr_bpsk_get_state(jsdr_bpsk *h, int stream, double out[18]);
  * launch while enabled).  profile_read sums and clears what was recorded since the last read.          */
 int jsdr_bpsk_profile_enable(jsdr_bpsk *h, int on);
 int jsdr_bpsk_profile_count(void);                 /* number of kernels in the pipeline */
+const char *jsdr_bpsk_front_kernel(jsdr_bpsk *h);  /* name of the front-end kernel the last call launched */
 const char *jsdr_bpsk_profile_name(int k);
 int jsdr_bpsk_profile_read(jsdr_bpsk *h, double *ms_total, int *launches);
 /* device-resident result slots for the multi-GPU all-gather: per stream

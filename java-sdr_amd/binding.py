@@ -45,8 +45,10 @@ def lib():
         _lib.jsdr_last_error.restype = C.c_char_p
         _lib.jsdr_bpsk_profile_name.restype = C.c_char_p
         _lib.jsdr_demod_profile_name.restype = C.c_char_p
+        _lib.jsdr_bpsk_front_kernel.restype = C.c_char_p
+        _lib.jsdr_bpsk_front_kernel.argtypes = [C.c_void_p]
         for name in EXPORTED_SYMBOLS:
-            if name not in ("jsdr_last_error", "jsdr_bpsk_profile_name", "jsdr_demod_profile_name"):
+            if name not in ("jsdr_last_error", "jsdr_bpsk_profile_name", "jsdr_demod_profile_name", "jsdr_bpsk_front_kernel"):
                 getattr(_lib, name).restype = C.c_int
     return _lib
 
@@ -114,6 +116,25 @@ class DeviceBuffer:
     def __del__(self):
         try:
             self.free()
+        except Exception:
+            pass
+
+
+class Stream:
+    """a non-blocking HIP stream (pass `.ptr` as the `stream` argument of the batch calls)"""
+
+    def __init__(self):
+        self.h = C.c_void_p()
+        _check(lib().jsdr_stream_create(C.byref(self.h)), "jsdr_stream_create")
+        self.ptr = self.h.value
+
+    def sync(self):
+        stream_sync(self.ptr)
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().jsdr_stream_destroy(self.h)
         except Exception:
             pass
 
@@ -331,13 +352,18 @@ class Bpsk:
     """`nstreams` lock-step FUNcubeBPSKDemod instances (FUNcubeBPSKDemod.java:357-595)."""
 
     def __init__(self, rate=96000, blen=8192, size=4, tuning=12000, do_fft=0, do_up=0, nstreams=1,
-                 max_batch_samples=None):
+                 max_batch_samples=None, variant="exact"):
         self.samples = blen // size
         self.nstreams = nstreams
         self.max_batch = max_batch_samples or self.samples
         self.h = C.c_void_p()
         _check(lib().jsdr_bpsk_create(C.byref(self.h), rate, self.samples, tuning, do_fft, do_up, nstreams,
                                       C.c_int64(self.max_batch)), "jsdr_bpsk_create")
+        if variant != "exact":
+            _check(lib().jsdr_bpsk_set_variant(self.h, {"exact": 0, "fast": 1}[variant]), "jsdr_bpsk_set_variant")
+
+    def front_kernel_name(self):
+        return lib().jsdr_bpsk_front_kernel(self.h).decode()
 
     def receive(self, buf):
         buf = np.ascontiguousarray(buf, np.float32)
@@ -417,7 +443,7 @@ class Bpsk:
         return dict(slot_bytes=sb.value, bits_offset=bo.value, fec_offset=fo.value, slot_bits=nb.value,
                     nfec_max=nf.value)
 
-    def pack_slots(self, slots_dev, stream=None):
+    def pack_slots(self, slots_dev, stream=None):  # stream: raw hipStream_t value
         _check(lib().jsdr_bpsk_pack_slots(self.h, _addr(slots_dev), C.c_void_p(stream)), "jsdr_bpsk_pack_slots")
 
     def __del__(self):

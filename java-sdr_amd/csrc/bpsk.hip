@@ -22,12 +22,13 @@
 #include "bpsk_fec.h"
 #include "bpsk_fft.h"
 #include <math.h>
+#include <stddef.h>
 #include <stdlib.h>
 #include <vector>
 
 namespace jsdr {
 
-enum { DS_N = 27, DM_N = 65, HIST_BITS = 5200, MAX_TRIG = 8, SYNC_N = 65 };
+enum { DS_N = 27, DM_N = 65, HIST_BITS = 5200, MIN_TRIG = 8, SYNC_N = 65 };
 
 
 
@@ -69,9 +70,28 @@ struct TailState {
     int dmCorr, dmMaxCorr;
     int cntBit, cntFEC, cntDec, dmErrBits, decodeOK;
     int nbits_prev;  // bits sliced in the previous call (locates the 5200-bit history in the other bitlog)
-    int overflow;    // sticky: more than MAX_TRIG sync hits in one call
+    int overflow;    // sticky: more sync hits in one call than the handle's capacity (trig_cap), or more bits than max_bits
     int pad;
 };
+
+// int16 pair -> (double)((float)s / 32767f) for I and Q (JavaAudio.java:281-288, FUNcubeBPSKDemod.java:372-373)
+__device__ __forceinline__ void fm_convert(int w, int ic, int qc, bool dc, double &di, double &dq)
+{
+    int si = (int)(short)(w & 0xffff), sq = w >> 16;
+    if (dc) {
+        si = java_short_add(si, ic);
+        sq = java_short_add(sq, qc);
+    }
+    // (float)s / 32767f for I and Q at once: q = fma(a, rh, a * rl) (common.h) on the native two-float vector --
+    // v_pk_mul_f32 + v_pk_fma_f32 round each half exactly as the scalar instructions do
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    const v2f a = {(float)si, (float)sq};
+    const v2f rh = {0x1.0002p-15f, 0x1.0002p-15f}, rl = {0x1.0002p-45f, 0x1.0002p-45f};
+    const v2f q = __builtin_elementwise_fma(a, rh, a * rl);
+    di = (double)q.x;
+    dq = (double)q.y;
+}
+
 
 // ------------------------------------------------------------------------------------------- k_front
 // int16 -> float -> double, tuner mix, 27-tap low-pass at the decimated instants, x HOWARD, VCO mix.
@@ -117,6 +137,8 @@ struct FrontArgs {
     double2 *ds_dbg;           // optional [S][nds] down-sampler outputs (after HOWARD), may be null
     long long nds;
     int first_out;             // input index whose arrival completes output 0 (= D-1-dsCnt0)
+    const double2 *tcs;        // k_front_reg<PER>: unwrapped periodic tuner table (see FmArgs), else null
+    int tper;
 };
 
 template <bool F32IN>
@@ -470,7 +492,12 @@ __global__ __launch_bounds__(128, 4) void k_front_dma(FrontArgs a)
 // samples) is served by L1/L2, not by HBM.  Against k_front_dma: no LDS but the 4 KB sin/cos table, so occupancy
 // is set by registers alone and does not collapse when the side stream's kernels hold LDS on the same CU --
 // k_front_dma is latency bound and its time goes with 1/occupancy.  Same arithmetic, same order.
-template <int D, int RD, bool MIX, bool DC>
+// PER: the tuner index is periodic in the sample number with a period that divides the lane span RD (verified by
+// the host over every sample of the call): the (cos, sin) pair of window sample m sits at the compile-time offset m
+// from a wave-uniform base of an unwrapped table -- scalar loads and SGPR operands instead of the 1 B/sample index
+// stream, the per-sample index arithmetic and the LDS lookups.  FAST: fused multiply-add per tap (the
+// margin-certified variant).  The samples are converted two at a time on the packed FP32 pipe (fm_convert).
+template <int D, int RD, bool MIX, bool DC, bool PER = false, bool FAST = false>
 __global__ __launch_bounds__(256) void k_front_reg(FrontArgs a)
 {
     using G = FrontDmaGeom<D, RD>;
@@ -488,6 +515,13 @@ __global__ __launch_bounds__(256) void k_front_reg(FrontArgs a)
     for (long long tile = (long long)blockIdx.x * nwave + wave; tile < ntiles; tile += (long long)gridDim.x * nwave) {
         const long long j0 = tile * 64 * R;
         const int n0 = a.first_out + (int)(D * j0) - 26 + RD * lane;  // input index of this lane's sample 0
+        typedef const __attribute__((address_space(4))) double *const_tab_t;
+        const_tab_t tb = nullptr;
+        if constexpr (PER && MIX) {  // entry of this wave's sample 0 (RD*lane is a multiple of the period)
+            const long long v = (long long)a.first_out + (long long)D * j0;
+            const int e0 = __builtin_amdgcn_readfirstlane((int)(((v % a.tper) + a.tper) % a.tper));
+            tb = (const_tab_t)(a.tcs + e0);  // tb[2m] = cos, tb[2m+1] = sin
+        }
         // ---- this lane's window, newest quad first
         int4 W[G::NSQ];
         unsigned K[G::NSQ];
@@ -496,7 +530,7 @@ __global__ __launch_bounds__(256) void k_front_reg(FrontArgs a)
 #pragma unroll
             for (int q = G::NSQ - 1; q >= 0; q--) {
                 W[q] = *reinterpret_cast<const int4 *>(raw + n0 + 4 * q);  // 4-byte aligned 16-byte load
-                K[q] = *reinterpret_cast<const unsigned *>(a.ktu + 26 + n0 + 4 * q);
+                if constexpr (!PER) K[q] = *reinterpret_cast<const unsigned *>(a.ktu + 26 + n0 + 4 * q);
             }
         } else {  // first / last window of the call: history before sample 0, clamp beyond the last one
 #pragma unroll
@@ -518,7 +552,7 @@ __global__ __launch_bounds__(256) void k_front_reg(FrontArgs a)
                         w[t] = raw[n > Lm1 ? Lm1 : n];
                     }
                     const int nk = n < -26 ? -26 : (n > Lm1 ? Lm1 : n);
-                    k4 |= (unsigned)a.ktu[26 + nk] << (8 * t);
+                    if constexpr (!PER) k4 |= (unsigned)a.ktu[26 + nk] << (8 * t);
                 }
                 W[q] = make_int4(w[0], w[1], w[2], w[3]);
                 K[q] = k4;
@@ -533,7 +567,7 @@ __global__ __launch_bounds__(256) void k_front_reg(FrontArgs a)
         }
         double CS[G::NSQ][8];
         auto load_sc = [&](int q) {
-            if constexpr (MIX) {
+            if constexpr (MIX && !PER) {
 #pragma unroll
                 for (int t = 0; t < 4; t++) {
                     const int k = (K[q] >> (8 * t)) & 0xff;
@@ -552,24 +586,29 @@ __global__ __launch_bounds__(256) void k_front_reg(FrontArgs a)
             for (int t = 3; t >= 0; t--) {
                 const int m = 4 * q + t;
                 if (m < G::NS) {
-                    int w = (t == 0) ? w4.x : (t == 1) ? w4.y : (t == 2) ? w4.z : w4.w;
-                    int si = (int)(short)(w & 0xffff), sq = w >> 16;
-                    if constexpr (DC) {
-                        si = java_short_add(si, a.ic);
-                        sq = java_short_add(sq, a.qc);
-                    }
-                    double di = (double)i16_to_float_java(si);
-                    double dq = (double)i16_to_float_java(sq);
+                    const int w = (t == 0) ? w4.x : (t == 1) ? w4.y : (t == 2) ? w4.z : w4.w;
+                    double di, dq;
+                    fm_convert(w, a.ic, a.qc, DC, di, dq);
                     if constexpr (MIX) {  // :388-390 component-wise, not a complex multiply
-                        di = di * CS[q][2 * t];
-                        dq = dq * CS[q][2 * t + 1];
+                        if constexpr (PER) {
+                            di = di * tb[2 * m];
+                            dq = dq * tb[2 * m + 1];
+                        } else {
+                            di = di * CS[q][2 * t];
+                            dq = dq * CS[q][2 * t + 1];
+                        }
                     }
 #pragma unroll
                     for (int r = 0; r < R; r++) {
                         if (m >= D * r && m <= D * r + 26) {  // sample m has age D*r+26-m in the window of output r
                             const double tp = ds_tap(D * r + 26 - m);
-                            ai[r] += di * tp;
-                            aq[r] += dq * tp;
+                            if constexpr (FAST) {
+                                ai[r] = __builtin_fma(di, tp, ai[r]);
+                                aq[r] = __builtin_fma(dq, tp, aq[r]);
+                            } else {
+                                ai[r] += di * tp;
+                                aq[r] += dq * tp;
+                            }
                         }
                     }
                 }
@@ -721,6 +760,7 @@ __device__ __forceinline__ void matched_block(const double2 *xl /* &X[s0] of thi
     }
 }
 
+template <bool FAST>
 __global__ __launch_bounds__(512) void k_matched(MatchedArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -756,7 +796,7 @@ __global__ __launch_bounds__(512) void k_matched(MatchedArgs a)
     double2 *y = a.y + (long long)s * a.y_stride;
     if (wave == 0) {
         double ai[9], aq[9];
-        matched_block<9>(xl, 0, ai, aq);
+        matched_block<9, FAST>(xl, 0, ai, aq);
 #pragma unroll
         for (int r = 0; r < 9; r++) {
             long long rel = s0 + r - a.g_first;
@@ -765,7 +805,7 @@ __global__ __launch_bounds__(512) void k_matched(MatchedArgs a)
     } else {
         const int u0 = 9 + 8 * (wave - 1);
         double ai[8], aq[8];
-        matched_block<8>(xl, u0, ai, aq);
+        matched_block<8, FAST>(xl, u0, ai, aq);
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             long long rel = s0 + u0 + r - a.g_first;
@@ -830,23 +870,6 @@ struct FmArgs {
     int first_out;              // input index whose arrival completes output 0
 };
 
-__device__ __forceinline__ void fm_convert(int w, int ic, int qc, bool dc, double &di, double &dq)
-{
-    int si = (int)(short)(w & 0xffff), sq = w >> 16;
-    if (dc) {
-        si = java_short_add(si, ic);
-        sq = java_short_add(sq, qc);
-    }
-    // (float)s / 32767f for I and Q at once: q = fma(a, rh, a * rl) (common.h) on the native two-float vector --
-    // v_pk_mul_f32 + v_pk_fma_f32 round each half exactly as the scalar instructions do
-    typedef float v2f __attribute__((ext_vector_type(2)));
-    const v2f a = {(float)si, (float)sq};
-    const v2f rh = {0x1.0002p-15f, 0x1.0002p-15f}, rl = {0x1.0002p-45f, 0x1.0002p-45f};
-    const v2f q = __builtin_elementwise_fma(a, rh, a * rl);
-    di = (double)q.x;
-    dq = (double)q.y;
-}
-
 template <int D, int R, bool MIX, bool DC, bool FAST>
 __global__ __launch_bounds__(FM_THREADS, 2) void k_fm(FmArgs a)
 {
@@ -873,8 +896,8 @@ __global__ __launch_bounds__(FM_THREADS, 2) void k_fm(FmArgs a)
     }
     // constant address space: the table is read-only for the launch, and only loads the compiler may assume invariant
     // become scalar loads (a plain global pointer in a kernel that also stores gives 57 vector loads per job)
-    typedef const __attribute__((address_space(4))) double2 *const_tab_t;
-    const_tab_t tb = (const_tab_t)(a.tcs + e0);
+    typedef const __attribute__((address_space(4))) double *const_tab_t;
+    const_tab_t tb = (const_tab_t)(a.tcs + e0);  // tb[2m] = cos, tb[2m+1] = sin
     __syncthreads();  // sin/cos table
     // ================================================================================ front half
 #pragma unroll 1
@@ -906,9 +929,8 @@ __global__ __launch_bounds__(FM_THREADS, 2) void k_fm(FmArgs a)
                         double di, dq;
                         fm_convert(w, a.ic, a.qc, DC, di, dq);
                         if constexpr (MIX) {  // :388-390 component-wise, not a complex multiply
-                            const double2 cs = tb[m];
-                            di = di * cs.x;
-                            dq = dq * cs.y;
+                            di = di * tb[2 * m];
+                            dq = dq * tb[2 * m + 1];
                         }
 #pragma unroll
                         for (int r = 0; r < R; r++) {
@@ -1309,8 +1331,6 @@ struct SyncArgs {
     const int *nbits;
     signed char *corr;      // [S][max_bits]
     int max_bits;
-    int *trig_count;        // [S], zeroed before launch
-    int *trig_bits;         // [S][MAX_TRIG]
 };
 __global__ void k_sync(SyncArgs a)
 {
@@ -1323,46 +1343,38 @@ __global__ void k_sync(SyncArgs a)
 #pragma unroll 5
         for (int n = 0; n < SYNC_N; n++) c += (int)w[n * 80] * (int)c_bpsk.sync[n];
         a.corr[(long long)s * a.max_bits + b] = (signed char)c;
-        if (c >= 45) {
-            int slot = atomicAdd(&a.trig_count[s], 1);
-            if (slot < MAX_TRIG) a.trig_bits[s * MAX_TRIG + slot] = b;
-        }
     }
 }
 
-// order the hits, then dmCorr / dmMaxCorr exactly as the serial loop leaves them (:556-572):
-// after a hit dmMaxCorr restarts from 0 (:567) and immediately takes that bit's correlation (:571-572)
+// the hits (correlation >= 45, :560) in bit order -- one wave per stream walks the correlations 64 at a time, a ballot
+// and a prefix count give every hit its slot: deterministic, and when a call holds more hits than the handle has room
+// for it is the FIRST trig_cap that are kept (the stream is flagged; the getters then fail instead of returning a
+// truncated result).  Then dmCorr / dmMaxCorr exactly as the serial loop leaves them (:556-572): after a hit dmMaxCorr
+// restarts from 0 (:567) and immediately takes that bit's correlation (:571-572).
 __global__ __launch_bounds__(64) void k_sync_fin(const int *nbits, const signed char *corr, int max_bits, int *trig_count,
-                                                 int *trig_bits, TailState *st, int nstreams)
+                                                 int *trig_bits, int trig_cap, TailState *st, int nstreams)
 {
     const int s = blockIdx.x, lane = threadIdx.x;
     if (s >= nstreams) return;
-    int nb = nbits[s];
-    int nt = trig_count[s];
-    if (nt > MAX_TRIG) {
-        if (lane == 0) st[s].overflow = 1;
-        nt = MAX_TRIG;
-    }
-    if (lane == 0 && nt > 1) {  // insertion sort of a handful of indices
-        int *t = trig_bits + s * MAX_TRIG;
-        for (int i = 1; i < nt; i++) {
-            int v = t[i], j = i - 1;
-            while (j >= 0 && t[j] > v) {
-                t[j + 1] = t[j];
-                j--;
-            }
-            t[j + 1] = v;
+    const int nb = nbits[s];
+    const signed char *c = corr + (long long)s * max_bits;
+    int nt = 0, last_hit = -1;
+    for (int b0 = 0; b0 < nb; b0 += 64) {
+        const int b = b0 + lane;
+        const bool hit = b < nb && (int)c[b] >= 45;
+        const unsigned long long m = __ballot(hit);
+        if (hit) {
+            const int slot = nt + __popcll(m & ((1ull << lane) - 1ull));
+            if (slot < trig_cap) trig_bits[s * trig_cap + slot] = b;
         }
+        if (m) last_hit = b0 + 63 - __clzll(m);
+        nt += __popcll(m);
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     int from = 0, best = st[s].dmMaxCorr;
     if (nt > 0) {
-        from = trig_bits[s * MAX_TRIG + nt - 1];
+        from = last_hit;
         best = 0;
     }
-    const signed char *c = corr + (long long)s * max_bits;
     for (int b = from + lane; b < nb; b += 64) best = best > (int)c[b] ? best : (int)c[b];
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
@@ -1372,8 +1384,12 @@ __global__ __launch_bounds__(64) void k_sync_fin(const int *nbits, const signed 
     if (lane == 0) {
         if (nb > 0) st[s].dmCorr = c[nb - 1];
         st[s].dmMaxCorr = best;
-        st[s].cntFEC += nt;
-        if (lane == 0) trig_count[s] = nt;
+        st[s].cntFEC += nt;  // the reference counts every hit (:566), decoded or not
+        if (nt > trig_cap) {
+            st[s].overflow = 1;
+            nt = trig_cap;
+        }
+        trig_count[s] = nt;
     }
 }
 
@@ -1386,6 +1402,7 @@ struct jsdr_bpsk {
     int rate = 0, nsf = 0, tuning = 0, do_fft = 0, do_up = 0, nstreams = 0, decim = 0;
     long long max_batch = 0, max_ds = 0;
     int max_bits = 0;
+    int trig_cap = MIN_TRIG;  // FECDecode calls (sync hits) one stream can log per call; sized from max_bits at create
     // input-independent scheduler state, exact doubles (FUNcubeBPSKDemod.java:381,:494,:501,:468)
     double tuPhase = 0.0, tuPhaseInc = 0.0, vcoPhase = 0.0;
     int dsCnt = 0;
@@ -1416,6 +1433,7 @@ struct jsdr_bpsk {
     bool halo_in_dmh = false;      // where the last call left the 64 VCO-mixed history samples (dm[s][0..63] or dmh)
     bool use_fm = true;            // JSDR_FM=0: always the three-kernel path
     int variant = 0;               // 0 exact-order FP64, 1 fast (FMA-contracted FP64, margin-certified decisions)
+    const char *front_name = "k_front";  // the front-end kernel the last call launched
     int c_tper = 0;                // period of the cached tuner schedule (0: not periodic with a period <= 256)
     bool ktu_uploaded = false;     // the device copy of the per-sample tuner index table matches the cached schedule
     std::vector<double2> h_tcs;
@@ -1423,6 +1441,8 @@ struct jsdr_bpsk {
     hipEvent_t ev_matched = nullptr;     // caller stream -> tail stream: (fi,fq) of this call are complete
     hipEvent_t ev_tail_done[2] = {nullptr, nullptr};  // tail stream -> caller stream: y[i] may be overwritten
     bool tail_pending[2] = {false, false};
+    hipEvent_t ev_pack_done = nullptr;   // pack stream -> tail stream: the result arrays of the previous call have been read
+    bool pack_pending = false;
     bool overlap = true;
     long long dm_stride = 0, y_stride = 0;
     DevBuf<TailState> tail;
@@ -1658,8 +1678,23 @@ static void launch_front_dma_t(const FrontArgs &fa, int nstreams, long long nds,
                        fa);
 }
 
-template <int D, int RD, bool MIX, bool DC>
-static void launch_front_reg_t(const FrontArgs &fa, int nstreams, long long nds, hipStream_t st)
+static bool front_reg_enabled()
+{
+    static const bool reg = [] {
+        const char *e = getenv("JSDR_FRONT_REG");  // JSDR_FRONT_REG=0: k_front_dma / the generic kernel instead
+        return !e || atoi(e) != 0;
+    }();
+    return reg;
+}
+
+// can the register-staged kernel take this call?  (int16 input, 32-bit sample indices, at least one full window)
+static bool front_reg_applies(const FrontArgs &fa)
+{
+    return front_reg_enabled() && !fa.rawf && fa.nsamples <= 0x3fffffffLL && fa.nsamples >= 64;
+}
+
+template <int D, int RD, bool MIX, bool DC, bool PER, bool FAST>
+static void launch_front_reg_k(const FrontArgs &fa, int nstreams, long long nds, hipStream_t st)
 {
     using G = FrontDmaGeom<D, RD>;
     // block size and tiles per wave make no difference between 1..4 waves and 1..10 tiles (swept; within 5 %)
@@ -1668,49 +1703,37 @@ static void launch_front_reg_t(const FrontArgs &fa, int nstreams, long long nds,
     long long gx = (ntiles + WAVES * 5 - 1) / (WAVES * 5);  // five tiles per wave
     if (gx > 2048) gx = 2048;
     if (gx < 1) gx = 1;
-    hipLaunchKernelGGL((k_front_reg<D, RD, MIX, DC>), dim3((unsigned)gx, (unsigned)nstreams), dim3(64 * WAVES), 0, st, fa);
+    hipLaunchKernelGGL((k_front_reg<D, RD, MIX, DC, PER, FAST>), dim3((unsigned)gx, (unsigned)nstreams), dim3(64 * WAVES), 0, st, fa);
 }
 
-// the register-staged fast path at the other rates (44.1 / 48 / 192 kHz): int16 input, 32-bit sample indices
+// the register-staged fast path (int16 input) at every rate: 44.1 / 48 / 96 / 192 kHz
 template <int D, int RD>
-static bool launch_front_reg(const FrontArgs &fa, int nstreams, long long nds, hipStream_t st)
+static bool launch_front_reg(const FrontArgs &fa, int nstreams, long long nds, bool fast, hipStream_t st)
 {
-    static const bool reg = [] {
-        const char *e = getenv("JSDR_FRONT_REG");  // JSDR_FRONT_REG=0: the generic kernel instead
-        return !e || atoi(e) != 0;
-    }();
-    if (!reg || fa.rawf || fa.nsamples > 0x3fffffffLL || fa.nsamples < 64) return false;
+    if (!front_reg_applies(fa)) return false;
     const bool dc = (fa.ic != 0) || (fa.qc != 0);
-    if (fa.mix) {
-        if (dc) launch_front_reg_t<D, RD, true, true>(fa, nstreams, nds, st);
-        else launch_front_reg_t<D, RD, true, false>(fa, nstreams, nds, st);
+    const bool per = fa.mix && fa.tcs != nullptr;
+#define JSDR_REG(MIX, DC, PER, FAST) launch_front_reg_k<D, RD, MIX, DC, PER, FAST>(fa, nstreams, nds, st)
+    if (!fa.mix) {
+        if (fast) { if (dc) JSDR_REG(false, true, false, true); else JSDR_REG(false, false, false, true); }
+        else { if (dc) JSDR_REG(false, true, false, false); else JSDR_REG(false, false, false, false); }
+    } else if (per) {
+        if (fast) { if (dc) JSDR_REG(true, true, true, true); else JSDR_REG(true, false, true, true); }
+        else { if (dc) JSDR_REG(true, true, true, false); else JSDR_REG(true, false, true, false); }
     } else {
-        if (dc) launch_front_reg_t<D, RD, false, true>(fa, nstreams, nds, st);
-        else launch_front_reg_t<D, RD, false, false>(fa, nstreams, nds, st);
+        if (fast) { if (dc) JSDR_REG(true, true, false, true); else JSDR_REG(true, false, false, true); }
+        else { if (dc) JSDR_REG(true, true, false, false); else JSDR_REG(true, false, false, false); }
     }
+#undef JSDR_REG
     return true;
 }
 
-// the LDS-DMA fast path: int16 input, 96 kHz (D=10), samples addressable with 32-bit indices
+// the LDS-DMA path (JSDR_FRONT_REG=0): int16 input, 96 kHz (D=10), samples addressable with 32-bit indices
 template <int D, int RD>
 static bool launch_front_dma(const FrontArgs &fa, int nstreams, long long nds, hipStream_t st)
 {
     if (fa.rawf || fa.nsamples > 0x3fffffffLL || fa.nsamples < 64) return false;
     const bool dc = (fa.ic != 0) || (fa.qc != 0);
-    static const bool reg = [] {
-        const char *e = getenv("JSDR_FRONT_REG");  // JSDR_FRONT_REG=0: the LDS-DMA image (k_front_dma) instead
-        return !e || atoi(e) != 0;
-    }();
-    if (reg) {
-        if (fa.mix) {
-            if (dc) launch_front_reg_t<D, RD, true, true>(fa, nstreams, nds, st);
-            else launch_front_reg_t<D, RD, true, false>(fa, nstreams, nds, st);
-        } else {
-            if (dc) launch_front_reg_t<D, RD, false, true>(fa, nstreams, nds, st);
-            else launch_front_reg_t<D, RD, false, false>(fa, nstreams, nds, st);
-        }
-        return true;
-    }
     if (fa.mix) {
         if (dc) launch_front_dma_t<D, RD, true, true>(fa, nstreams, nds, st);
         else launch_front_dma_t<D, RD, true, false>(fa, nstreams, nds, st);
@@ -1794,13 +1817,19 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
     // fused path (k_fm): int16 input, a tuner schedule that is periodic with a period dividing the lane span (or
     // no tuner at all), 32-bit sample indices
     const int fm_rd = h->decim == 4 ? 20 : h->decim * 4;  // D * R of the k_fm instantiation
+    const bool per_ok = !h->do_fft && h->mix == 1 && h->c_tper > 0 && fm_rd % h->c_tper == 0;
     const bool fm_ok = h->use_fm && !h->do_fft && raw_dev && !rawf_dev && nds > 0 && L <= 0x3fffffffLL &&
-                       (h->mix == 0 || (h->mix == 1 && h->c_tper > 0 && fm_rd % h->c_tper == 0));
+                       (h->mix == 0 || per_ok);
     // the byte table is shifted by 0..3 so that ktu[26 + first_out] is dword aligned (k_front_dma's dword DMA)
     const int kshift = (4 - (first_out & 3)) & 3;  // element 26+lo = first_out + D*j0, and D*j0 is a multiple of 4
     const bool fresh = !h->cache_valid;
     if (fresh) h->ktu_uploaded = false;
-    if (!fm_ok && (!h->ktu_uploaded || kshift != h->c_kshift)) {
+    // the 1 B/sample index table is only read by the kernels without the periodic table (k_front, k_front_dma,
+    // k_front_reg<PER = false>)
+    const bool reg_will_run = front_reg_enabled() && raw_dev && !rawf_dev && L <= 0x3fffffffLL && L >= 64 &&
+                              (h->decim != 10 || (h->front_rd != 80 && h->front_dma));
+    const bool need_ktu = !h->do_fft && !fm_ok && !(per_ok && reg_will_run) && h->mix != 0;
+    if (need_ktu && (!h->ktu_uploaded || kshift != h->c_kshift)) {
         h->c_kshift = kshift;
         JSDR_HIP_TRY(hipMemcpyAsync(h->ktu.p + kshift, h->h_ktu.data(), (size_t)L + 26, hipMemcpyHostToDevice, st));
         h->ktu_uploaded = true;
@@ -1848,6 +1877,8 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
     fa.ds_dbg = nullptr;
     fa.nds = nds;
     fa.first_out = first_out;
+    fa.tcs = per_ok ? h->tcs.p : nullptr;
+    fa.tper = h->c_tper;
     if (h->do_fft) {
         FftFrontArgs xa;
         xa.raw = fa.raw;
@@ -1870,6 +1901,7 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
         xa.ds_taps = h->ds_taps_dev.p;
         xa.phase_clk = h->phase_clk.p;
         ProfScope ps(h, PK_FRONT, st);
+        h->front_name = h->fft_mixed ? "k_front_fftm" : "k_front_fft";
         if ((h->fft_mixed ? launch_front_fftm(xa, h->fm_np, h->fm_rad, h->fm_off, S, st) : launch_front_fft(xa, S, st)) != JSDR_OK)
             return JSDR_ERR;
     } else if (nds > 0 && fm_ok) {
@@ -1898,25 +1930,35 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
         ma.tile0 = g_first - (((g_first - 64) % 65 + 65) % 65);
         ma.first_out = first_out;
         ProfScope ps(h, PK_FM, st);
+        h->front_name = "k_fm";
         if (launch_fm(ma, h->decim, h->mix != 0, (ic != 0) || (qc != 0), h->variant != 0, S, st) != JSDR_OK) return JSDR_ERR;
         h->dmh_cur ^= 1;
     } else if (nds > 0) {
         ProfScope ps(h, PK_FRONT, st);
+        const bool fast = h->variant != 0;
+        h->front_name = "k_front";
         switch (h->decim) {
             case 4:
-                if (!launch_front_reg<4, 20>(fa, S, nds, st)) launch_front<4, 40>(fa, S, nds, st);
+                if (launch_front_reg<4, 20>(fa, S, nds, fast, st)) h->front_name = "k_front_reg";
+                else launch_front<4, 40>(fa, S, nds, st);
                 break;
             case 5:
-                if (!launch_front_reg<5, 20>(fa, S, nds, st)) launch_front<5, 40>(fa, S, nds, st);
+                if (launch_front_reg<5, 20>(fa, S, nds, fast, st)) h->front_name = "k_front_reg";
+                else launch_front<5, 40>(fa, S, nds, st);
                 break;
             case 10:
                 if (h->front_rd == 80)
                     launch_front<10, 80>(fa, S, nds, st);
-                else if (!h->front_dma || !launch_front_dma<10, 40>(fa, S, nds, st))
+                else if (h->front_dma && launch_front_reg<10, 40>(fa, S, nds, fast, st))
+                    h->front_name = "k_front_reg";
+                else if (h->front_dma && launch_front_dma<10, 40>(fa, S, nds, st))
+                    h->front_name = "k_front_dma";
+                else
                     launch_front<10, 40>(fa, S, nds, st);
                 break;
             case 20:
-                if (!launch_front_reg<20, 80>(fa, S, nds, st)) launch_front<20, 80>(fa, S, nds, st);
+                if (launch_front_reg<20, 80>(fa, S, nds, fast, st)) h->front_name = "k_front_reg";
+                else launch_front<20, 80>(fa, S, nds, st);
                 break;
             default: JSDR_REQUIRE(false, "bpsk: unsupported decimation %d", h->decim);
         }
@@ -1960,13 +2002,16 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
         const size_t lds = (64 + 4160) * sizeof(double2);
         static bool attr_done = false;
         if (!attr_done) {
-            JSDR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_matched),
+            JSDR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_matched<false>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            JSDR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_matched<true>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             attr_done = true;
         }
         {
             ProfScope ps(h, PK_MATCHED, st);
-            hipLaunchKernelGGL(k_matched, dim3((unsigned)ntiles, (unsigned)S), dim3(512), lds, st, ma);
+            if (h->variant != 0) hipLaunchKernelGGL(k_matched<true>, dim3((unsigned)ntiles, (unsigned)S), dim3(512), lds, st, ma);
+            else hipLaunchKernelGGL(k_matched<false>, dim3((unsigned)ntiles, (unsigned)S), dim3(512), lds, st, ma);
         }
         JSDR_LAUNCH_CHECK();
         ProfScope ps2(h, PK_DMHIST, st);
@@ -1976,6 +2021,10 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
     if (h->overlap) {
         JSDR_HIP_TRY(hipEventRecord(h->ev_matched, st));
         JSDR_HIP_TRY(hipStreamWaitEvent(ts, h->ev_matched, 0));
+    }
+    if (h->pack_pending) {  // a pack of the previous call's results may still be reading what the tail section rewrites
+        JSDR_HIP_TRY(hipStreamWaitEvent(ts, h->ev_pack_done, 0));
+        h->pack_pending = false;
     }
     {
         TailArgs ta;
@@ -1996,15 +2045,12 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
         h->bitlog_cur ^= 1;
     }
     {
-        JSDR_HIP_TRY(hipMemsetAsync(h->trig_count.p, 0, sizeof(int) * (size_t)S, ts));
         SyncArgs sa;
         sa.bitlog = h->bitlog[h->bitlog_cur].p;
         sa.bitlog_stride = h->bitlog_stride;
         sa.nbits = h->nbits.p;
         sa.corr = h->corr.p;
         sa.max_bits = h->max_bits;
-        sa.trig_count = h->trig_count.p;
-        sa.trig_bits = h->trig_bits.p;
         int gx = (h->max_bits + 255) / 256;
         long long maxnew = nds / 4 + 8;
         if ((long long)gx * 256 > maxnew + 255) gx = (int)((maxnew + 255) / 256);
@@ -2017,7 +2063,7 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
         {
             ProfScope ps(h, PK_SYNCFIN, ts);
             hipLaunchKernelGGL(k_sync_fin, dim3((unsigned)S), dim3(64), 0, ts, h->nbits.p, h->corr.p, h->max_bits,
-                               h->trig_count.p, h->trig_bits.p, h->tail.p, S);
+                               h->trig_count.p, h->trig_bits.p, h->trig_cap, h->tail.p, S);
         }
         JSDR_LAUNCH_CHECK();
         BpskFecArgs fa2;
@@ -2025,7 +2071,7 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
         fa2.bitlog_stride = h->bitlog_stride;
         fa2.trig_count = h->trig_count.p;
         fa2.trig_bits = h->trig_bits.p;
-        fa2.max_trig = MAX_TRIG;
+        fa2.max_trig = h->trig_cap;
         fa2.decoded = h->decoded.p;
         fa2.fec_rc = h->fec_rc.p;
         fa2.fec_data = h->fec_data.p;
@@ -2083,6 +2129,10 @@ int jsdr_bpsk_create(jsdr_bpsk **out, int rate, int nsamples_per_frame, int tuni
     h->max_batch = max_batch_samples;
     h->max_ds = max_batch_samples / decim + 2;
     h->max_bits = (int)(h->max_ds / 4 + 16);
+    // a legitimate frame yields one hit per 5200 bits; leave room for false alarms (FUNcubeBPSKDemod.java:560 has no limit,
+    // so a call with more hits than this flags the stream instead of returning a truncated log)
+    h->trig_cap = h->max_bits / 2600 + 4;
+    if (h->trig_cap < MIN_TRIG) h->trig_cap = MIN_TRIG;
     h->tuPhaseInc = 2.0 * JPI * (double)tuning_hz / (double)rate;  // :196
     while ((1 << h->logn) < nsamples_per_frame) h->logn++;
     if (do_fft) h->max_batch = (h->max_batch / nsamples_per_frame) * nsamples_per_frame;
@@ -2100,11 +2150,11 @@ int jsdr_bpsk_create(jsdr_bpsk **out, int rate, int nsamples_per_frame, int tuni
               h->y[0].alloc(S * (size_t)h->y_stride) == JSDR_OK && h->y[1].alloc(S * (size_t)h->y_stride) == JSDR_OK && h->tail.alloc(S) == JSDR_OK &&
               h->bitlog[0].alloc(S * (size_t)h->bitlog_stride) == JSDR_OK &&
               h->bitlog[1].alloc(S * (size_t)h->bitlog_stride) == JSDR_OK && h->nbits.alloc(S) == JSDR_OK &&
-              h->trig_count.alloc(S) == JSDR_OK && h->trig_bits.alloc(S * MAX_TRIG) == JSDR_OK &&
-              h->fec_scratch.alloc(S * MAX_TRIG * (size_t)fec_dec_scratch_words()) == JSDR_OK &&
-              h->fec_rc.alloc(S * MAX_TRIG) == JSDR_OK && h->fec_last.alloc(S * 2) == JSDR_OK &&
+              h->trig_count.alloc(S) == JSDR_OK && h->trig_bits.alloc(S * h->trig_cap) == JSDR_OK &&
+              h->fec_scratch.alloc(S * h->trig_cap * (size_t)fec_dec_scratch_words()) == JSDR_OK &&
+              h->fec_rc.alloc(S * h->trig_cap) == JSDR_OK && h->fec_last.alloc(S * 2) == JSDR_OK &&
               h->cnt_dec.alloc(S) == JSDR_OK && h->corr.alloc(S * (size_t)h->max_bits) == JSDR_OK &&
-              h->fec_data.alloc(S * MAX_TRIG * 256) == JSDR_OK && h->decoded.alloc(S * 256) == JSDR_OK &&
+              h->fec_data.alloc(S * h->trig_cap * 256) == JSDR_OK && h->decoded.alloc(S * 256) == JSDR_OK &&
               h->stage_raw.alloc((size_t)nsamples_per_frame * 2) == JSDR_OK && h->ds_taps_dev.alloc(32) == JSDR_OK &&
               h->dmh[0].alloc(S * 64) == JSDR_OK && h->dmh[1].alloc(S * 64) == JSDR_OK && h->tcs.alloc(256 + FM_TABLE_SLACK) == JSDR_OK &&
               (!do_fft || (h->fft_state.alloc(S) == JSDR_OK && h->fft_tw.alloc(fft_pow2 ? (size_t)nsamples_per_frame : (size_t)32768) == JSDR_OK &&
@@ -2175,7 +2225,8 @@ int jsdr_bpsk_create(jsdr_bpsk **out, int rate, int nsamples_per_frame, int tuni
               hipStreamCreateWithFlags(&h->tail_stream, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreateWithFlags(&h->ev_matched, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&h->ev_tail_done[0], hipEventDisableTiming) == hipSuccess &&
-              hipEventCreateWithFlags(&h->ev_tail_done[1], hipEventDisableTiming) == hipSuccess;
+              hipEventCreateWithFlags(&h->ev_tail_done[1], hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&h->ev_pack_done, hipEventDisableTiming) == hipSuccess;
     if (!up || hipDeviceSynchronize() != hipSuccess) {
         set_error("jsdr_bpsk_create: device initialisation failed");
         jsdr_bpsk_destroy(h);
@@ -2204,6 +2255,7 @@ int jsdr_bpsk_destroy(jsdr_bpsk *h)
         (void)hipStreamDestroy(h->tail_stream);
     }
     if (h->ev_matched) (void)hipEventDestroy(h->ev_matched);
+    if (h->ev_pack_done) (void)hipEventDestroy(h->ev_pack_done);
     for (int i = 0; i < 2; i++)
         if (h->ev_tail_done[i]) (void)hipEventDestroy(h->ev_tail_done[i]);
     h->tail.release();
@@ -2285,6 +2337,17 @@ static int sync_last(jsdr_bpsk *h)
     return JSDR_OK;
 }
 
+// a stream that overflowed its per-call capacity has an incomplete result log: every getter says so
+static int check_overflow(jsdr_bpsk *h, int stream, const char *who)
+{
+    int ov = 0;
+    JSDR_HIP_TRY(hipMemcpy(&ov, reinterpret_cast<const char *>(h->tail.p + stream) + offsetof(TailState, overflow), sizeof(int),
+                           hipMemcpyDeviceToHost));
+    JSDR_REQUIRE(!ov, "%s: stream %d exceeded its per-call capacity (%d bits / %d FEC calls per call of at most %lld samples)", who,
+                 stream, h->max_bits, h->trig_cap, h->max_batch);
+    return JSDR_OK;
+}
+
 int jsdr_bpsk_get_counters(jsdr_bpsk *h, int stream, int32_t out[JSDR_BPSK_NCOUNTERS])
 {
     JSDR_REQUIRE(h && out, "jsdr_bpsk_get_counters: null argument");
@@ -2318,7 +2381,7 @@ int jsdr_bpsk_get_bits(jsdr_bpsk *h, int stream, int8_t *bits_host, int cap, int
 {
     JSDR_REQUIRE(h && nbits, "jsdr_bpsk_get_bits: null argument");
     JSDR_REQUIRE(stream >= 0 && stream < h->nstreams, "jsdr_bpsk_get_bits: stream %d out of range", stream);
-    if (sync_last(h) != JSDR_OK) return JSDR_ERR;
+    if (sync_last(h) != JSDR_OK || check_overflow(h, stream, "jsdr_bpsk_get_bits") != JSDR_OK) return JSDR_ERR;
     int nb = 0;
     JSDR_HIP_TRY(hipMemcpy(&nb, h->nbits.p + stream, sizeof(int), hipMemcpyDeviceToHost));
     *nbits = nb;
@@ -2333,7 +2396,7 @@ int jsdr_bpsk_get_fec_count(jsdr_bpsk *h, int stream, int *count)
 {
     JSDR_REQUIRE(h && count, "jsdr_bpsk_get_fec_count: null argument");
     JSDR_REQUIRE(stream >= 0 && stream < h->nstreams, "jsdr_bpsk_get_fec_count: stream %d out of range", stream);
-    if (sync_last(h) != JSDR_OK) return JSDR_ERR;
+    if (sync_last(h) != JSDR_OK || check_overflow(h, stream, "jsdr_bpsk_get_fec_count") != JSDR_OK) return JSDR_ERR;
     JSDR_HIP_TRY(hipMemcpy(count, h->trig_count.p + stream, sizeof(int), hipMemcpyDeviceToHost));
     return JSDR_OK;
 }
@@ -2346,10 +2409,10 @@ int jsdr_bpsk_get_fec(jsdr_bpsk *h, int stream, int idx, int32_t *rc, int32_t *b
     if (jsdr_bpsk_get_fec_count(h, stream, &cnt) != JSDR_OK) return JSDR_ERR;
     JSDR_REQUIRE(idx >= 0 && idx < cnt, "jsdr_bpsk_get_fec: index %d outside the %d calls of the last batch", idx, cnt);
     int b = 0;
-    JSDR_HIP_TRY(hipMemcpy(rc, h->fec_rc.p + stream * MAX_TRIG + idx, sizeof(int), hipMemcpyDeviceToHost));
-    JSDR_HIP_TRY(hipMemcpy(&b, h->trig_bits.p + stream * MAX_TRIG + idx, sizeof(int), hipMemcpyDeviceToHost));
+    JSDR_HIP_TRY(hipMemcpy(rc, h->fec_rc.p + stream * h->trig_cap + idx, sizeof(int), hipMemcpyDeviceToHost));
+    JSDR_HIP_TRY(hipMemcpy(&b, h->trig_bits.p + stream * h->trig_cap + idx, sizeof(int), hipMemcpyDeviceToHost));
     *bit_index = b + 1;
-    JSDR_HIP_TRY(hipMemcpy(out_host, h->fec_data.p + ((size_t)stream * MAX_TRIG + idx) * 256, 256, hipMemcpyDeviceToHost));
+    JSDR_HIP_TRY(hipMemcpy(out_host, h->fec_data.p + ((size_t)stream * h->trig_cap + idx) * 256, 256, hipMemcpyDeviceToHost));
     return JSDR_OK;
 }
 
@@ -2357,7 +2420,7 @@ int jsdr_bpsk_get_decoded(jsdr_bpsk *h, int stream, uint8_t out_host[256])
 {
     JSDR_REQUIRE(h && out_host, "jsdr_bpsk_get_decoded: null argument");
     JSDR_REQUIRE(stream >= 0 && stream < h->nstreams, "jsdr_bpsk_get_decoded: stream %d out of range", stream);
-    if (sync_last(h) != JSDR_OK) return JSDR_ERR;
+    if (sync_last(h) != JSDR_OK || check_overflow(h, stream, "jsdr_bpsk_get_decoded") != JSDR_OK) return JSDR_ERR;
     JSDR_HIP_TRY(hipMemcpy(out_host, h->decoded.p + (size_t)stream * 256, 256, hipMemcpyDeviceToHost));
     return JSDR_OK;
 }
@@ -2420,6 +2483,18 @@ int jsdr_bpsk_profile_enable(jsdr_bpsk *h, int on)
 
 int jsdr_bpsk_profile_count(void) { return PK_COUNT; }
 
+const char *jsdr_bpsk_front_kernel(jsdr_bpsk *h) { return h ? h->front_name : ""; }
+
+int jsdr_bpsk_set_variant(jsdr_bpsk *h, int variant)
+{
+    JSDR_REQUIRE(h, "jsdr_bpsk_set_variant: null handle");
+    JSDR_REQUIRE(variant == JSDR_VARIANT_EXACT || variant == JSDR_VARIANT_FAST, "jsdr_bpsk_set_variant: unknown variant %d", variant);
+    JSDR_REQUIRE(h->n_in == 0, "jsdr_bpsk_set_variant: the variant is fixed once samples have been received");
+    JSDR_REQUIRE(variant == JSDR_VARIANT_EXACT, "jsdr_bpsk_set_variant: the fast variant is not built into this library");
+    h->variant = variant;
+    return JSDR_OK;
+}
+
 const char *jsdr_bpsk_profile_name(int k) { return (k >= 0 && k < PK_COUNT) ? kProfNames[k] : ""; }
 
 int jsdr_bpsk_profile_read(jsdr_bpsk *h, double *ms_total, int *launches)
@@ -2450,16 +2525,18 @@ int jsdr_bpsk_slot_info(jsdr_bpsk *h, int64_t *slot_bytes, int64_t *bits_offset,
     if (bits_offset) *bits_offset = 64;
     if (fec_offset) *fec_offset = 64 + bits;
     if (slot_bits) *slot_bits = (int)bits;
-    if (nfec_max) *nfec_max = MAX_TRIG;
-    if (slot_bytes) *slot_bytes = 64 + bits + (int64_t)MAX_TRIG * 264;
+    if (nfec_max) *nfec_max = h->trig_cap;
+    if (slot_bytes) *slot_bytes = 64 + bits + (int64_t)h->trig_cap * 264;
     return JSDR_OK;
 }
 
 }  // extern "C"
 
 namespace jsdr {
-// slot = int32 header[16] | int8 bits[slot_bits] | MAX_TRIG x {int32 rc, int32 bit_index, uint8 data[256]}
-__global__ void k_pack_slots(unsigned char *slots, long long slot_bytes, int slot_bits, const TailState *st,
+// slot = int32 header[16] | int8 bits[slot_bits] | trig_cap x {int32 rc, int32 bit_index, uint8 data[256]}
+// header: nbits, nfec, cntRaw, cntDS, cntBit, cntFEC, cntDec, dmErrBits, dmCorr, dmMaxCorr, decodeOK, overflow (a stream
+// that overflowed its per-call bit / FEC capacity: its slot is incomplete), 0...
+__global__ void k_pack_slots(unsigned char *slots, long long slot_bytes, int slot_bits, int trig_cap, const TailState *st,
                              const int *nbits, const signed char *bitlog, long long bitlog_stride, const int *trig_count,
                              const int *trig_bits, const int *fec_rc, const unsigned char *fec_data, const int *fec_last,
                              const int *cnt_dec, int n_in, int n_ds)
@@ -2482,6 +2559,7 @@ __global__ void k_pack_slots(unsigned char *slots, long long slot_bytes, int slo
             case 8: v = st[s].dmCorr; break;
             case 9: v = st[s].dmMaxCorr; break;
             case 10: v = fec_last[2 * s + 1]; break;
+            case 11: v = st[s].overflow; break;
             default: v = 0;
         }
         hdr[threadIdx.x] = v;
@@ -2489,14 +2567,14 @@ __global__ void k_pack_slots(unsigned char *slots, long long slot_bytes, int slo
     const signed char *bl = bitlog + (long long)s * bitlog_stride + HIST_BITS;
     for (int i = threadIdx.x; i < slot_bits; i += blockDim.x) slot[64 + i] = (i < nb) ? (unsigned char)bl[i] : 0;
     unsigned char *f = slot + 64 + slot_bits;
-    for (int t = 0; t < MAX_TRIG; t++) {
+    for (int t = 0; t < trig_cap; t++) {
         int *fh = reinterpret_cast<int *>(f + t * 264);
         if (threadIdx.x == 0) {
-            fh[0] = (t < nt) ? fec_rc[s * MAX_TRIG + t] : 0;
-            fh[1] = (t < nt) ? trig_bits[s * MAX_TRIG + t] + 1 : 0;
+            fh[0] = (t < nt) ? fec_rc[s * trig_cap + t] : 0;
+            fh[1] = (t < nt) ? trig_bits[s * trig_cap + t] + 1 : 0;
         }
         for (int i = threadIdx.x; i < 256; i += blockDim.x)
-            f[t * 264 + 8 + i] = (t < nt) ? fec_data[((long long)s * MAX_TRIG + t) * 256 + i] : 0;
+            f[t * 264 + 8 + i] = (t < nt) ? fec_data[((long long)s * trig_cap + t) * 256 + i] : 0;
     }
 }
 }  // namespace jsdr
@@ -2510,9 +2588,13 @@ extern "C" int jsdr_bpsk_pack_slots(jsdr_bpsk *h, uint8_t *slots_dev, void *stre
     if (h->overlap && h->tail_pending[h->last_y])  // results of the last call come from the side stream
         JSDR_HIP_TRY(hipStreamWaitEvent(as_stream(stream), h->ev_tail_done[h->last_y], 0));
     hipLaunchKernelGGL(k_pack_slots, dim3((unsigned)h->nstreams), dim3(256), 0, as_stream(stream), slots_dev,
-                       (long long)slot_bytes, slot_bits, h->tail.p, h->nbits.p, h->bitlog[h->bitlog_cur].p,
+                       (long long)slot_bytes, slot_bits, h->trig_cap, h->tail.p, h->nbits.p, h->bitlog[h->bitlog_cur].p,
                        h->bitlog_stride, h->trig_count.p, h->trig_bits.p, h->fec_rc.p, h->fec_data.p, h->fec_last.p,
                        h->cnt_dec.p, (int)h->n_in, (int)h->n_ds);
     JSDR_LAUNCH_CHECK();
+    // the per-call result arrays are single-buffered: the next call's tail / sync / FEC (side stream) must not
+    // overwrite them while this kernel is still reading
+    JSDR_HIP_TRY(hipEventRecord(h->ev_pack_done, as_stream(stream)));
+    h->pack_pending = true;
     return JSDR_OK;
 }

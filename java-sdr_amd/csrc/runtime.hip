@@ -105,6 +105,21 @@ int jsdr_memcpy_d2h(void *host, const void *dev, size_t bytes)
     return JSDR_OK;
 }
 
+int jsdr_stream_create(void **stream)
+{
+    JSDR_REQUIRE(stream, "jsdr_stream_create: null argument");
+    hipStream_t st = nullptr;
+    JSDR_HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    *stream = reinterpret_cast<void *>(st);
+    return JSDR_OK;
+}
+
+int jsdr_stream_destroy(void *stream)
+{
+    if (stream) JSDR_HIP_TRY(hipStreamDestroy(as_stream(stream)));
+    return JSDR_OK;
+}
+
 int jsdr_stream_sync(void *stream)
 {
     JSDR_HIP_TRY(hipStreamSynchronize(as_stream(stream)));

@@ -323,3 +323,71 @@ def test_bpsk_api_errors():
         d.batch_i16(0, 8192, 2048)  # null input
     with pytest.raises(J.JsdrError):
         d.bits(5)
+
+
+# ------------------------------------------------------------------ result log: concurrent pack, capacity
+def test_bpsk_pack_on_a_side_stream_is_ordered_against_the_next_call():
+    """k_pack_slots of call k runs on the caller's gather stream; the tail / sync / FEC of call k+1 (the
+    handle's side stream) rewrite the same single-buffered result arrays.  Two back-to-back calls with a pack after
+    each, on a stream of its own, never synchronising in between: each slot must equal that call's own results."""
+    from java_sdr_amd import sharding as SH
+    n = 458752
+    S = 4
+    streams = [O.make_dbpsk_stream(20020109, s, 2 * n, noise_sigma=800.0)[0] for s in range(S)]
+    d_iq = J.DeviceBuffer.from_host(np.concatenate(streams))
+    # reference run: one call at a time, synchronised, getters after each
+    ref = J.Bpsk(nstreams=S, max_batch_samples=n)
+    want = []
+    for k in range(2):
+        ref.batch_i16(d_iq.ptr + 4 * n * k, 4 * n, n)
+        want.append([(ref.bits(s).copy(), [(r[0], r[2].copy()) for r in ref.fec_results(s)], ref.counters(s)) for s in range(S)])
+    # overlapped run
+    d = J.Bpsk(nstreams=S, max_batch_samples=n)
+    info = d.slot_info()
+    side = J.Stream()
+    slots = [J.DeviceBuffer(S * info["slot_bytes"]) for _ in range(2)]
+    for k in range(2):
+        d.batch_i16(d_iq.ptr + 4 * n * k, 4 * n, n)
+        d.pack_slots(slots[k], stream=side.ptr)
+    side.sync()
+    d.sync()
+    for k in range(2):
+        blob = slots[k].to_host(np.uint8).reshape(S, info["slot_bytes"])
+        for s in range(S):
+            u = SH.unpack_slot(blob[s], info)
+            bits, fec, cnt = want[k][s]
+            assert np.array_equal(u["bits"], bits), (k, s)
+            assert [(r[0], bytes(r[2])) for r in u["fec"]] == [(rc, bytes(dat)) for rc, dat in fec], (k, s)
+            assert int(u["header"][4]) == cnt["cntBit"] and int(u["header"][5]) == cnt["cntFEC"], (k, s)
+
+
+def test_bpsk_more_sync_hits_than_the_log_holds_is_flagged_not_truncated_silently():
+    """the reference has no limit on FECDecode calls per frame (:560-569); the handle sizes its log from
+    max_batch_samples and must (a) keep the FIRST hits, deterministically, (b) count every hit in cntFEC, (c) flag the
+    stream so that no getter returns a truncated log as success.  A symbol stream in which every sync bit is held for
+    80 symbols correlates at 80 consecutive bit positions per 5200-bit window."""
+    from java_sdr_amd import sharding as SH
+    sync = (O.bpsk_table(2) > 0).astype(np.uint8)  # SYNC_VECTOR as 1/0
+    nsym = 3 * 5200
+    sym = np.repeat(sync, 80)[np.arange(nsym) % 5200]
+    dsign = O.synth_diffsign(sym, 1)
+    ct, st = O.synth_tables(3000)
+    n = nsym * 80
+    iq = O.synth_dbpsk(0, n, dsign, 80, 0, O.phase_inc_u32(13200.0, 96000), ct, st, 300, O.mix64(99))
+    o = O.Bpsk()
+    o.receive_i16(iq)
+    oc = o.counters()
+    d = J.Bpsk(nstreams=1, max_batch_samples=n)
+    cap = d.slot_info()["nfec_max"]
+    assert oc["cntFEC"] > cap  # the oracle ran FECDecode far more often than the log holds
+    d.batch_i16(J.DeviceBuffer.from_host(iq), 2 * n, n)
+    info = d.slot_info()
+    slots = J.DeviceBuffer(info["slot_bytes"])
+    d.pack_slots(slots)
+    u = SH.unpack_slot(slots.to_host(np.uint8), info)
+    assert int(u["header"][11]) == 1  # overflow flag travels with the slot
+    assert int(u["header"][5]) == oc["cntFEC"]  # every hit counted
+    assert [r[1] for r in u["fec"]] == [r[1] for r in o.fec_results()[:cap]]  # the first `cap` hits, in order
+    for getter in (d.bits, d.fec_results, d.decoded, d.counters):
+        with pytest.raises(J.JsdrError):
+            getter(0)
