@@ -36,7 +36,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # algorithmic HBM bytes per IQ sample: 4 B int16 pair read; fft writes 4 B psd (+8 B/frame);
 # the demodulator writes ~0.0125 B of bits
 BYTES_PER_SAMPLE = {"fft": 4.0 + 4.0 * 2050.0 / 2048.0, "bpsk": 4.0125, "pipeline": 4.0 + 4.0 * 2050.0 / 2048.0 + 0.0125,
-                    "demod": 8.0}  # demod.java: 4 B read, one (L,R) int16 pair written per sample
+                    "demod": 8.0, "fir": 4.0 + 1.6}  # fir (config 3): one double2 per 10 input samples  # demod.java: 4 B read, one (L,R) int16 pair written per sample
 DEMOD_MODES = {"raw": 1, "am": 2, "nfm": 3, "wfm": 4}
 N_FFT = 2048
 RATE = 96000
@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="pipeline", choices=["pipeline", "fft", "bpsk", "demod"])
+    ap.add_argument("--workload", default="pipeline", choices=["pipeline", "fft", "bpsk", "demod", "fir"])
     ap.add_argument("--total-streams", type=int, default=8192,
                     help="streams of the whole job, sharded over the GPUs (strong scaling, BASELINE config 5)")
     ap.add_argument("--streams", type=int, default=0, help="streams PER GPU (weak scaling) instead of --total-streams")
@@ -67,6 +67,9 @@ def parse():
     ap.add_argument("--bpsk-frame", type=int, default=N_FFT,
                     help="--workload bpsk: samples per demodulator frame (blen/size); 9600 = the reference's default, the "
                          "only size at which its FFT-acquire mode (10 Hz bins) brings FEC blocks through")
+    ap.add_argument("--fir-taps", type=int, default=27, choices=[21, 27, 65],
+                    help="--workload fir: 27 = dsFilter (FUNcubeBPSKDemod.java:27-55), 65 = dmFilter (:58-77), 21 = fir.java weights(500,1500)")
+    ap.add_argument("--fir-decim", type=int, default=10, choices=[1, 10, 20], help="--workload fir: decimation")
     ap.add_argument("--fft-acquire", action="store_true", help="demodulator in FFT-acquire mode (bpsk-dofft=1) instead of tune mode")
     return ap.parse_args()
 
@@ -180,7 +183,9 @@ def workload_text(a):
             "fft": "batched 2048-pt waterfall FFT+PSD (BASELINE config 2)",
             "bpsk": f"FUNcubeBPSKDemod {mode} + FECDecoder (BASELINE config 4), {a.bpsk_frame}-sample frames",
             "demod": f"demod.java {a.demod_mode.upper()} chain (8f next-3): 21-tap complex FIR + NCO + detector + AGC -> "
-                     "int16 stereo, 2048-sample frames"}[a.workload]
+                     "int16 stereo, 2048-sample frames",
+            "fir": f"batched {a.fir_taps}-tap complex FIR + decimate by {a.fir_decim} over int16 IQ (BASELINE config 3), "
+                   "double2 outputs"}[a.workload]
 
 
 def variant_text(a):
@@ -188,6 +193,8 @@ def variant_text(a):
         return "float32 Stockham FFT + PSD (1e-5 of frame peak)"
     if a.workload == "demod":
         return "exact-order float32 (bit-exact int16 audio)"
+    if a.workload == "fir":
+        return "exact-order FP64 (newest sample first, products and sums rounded separately: bit-identical to the Java loop)"
     front = "FFT-acquire front end" if a.fft_acquire else "tuner front end"
     if a.variant == "fast":
         return f"FMA-contracted FP64, every slicer decision margin-certified or recomputed in exact order (bit-exact bits/bytes), {front}"
@@ -264,6 +271,12 @@ def main():
     # the PSD kernel is HBM-bound, the demodulator FP64-issue bound: on streams of their own they share the CUs
     psd_stream = J.Stream() if (fft is not None and dem is not None and not a.serial_psd) else None
     ps = psd_stream.ptr if psd_stream else None
+    fir_taps = d_fir = None
+    if a.workload == "fir":
+        fir_taps = J.bpsk_table(0) if a.fir_taps == 27 else (J.bpsk_table(1) if a.fir_taps == 65 else J.Fir(44100.0).weights(500, 1500))
+        d_fir = J.DeviceBuffer(S * (L // a.fir_decim) * 16)
+        BYTES_PER_SAMPLE["fir"] = 4.0 + 16.0 / a.fir_decim
+    fir_timer = [J.Timer() for _ in range(a.steps)] if a.workload == "fir" else []
     amfm = d_audio = None
     if a.workload == "demod":
         amfm = J.Demod(rate=RATE, n=N_FFT, nstreams=S, max_batch_samples=L)
@@ -297,6 +310,12 @@ def main():
                 J.waterfall_lines_dev(d_psd, nframes, N_FFT, wf, d_pix, stream=ps)
                 if timed:
                     wf_timer[i].stop(ps)
+        if fir_taps is not None:
+            if timed:
+                fir_timer[i].start(None)
+            J.fir_batch_decimate_i16(d_iq, S, 2 * L, L, fir_taps, a.fir_decim, 0.9 * 32768.0, d_fir, L // a.fir_decim)
+            if timed:
+                fir_timer[i].stop(None)
         if amfm is not None:
             amfm.batch_i16(d_iq, 2 * L, L, d_audio, 2 * L)
         if dem is not None:
@@ -344,6 +363,9 @@ def main():
     if fft is not None:
         ms = [t.elapsed_ms() for t in fft_timer]
         kern["k_fft"] = (float(np.sum(ms)), len(ms), BYTES_PER_SAMPLE["fft"])
+    if fir_timer:
+        ms = [t.elapsed_ms() for t in fir_timer]
+        kern["k_fir_batch"] = (float(np.sum(ms)), len(ms), BYTES_PER_SAMPLE["fir"])
     if wf:
         ms = [t.elapsed_ms() for t in wf_timer]
         kern["k_waterfall"] = (float(np.sum(ms)), len(ms), 4.0 + 4.0 * wf / N_FFT)  # reads the PSD, writes the pixels
@@ -421,7 +443,7 @@ def main():
             "higher_is_better": True,
             "scaling": scaling,
             "vs_baseline": None,
-            "dtype": "f64" if a.workload in ("pipeline", "bpsk") else "f32",  # the arithmetic type of the dominant path
+            "dtype": "f64" if a.workload in ("pipeline", "bpsk", "fir") else "f32",  # the arithmetic type of the dominant path
             "data": "synthetic",
             "config": {"workload": workload_text(a), "streams_per_gpu": S, "total_streams": N * S, "samples_per_stream": L,
                        "rate_hz": RATE, "frame": a.bpsk_frame if a.workload == "bpsk" else N_FFT, "input_bytes_per_gpu": S * L * 4,

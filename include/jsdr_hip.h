@@ -95,6 +95,15 @@ int jsdr_fir_weights(jsdr_fir *h, int f1, int f2, double w_out[21]);
 int jsdr_fir_filter(jsdr_fir *h, const int32_t *in_host, int32_t *out_host, int64_t n);
 int jsdr_fir_complex_gen(jsdr_fir *h, int freq, int start, int32_t *sig_host /*[n][2]*/, int64_t n);
 int jsdr_fir_complex_mod(jsdr_fir *h, const int32_t *a_host, const int32_t *b_host, int32_t *out_host, int64_t n);
+/* batched complex FIR + decimate over device-resident int16 IQ streams (BASELINE config 3), exact-order FP64:
+ *   out[s][j] = scale * SUM_{a<ntaps} x[s][decim*(j+1)-1-a] * taps[a]   per rail, newest sample first, every product
+ *   and sum rounded separately; x = (double)((float)int16/32767f); samples before the batch are zero (cleared delay
+ *   line).  = RxDownSample (FUNcubeBPSKDemod.java:466-492) for taps = dsFilter, decim = rate/9600, scale = 0.9*32768;
+ *   any ntaps <= 128 and decim >= 1 (27/65/21 taps x decimation 1/10/20 have register-blocked kernels).
+ * out_dev: double[nstreams][out_stride_pairs][2]; *nout = nsamples / decim outputs per stream.  Asynchronous. */
+int jsdr_fir_batch_decimate_i16(const int16_t *raw_dev, int nstreams, int64_t stream_stride_i16, int64_t nsamples,
+                                const double *taps_host, int ntaps, int decim, double scale, double *out_dev,
+                                int64_t out_stride_pairs, int64_t *nout, void *stream);
 
 /* ------------------------------------------------------------------ FECDecoder.java
  * FECDecode (FECDecoder.java:703-852): 5200 soft symbols -> 256 bytes, return -1 or channel errors.
@@ -113,6 +122,9 @@ typedef struct jsdr_bpsk jsdr_bpsk;
 int jsdr_bpsk_create(jsdr_bpsk **h, int rate, int nsamples_per_frame, int tuning_hz, int do_fft,
                      int do_up, int nstreams, int64_t max_batch_samples);
 int jsdr_bpsk_destroy(jsdr_bpsk *h);
+/* the constant tables as the library holds them (host side): which = 0 dsFilter[27] (:27-55), 1 dmFilter[65] (:58-77),
+ * 2 SYNC_VECTOR[65] (:79-81) as +1/-1 */
+int jsdr_bpsk_table(int which, double *out, int cap);
 /* arithmetic of the demodulator (before the first sample): EXACT = every double product and sum rounded separately in
  * the reference's order (bits, bytes AND doubles identical to the Java arithmetic); FAST = fused multiply-adds in the
  * two FIR stages, every slicer decision certified by a proven error margin or recomputed in exact order (bits and

@@ -293,6 +293,17 @@ class Fir:
             pass
 
 
+def fir_batch_decimate_i16(raw_dev, nstreams, stride_i16, nsamples, taps, decim, scale, out_dev, out_stride_pairs, stream=None):
+    """batched FIR + decimate (BASELINE config 3); returns the number of outputs per stream"""
+    taps = np.ascontiguousarray(taps, np.float64)
+    nout = C.c_int64()
+    _check(lib().jsdr_fir_batch_decimate_i16(_addr(raw_dev), nstreams, C.c_int64(stride_i16), C.c_int64(nsamples), _addr(taps),
+                                             int(taps.size), int(decim), C.c_double(scale), _addr(out_dev),
+                                             C.c_int64(out_stride_pairs), C.byref(nout), C.c_void_p(stream)),
+           "jsdr_fir_batch_decimate_i16")
+    return nout.value
+
+
 # ------------------------------------------------------------------ FECDecoder.java
 def fec_decode(raw, out_init=None):
     raw = np.ascontiguousarray(raw, np.uint8)
@@ -346,6 +357,12 @@ def fec_decode_dev(raw_dev, nblocks, out_dev, rc_dev, stream=None):
 # ------------------------------------------------------------------ FUNcubeBPSKDemod.java
 COUNTER_NAMES = ["cntRaw", "cntDS", "cntBit", "cntFEC", "cntDec", "dmErrBits", "dmCorr", "dmMaxCorr", "decodeOK",
                  "centreBin"]
+
+
+def bpsk_table(which):
+    out = np.empty(65, np.float64)
+    _check(lib().jsdr_bpsk_table(which, _addr(out), 65), "jsdr_bpsk_table")
+    return out[:27 if which == 0 else 65].copy()
 
 
 class Bpsk:

@@ -23,6 +23,7 @@ SOURCES = {
     "fft_psd.hip": [],
     "fft_mixed.hip": [],
     "fir_phase.hip": ["-ffp-contract=off"],
+    "fir_batch.hip": ["-ffp-contract=off"],
     "fec.hip": [],
     "synth.hip": [],
     "formats.hip": [],

@@ -74,25 +74,6 @@ struct TailState {
     int pad;
 };
 
-// int16 pair -> (double)((float)s / 32767f) for I and Q (JavaAudio.java:281-288, FUNcubeBPSKDemod.java:372-373)
-__device__ __forceinline__ void fm_convert(int w, int ic, int qc, bool dc, double &di, double &dq)
-{
-    int si = (int)(short)(w & 0xffff), sq = w >> 16;
-    if (dc) {
-        si = java_short_add(si, ic);
-        sq = java_short_add(sq, qc);
-    }
-    // (float)s / 32767f for I and Q at once: q = fma(a, rh, a * rl) (common.h) on the native two-float vector --
-    // v_pk_mul_f32 + v_pk_fma_f32 round each half exactly as the scalar instructions do
-    typedef float v2f __attribute__((ext_vector_type(2)));
-    const v2f a = {(float)si, (float)sq};
-    const v2f rh = {0x1.0002p-15f, 0x1.0002p-15f}, rl = {0x1.0002p-45f, 0x1.0002p-45f};
-    const v2f q = __builtin_elementwise_fma(a, rh, a * rl);
-    di = (double)q.x;
-    dq = (double)q.y;
-}
-
-
 // ------------------------------------------------------------------------------------------- k_front
 // int16 -> float -> double, tuner mix, 27-tap low-pass at the decimated instants, x HOWARD, VCO mix.
 //
@@ -2478,6 +2459,31 @@ int jsdr_bpsk_profile_enable(jsdr_bpsk *h, int on)
 {
     JSDR_REQUIRE(h, "jsdr_bpsk_profile_enable: null handle");
     h->prof_on = on != 0;
+    return JSDR_OK;
+}
+
+// the demodulator's constant tables as this library holds them (host side, no device needed): 0 = dsFilter[27]
+// (FUNcubeBPSKDemod.java:27-55), 1 = dmFilter[65] (:58-77, one of the two identical copies), 2 = SYNC_VECTOR[65] (:79-81)
+int jsdr_bpsk_table(int which, double *out, int cap)
+{
+    JSDR_REQUIRE(out, "jsdr_bpsk_table: null argument");
+    const int n = which == 0 ? 27 : ((which == 1 || which == 2) ? 65 : 0);
+    JSDR_REQUIRE(n > 0 && cap >= n, "jsdr_bpsk_table: table %d needs room for %d values", which, n);
+    if (which == 0) {
+        for (int i = 0; i < 14; i++) out[i] = out[26 - i] = (double)h_ds_half[i];
+    } else if (which == 1) {
+        for (int i = 0; i < 33; i++) out[i] = out[64 - i] = (double)h_dm_half[i];
+    } else {
+        int sr = 0x7f;  // the sync LFSR (FECDecoder.java:600-605) == SYNC_VECTOR
+        for (int i = 0; i < 65; i++) {
+            out[i] = (sr & 64) ? 1.0 : -1.0;
+            int v = sr & 0x48;
+            v ^= v >> 4;
+            v ^= v >> 2;
+            v ^= v >> 1;
+            sr = ((sr << 1) | (v & 1)) & 0xffff;
+        }
+    }
     return JSDR_OK;
 }
 

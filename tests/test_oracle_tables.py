@@ -37,6 +37,15 @@ def test_filter_tables_match_reference_digests():
     assert dig_ints(sv.astype(np.int32)) == GOLD["SYNC_VECTOR"]["sha256"]
 
 
+def test_product_filter_tables_match_reference_digests():
+    """the tables libjsdr_hip.so itself holds (host side, no device needed)"""
+    import java_sdr_amd as J
+    ds, dm, sv = J.bpsk_table(0), J.bpsk_table(1), J.bpsk_table(2)
+    assert dig_f64(ds) == GOLD["dsFilter"]["sha256"]
+    assert dig_f64(np.concatenate([dm, dm])) == GOLD["dmFilter"]["sha256"]
+    assert dig_ints(sv.astype(np.int32)) == GOLD["SYNC_VECTOR"]["sha256"]
+
+
 def test_kat_gf256_tables():
     a = O.fec_table("ALPHA_TO")
     idx = O.fec_table("INDEX_OF")
