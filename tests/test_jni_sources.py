@@ -1,0 +1,101 @@
+"""The JNI shim and the Java plugin classes are committed as complete sources (jni/, java/) but cannot be compiled
+against a JDK here (none in the image).  What can be checked without one:
+  * every native method of HipNative.java has exactly one JNI function in jsdr_jni.c, with the matching argument
+    count, and vice versa;
+  * every native method the Hip* plugin classes call exists;
+  * every jsdr_* function the shim calls is declared in include/jsdr_hip.h and exported by libjsdr_hip.so;
+  * the shim type-checks (gcc -fsyntax-only -Wall -Werror) against prototype-only JNI declarations;
+  * the plugin classes implement the reference's handler interfaces and keep its constructor shapes
+    (IAudioHandler.java:3-6, IRawHandler.java:3-6, jsdr.java:475-483)."""
+import os
+import re
+import subprocess
+
+import java_sdr_amd as J
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+JDIR = os.path.join(ROOT, "java", "com", "ashbysoft", "java_sdr")
+SHIM = os.path.join(ROOT, "jni", "jsdr_jni.c")
+PREFIX = "Java_com_ashbysoft_java_1sdr_HipNative_"
+
+
+def strip_comments(src):
+    src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
+    return re.sub(r"//[^\n]*", " ", src)
+
+
+def native_methods():
+    src = strip_comments(open(os.path.join(JDIR, "HipNative.java")).read())
+    out = {}
+    for m in re.finditer(r"static\s+native\s+\w+(?:\[\])?\s+(\w+)\s*\(([^)]*)\)\s*;", src):
+        args = [a for a in m.group(2).split(",") if a.strip()]
+        out[m.group(1)] = len(args)
+    return out
+
+
+def jni_functions():
+    src = strip_comments(open(SHIM).read())
+    out = {}
+    for m in re.finditer(r"JNIEXPORT\s+\w+\s+JNICALL\s+" + PREFIX + r"(\w+)\s*\(([^)]*)\)", src):
+        out[m.group(1)] = len([a for a in m.group(2).split(",") if a.strip()])
+    return out
+
+
+def test_every_native_method_has_its_jni_function_and_vice_versa():
+    nat, jni = native_methods(), jni_functions()
+    assert len(nat) == 19
+    assert set(nat) == set(jni)
+    for name, nargs in nat.items():
+        assert jni[name] == nargs + 2, (name, nargs, jni[name])  # JNIEnv*, jclass + the Java arguments
+
+
+def test_plugin_classes_call_only_declared_native_methods():
+    nat = native_methods()
+    used = set()
+    for fn in ("HipFft.java", "HipFUNcubeBPSKDemod.java", "HipDemod.java"):
+        src = strip_comments(open(os.path.join(JDIR, fn)).read())
+        used |= set(re.findall(r"HipNative\.(\w+)\s*\(", src))
+    assert used and used <= set(nat), used - set(nat)
+    # nothing declared is dead, except fecDecode (a utility for code that holds soft symbols itself)
+    assert set(nat) - used <= {"fecDecode"}
+
+
+def test_shim_calls_only_functions_of_the_c_abi():
+    src = strip_comments(open(SHIM).read())
+    called = set(re.findall(r"\b(jsdr_[a-z0-9_]+)\s*\(", src))
+    header = strip_comments(open(os.path.join(ROOT, "include", "jsdr_hip.h")).read())
+    declared = set(re.findall(r"\b(jsdr_[a-z0-9_]+)\s*\(", header))
+    assert called and called <= declared, called - declared
+    assert called <= set(J.EXPORTED_SYMBOLS), called - set(J.EXPORTED_SYMBOLS)
+    lib = J.lib()
+    for name in called:
+        assert hasattr(lib, name), name
+
+
+def test_shim_type_checks_against_prototype_only_jni_declarations():
+    r = subprocess.run(["gcc", "-std=c99", "-fsyntax-only", "-Wall", "-Wextra", "-Werror", "-Wno-unused-parameter",
+                        "-I" + os.path.join(ROOT, "tests", "jni_decls"), "-I" + os.path.join(ROOT, "include"), SHIM],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
+def test_plugin_classes_keep_the_reference_surface():
+    fft = strip_comments(open(os.path.join(JDIR, "HipFft.java")).read())
+    bpsk = strip_comments(open(os.path.join(JDIR, "HipFUNcubeBPSKDemod.java")).read())
+    dem = strip_comments(open(os.path.join(JDIR, "HipDemod.java")).read())
+    for src in (fft, bpsk, dem):
+        assert "package com.ashbysoft.java_sdr;" in src
+        assert re.search(r"implements\s+IAudioHandler", src)
+        assert "public synchronized void receive(float[] buf)" in src
+        assert '"audio-change".equals(key)' in src
+        assert not re.search(r"same pattern|TODO|\.\.\.", src)
+    for src in (fft, bpsk):
+        assert "IRawHandler" in src and "public synchronized void receive(byte[] raw)" in src
+    assert re.search(r"public HipFft\(IConfig \w+, IPublish \w+, ILogger \w+, IUIHost \w+, IAudio \w+\)", fft)
+    assert re.search(r"public HipDemod\(IConfig \w+, IPublish \w+, ILogger \w+, IUIHost \w+, IAudio \w+\)", dem)
+    assert re.search(r"public HipFUNcubeBPSKDemod\(int \w+, IConfig \w+, IPublish \w+, ILogger \w+, IUIHost \w+, IAudio \w+\)", bpsk)
+    for key in ('"bpsk-tuning"', '"bpsk-dofft"', '"bpsk-upper"', '"-bpsk-centre"', '"-bpsk-tune"'):
+        assert key in bpsk, key
+    for key in ('"demod-filter-low"', '"demod-filter-high"', '"demod-mode"', '"demod-fir-enable"', '"demod-agc-enable"'):
+        assert key in dem, key
+    assert '"fft-psd"' in fft
