@@ -156,6 +156,19 @@ int jsdr_bpsk_get_trace(jsdr_bpsk *h, int stream, double *out_host, int64_t cap_
 /* scalar state, same 18-value layout as the oracle: tuPhase,vcoPhase,dmBitPhase,dmEnergyOut,energy1,
  * energy2,avePeakPower,aveCentreBin,dmEnergy[8],dmLastIQ[2]                                       */
 int jsdr_bpsk_get_state(jsdr_bpsk *h, int stream, double out[18]);
+/* Results of the last completed receive_f32 / receive_i16 of a 1-stream handle, for a reader on ANOTHER thread (the
+ * reference's Swing thread paints these fields while the audio thread is inside receive(), FUNcubeBPSKDemod.java:
+ * 220-228,331-337): double-buffered on the host, published after every receive; the read takes no lock, makes no
+ * device call and never sees a half-written frame.  The getters above belong to the thread that calls receive. */
+typedef struct jsdr_bpsk_snapshot {
+    int64_t frames;                        /* receive() calls completed */
+    int32_t counters[JSDR_BPSK_NCOUNTERS]; /* as jsdr_bpsk_get_counters */
+    int32_t nbits;                         /* bits sliced during that frame (first 512 kept) */
+    double state[18];                      /* as jsdr_bpsk_get_state */
+    uint8_t decoded[256];                  /* decoded[] (:111) */
+    int8_t bits[512];
+} jsdr_bpsk_snapshot;
+int jsdr_bpsk_snapshot_read(jsdr_bpsk *h, jsdr_bpsk_snapshot *out);
 /* per-kernel HIP-event timing of the batch pipeline (events recorded on the caller's stream around each
  * launch while enabled).  profile_read sums and clears what was recorded since the last read.          */
 int jsdr_bpsk_profile_enable(jsdr_bpsk *h, int on);

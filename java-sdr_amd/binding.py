@@ -359,6 +359,11 @@ COUNTER_NAMES = ["cntRaw", "cntDS", "cntBit", "cntFEC", "cntDec", "dmErrBits", "
                  "centreBin"]
 
 
+class BpskSnapshot(C.Structure):
+    _fields_ = [("frames", C.c_int64), ("counters", C.c_int32 * 10), ("nbits", C.c_int32), ("state", C.c_double * 18),
+                ("decoded", C.c_uint8 * 256), ("bits", C.c_int8 * 512)]
+
+
 def bpsk_table(which):
     out = np.empty(65, np.float64)
     _check(lib().jsdr_bpsk_table(which, _addr(out), 65), "jsdr_bpsk_table")
@@ -378,6 +383,12 @@ class Bpsk:
                                       C.c_int64(self.max_batch)), "jsdr_bpsk_create")
         if variant != "exact":
             _check(lib().jsdr_bpsk_set_variant(self.h, {"exact": 0, "fast": 1}[variant]), "jsdr_bpsk_set_variant")
+
+    def snapshot(self):
+        """results of the last completed receive(); callable from any thread while another one is inside receive()"""
+        sn = BpskSnapshot()
+        _check(lib().jsdr_bpsk_snapshot_read(self.h, C.byref(sn)), "jsdr_bpsk_snapshot_read")
+        return sn
 
     def front_kernel_name(self):
         return lib().jsdr_bpsk_front_kernel(self.h).decode()

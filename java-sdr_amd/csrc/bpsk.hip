@@ -22,6 +22,7 @@
 #include "bpsk_fec.h"
 #include "bpsk_fft.h"
 #include <math.h>
+#include <atomic>
 #include <stddef.h>
 #include <stdlib.h>
 #include <vector>
@@ -1422,6 +1423,12 @@ struct jsdr_bpsk {
     hipEvent_t ev_matched = nullptr;     // caller stream -> tail stream: (fi,fq) of this call are complete
     hipEvent_t ev_tail_done[2] = {nullptr, nullptr};  // tail stream -> caller stream: y[i] may be overwritten
     bool tail_pending[2] = {false, false};
+    // results of the last receive_*() of a 1-stream handle, double-buffered for a reader on another thread (the Swing
+    // EDT paints while the audio thread receives): the writer fills the idle copy, then publishes it
+    jsdr_bpsk_snapshot snap[2];
+    std::atomic<unsigned> snap_seq[2];   // odd while that copy is being written
+    std::atomic<int> snap_cur{-1};       // -1: nothing received yet
+    long long snap_count = 0;
     hipEvent_t ev_pack_done = nullptr;   // pack stream -> tail stream: the result arrays of the previous call have been read
     bool pack_pending = false;
     bool overlap = true;
@@ -1780,6 +1787,7 @@ static int launch_fm(const FmArgs &a, int decim, bool mix, bool dc, bool fast, i
 }
 
 static int sync_last(jsdr_bpsk *h);
+static int publish_snapshot(jsdr_bpsk *h);
 
 static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev, long long stride_i16, long long L,
                     int ic, int qc, hipStream_t st)
@@ -2100,6 +2108,9 @@ int jsdr_bpsk_create(jsdr_bpsk **out, int rate, int nsamples_per_frame, int tuni
     JSDR_REQUIRE(bit_clock_is_regular(), "jsdr_bpsk_create: bit clock schedule is not the regular 8-cycle");
     if (fec_prepare() != JSDR_OK) return JSDR_ERR;
     jsdr_bpsk *h = new jsdr_bpsk();
+    h->snap_seq[0].store(0);
+    h->snap_seq[1].store(0);
+    memset(h->snap, 0, sizeof(h->snap));
     h->rate = rate;
     h->nsf = nsamples_per_frame;
     h->tuning = tuning_hz;
@@ -2297,7 +2308,7 @@ int jsdr_bpsk_receive_i16(jsdr_bpsk *h, const int16_t *raw_host, int ic, int qc)
     JSDR_HIP_TRY(hipMemcpy(h->stage_raw.p, raw_host, sizeof(int16_t) * 2 * (size_t)h->nsf, hipMemcpyHostToDevice));
     if (bpsk_run(h, reinterpret_cast<const int16_t *>(h->stage_raw.p), nullptr, 2LL * h->nsf, h->nsf, ic, qc, 0) != JSDR_OK)
         return JSDR_ERR;
-    return sync_last(h);
+    return publish_snapshot(h);
 }
 
 int jsdr_bpsk_receive_f32(jsdr_bpsk *h, const float *iq_host)
@@ -2308,7 +2319,25 @@ int jsdr_bpsk_receive_f32(jsdr_bpsk *h, const float *iq_host)
     JSDR_HIP_TRY(hipMemcpy(h->stage_raw.p, iq_host, sizeof(float) * 2 * (size_t)h->nsf, hipMemcpyHostToDevice));
     if (bpsk_run(h, nullptr, reinterpret_cast<const float *>(h->stage_raw.p), 2LL * h->nsf, h->nsf, 0, 0, 0) != JSDR_OK)
         return JSDR_ERR;
-    return sync_last(h);
+    return publish_snapshot(h);
+}
+
+static int publish_snapshot(jsdr_bpsk *h)
+{
+    const int cur = h->snap_cur.load(std::memory_order_relaxed);
+    const int w = cur == 0 ? 1 : 0;  // the copy no reader is directed to
+    h->snap_seq[w].fetch_add(1, std::memory_order_acq_rel);  // odd: writing
+    jsdr_bpsk_snapshot &sn = h->snap[w];
+    int nb = 0;
+    int rc = jsdr_bpsk_get_counters(h, 0, sn.counters);
+    if (rc == JSDR_OK) rc = jsdr_bpsk_get_state(h, 0, sn.state);
+    if (rc == JSDR_OK) rc = jsdr_bpsk_get_decoded(h, 0, sn.decoded);
+    if (rc == JSDR_OK) rc = jsdr_bpsk_get_bits(h, 0, sn.bits, (int)sizeof(sn.bits), &nb);
+    sn.nbits = nb;
+    sn.frames = ++h->snap_count;
+    h->snap_seq[w].fetch_add(1, std::memory_order_release);  // even: complete
+    if (rc == JSDR_OK) h->snap_cur.store(w, std::memory_order_release);
+    return rc;
 }
 
 static int sync_last(jsdr_bpsk *h)
@@ -2453,6 +2482,23 @@ int jsdr_bpsk_sync(jsdr_bpsk *h)
 {
     JSDR_REQUIRE(h, "jsdr_bpsk_sync: null handle");
     return sync_last(h);
+}
+
+// any thread, no HIP call, no lock: the results of the last completed receive_*() of a 1-stream handle
+int jsdr_bpsk_snapshot_read(jsdr_bpsk *h, jsdr_bpsk_snapshot *out)
+{
+    JSDR_REQUIRE(h && out, "jsdr_bpsk_snapshot_read: null argument");
+    for (int attempt = 0; attempt < 1000; attempt++) {
+        const int cur = h->snap_cur.load(std::memory_order_acquire);
+        JSDR_REQUIRE(cur >= 0, "jsdr_bpsk_snapshot_read: nothing received yet");
+        const unsigned s0 = h->snap_seq[cur].load(std::memory_order_acquire);
+        if (s0 & 1u) continue;  // being rewritten: the writer has lapped us, take the newer copy
+        memcpy(out, &h->snap[cur], sizeof(*out));
+        std::atomic_thread_fence(std::memory_order_acquire);
+        if (h->snap_seq[cur].load(std::memory_order_relaxed) == s0) return JSDR_OK;
+    }
+    set_error("jsdr_bpsk_snapshot_read: could not get a stable copy");
+    return JSDR_ERR;
 }
 
 int jsdr_bpsk_profile_enable(jsdr_bpsk *h, int on)

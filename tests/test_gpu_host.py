@@ -7,6 +7,7 @@ import subprocess
 import numpy as np
 import pytest
 
+import java_sdr_amd as J
 import oracle_lib as O
 
 pytestmark = pytest.mark.gpu
@@ -126,3 +127,48 @@ def test_harness_at_the_192k_default_frame(tmp_path):
         assert abs(float(m.group(1)) - ref[n + 1]) < 1e-3 and float(m.group(2)) == ref[n]
         o.receive(buf[k * 2 * n:(k + 1) * 2 * n])
         assert int(m.group(3)) == o.counters()["cntDS"] and int(m.group(4)) == o.counters()["cntBit"]
+
+
+def test_bpsk_snapshot_for_a_concurrent_reader():
+    """outputs double-buffered for a reader on another thread (the reference's Swing thread paints the
+    demodulator's fields while the audio thread is inside receive()).  A reader thread polls the snapshot without any
+    lock while the main thread feeds frames; every snapshot must be one whole frame's results (never torn), frames
+    must only move forward, and the final one must equal the getters."""
+    import threading
+    import oracle_lib as O
+    n = 2048 * 120
+    iq, _, _ = O.make_dbpsk_stream(8, 0, n, noise_sigma=700.0)
+    buf = O.convert_i16(iq)
+    d = J.Bpsk(nstreams=1)
+    with pytest.raises(J.JsdrError):
+        d.snapshot()  # nothing received yet
+    seen, stop, bad = [], threading.Event(), []
+
+    def reader():
+        last = 0
+        while not stop.is_set():
+            try:
+                sn = d.snapshot()
+            except J.JsdrError:
+                continue
+            c = list(sn.counters)
+            if sn.frames < last or c[0] != 2048 * sn.frames or c[1] != (2048 * sn.frames) // 10:
+                bad.append((sn.frames, c[:3]))
+            last = sn.frames
+            seen.append(sn.frames)
+
+    t = threading.Thread(target=reader)
+    t.start()
+    for k in range(120):
+        d.receive(buf[k * 4096:(k + 1) * 4096])
+    stop.set()
+    t.join()
+    assert not bad, bad[:5]
+    assert len(set(seen)) > 3  # the reader really ran beside the writer
+    sn = d.snapshot()
+    assert sn.frames == 120
+    c = d.counters()
+    assert list(sn.counters) == [c[k] for k in J.binding.COUNTER_NAMES]
+    assert np.array_equal(np.array(sn.state[:]), d.state())
+    assert np.array_equal(np.frombuffer(bytes(sn.decoded), np.uint8), d.decoded())
+    assert np.array_equal(np.array(sn.bits[:sn.nbits], np.int8), d.bits())
