@@ -1451,7 +1451,10 @@ struct jsdr_bpsk {
     DevBuf<long long> phase_clk;  // JSDR_FFT_PHASECLK=1: k_front_fft's per-phase cycle counts, printed at destroy
     int logn = 0;
     bool fft_mixed = false;  // FFT-acquire frame is not a power of two (bpsk_fftm.hip)
-    int fm_np = 0, fm_rad[12] = {0}, fm_off[12] = {0};
+    bool fft_2x = false;     // ... and is 2 m with m an LDS-sized frame (n = 19200): two m-point halves per transform
+    int fm_np = 0, fm_rad[12] = {0}, fm_off[12] = {0}, fm_off1[12] = {0};
+    DevBuf<double2> fft2x_ek;  // per-stream scratch of the 2 m front end
+    DevBuf<double> fft2x_r0;
     long long last_nds = 0;
     int last_y = 0;
     hipStream_t last_stream = 0;
@@ -1890,9 +1893,10 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
         xa.ds_taps = h->ds_taps_dev.p;
         xa.phase_clk = h->phase_clk.p;
         ProfScope ps(h, PK_FRONT, st);
-        h->front_name = h->fft_mixed ? "k_front_fftm" : "k_front_fft";
-        if ((h->fft_mixed ? launch_front_fftm(xa, h->fm_np, h->fm_rad, h->fm_off, S, st) : launch_front_fft(xa, S, st)) != JSDR_OK)
-            return JSDR_ERR;
+        h->front_name = h->fft_2x ? "k_front_fft2x" : (h->fft_mixed ? "k_front_fftm" : "k_front_fft");
+        const int frc = h->fft_2x ? launch_front_fft2x(xa, h->fm_np, h->fm_rad, h->fm_off, h->fm_off1, h->fft2x_ek.p, h->fft2x_r0.p, S, st)
+                                  : (h->fft_mixed ? launch_front_fftm(xa, h->fm_np, h->fm_rad, h->fm_off, S, st) : launch_front_fft(xa, S, st));
+        if (frc != JSDR_OK) return JSDR_ERR;
     } else if (nds > 0 && fm_ok) {
         // wait for the tail that last read y[y_cur] (two calls ago) before the fused kernel overwrites it
         if (h->overlap && h->tail_pending[h->y_cur]) {
@@ -2101,9 +2105,9 @@ int jsdr_bpsk_create(jsdr_bpsk **out, int rate, int nsamples_per_frame, int tuni
     if (max_batch_samples < nsamples_per_frame) max_batch_samples = nsamples_per_frame;
     const bool fft_pow2 = nsamples_per_frame >= 1024 && nsamples_per_frame <= 8192 &&
                           (nsamples_per_frame & (nsamples_per_frame - 1)) == 0;
-    JSDR_REQUIRE(!do_fft || fft_pow2 || fftm_supported(nsamples_per_frame),
+    JSDR_REQUIRE(!do_fft || fft_pow2 || fftm_supported(nsamples_per_frame) || fft2x_supported(nsamples_per_frame),
                  "jsdr_bpsk_create: FFT-acquire mode needs a frame of 1024 / 2048 / 4096 / 8192 samples, or n = 2^a 3^b 5^c with "
-                 "n %% 16 == 0 and 1024 < n <= 9600 such as the default 9600 / 4800 (got %d)",
+                 "n %% 16 == 0 and 1024 < n <= 9600 such as the default 9600 / 4800, or twice such a frame (19200) (got %d)",
                  nsamples_per_frame);
     JSDR_REQUIRE(bit_clock_is_regular(), "jsdr_bpsk_create: bit clock schedule is not the regular 8-cycle");
     if (fec_prepare() != JSDR_OK) return JSDR_ERR;
@@ -2149,8 +2153,11 @@ int jsdr_bpsk_create(jsdr_bpsk **out, int rate, int nsamples_per_frame, int tuni
               h->fec_data.alloc(S * h->trig_cap * 256) == JSDR_OK && h->decoded.alloc(S * 256) == JSDR_OK &&
               h->stage_raw.alloc((size_t)nsamples_per_frame * 2) == JSDR_OK && h->ds_taps_dev.alloc(32) == JSDR_OK &&
               h->dmh[0].alloc(S * 64) == JSDR_OK && h->dmh[1].alloc(S * 64) == JSDR_OK && h->tcs.alloc(256 + FM_TABLE_SLACK) == JSDR_OK &&
-              (!do_fft || (h->fft_state.alloc(S) == JSDR_OK && h->fft_tw.alloc(fft_pow2 ? (size_t)nsamples_per_frame : (size_t)32768) == JSDR_OK &&
-                            h->vco_cs.alloc((size_t)h->max_ds) == JSDR_OK));
+              (!do_fft || (h->fft_state.alloc(S) == JSDR_OK && h->fft_tw.alloc(fft_pow2 ? (size_t)nsamples_per_frame : (size_t)65536) == JSDR_OK &&
+                            h->vco_cs.alloc((size_t)h->max_ds) == JSDR_OK)) &&
+              (!(do_fft && fft2x_supported(nsamples_per_frame)) ||
+               (h->fft2x_ek.alloc(S * fft2x_scratch_ek(nsamples_per_frame)) == JSDR_OK &&
+                h->fft2x_r0.alloc(S * fft2x_scratch_r0(nsamples_per_frame)) == JSDR_OK));
     if (!ok) {
         jsdr_bpsk_destroy(h);
         return JSDR_ERR;
@@ -2184,8 +2191,11 @@ int jsdr_bpsk_create(jsdr_bpsk **out, int rate, int nsamples_per_frame, int tuni
     if (do_fft) {
         std::vector<double2> tw;
         h->fft_mixed = !fft_pow2;
+        h->fft_2x = !fft_pow2 && fft2x_supported(nsamples_per_frame);
         if (fft_pow2)
             fft_twiddles_f64(tw, nsamples_per_frame);
+        else if (h->fft_2x)
+            fft2x_twiddles(tw, nsamples_per_frame, &h->fm_np, h->fm_rad, h->fm_off, h->fm_off1);
         else
             fftm_twiddles(tw, nsamples_per_frame, &h->fm_np, h->fm_rad, h->fm_off);
         if (tw.size() > h->fft_tw.n || hipMemcpy(h->fft_tw.p, tw.data(), sizeof(double2) * tw.size(), hipMemcpyHostToDevice) != hipSuccess ||
@@ -2266,6 +2276,8 @@ int jsdr_bpsk_destroy(jsdr_bpsk *h)
     h->stage_raw.release();
     h->fft_state.release();
     h->fft_tw.release();
+    h->fft2x_ek.release();
+    h->fft2x_r0.release();
     h->vco_cs.release();
     if (h->phase_clk.p) {
         static const char *const names_p2[8] = {"load+scatter", "forward FFT", "|X|", "boxcar+argmax", "centre-bin rule",

@@ -95,5 +95,12 @@ bool fftm_supported(int n);
 void fftm_twiddles(std::vector<double2> &w, int n, int *np_out, int *rad, int *tw_off);
 int launch_front_fftm(const FftFrontArgs &a, int np, const int *rad, const int *tw_off, int nstreams, hipStream_t st);
 void fft_twiddles_f64(std::vector<double2> &w, int n);
+// frames of 2 m samples, m an LDS-sized mixed-radix frame (n = 19200 at 192 kHz): two m-point halves per transform
+bool fft2x_supported(int n);
+void fft2x_twiddles(std::vector<double2> &w, int n, int *np_out, int *rad, int *tw_off, int *tw1_off);
+size_t fft2x_scratch_ek(int n);
+size_t fft2x_scratch_r0(int n);
+int launch_front_fft2x(const FftFrontArgs &a, int np, const int *rad, const int *tw_off, const int *tw1_off, double2 *ek,
+                       double *r0, int nstreams, hipStream_t st);
 
 }  // namespace jsdr

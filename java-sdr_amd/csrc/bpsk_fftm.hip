@@ -567,6 +567,266 @@ __global__ __launch_bounds__(FM_T) void k_front_fftm(FftmArgs aa)
     }
 }
 
+// ============================================================================================== frames of 2 m samples
+// n = 19200 (192 kHz with java-sdr's default buffer, JavaAudio.java:58-59: the FUNcube Dongle Pro+ frame): 307 KB as
+// double2, twice a workgroup's LDS.  The oracle's transform for n > 9600 starts with ONE radix-2 pass
+// (jo_fft_mixed_radices), which splits it into two INDEPENDENT m = n/2 point halves: half c (0 / 1) holds, pass after
+// pass, the elements of parity c, and ends as the even / odd output bins.  In half-array coordinates every later
+// pass is the m-point Stockham pass; only its twiddles differ: T_{2P'r}[(2k'+c) j] instead of T_{P'r}[k' j] -- for c = 0
+// the same numbers (the m-point tables; the long-double arguments scale by an exact 2), for c = 1 a table of its own.
+// So a frame is four m-point transforms in the one LDS image (forward c = 0, 1, inverse c = 0, 1); what has to
+// outlive the image goes through a per-stream scratch in global memory (L2 sized: 154 KB):
+//   ek : the even bins the 204-bin gather may need (bins below n/2 + 102) -- written after the forward c = 0 half
+//   r0 : the even output samples re * (1/n) of the inverse -- read by RxDownSample beside the odd ones in LDS
+// Same butterflies, same tables, same order as the oracle's fft_f64_mixed with radices 2,4,4,4,2,3,5,5: bit-identical
+// centre bins, traces, bits.  Not tuned: single passes for the c = 1 halves, twiddles from L2.
+struct Fft2xArgs {
+    FftmArgs sub;             // the m-point plan (sub.f.n = m) and everything else of the front end
+    int n;                    // 2 m
+    int tw1_off[FM_MAXPASS];  // c = 1 tables, [(j-1) P' + k'] = T_{2 P' r}[(2 k' + 1) j], behind the m-point tables in sub.f.tw
+    double2 *ek;              // [S][ek_stride]
+    double *r0;               // [S][r0_stride]
+    long long ek_stride, r0_stride;
+};
+
+// one Stockham pass with a two-dimensional twiddle table tw[(j-1) P + k], every input j >= 1 multiplied (also at P = 1)
+template <int R>
+__device__ __attribute__((noinline)) void fm_pass_t(double2 *X, const double2 *tw, int n, int P, unsigned pmagic, int tid)
+{
+    constexpr int ITERS = ((FM_NMAX / R) + FM_T - 1) / FM_T;
+    const int nb = n / R;
+    double2 v[ITERS][R];
+#pragma unroll
+    for (int it = 0; it < ITERS; it++) {
+        const int b = it * FM_T + tid;
+        if (b < nb) {
+            const int k = (P == 1) ? 0 : b - (int)__umulhi((unsigned)b, pmagic) * P;
+#pragma unroll
+            for (int j = 0; j < R; j++) {
+                v[it][j] = X[b + j * nb];
+                if (j >= 1) v[it][j] = cdmul(v[it][j], tw[(j - 1) * P + k]);
+            }
+            dft_r<R>(v[it]);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < ITERS; it++) {
+        const int b = it * FM_T + tid;
+        if (b < nb) {
+            const int k = (P == 1) ? 0 : b - (int)__umulhi((unsigned)b, pmagic) * P;
+            const int j0 = (b - k) * R + k;
+#pragma unroll
+            for (int q = 0; q < R; q++) X[j0 + q * P] = v[it][q];
+        }
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void fm_forward_odd(double2 *X, const Fft2xArgs &a, int tid)
+{
+    const FftmArgs &m = a.sub;
+    int P = 1;
+    for (int p = 0; p < m.np; p++) {
+        const int r = m.rad[p];
+        const double2 *tw = m.f.tw + a.tw1_off[p];
+        if (r == 4)
+            fm_pass_t<4>(X, tw, m.f.n, P, m.pmagic[p], tid);
+        else if (r == 2)
+            fm_pass_t<2>(X, tw, m.f.n, P, m.pmagic[p], tid);
+        else if (r == 3)
+            fm_pass_t<3>(X, tw, m.f.n, P, m.pmagic[p], tid);
+        else
+            fm_pass_t<5>(X, tw, m.f.n, P, m.pmagic[p], tid);
+        P *= r;
+    }
+}
+
+template <bool F32IN>
+__global__ __launch_bounds__(FM_T) void k_front_fft2x(Fft2xArgs aa)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const FftFrontArgs &a = aa.sub.f;
+    const int n = aa.n, m = n / 2;
+    double2 *X = reinterpret_cast<double2 *>(smem);      // [m]: one half at a time
+    double *hist = reinterpret_cast<double *>(X + m);    // [64]: [0,26) the previous frame's last 26 scaled samples
+    double *redv = hist + 64;
+    int *redi = reinterpret_cast<int *>(redv + 16);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int s = blockIdx.x;
+    const int beg = a.do_up ? n / 4 : 0;
+    const int end = a.do_up ? n / 2 : n / 4;
+    const int pbase = beg + 24, abase = beg + 74;
+    // |X| and the boxcar sums live behind the odd bins the gather may still need (bins < n/2 + 102 <=> slot < m/2 + 51)
+    double *P = reinterpret_cast<double *>(X + (m / 2 + 56));
+    double *A = P + (n / 4 - 48);
+    FftFrontState *sp = &a.st[s];
+    if (tid < 26) hist[tid] = sp->hist[tid];
+    double avePeakPower = sp->avePeakPower, aveCentreBin = sp->aveCentreBin;
+    int centreBin = sp->centreBin;
+    const double CFREQ_INV = (double)(1.0F - (2.0F / (1 + 1))), CFREQ_AVG = (double)(2.0F / (1 + 1));
+    const double PSD_INV = (double)(1.0F - (2.0F / (10 + 1))), PSD_AVG = (double)(2.0F / (10 + 1));
+    const double HOWARD = 0.9 * 32768.0;
+    const int D = a.decim;
+    const double norm = 1.0 / (double)n;
+    const int *__restrict__ raw = a.raw + (long long)s * a.stride_pairs;
+    const float2 *__restrict__ rawf = a.rawf + (long long)s * a.stride_pairs;
+    double2 *dm = a.dm + (long long)s * a.dm_stride;
+    double2 *ek = aa.ek + (long long)s * aa.ek_stride;
+    double *r0 = aa.r0 + (long long)s * aa.r0_stride;
+    const int nek = m / 2 + 52;
+    __syncthreads();
+
+    // the radix-2 first pass straight from the frame's samples: X[b] = x[b] +/- x[b + m]   (:416-421, dft_r<2>)
+    auto load_half = [&](long long t0, int c, int tf) {
+        for (int b = tf; b < m; b += FM_T) {
+            double2 v0, v1;
+            if (F32IN) {
+                const float2 f0 = rawf[t0 + b], f1 = rawf[t0 + b + m];
+                v0 = make_double2((double)f0.x, (double)f0.y);
+                v1 = make_double2((double)f1.x, (double)f1.y);
+            } else {
+                const int w0 = raw[t0 + b], w1 = raw[t0 + b + m];
+                v0 = make_double2((double)i16_to_float_java(java_short_add((int)(short)(w0 & 0xffff), a.ic)),
+                                  (double)i16_to_float_java(java_short_add(w0 >> 16, a.qc)));
+                v1 = make_double2((double)i16_to_float_java(java_short_add((int)(short)(w1 & 0xffff), a.ic)),
+                                  (double)i16_to_float_java(java_short_add(w1 >> 16, a.qc)));
+            }
+            X[b] = c ? cdsub(v0, v1) : cdadd(v0, v1);
+        }
+        __syncthreads();
+    };
+    // bin `bin` of the full spectrum after both forward halves: even bins from the scratch, odd ones from the image
+    auto spectrum = [&](int bin) -> double2 { return (bin & 1) ? X[bin >> 1] : ek[bin >> 1]; };
+
+    for (int f = 0; f < a.nframes; f++) {
+        const long long t0 = (long long)f * n;
+        int tf = tid;
+        asm volatile("" : "+v"(tf));
+        // ---- forward, even bins
+        load_half(t0, 0, tf);
+        fm_forward(X, nullptr, aa.sub, tf, false);
+        for (int i = tf; i < nek; i += FM_T) ek[i] = X[i];
+        __threadfence_block();
+        __syncthreads();
+        // ---- forward, odd bins
+        load_half(t0, 1, tf);
+        fm_forward_odd(X, aa, tf);
+        // ---- |X| over the band the boxcar reads (:425-427)
+        for (int i = pbase + tf; i < end - 24; i += FM_T) {
+            const double2 v = spectrum(i);
+            P[i - pbase] = sqrt(v.x * v.x + v.y * v.y);
+        }
+        __syncthreads();
+        // ---- 100-wide boxcar, first maximum (:433-442)
+        double bestv = 0.0;
+        int besti = -1;
+        for (int i = beg + 74 + 2 * tf; i < end - 75; i += 2 * FM_T) {
+            const double2 *w = reinterpret_cast<const double2 *>(P + (i - 50 - pbase));
+            double a0, a1;
+            boxcar_pair(w, a0, a1);
+            asm volatile("" : "+v"(a0), "+v"(a1));
+            if (i >= beg + 75) {
+                A[i - abase] = a0;
+                if (bestv < a0) {
+                    bestv = a0;
+                    besti = i;
+                }
+            }
+            if (i + 1 < end - 75) {
+                A[i + 1 - abase] = a1;
+                if (bestv < a1) {
+                    bestv = a1;
+                    besti = i + 1;
+                }
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const double ov = __shfl_xor(bestv, off, 64);
+            const int oi = __shfl_xor(besti, off, 64);
+            if (oi >= 0 && (ov > bestv || (ov == bestv && (besti < 0 || oi < besti)))) {
+                bestv = ov;
+                besti = oi;
+            }
+        }
+        if (lane == 0) {
+            redv[wave] = bestv;
+            redi[wave] = besti;
+        }
+        __syncthreads();
+        // ---- centre-bin rule (:444-453)
+        {
+            double maxBin = 0.0;
+            int binPos = -1;
+            for (int w = 0; w < FM_T / 64; w++) {
+                const double ov = redv[w];
+                const int oi = redi[w];
+                if (oi >= 0 && (ov > maxBin || (ov == maxBin && (binPos < 0 || oi < binPos)))) {
+                    maxBin = ov;
+                    binPos = oi;
+                }
+            }
+            if (centreBin < 0) centreBin = 0;
+            if (centreBin > end - 1) centreBin = end - 1;
+            const double atc = (centreBin >= beg + 75 && centreBin < end - 75) ? A[centreBin - abase] : 0.0;
+            avePeakPower = (PSD_AVG * atc) + (PSD_INV * avePeakPower);
+            if (maxBin > (avePeakPower / 4) * 5 && binPos > 0) {
+                aveCentreBin = (CFREQ_AVG * (double)(float)binPos) + (CFREQ_INV * aveCentreBin);
+                centreBin = (int)(aveCentreBin + (double)1.0F);
+            }
+            if (centreBin < 102) centreBin = 102;
+        }
+        // ---- 204 bins around the centre to bin 0 of a zeroed array (:458); inverse (:459) as conj o forward o conj
+        double2 keep = make_double2(0.0, -0.0);  // conj of the zeroed array
+        if (tf < 204) {
+            const double2 v = spectrum(centreBin - 102 + tf);
+            keep = make_double2(v.x, -v.y);
+        }
+        __syncthreads();
+        const double2 Z = make_double2(0.0, -0.0);
+        // even output samples: first-pass sums z[b] + z[b + m], z[b + m] being the zeroed array's
+        for (int b = tf; b < m; b += FM_T) X[b] = cdadd(b < 204 ? keep : Z, Z);
+        __syncthreads();
+        fm_forward(X, nullptr, aa.sub, tf, false);
+        for (int i = tf; i < m; i += FM_T) r0[i] = X[i].x * norm;  // re = X.x / n (:462), sample 2 i
+        __threadfence_block();
+        __syncthreads();
+        // odd output samples: first-pass differences
+        for (int b = tf; b < m; b += FM_T) X[b] = cdsub(b < 204 ? keep : Z, Z);
+        __syncthreads();
+        fm_forward_odd(X, aa, tf);
+        // ---- RxDownSample(re, re) (:461-463, :470-492): sample t of the frame = r0[t/2] (t even) or X[t/2].x / n (t odd)
+        auto sample = [&](int t) -> double { return t < 0 ? hist[26 + t] : ((t & 1) ? X[t >> 1].x * norm : r0[t >> 1]); };
+        {
+            long long jlo = (t0 - a.first_out + D - 1) / D;
+            if (t0 <= a.first_out) jlo = 0;
+            for (long long j = jlo + tf;; j += FM_T) {
+                const long long te = (long long)a.first_out + (long long)D * j;
+                if (te >= t0 + n || j >= a.nds) break;
+                const double2 cs = a.vco_cs[j];
+                const int e = (int)(te - t0);
+                double fi = 0.0;
+#pragma unroll
+                for (int k = 0; k < 27; k++) fi += sample(e - k) * ds_tap(k);  // newest first (:479-483)
+                const double o = fi * HOWARD;
+                dm[64 + j] = make_double2(o * cs.x, o * cs.y);  // :515-516
+            }
+        }
+        double hnew = 0.0;
+        if (tf < 26) hnew = sample(n - 26 + tf);
+        __syncthreads();
+        if (tf < 26) hist[tf] = hnew;
+        __syncthreads();
+    }
+    if (tid < 26) sp->hist[tid] = hist[tid];
+    if (tid == 0) {
+        sp->avePeakPower = avePeakPower;
+        sp->aveCentreBin = aveCentreBin;
+        sp->centreBin = centreBin;
+    }
+}
+
 // radix list for n = 2^a 3^b 5^c (the oracle's jo_fft_mixed_radices); 0: unsupported
 int fftm_radices(int n, int *rad)
 {
@@ -660,6 +920,81 @@ int launch_front_fftm(const FftFrontArgs &a, int np, const int *rad, const int *
         hipLaunchKernelGGL(k_front_fftm<true>, dim3((unsigned)nstreams), dim3(FM_T), lds, st, aa);
     else
         hipLaunchKernelGGL(k_front_fftm<false>, dim3((unsigned)nstreams), dim3(FM_T), lds, st, aa);
+    JSDR_LAUNCH_CHECK();
+    return JSDR_OK;
+}
+
+// frames of n = 2 m samples with m an LDS-sized mixed-radix frame (n = 19200: m = 9600)
+bool fft2x_supported(int n) { return n > FM_NMAX && (n % 2) == 0 && fftm_supported(n / 2); }
+
+// the m-point tables (fftm_twiddles) followed by the c = 1 tables U_p[(j-1) P' + k'] = T_{2 P' r}[(2 k' + 1) j]
+void fft2x_twiddles(std::vector<double2> &w, int n, int *np_out, int *rad, int *tw_off, int *tw1_off)
+{
+    const int m = n / 2;
+    fftm_twiddles(w, m, np_out, rad, tw_off);
+    int P = 1;
+    for (int p = 0; p < *np_out; p++) {
+        const int r = rad[p], len = 2 * P * r;
+        tw1_off[p] = (int)w.size();
+        const size_t o = w.size();
+        w.resize(o + (size_t)(r - 1) * P);
+        for (int j = 1; j < r; j++) {
+            for (int k = 0; k < P; k++) {
+                const int mm = (2 * k + 1) * j;  // < len
+                const long double ang = 2.0L * 3.14159265358979323846264338327950288L * (long double)mm / (long double)len;
+                double2 t = make_double2((double)cosl(ang), (double)(-sinl(ang)));
+                // exact on the axes, as jo_fft_mixed_table
+                if (mm == 0) t = make_double2(1.0, -0.0);
+                if (len % 4 == 0 && mm == len / 4) t = make_double2(0.0, -1.0);
+                if (len % 4 == 0 && mm == 3 * len / 4) t = make_double2(-0.0, 1.0);
+                if (len % 2 == 0 && mm == len / 2) t = make_double2(-1.0, -0.0);
+                w[o + (size_t)(j - 1) * P + k] = t;
+            }
+        }
+        P *= r;
+    }
+}
+
+size_t fft2x_scratch_ek(int n) { return (size_t)(n / 4 + 52); }
+size_t fft2x_scratch_r0(int n) { return (size_t)(n / 2); }
+
+int launch_front_fft2x(const FftFrontArgs &a, int np, const int *rad, const int *tw_off, const int *tw1_off, double2 *ek,
+                       double *r0, int nstreams, hipStream_t st)
+{
+    Fft2xArgs aa;
+    aa.sub.f = a;
+    aa.sub.f.n = a.n / 2;
+    aa.sub.np = np;
+    aa.sub.lds_tw = 0;
+    aa.n = a.n;
+    int P = 1;
+    for (int p = 0; p < FM_MAXPASS; p++) {
+        aa.sub.rad[p] = p < np ? rad[p] : 1;
+        aa.sub.tw_off[p] = p < np ? tw_off[p] : 0;
+        aa.tw1_off[p] = p < np ? tw1_off[p] : 0;
+        aa.sub.pmagic[p] = (unsigned)(((1ull << 32) + (unsigned)P - 1) / (unsigned)P);
+        if (p < np) P *= rad[p];
+    }
+    aa.ek = ek;
+    aa.r0 = r0;
+    aa.ek_stride = (long long)fft2x_scratch_ek(a.n);
+    aa.r0_stride = (long long)fft2x_scratch_r0(a.n);
+    const size_t lds = sizeof(double2) * (size_t)(a.n / 2) + sizeof(double) * (64 + 16) + sizeof(int) * 16 + 64;
+    const bool f32 = a.rawf != nullptr;
+    static size_t attr_for[2] = {0, 0};
+    if (attr_for[f32] < lds) {
+        if (f32)
+            JSDR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_front_fft2x<true>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        else
+            JSDR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_front_fft2x<false>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_for[f32] = lds;
+    }
+    if (f32)
+        hipLaunchKernelGGL(k_front_fft2x<true>, dim3((unsigned)nstreams), dim3(FM_T), lds, st, aa);
+    else
+        hipLaunchKernelGGL(k_front_fft2x<false>, dim3((unsigned)nstreams), dim3(FM_T), lds, st, aa);
     JSDR_LAUNCH_CHECK();
     return JSDR_OK;
 }

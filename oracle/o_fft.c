@@ -73,7 +73,8 @@ void jo_fft_twiddles_f64(double *w, int n)
  * The HIP double FFT (csrc/bpsk_fft.hip) performs the same butterflies on the same
  * twiddle table, so both are bit-identical.  PARITY UNPINNED vs JTransforms.          */
 /* ---- non power-of-two frames (n = 2^a 3^b 5^c, e.g. the reference's default 9600 = blen/size):
- * Stockham autosort passes, radices 4,4,..,(2),3..,5.. in this order; pass with radix r and P = product of the
+ * Stockham autosort passes, radices 4,4,..,(2),3..,5.. in this order (frames above 9600 samples: one radix-2 pass
+ * first, see jo_fft_mixed_radices); pass with radix r and P = product of the
  * earlier radices takes butterfly b (k = b mod P) from in[b + j*n/r], j < r, multiplies input j >= 1 by the
  * table entry T[k*j] = exp(-2 pi i k j/(P r)) (cosl/sinl rounded once; exact on the axes), applies the fixed-order
  * r-point DFT below and stores output q at out[(b-k)*r + k + q*P].  The inverse transform is
@@ -128,6 +129,10 @@ int jo_fft_mixed_radices(int n, int *rad)
 {
     int c = 0;
     if (n < 2) return 0;
+    /* frames above 9600 samples (19200 = the FCD Pro+ default at 192 kHz, JavaAudio.java:58-59) start with ONE radix-2
+     * pass: it splits the transform into two independent 9600-point halves (even and odd output bins), each of which
+     * fits a workgroup's LDS on the GPU; the order is this definition's to choose (JTransforms' is unknowable here) */
+    if (n > 9600 && n % 2 == 0) { rad[c++] = 2; n /= 2; }
     while (n % 4 == 0) { rad[c++] = 4; n /= 4; }
     if (n % 2 == 0) { rad[c++] = 2; n /= 2; }
     while (n % 3 == 0) { rad[c++] = 3; n /= 3; }

@@ -264,6 +264,35 @@ def test_bpsk_fft_mode_at_the_reference_default_frames():
     same_state(d.state(), o.state())
 
 
+def test_bpsk_fft_mode_at_the_fcd_pro_plus_default_frame_19200():
+    """bpsk-dofft with java-sdr's default buffer at 192 kHz: blen = rate*size/10 = 76800 -> n = 19200 (JavaAudio.java:58-59),
+    the FUNcube Dongle Pro+ frame.  307 KB in FP64: the transform is two 9600-point halves behind one radix-2 pass
+    (k_front_fft2x), the order the oracle defines for n > 9600 -- bit-identical centre bins, traces, bits."""
+    nsf, rate = 19200, 192000
+    n = nsf * 14
+    for do_up, carrier in ((0, 13200.0), (1, 61000.0)):
+        iq = O.make_dbpsk_stream(91, 0, n, rate=rate, carrier_hz=carrier, noise_sigma=800.0)[0]
+        iq2 = O.make_dbpsk_stream(91, 1, n, rate=rate, carrier_hz=carrier + 410.0, noise_sigma=300.0)[0]
+        rng = np.random.default_rng(int(carrier))
+        noise = rng.integers(-9000, 9000, 2 * n).astype(np.int16)
+        d, oracles = run_both([iq, iq2, noise], n, [nsf * 3, nsf, nsf * 10], rate=rate, do_fft=1, do_up=do_up, blen=4 * nsf)
+        assert oracles[0].counters()["centreBin"] > 102
+    # float frames through receive(), one frame at a time; and 15360 = 2 x 7680 through the same kernel
+    d = J.Bpsk(rate=rate, blen=4 * nsf, nstreams=1, do_fft=1)
+    o = O.Bpsk(rate=rate, blen=4 * nsf, do_fft=1, trace=8192)
+    buf = O.convert_i16(O.make_dbpsk_stream(92, 0, nsf * 3, rate=rate, carrier_hz=12900.0)[0])
+    tr = []
+    for k in range(3):
+        d.receive(buf[k * 2 * nsf:(k + 1) * 2 * nsf])
+        o.receive(buf[k * 2 * nsf:(k + 1) * 2 * nsf])
+        tr.append(d.trace().copy())
+    assert np.array_equal(np.concatenate(tr), o.trace())
+    same_counters(d.counters(), o.counters())
+    same_state(d.state(), o.state())
+    iq = O.make_dbpsk_stream(93, 0, 15360 * 6, rate=rate, carrier_hz=13000.0, noise_sigma=500.0)[0]
+    run_both([iq], 15360 * 6, [15360 * 2, 15360 * 4], rate=rate, do_fft=1, blen=4 * 15360)
+
+
 def test_bpsk_fft_mode_other_mixed_radix_frames():
     """frames of 2^a 3^b 5^c samples other than the two defaults go through the run-time (unspecialised) Stockham passes
     and pass pairs: 7680 = 4.4.4.4.2.3.5 -> [4][4,4][4,2][3,5], 1440 = 4.4.2.3.3.5 -> [4][4,2][3][3,5], 1200 = 4.4.3.5.5"""
@@ -306,7 +335,7 @@ def test_bpsk_fft_mode_rejects_partial_frames_and_odd_sizes():
     with pytest.raises(J.JsdrError):
         J.Bpsk(nstreams=1, do_fft=1, blen=2000)
     with pytest.raises(J.JsdrError):
-        J.Bpsk(nstreams=1, do_fft=1, blen=76800, rate=192000)  # n = 19200 does not fit the FP64 LDS image
+        J.Bpsk(nstreams=1, do_fft=1, blen=4 * 38400, rate=192000)  # n = 38400: neither an LDS-sized frame nor twice one
     with pytest.raises(J.JsdrError):
         J.Bpsk(nstreams=1, do_fft=1, blen=4 * 7000)  # 7000 = 2^3 5^3 7: no radix-7
 
