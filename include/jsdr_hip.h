@@ -174,6 +174,9 @@ int jsdr_bpsk_snapshot_read(jsdr_bpsk *h, jsdr_bpsk_snapshot *out);
 int jsdr_bpsk_profile_enable(jsdr_bpsk *h, int on);
 int jsdr_bpsk_profile_count(void);                 /* number of kernels in the pipeline */
 const char *jsdr_bpsk_front_kernel(jsdr_bpsk *h);  /* name of the front-end kernel the last call launched */
+/* the input-independent tuner / VCO schedules built so far: on the calling thread / taken from the look-ahead worker
+ * (periodic configurations reuse one schedule and build none after the first calls) */
+int jsdr_bpsk_schedule_stats(jsdr_bpsk *h, int64_t *computed_inline, int64_t *prefetched);
 const char *jsdr_bpsk_profile_name(int k);
 int jsdr_bpsk_profile_read(jsdr_bpsk *h, double *ms_total, int *launches);
 /* device-resident result slots for the multi-GPU all-gather: per stream

@@ -390,6 +390,11 @@ class Bpsk:
         _check(lib().jsdr_bpsk_snapshot_read(self.h, C.byref(sn)), "jsdr_bpsk_snapshot_read")
         return sn
 
+    def schedule_stats(self):
+        a, b = C.c_int64(), C.c_int64()
+        _check(lib().jsdr_bpsk_schedule_stats(self.h, C.byref(a), C.byref(b)), "jsdr_bpsk_schedule_stats")
+        return dict(computed_inline=a.value, prefetched=b.value)
+
     def front_kernel_name(self):
         return lib().jsdr_bpsk_front_kernel(self.h).decode()
 

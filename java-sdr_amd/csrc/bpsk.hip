@@ -23,6 +23,7 @@
 #include "bpsk_fft.h"
 #include <math.h>
 #include <atomic>
+#include <thread>
 #include <stddef.h>
 #include <stdlib.h>
 #include <vector>
@@ -1380,6 +1381,21 @@ __global__ __launch_bounds__(64) void k_sync_fin(const int *nbits, const signed 
 using namespace jsdr;
 
 // =============================================================================================== host
+// the input-independent schedule of one call: tuner / VCO table indices per sample (FUNcubeBPSKDemod.java:384-390, :511-516)
+struct Schedule {
+    bool valid = false;
+    double tu0 = 0, vco0 = 0;  // phase state at the start of the call ...
+    int ds0 = 0;
+    long long L = -1;
+    bool first = false;        // ... which is the first of the stream (history samples are zeros)
+    unsigned char khist0[26] = {0};
+    double tu1 = 0, vco1 = 0;  // state at its end
+    int ds1 = 0, mix = 1, tper = 0;
+    long long nds = 0;
+    std::vector<unsigned char> ktu, kvco;
+    std::vector<double2> tcs;
+};
+
 struct jsdr_bpsk {
     int rate = 0, nsf = 0, tuning = 0, do_fft = 0, do_up = 0, nstreams = 0, decim = 0;
     long long max_batch = 0, max_ds = 0;
@@ -1419,6 +1435,10 @@ struct jsdr_bpsk {
     int c_tper = 0;                // period of the cached tuner schedule (0: not periodic with a period <= 256)
     bool ktu_uploaded = false;     // the device copy of the per-sample tuner index table matches the cached schedule
     std::vector<double2> h_tcs;
+    Schedule prefetch;             // the next call's schedule, stepped on `worker` while the GPU runs the current call
+    std::thread worker;
+    bool prefetch_on = true;       // JSDR_SCHED_PREFETCH=0: always on the calling thread
+    long long sched_sync = 0, sched_prefetched = 0;  // schedules computed on the calling thread / taken from the worker
     hipStream_t tail_stream = nullptr;   // non-blocking side stream for the latency-bound 9600 Hz tail + FEC
     hipEvent_t ev_matched = nullptr;     // caller stream -> tail stream: (fi,fq) of this call are complete
     hipEvent_t ev_tail_done[2] = {nullptr, nullptr};  // tail stream -> caller stream: y[i] may be overwritten
@@ -1509,8 +1529,96 @@ struct ProfScope {
 
 static const double JPI = 3.14159265358979323846;
 
-// FUNcubeBPSKDemod.java:384-390 / :511-516 -- advance the phase accumulators exactly as the reference
-// does and record the table index each sample will use.  Returns the number of decimated outputs.
+// FUNcubeBPSKDemod.java:384-390 / :511-516 -- advance the phase accumulators exactly as the reference does and record
+// the table index each sample will use.  Input independent: a function of the phase state at the start of the call,
+// the call's length and the configuration.  The recurrences round state-dependently (tuPhase += inc; wrap at 2 pi;
+// truncate tuPhase*256/(2 pi)), so they are stepped one sample at a time in double, mul THEN div -- on the host: a
+// single GPU lane needs ~35 cycles per link of this dependent FP64 chain (17 ms per 2^20 samples, against ~4 ms on a
+// host core), and the links cannot be spread over lanes.  What keeps it off the critical path instead: the state
+// repeats exactly for periodic configurations (cache hit, nothing computed), and for the others the schedule of the
+// NEXT call is computed on a worker thread while the GPU works on this one (compute_schedule + the prefetch below).
+static void compute_schedule(Schedule &sc, bool do_fft, double tuPhaseInc, int decim, const double *sincos)
+{
+    const double two_pi = 2.0 * JPI;
+    const double vinc = 2.0 * JPI * 1200.0 / (double)9600;  // VCO_PHASE_INC (:88)
+    const long long L = sc.L;
+    sc.ktu.resize((size_t)L + 26);
+    memcpy(sc.ktu.data(), sc.khist0, 26);
+    sc.kvco.clear();
+    sc.kvco.reserve((size_t)(L / decim + 2));
+    double tu = sc.tu0, vco = sc.vco0;
+    int cnt = sc.ds0;
+    long long nmix = 0;
+    unsigned char *kt = sc.ktu.data() + 26;
+    for (long long n = 0; n < L; n++) {
+        int k = 0;
+        if (!do_fft) {  // doBufferFFT never runs the tuner (:406-464)
+            tu += tuPhaseInc;
+            if (tu > two_pi) tu -= two_pi;
+            if (tu > 0.0) {  // :388
+                k = (int)(tu * (double)256 / two_pi) % 256;
+                nmix++;
+            }
+        }
+        kt[n] = (unsigned char)k;
+        if (++cnt >= decim) {
+            cnt = 0;
+            vco += vinc;
+            if (vco > two_pi) vco -= two_pi;
+            sc.kvco.push_back((unsigned char)((int)(vco * (double)256 / two_pi) % 256));
+        }
+    }
+    // tuPhase > 0 holds for every sample (tuning > 0) or for none (tuning <= 0): one flag per call
+    sc.mix = (nmix == L) ? 1 : (nmix == 0 ? 0 : -1);
+    sc.tu1 = tu;
+    sc.vco1 = vco;
+    sc.ds1 = cnt;
+    sc.nds = (long long)sc.kvco.size();
+    // Is the tuner index periodic in the sample number?  (An exact 8-cycle at 12 kHz / 96 kHz.)  Candidate from the
+    // head of the table, then verified over EVERY sample of the call, history included -- at the start of a stream
+    // the 26 history samples are zeros, whose table entry does not matter.
+    sc.tper = 0;
+    if (!do_fft && sc.mix == 1) {
+        const unsigned char *k = sc.ktu.data() + (sc.first ? 26 : 0);
+        const long long len = L + (sc.first ? 0 : 26);
+        const long long head = len < 1024 ? len : 1024;
+        for (int p = 1; p <= 256 && p < len; p++) {
+            if (memcmp(k, k + p, (size_t)(head - p)) != 0) continue;
+            if (memcmp(k, k + p, (size_t)(len - p)) == 0) {
+                sc.tper = p;
+                // unwrapped table: entry e <-> samples n with (n + 26) mod p == e mod p
+                const long long off = (sc.first ? 26 : 0);  // k[i] is the index of sample n = i + off - 26
+                sc.tcs.resize((size_t)p + FM_TABLE_SLACK);
+                for (int e = 0; e < p + FM_TABLE_SLACK; e++) {
+                    const int i = (int)(((e - off) % p + p) % p);  // smallest i >= 0 with (i + off) mod p == e mod p
+                    const int kk = k[i];
+                    sc.tcs[(size_t)e] = make_double2(sincos[kk], sincos[256 + kk]);
+                }
+            }
+            break;
+        }
+    }
+    sc.valid = true;
+}
+
+static bool schedule_matches(const Schedule &sc, double tu, double vco, int ds, const unsigned char *khist, long long L, bool first)
+{
+    return sc.valid && sc.L == L && sc.tu0 == tu && sc.vco0 == vco && sc.ds0 == ds && sc.first == first &&
+           memcmp(sc.khist0, khist, 26) == 0;
+}
+
+static void schedule_key(Schedule &sc, double tu, double vco, int ds, const unsigned char *khist, long long L, bool first)
+{
+    sc.valid = false;
+    sc.tu0 = tu;
+    sc.vco0 = vco;
+    sc.ds0 = ds;
+    sc.L = L;
+    sc.first = first;
+    memcpy(sc.khist0, khist, 26);
+}
+
+// Returns the number of decimated outputs of a call of L samples and leaves its schedule in the handle.
 static long long build_schedule(jsdr_bpsk *h, long long L)
 {
     if (h->cache_valid && h->c_L == L && h->c_tu0 == h->tuPhase && h->c_vco0 == h->vcoPhase && h->c_ds0 == h->dsCnt &&
@@ -1522,73 +1630,46 @@ static long long build_schedule(jsdr_bpsk *h, long long L)
         memcpy(h->h_khist, h->h_ktu.data() + L, 26);
         return h->c_nds;
     }
-    const double two_pi = 2.0 * JPI;
-    const double vinc = 2.0 * JPI * 1200.0 / (double)9600;  // VCO_PHASE_INC (:88)
-    h->c_tu0 = h->tuPhase;
-    h->c_vco0 = h->vcoPhase;
-    h->c_ds0 = h->dsCnt;
-    memcpy(h->c_khist, h->h_khist, 26);
-    h->h_ktu.resize((size_t)L + 26);
-    memcpy(h->h_ktu.data(), h->h_khist, 26);
-    h->h_kvco.clear();
-    double tu = h->tuPhase, vco = h->vcoPhase;
-    int cnt = h->dsCnt;
-    long long nmix = 0;
-    for (long long n = 0; n < L; n++) {
-        int k = 0;
-        if (!h->do_fft) {  // doBufferFFT never runs the tuner (:406-464)
-            tu += h->tuPhaseInc;
-            if (tu > two_pi) tu -= two_pi;
-            if (tu > 0.0) {  // :388
-                k = (int)(tu * (double)256 / two_pi) % 256;
-                nmix++;
-            }
-        }
-        h->h_ktu[(size_t)n + 26] = (unsigned char)k;
-        if (++cnt >= h->decim) {
-            cnt = 0;
-            vco += vinc;
-            if (vco > two_pi) vco -= two_pi;
-            h->h_kvco.push_back((unsigned char)((int)(vco * (double)256 / two_pi) % 256));
-        }
+    if (h->worker.joinable()) h->worker.join();
+    Schedule &pf = h->prefetch;
+    const bool first = h->n_in == 0;
+    if (!schedule_matches(pf, h->tuPhase, h->vcoPhase, h->dsCnt, h->h_khist, L, first)) {
+        schedule_key(pf, h->tuPhase, h->vcoPhase, h->dsCnt, h->h_khist, L, first);
+        compute_schedule(pf, h->do_fft != 0, h->tuPhaseInc, h->decim, h->h_sincos.data());
+        h->sched_sync++;
+    } else {
+        h->sched_prefetched++;
     }
-    // tuPhase > 0 holds for every sample (tuning > 0) or for none (tuning <= 0): one flag per handle
-    h->mix = (nmix == L) ? 1 : (nmix == 0 ? 0 : -1);
-    h->tuPhase = tu;
-    h->vcoPhase = vco;
-    h->dsCnt = cnt;
-    h->c_tu1 = tu;
-    h->c_vco1 = vco;
-    h->c_ds1 = cnt;
+    // adopt it (the vectors change hands: the outgoing ones become the worker's scratch)
+    h->c_tu0 = pf.tu0;
+    h->c_vco0 = pf.vco0;
+    h->c_ds0 = pf.ds0;
+    memcpy(h->c_khist, pf.khist0, 26);
+    h->h_ktu.swap(pf.ktu);
+    h->h_kvco.swap(pf.kvco);
+    if (pf.tper > 0) h->h_tcs.swap(pf.tcs);
+    h->c_tper = pf.tper;
+    h->mix = h->c_mix = pf.mix;
+    h->tuPhase = h->c_tu1 = pf.tu1;
+    h->vcoPhase = h->c_vco1 = pf.vco1;
+    h->dsCnt = h->c_ds1 = pf.ds1;
     h->c_L = L;
-    h->c_mix = h->mix;
-    h->c_nds = (long long)h->h_kvco.size();
+    h->c_nds = pf.nds;
     memcpy(h->h_khist, h->h_ktu.data() + L, 26);
     h->cache_valid = false;  // device copy refreshed by the caller
-    // Is the tuner index periodic in the sample number?  (An exact 8-cycle at 12 kHz / 96 kHz.)  Candidate from the
-    // head of the table, then verified over EVERY sample of the call, history included -- at the start of a stream
-    // the 26 history samples are zeros, whose table entry does not matter.
-    h->c_tper = 0;
-    if (!h->do_fft && h->mix == 1) {
-        const unsigned char *k = h->h_ktu.data() + (h->n_in == 0 ? 26 : 0);
-        const long long len = L + (h->n_in == 0 ? 0 : 26);
-        const long long head = len < 1024 ? len : 1024;
-        for (int p = 1; p <= 256 && p < len; p++) {
-            if (memcmp(k, k + p, (size_t)(head - p)) != 0) continue;
-            if (memcmp(k, k + p, (size_t)(len - p)) == 0) {
-                h->c_tper = p;
-                // unwrapped table: entry e <-> samples n with (n + 26) mod p == e mod p
-                const long long off = (h->n_in == 0 ? 26 : 0);  // k[i] is the index of sample n = i + off - 26
-                h->h_tcs.resize((size_t)p + FM_TABLE_SLACK);
-                for (int e = 0; e < p + FM_TABLE_SLACK; e++) {
-                    // smallest i >= 0 with (i + off) mod p == e mod p
-                    const int i = (int)(((e - off) % p + p) % p);
-                    const int kk = k[i];
-                    h->h_tcs[(size_t)e] = make_double2(h->h_sincos[kk], h->h_sincos[256 + kk]);
-                }
-            }
-            break;
-        }
+    pf.valid = false;
+    // the next call, assuming the same length: nothing to do if the state has come back to where this call started (the
+    // cache will hit), otherwise step it on the worker thread while the GPU runs this call
+    const bool comes_back = h->c_tu1 == h->c_tu0 && h->c_vco1 == h->c_vco0 && h->c_ds1 == h->c_ds0 &&
+                            memcmp(h->h_khist, h->c_khist, 26) == 0;
+    if (!comes_back && h->prefetch_on && L >= 65536) {  // (a short call's schedule costs less than starting a thread)
+        schedule_key(pf, h->tuPhase, h->vcoPhase, h->dsCnt, h->h_khist, L, false);
+        const bool do_fft = h->do_fft != 0;
+        const double inc = h->tuPhaseInc;
+        const int decim = h->decim;
+        const double *sincos = h->h_sincos.data();
+        Schedule *dst = &pf;
+        h->worker = std::thread([dst, do_fft, inc, decim, sincos] { compute_schedule(*dst, do_fft, inc, decim, sincos); });
     }
     return h->c_nds;
 }
@@ -2136,6 +2217,7 @@ int jsdr_bpsk_create(jsdr_bpsk **out, int rate, int nsamples_per_frame, int tuni
     if (const char *e = getenv("JSDR_NO_OVERLAP")) h->overlap = atoi(e) == 0;
     if (const char *e = getenv("JSDR_FRONT_DMA")) h->front_dma = atoi(e) != 0;
     if (const char *e = getenv("JSDR_FM")) h->use_fm = atoi(e) != 0;
+    if (const char *e = getenv("JSDR_SCHED_PREFETCH")) h->prefetch_on = atoi(e) != 0;
     const size_t S = (size_t)nstreams;
     h->dm_stride = 64 + h->max_ds + 64;
     h->y_stride = h->max_ds;
@@ -2241,6 +2323,7 @@ int jsdr_bpsk_create(jsdr_bpsk **out, int rate, int nsamples_per_frame, int tuni
 int jsdr_bpsk_destroy(jsdr_bpsk *h)
 {
     if (!h) return JSDR_OK;
+    if (h->worker.joinable()) h->worker.join();
     h->sincos.release();
     h->ktu.release();
     h->kvco.release();
@@ -2548,6 +2631,14 @@ int jsdr_bpsk_table(int which, double *out, int cap)
 int jsdr_bpsk_profile_count(void) { return PK_COUNT; }
 
 const char *jsdr_bpsk_front_kernel(jsdr_bpsk *h) { return h ? h->front_name : ""; }
+
+int jsdr_bpsk_schedule_stats(jsdr_bpsk *h, int64_t *computed_inline, int64_t *prefetched)
+{
+    JSDR_REQUIRE(h, "jsdr_bpsk_schedule_stats: null handle");
+    if (computed_inline) *computed_inline = h->sched_sync;
+    if (prefetched) *prefetched = h->sched_prefetched;
+    return JSDR_OK;
+}
 
 int jsdr_bpsk_set_variant(jsdr_bpsk *h, int variant)
 {

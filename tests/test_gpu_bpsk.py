@@ -420,3 +420,26 @@ def test_bpsk_more_sync_hits_than_the_log_holds_is_flagged_not_truncated_silentl
     for getter in (d.bits, d.fec_results, d.decoded, d.counters):
         with pytest.raises(J.JsdrError):
             getter(0)
+
+
+def test_bpsk_schedule_look_ahead_for_non_periodic_tuning():
+    """a tuning whose phase never repeats (12345 Hz at 192 kHz) needs a fresh tuner / VCO schedule
+    every call.  The schedule of call k+1 is stepped on a worker thread while the GPU runs call k; results stay
+    bit-identical to the oracle, with and without the look-ahead."""
+    rate, n, chunk = 192000, 4 * 131072, 131072
+    iq = O.make_dbpsk_stream(61, 0, n, rate=rate, carrier_hz=13545.0, noise_sigma=600.0)[0]
+    noise = np.random.default_rng(3).integers(-15000, 15000, 2 * n).astype(np.int16)
+    d, _ = run_both([iq, noise], n, [chunk] * 4, rate=rate, tuning=12345)
+    st = d.schedule_stats()
+    assert st["prefetched"] == 3 and st["computed_inline"] == 1, st
+    # a call of another length than the one looked ahead for: computed on the spot, still exact
+    d2, _ = run_both([iq], n, [chunk, chunk, 2 * chunk], rate=rate, tuning=12345)
+    st = d2.schedule_stats()
+    assert st["prefetched"] == 1 and st["computed_inline"] == 2, st
+    # the periodic default (12 kHz at 96 kHz) with calls that are whole tuner / decimator periods long: the state comes
+    # back to where it was, one schedule (two: the first call's history is the stream start's zeros) serves every call
+    c96 = 131040  # a multiple of 8 (tuner cycle) and of 10 (decimation)
+    iq96 = O.make_dbpsk_stream(62, 0, 4 * c96, noise_sigma=600.0)[0]
+    d3, _ = run_both([iq96], 4 * c96, [c96] * 4)
+    st = d3.schedule_stats()
+    assert st["prefetched"] + st["computed_inline"] <= 2, st
