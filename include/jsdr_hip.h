@@ -131,6 +131,10 @@ int jsdr_bpsk_table(int which, double *out, int cap);
  * bytes identical, doubles within 1e-12 relative).                                                          */
 enum { JSDR_VARIANT_EXACT = 0, JSDR_VARIANT_FAST = 1 };
 int jsdr_bpsk_set_variant(jsdr_bpsk *h, int variant);
+/* FAST: decisions recomputed in exact order so far (all streams), streams that could not be certified (their getters
+ * fail), and the bound on |fi' - fi|, |fq' - fq| the margins are built on.  In FAST mode the input buffer of a batch
+ * call must stay unmodified until the next jsdr_bpsk_sync() / getter: the certification pass may re-read it. */
+int jsdr_bpsk_cert_stats(jsdr_bpsk *h, int64_t *redone, int64_t *uncertified_streams, double *ey);
 /* receive(float[]) / raw form for stream 0 of a 1-stream handle (:357-364) */
 int jsdr_bpsk_receive_f32(jsdr_bpsk *h, const float *iq_host);
 int jsdr_bpsk_receive_i16(jsdr_bpsk *h, const int16_t *raw_host, int ic, int qc);

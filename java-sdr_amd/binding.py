@@ -390,6 +390,11 @@ class Bpsk:
         _check(lib().jsdr_bpsk_snapshot_read(self.h, C.byref(sn)), "jsdr_bpsk_snapshot_read")
         return sn
 
+    def cert_stats(self):
+        r, u, e = C.c_int64(), C.c_int64(), C.c_double()
+        _check(lib().jsdr_bpsk_cert_stats(self.h, C.byref(r), C.byref(u), C.byref(e)), "jsdr_bpsk_cert_stats")
+        return dict(decisions_redone_exactly=r.value, streams_uncertified=u.value, fi_fq_error_bound=e.value)
+
     def schedule_stats(self):
         a, b = C.c_int64(), C.c_int64()
         _check(lib().jsdr_bpsk_schedule_stats(self.h, C.byref(a), C.byref(b)), "jsdr_bpsk_schedule_stats")

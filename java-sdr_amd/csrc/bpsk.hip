@@ -73,7 +73,11 @@ struct TailState {
     int cntBit, cntFEC, cntDec, dmErrBits, decodeOK;
     int nbits_prev;  // bits sliced in the previous call (locates the 5200-bit history in the other bitlog)
     int overflow;    // sticky: more sync hits in one call than the handle's capacity (trig_cap), or more bits than max_bits
-    int pad;
+    int uncertified; // fast variant, sticky: a slicer decision fell inside the error margin and could not be redone exactly
+    // fast variant only (k_tail<CERT>)
+    double emax;        // running maximum of fi*fi+fq*fq over the life of the stream: scales the error bounds
+    long long last_g;   // 9600 Hz index of the sample of the last decision (whose (fi,fq) are lastI, lastQ); -1: none yet
+    long long redone;   // decisions recomputed in exact order because they fell inside the margin
 };
 
 // ------------------------------------------------------------------------------------------- k_front
@@ -1043,8 +1047,72 @@ struct TailArgs {
     int *nbits;                     // [S] bits sliced in this call
     int max_bits;
     int nstreams;
+    // ---- fast variant (k_tail<true>): what it takes to bound the error of (fi,fq) and to redo a sample in exact order
+    double ey;                      // bound on |fi' - fi|, |fq' - fq| of the FMA-contracted front end + matched filter
+    double margin_scale;            // safety factor on the detector margins (>= 1; tests raise it to force the exact path)
+    double argmax_scale;            // ... on the argmax margin (tests raise it to provoke an uncertifiable decision)
+    const int *raw;                 // the call's input, as FmArgs
+    long long stride_pairs;
+    int ic, qc, decim, first_out, mix, tper;
+    const double2 *tcs;
+    const unsigned char *kvco;
+    const double *sincos;
 };
 
+// (fi,fq) of the 9600 Hz sample g in EXACT order, by the whole wave, from the call's raw input: the 65 VCO-mixed samples
+// g-64..g (27-tap low-pass each, :479-483, one per lane) through LDS, then the 65 products in ring-slot order (:519-523).
+// The cold path of the fast variant: only samples whose 65-sample window lies inside this call (j0 >= 7, checked by the
+// caller, keeps every input index >= 0).
+__device__ __attribute__((noinline)) double2 tail_exact_sample(const TailArgs &a, int s, long long g, double2 *dmL, int lane)
+{
+    const int *raw = a.raw + (long long)s * a.stride_pairs;
+    const double HOWARD = 0.9 * 32768.0;
+    const bool dc = (a.ic != 0) || (a.qc != 0);
+    for (int i = lane; i < 65; i += 64) {
+        const long long j = g - 64 + i - a.g_first;  // call-relative index of the decimated sample
+        double fi = 0.0, fq = 0.0;
+        for (int age = 0; age < 27; age++) {
+            const long long n = (long long)a.first_out + (long long)a.decim * j - age;
+            double di, dq;
+            fm_convert(raw[n], a.ic, a.qc, dc, di, dq);
+            if (a.mix) {
+                const double2 cs = a.tcs[(int)((n + 26) % a.tper)];
+                di = di * cs.x;
+                dq = dq * cs.y;
+            }
+            const double tp = c_bpsk.ds_taps[age];
+            fi += di * tp;
+            fq += dq * tp;
+        }
+        const double oi = fi * HOWARD, oq = fq * HOWARD;
+        const int kv = a.kvco[j];
+        dmL[i] = make_double2(oi * a.sincos[kv], oq * a.sincos[256 + kv]);
+    }
+    JSDR_WAVE_SYNC();
+    const int u = (int)(((g - 64) % 65 + 65) % 65);  // g = s0 + u, s0 the sample in ring slot 0
+    const double *f = c_bpsk.dm_taps;
+    double yi = 0.0, yq = 0.0;
+    for (int i = 0; i <= 64 - u; i++) {  // s0, s0-1, .., g-64: ages u .. 64
+        const double2 x = dmL[64 - u - i];
+        yi += x.x * f[u + i];
+        yq += x.y * f[u + i];
+    }
+    for (int m = 0; m < u; m++) {        // g, g-1, .., s0+1: ages 0 .. u-1
+        const double2 x = dmL[64 - m];
+        yi += x.x * f[m];
+        yq += x.y * f[m];
+    }
+    JSDR_WAVE_SYNC();
+    return make_double2(yi, yq);
+}
+
+// CERT = the fast variant's tail: the same arithmetic on (fi,fq) that carry a bounded error |d| <= ey, plus, for every
+// data-dependent decision, a margin that covers the worst case of that error (DESIGN.md "fast variant"):
+//   argmax of the eight smoothed energies (:586-592): certified when the winner leads by more than twice the bound on
+//     an energy's error; otherwise the stream is marked uncertified (the IIR state cannot be redone locally)
+//   energy2 > 100 (:544) and di < 0 (:545): when inside the margin, the two (fi,fq) samples of the detector are
+//     recomputed from the raw input in exact order and the decision is taken on those
+template <bool CERT>
 __global__ __launch_bounds__(64) void k_tail(TailArgs a)
 {
     __shared__ double2 yL[512];        // [period*8 + bitPos]
@@ -1052,10 +1120,15 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs a)
     __shared__ double eL[64][9];       // dmEnergy[c] after each period (row padded: conflict-free column walk)
     __shared__ unsigned char maskL[64];
     __shared__ short declist[136];
+    __shared__ double2 dmL[CERT ? 66 : 1];
     const int lane = threadIdx.x;
     const int s = blockIdx.x;
     if (s >= a.nstreams) return;
     TailState *sp = &a.st[s];
+    double emax = CERT ? sp->emax : 0.0;
+    long long last_g = CERT ? sp->last_g : -1;
+    int uncert = 0;
+    long long redone = 0;
     const double2 *y = a.y + (long long)s * a.y_stride;
     signed char *blog = a.bitlog_new + (long long)s * a.bitlog_stride;
     const int nbits_prev = sp->nbits_prev;
@@ -1111,6 +1184,27 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs a)
             enL[k * 64 + lane] = pre[k].x * pre[k].x + pre[k].y * pre[k].y;  // :534
         }
         JSDR_WAVE_SYNC();
+        double m_en = 0.0, m_d = 0.0, m_e2 = 0.0;  // this chunk's margins
+        if constexpr (CERT) {
+            double em = 0.0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const double en = pre[k].x * pre[k].x + pre[k].y * pre[k].y;
+                em = en > em ? en : em;
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const double o = __shfl_xor(em, off, 64);
+                em = o > em ? o : em;
+            }
+            emax = em > emax ? em : emax;
+            // |fi|,|fq| <= sqrt(emax); u = 2^-53.  energy1: 2 sqrt2 sqrt(emax) ey + 7 u emax; through the IIR (gain 1, 3
+            // roundings a link, 1/(1-K) = 200 links deep): + 1200 u emax.  di, dq: 4 sqrt(emax) ey + 7 u emax.
+            const double sq = sqrt(emax), U = 1.1102230246251565e-16;
+            m_en = a.argmax_scale * 2.0 * (2.83 * sq * a.ey + 1207.0 * U * emax);
+            m_d = a.margin_scale * (4.1 * sq * a.ey + 7.0 * U * emax);
+            m_e2 = 1.5 * m_d + 4.0e-14;
+        }
         if (MB + 64 <= M_last) fetch(MB + 64);
         const int nper = (int)((M_last - MB + 1) < 64 ? (M_last - MB + 1) : 64);
         const bool interior = (8 * MB >= g_first) && (8 * (MB + 64) <= g_end);  // every sample of all 64 periods is in range (uniform)
@@ -1162,15 +1256,21 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs a)
         if (lane < nper) {
             const long long g7 = 8 * (MB + lane) + 7;
             if (g7 >= g_first && g7 < g_end) {
-                double bv = eL[lane][0];
+                double bv = eL[lane][0], sv = -1.0e300;
                 np = 0;
 #pragma unroll
                 for (int c = 1; c < 8; c++) {
                     double ov = eL[lane][c];
                     if (ov > bv) {  // strict: the first maximum wins
+                        sv = bv;
                         bv = ov;
                         np = c;
+                    } else if (CERT && ov > sv) {
+                        sv = ov;
                     }
+                }
+                if constexpr (CERT) {
+                    if (!(bv - sv > m_en)) uncert = 1;  // the order of the two largest is not certain
                 }
             }
         }
@@ -1259,9 +1359,42 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs a)
                 cur = yL[fastd ? 8 * d + v : (int)declist[d]];
                 if (d > 0) prv = yL[fastd ? 8 * (d - 1) + v : (int)declist[d - 1]];
             }
-            const double di = -((prv.x * cur.x) + (prv.y * cur.y));
-            const double dq = (prv.x * cur.y) - (prv.y * cur.x);
-            const double e2 = sqrt((di * di) + (dq * dq));
+            double di = -((prv.x * cur.x) + (prv.y * cur.y));
+            double dq = (prv.x * cur.y) - (prv.y * cur.x);
+            double e2 = sqrt((di * di) + (dq * dq));
+            if constexpr (CERT) {
+                const bool unsure = have && (fabs(e2 - 100.0) <= m_e2 || (e2 > 100.0 && fabs(di) <= m_d));
+                unsigned long long um = __ballot(unsure);
+                if (um) {  // cold: redo those decisions on (fi,fq) recomputed from the raw input in exact order
+                    const int ci = have ? (fastd ? 8 * d + v : (int)declist[d]) : 0;
+                    const int pi = (have && d > 0) ? (fastd ? 8 * (d - 1) + v : (int)declist[d - 1]) : -1;
+                    while (um) {
+                        const int L = __ffsll((long long)um) - 1;
+                        um &= um - 1ull;
+                        const long long gc = 8 * MB + __shfl(ci, L, 64);
+                        const int pl = __shfl(pi, L, 64);
+                        const long long gp = pl >= 0 ? 8 * MB + pl : last_g;
+                        // both windows (65 VCO-mixed samples of 27 inputs each) must lie inside this call
+                        const bool can = gp >= 0 && gp - 64 - a.g_first >= 7 && gc - 64 - a.g_first >= 7 && gc < a.g_first + a.nds &&
+                                         (a.mix == 0 || a.tper > 0);
+                        if (!can) {
+                            // (the first samples of a call reach back into the previous one) not recomputable: the decision
+                            // stands if it clears the margin proper -- margin_scale only widens what is sent to the redo
+                            const double e2L = __shfl(e2, L, 64), diL = __shfl(di, L, 64);
+                            if (fabs(e2L - 100.0) <= m_e2 / a.margin_scale || (e2L > 100.0 && fabs(diL) <= m_d / a.margin_scale)) uncert = 1;
+                            continue;
+                        }
+                        const double2 ec = tail_exact_sample(a, s, gc, dmL, lane);
+                        const double2 ep = tail_exact_sample(a, s, gp, dmL, lane);
+                        if (lane == L) {
+                            di = -((ep.x * ec.x) + (ep.y * ec.y));
+                            dq = (ep.x * ec.y) - (ep.y * ec.x);
+                            e2 = sqrt((di * di) + (dq * dq));
+                        }
+                        redone++;
+                    }
+                }
+            }
             const bool valid = have && (e2 > 100.0);
             const unsigned long long vm = __ballot(valid);
             if (valid) {
@@ -1276,6 +1409,10 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs a)
                 energy2 = __shfl(e2, lastd, 64);
                 lastI = __shfl(cur.x, lastd, 64);
                 lastQ = __shfl(cur.y, lastd, 64);
+                if constexpr (CERT) {
+                    const int li = have ? (fastd ? 8 * d + v : (int)declist[d]) : 0;
+                    last_g = 8 * MB + __shfl(li, lastd, 64);
+                }
             }
         }
         // energy1 = that of the last sample processed (:534)
@@ -1287,6 +1424,7 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs a)
         JSDR_WAVE_SYNC();
     }
     // ---------------- write back
+    const bool any_uncert = CERT && (__ballot(uncert != 0) != 0ull);
     const double e8 = __shfl(e, 8, 64);
     if (lane < 8) sp->dmEnergy[lane] = e;
     if (lane == 0) {
@@ -1302,6 +1440,12 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs a)
         sp->nbits_prev = nb;
         if (nbits > a.max_bits) sp->overflow = 1;
         a.nbits[s] = nb;
+        if constexpr (CERT) {
+            sp->emax = emax;
+            sp->last_g = last_g;
+            sp->redone += redone;
+            if (any_uncert) sp->uncertified = 1;
+        }
     }
 }
 
@@ -1431,6 +1575,9 @@ struct jsdr_bpsk {
     bool halo_in_dmh = false;      // where the last call left the 64 VCO-mixed history samples (dm[s][0..63] or dmh)
     bool use_fm = true;            // JSDR_FM=0: always the three-kernel path
     int variant = 0;               // 0 exact-order FP64, 1 fast (FMA-contracted FP64, margin-certified decisions)
+    double fast_ey = 0.0;          // bound on the error of (fi,fq) in the fast variant (set at create from the taps)
+    double margin_scale = 1.0;     // JSDR_FAST_MARGIN_SCALE: widens the detector margins (tests force the exact redo path with it)
+    double argmax_scale = 1.0;     // JSDR_FAST_ARGMAX_SCALE: widens the argmax margin (tests provoke an uncertifiable stream)
     const char *front_name = "k_front";  // the front-end kernel the last call launched
     int c_tper = 0;                // period of the cached tuner schedule (0: not periodic with a period <= 256)
     bool ktu_uploaded = false;     // the device copy of the per-sample tuner index table matches the cached schedule
@@ -1897,6 +2044,12 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
     const int kshift = (4 - (first_out & 3)) & 3;  // element 26+lo = first_out + D*j0, and D*j0 is a multiple of 4
     const bool fresh = !h->cache_valid;
     if (fresh) h->ktu_uploaded = false;
+    if (fresh && h->variant != 0 && h->overlap) {
+        // the fast variant's tail (side stream) may re-read the VCO / tuner tables of the previous call: let it finish
+        // before they are overwritten
+        for (int i = 0; i < 2; i++)
+            if (h->tail_pending[i]) JSDR_HIP_TRY(hipStreamWaitEvent(st, h->ev_tail_done[i], 0));
+    }
     // the 1 B/sample index table is only read by the kernels without the periodic table (k_front, k_front_dma,
     // k_front_reg<PER = false>)
     const bool reg_will_run = front_reg_enabled() && raw_dev && !rawf_dev && L <= 0x3fffffffLL && L >= 64 &&
@@ -2113,8 +2266,25 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
         ta.nbits = h->nbits.p;
         ta.max_bits = h->max_bits;
         ta.nstreams = S;
+        ta.ey = h->fast_ey;
+        ta.margin_scale = h->margin_scale;
+        ta.argmax_scale = h->argmax_scale;
+        ta.raw = fa.raw;
+        ta.stride_pairs = fa.stride_pairs;
+        ta.ic = ic;
+        ta.qc = qc;
+        ta.decim = h->decim;
+        ta.first_out = first_out;
+        ta.mix = h->mix;
+        ta.tper = (h->mix == 1) ? h->c_tper : 0;
+        ta.tcs = h->tcs.p;
+        ta.kvco = h->kvco.p;
+        ta.sincos = h->sincos.p;
         ProfScope ps(h, PK_TAIL, ts);
-        hipLaunchKernelGGL(k_tail, dim3((unsigned)S), dim3(64), 0, ts, ta);
+        if (h->variant != 0 && !h->do_fft && fa.raw)
+            hipLaunchKernelGGL(k_tail<true>, dim3((unsigned)S), dim3(64), 0, ts, ta);
+        else
+            hipLaunchKernelGGL(k_tail<false>, dim3((unsigned)S), dim3(64), 0, ts, ta);
         JSDR_LAUNCH_CHECK();
         h->bitlog_cur ^= 1;
     }
@@ -2296,7 +2466,31 @@ int jsdr_bpsk_create(jsdr_bpsk **out, int rate, int nsamples_per_frame, int tuni
     }
     std::vector<TailState> ts(S);
     memset(ts.data(), 0, sizeof(TailState) * S);
-    for (size_t i = 0; i < S; i++) ts[i].dmEnergyOut = 1.0;  // :499
+    for (size_t i = 0; i < S; i++) {
+        ts[i].dmEnergyOut = 1.0;  // :499
+        ts[i].last_g = -1;
+    }
+    {
+        // Worst-case error of (fi,fq) when both FIR stages use fused multiply-adds instead of the reference's separately
+        // rounded products and sums (u = 2^-53; |x| <= 32768/32767, |cos|,|sin| <= 1):
+        //   27-tap stage : |s' - s| <= (gamma_28 + gamma_27) T1,            T1 = sum |x_k| |t_k| <= 1.00004 sum|dsFilter|
+        //   x HOWARD, VCO: |dm' - dm| <= 56 u T1 HOWARD + 4 u Dmax,         Dmax = HOWARD T1 bounds |dm|
+        //   65-tap stage : |y' - y| <= (gamma_66 + gamma_65) F1 Dmax + F1 |dm' - dm|,   F1 = sum|dmFilter|
+        double t1 = 0.0, f1 = 0.0;
+        for (int i = 0; i < 27; i++) t1 += fabs(bc.ds_taps[i]);
+        for (int i = 0; i < 65; i++) f1 += fabs(bc.dm_taps[i]);
+        t1 *= 1.00004;
+        const double U = 1.1102230246251565e-16, HOWARD = 0.9 * 32768.0, dmax = HOWARD * t1;
+        h->fast_ey = 1.01 * U * f1 * (131.0 * dmax + 56.0 * t1 * HOWARD + 4.0 * dmax);
+        if (const char *e = getenv("JSDR_FAST_MARGIN_SCALE")) {
+            const double v = atof(e);
+            if (v >= 1.0) h->margin_scale = v;
+        }
+        if (const char *e = getenv("JSDR_FAST_ARGMAX_SCALE")) {
+            const double v = atof(e);
+            if (v >= 1.0) h->argmax_scale = v;
+        }
+    }
     h->h_sincos = sc;
     bool up = hipMemcpy(h->sincos.p, sc.data(), sizeof(double) * 512, hipMemcpyHostToDevice) == hipSuccess &&
               hipMemcpyToSymbol(HIP_SYMBOL(c_bpsk), &bc, sizeof(bc)) == hipSuccess &&
@@ -2450,6 +2644,13 @@ static int check_overflow(jsdr_bpsk *h, int stream, const char *who)
                            hipMemcpyDeviceToHost));
     JSDR_REQUIRE(!ov, "%s: stream %d exceeded its per-call capacity (%d bits / %d FEC calls per call of at most %lld samples)", who,
                  stream, h->max_bits, h->trig_cap, h->max_batch);
+    if (h->variant != 0) {
+        int un = 0;
+        JSDR_HIP_TRY(hipMemcpy(&un, reinterpret_cast<const char *>(h->tail.p + stream) + offsetof(TailState, uncertified), sizeof(int),
+                               hipMemcpyDeviceToHost));
+        JSDR_REQUIRE(!un, "%s: stream %d: the fast variant could not certify a slicer decision (inside its error margin and not "
+                     "recomputable in exact order); run this stream with JSDR_VARIANT_EXACT", who, stream);
+    }
     return JSDR_OK;
 }
 
@@ -2463,7 +2664,7 @@ int jsdr_bpsk_get_counters(jsdr_bpsk *h, int stream, int32_t out[JSDR_BPSK_NCOUN
     JSDR_HIP_TRY(hipMemcpy(&t, h->tail.p + stream, sizeof(t), hipMemcpyDeviceToHost));
     JSDR_HIP_TRY(hipMemcpy(last, h->fec_last.p + 2 * stream, sizeof(last), hipMemcpyDeviceToHost));
     JSDR_HIP_TRY(hipMemcpy(&cdec, h->cnt_dec.p + stream, sizeof(int), hipMemcpyDeviceToHost));
-    JSDR_REQUIRE(!t.overflow, "jsdr_bpsk_get_counters: stream %d overflowed its per-call bit/FEC capacity", stream);
+    if (check_overflow(h, stream, "jsdr_bpsk_get_counters") != JSDR_OK) return JSDR_ERR;
     out[0] = (int32_t)h->n_in;
     out[1] = (int32_t)h->n_ds;
     out[2] = t.cntBit;
@@ -2632,6 +2833,25 @@ int jsdr_bpsk_profile_count(void) { return PK_COUNT; }
 
 const char *jsdr_bpsk_front_kernel(jsdr_bpsk *h) { return h ? h->front_name : ""; }
 
+// fast variant: decisions redone in exact order (all streams, since creation), streams that ended up uncertified, the
+// error bound of (fi,fq) the margins are built on
+int jsdr_bpsk_cert_stats(jsdr_bpsk *h, int64_t *redone, int64_t *uncertified_streams, double *ey)
+{
+    JSDR_REQUIRE(h, "jsdr_bpsk_cert_stats: null handle");
+    if (sync_last(h) != JSDR_OK) return JSDR_ERR;
+    std::vector<TailState> ts((size_t)h->nstreams);
+    JSDR_HIP_TRY(hipMemcpy(ts.data(), h->tail.p, sizeof(TailState) * ts.size(), hipMemcpyDeviceToHost));
+    long long r = 0, u = 0;
+    for (auto &t : ts) {
+        r += t.redone;
+        u += t.uncertified ? 1 : 0;
+    }
+    if (redone) *redone = r;
+    if (uncertified_streams) *uncertified_streams = u;
+    if (ey) *ey = h->fast_ey * h->margin_scale;
+    return JSDR_OK;
+}
+
 int jsdr_bpsk_schedule_stats(jsdr_bpsk *h, int64_t *computed_inline, int64_t *prefetched)
 {
     JSDR_REQUIRE(h, "jsdr_bpsk_schedule_stats: null handle");
@@ -2645,7 +2865,7 @@ int jsdr_bpsk_set_variant(jsdr_bpsk *h, int variant)
     JSDR_REQUIRE(h, "jsdr_bpsk_set_variant: null handle");
     JSDR_REQUIRE(variant == JSDR_VARIANT_EXACT || variant == JSDR_VARIANT_FAST, "jsdr_bpsk_set_variant: unknown variant %d", variant);
     JSDR_REQUIRE(h->n_in == 0, "jsdr_bpsk_set_variant: the variant is fixed once samples have been received");
-    JSDR_REQUIRE(variant == JSDR_VARIANT_EXACT, "jsdr_bpsk_set_variant: the fast variant is not built into this library");
+    JSDR_REQUIRE(variant == JSDR_VARIANT_EXACT || !h->do_fft, "jsdr_bpsk_set_variant: the fast variant covers the tune mode only");
     h->variant = variant;
     return JSDR_OK;
 }

@@ -127,3 +127,63 @@ def test_config5_shard_shape_1024_streams_by_2pow20_samples():
         assert [c[n] for n in CN] == [oc[n] for n in CN], s
         for (rc, _, data), (orc, _, odata) in zip(d.fec_results(s), o.fec_results()):
             assert rc == orc and np.array_equal(data, odata)
+
+
+# ------------------------------------------------------------------ the fast variant (FMA-contracted FP64, certified decisions)
+@pytest.mark.parametrize("name", list(STREAMS))
+def test_fast_variant_bits_and_fec_bytes_equal_python_restatement(name):
+    """north_star: bit-exact slicer bits and FECDecoder bytes; the doubles may differ (they do, within the bound)"""
+    d = _check_stream(name, [STREAMS[name]["n"]], variant="fast")
+    st = d.cert_stats()
+    assert st["streams_uncertified"] == 0
+
+
+@pytest.mark.parametrize("name", ["clean", "noisy", "r48k_dc"])
+def test_fast_variant_ragged_calls(name):
+    n = STREAMS[name]["n"]
+    _check_stream(name, [2048] * 8 + [77, 1, 4099, n - 2048 * 8 - 77 - 1 - 4099 - 65536, 65536], variant="fast")
+
+
+def test_fast_variant_error_of_fi_fq_is_inside_the_proven_bound():
+    p = STREAMS["noisy"]
+    raw = stream_input("noisy")
+    d_iq = J.DeviceBuffer.from_host(raw)
+    tr = {}
+    for variant in ("exact", "fast"):
+        d = J.Bpsk(rate=p["rate"], blen=8192, tuning=p["tuning"], nstreams=1, max_batch_samples=p["n"], variant=variant)
+        d.batch_i16(d_iq, 2 * p["n"], p["n"])
+        tr[variant] = d.trace(0).copy()
+        if variant == "fast":
+            bound = d.cert_stats()["fi_fq_error_bound"]
+            assert d.front_kernel_name() == "k_fm"
+    err = np.abs(tr["fast"] - tr["exact"]).max()
+    assert 0.0 < err <= bound, (err, bound)  # FMA really is in use, and the worst-case bound holds with room
+    assert err < 0.05 * bound  # full-scale input would be ~10x larger; this stream's amplitude is 0.1 FS
+
+
+def test_fast_variant_redoes_unsure_decisions_in_exact_order(monkeypatch):
+    """widen the detector margins by 1e12: most decisions fall inside and take the cold path (two samples recomputed
+    from the raw input in exact order); bits and bytes must not change"""
+    monkeypatch.setenv("JSDR_FAST_MARGIN_SCALE", "1e12")
+    d = _check_stream("clean", [STREAMS["clean"]["n"]], variant="fast")
+    st = d.cert_stats()
+    assert st["decisions_redone_exactly"] > 100 and st["streams_uncertified"] == 0, st
+    d = _check_stream("noisy", [200000, STREAMS["noisy"]["n"] - 200000], variant="fast")
+    assert d.cert_stats()["decisions_redone_exactly"] > 100
+
+
+def test_fast_variant_flags_a_stream_it_cannot_certify(monkeypatch):
+    monkeypatch.setenv("JSDR_FAST_ARGMAX_SCALE", "1e14")
+    p = STREAMS["clean"]
+    d = J.Bpsk(rate=p["rate"], blen=8192, tuning=p["tuning"], nstreams=2, max_batch_samples=65536, variant="fast")
+    raw = stream_input("clean")[:2 * 65536]
+    d.batch_i16(J.DeviceBuffer.from_host(np.concatenate([raw, raw])), 2 * 65536, 65536)
+    assert d.cert_stats()["streams_uncertified"] == 2
+    for getter in (d.bits, d.fec_results, d.decoded, d.counters):
+        with pytest.raises(J.JsdrError):
+            getter(0)
+
+
+def test_fast_variant_is_tune_mode_only():
+    with pytest.raises(J.JsdrError):
+        J.Bpsk(nstreams=1, do_fft=1, variant="fast")
