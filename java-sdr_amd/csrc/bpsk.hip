@@ -835,7 +835,10 @@ __global__ __launch_bounds__(64) void k_dm_history(double2 *dm, long long dm_str
 // Every floating-point operation and its order are those of k_front_reg + k_matched (FAST = false), so (fi,fq)
 // stay bit-identical to the reference.  Used when the input is int16, the tuner schedule is periodic with a period
 // that divides the lane span (or the tuner is off, tuning <= 0); everything else takes the three-kernel path.
-enum { FM_NB = 62, FM_NT = 64 + 65 * FM_NB, FM_THREADS = 512, FM_TABLE_SLACK = 128 };
+#ifndef JSDR_FM_NB
+#define JSDR_FM_NB 62
+#endif
+enum { FM_NB = JSDR_FM_NB, FM_NT = 64 + 65 * FM_NB, FM_THREADS = 512, FM_TABLE_SLACK = 128 };
 
 struct FmArgs {
     const int *raw;             // int16 pairs as dwords, [S][stride]
@@ -1572,6 +1575,7 @@ struct jsdr_bpsk {
     // an unwrapped periodic (cos, sin) table
     DevBuf<double2> dmh[2], tcs;
     int dmh_cur = 0;
+    int tab_cur = 0;               // which half of kvco / tcs holds the current schedule's tables
     bool halo_in_dmh = false;      // where the last call left the 64 VCO-mixed history samples (dm[s][0..63] or dmh)
     bool use_fm = true;            // JSDR_FM=0: always the three-kernel path
     int variant = 0;               // 0 exact-order FP64, 1 fast (FMA-contracted FP64, margin-certified decisions)
@@ -2044,12 +2048,18 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
     const int kshift = (4 - (first_out & 3)) & 3;  // element 26+lo = first_out + D*j0, and D*j0 is a multiple of 4
     const bool fresh = !h->cache_valid;
     if (fresh) h->ktu_uploaded = false;
-    if (fresh && h->variant != 0 && h->overlap) {
-        // the fast variant's tail (side stream) may re-read the VCO / tuner tables of the previous call: let it finish
-        // before they are overwritten
-        for (int i = 0; i < 2; i++)
-            if (h->tail_pending[i]) JSDR_HIP_TRY(hipStreamWaitEvent(st, h->ev_tail_done[i], 0));
+    if (fresh) {
+        // The VCO / tuner tables are double-buffered: the fast variant's tail (side stream) may still re-read those of
+        // the previous call.  The half written now was last used two schedules ago; the tail that read it is the one
+        // that also frees y[y_cur], so waiting for that one (not for the previous call's) keeps the overlap.
+        h->tab_cur ^= 1;
+        if (h->variant != 0 && h->overlap && h->tail_pending[h->y_cur]) {
+            JSDR_HIP_TRY(hipStreamWaitEvent(st, h->ev_tail_done[h->y_cur], 0));
+            h->tail_pending[h->y_cur] = false;
+        }
     }
+    unsigned char *kvco_p = h->kvco.p + (size_t)h->tab_cur * (size_t)h->max_ds;
+    double2 *tcs_p = h->tcs.p + (size_t)h->tab_cur * (256 + FM_TABLE_SLACK);
     // the 1 B/sample index table is only read by the kernels without the periodic table (k_front, k_front_dma,
     // k_front_reg<PER = false>)
     const bool reg_will_run = front_reg_enabled() && raw_dev && !rawf_dev && L <= 0x3fffffffLL && L >= 64 &&
@@ -2062,7 +2072,7 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
     }
     if (fresh) {
         if (nds > 0)
-            JSDR_HIP_TRY(hipMemcpyAsync(h->kvco.p, h->h_kvco.data(), (size_t)nds, hipMemcpyHostToDevice, st));
+            JSDR_HIP_TRY(hipMemcpyAsync(kvco_p, h->h_kvco.data(), (size_t)nds, hipMemcpyHostToDevice, st));
         if (nds > 0 && h->do_fft) {
             h->h_vco_cs.resize((size_t)nds);
             for (long long j = 0; j < nds; j++)
@@ -2070,7 +2080,7 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
             JSDR_HIP_TRY(hipMemcpyAsync(h->vco_cs.p, h->h_vco_cs.data(), sizeof(double2) * (size_t)nds, hipMemcpyHostToDevice, st));
         }
         if (h->c_tper > 0)
-            JSDR_HIP_TRY(hipMemcpyAsync(h->tcs.p, h->h_tcs.data(), sizeof(double2) * h->h_tcs.size(), hipMemcpyHostToDevice, st));
+            JSDR_HIP_TRY(hipMemcpyAsync(tcs_p, h->h_tcs.data(), sizeof(double2) * h->h_tcs.size(), hipMemcpyHostToDevice, st));
         // the host vectors must stay untouched until the copies ran; pageable memcpyAsync stages
         // synchronously, so they are safe to reuse on return
         h->cache_valid = true;
@@ -2095,7 +2105,7 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
     fa.qc = qc;
     fa.mix = h->mix;
     fa.ktu = h->ktu.p + kshift;
-    fa.kvco = h->kvco.p;
+    fa.kvco = kvco_p;
     fa.sincos = h->sincos.p;
     fa.hist = h->hist_in[h->hist_cur].p;
     fa.dm = h->dm.p;
@@ -2103,7 +2113,7 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
     fa.ds_dbg = nullptr;
     fa.nds = nds;
     fa.first_out = first_out;
-    fa.tcs = per_ok ? h->tcs.p : nullptr;
+    fa.tcs = per_ok ? tcs_p : nullptr;
     fa.tper = h->c_tper;
     if (h->do_fft) {
         FftFrontArgs xa;
@@ -2144,9 +2154,9 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
         ma.ic = ic;
         ma.qc = qc;
         ma.hist = fa.hist;
-        ma.tcs = h->tcs.p;
+        ma.tcs = tcs_p;
         ma.tper = h->mix ? h->c_tper : 1;
-        ma.kvco = h->kvco.p;
+        ma.kvco = kvco_p;
         ma.sincos = h->sincos.p;
         ma.dmh_old = h->dmh[h->dmh_cur].p;
         ma.dmh_new = h->dmh[h->dmh_cur ^ 1].p;
@@ -2277,8 +2287,8 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
         ta.first_out = first_out;
         ta.mix = h->mix;
         ta.tper = (h->mix == 1) ? h->c_tper : 0;
-        ta.tcs = h->tcs.p;
-        ta.kvco = h->kvco.p;
+        ta.tcs = tcs_p;
+        ta.kvco = kvco_p;
         ta.sincos = h->sincos.p;
         ProfScope ps(h, PK_TAIL, ts);
         if (h->variant != 0 && !h->do_fft && fa.raw)
@@ -2393,7 +2403,7 @@ int jsdr_bpsk_create(jsdr_bpsk **out, int rate, int nsamples_per_frame, int tuni
     h->y_stride = h->max_ds;
     h->bitlog_stride = HIST_BITS + h->max_bits + 64;
     bool ok = h->sincos.alloc(512) == JSDR_OK && h->ktu.alloc((size_t)h->max_batch + 8192) == JSDR_OK &&
-              h->kvco.alloc((size_t)h->max_ds) == JSDR_OK && h->hist_in[0].alloc(S * 32) == JSDR_OK &&
+              h->kvco.alloc(2 * (size_t)h->max_ds) == JSDR_OK && h->hist_in[0].alloc(S * 32) == JSDR_OK &&
               h->hist_in[1].alloc(S * 32) == JSDR_OK && h->dm.alloc(S * (size_t)h->dm_stride) == JSDR_OK &&
               h->y[0].alloc(S * (size_t)h->y_stride) == JSDR_OK && h->y[1].alloc(S * (size_t)h->y_stride) == JSDR_OK && h->tail.alloc(S) == JSDR_OK &&
               h->bitlog[0].alloc(S * (size_t)h->bitlog_stride) == JSDR_OK &&
@@ -2404,7 +2414,7 @@ int jsdr_bpsk_create(jsdr_bpsk **out, int rate, int nsamples_per_frame, int tuni
               h->cnt_dec.alloc(S) == JSDR_OK && h->corr.alloc(S * (size_t)h->max_bits) == JSDR_OK &&
               h->fec_data.alloc(S * h->trig_cap * 256) == JSDR_OK && h->decoded.alloc(S * 256) == JSDR_OK &&
               h->stage_raw.alloc((size_t)nsamples_per_frame * 2) == JSDR_OK && h->ds_taps_dev.alloc(32) == JSDR_OK &&
-              h->dmh[0].alloc(S * 64) == JSDR_OK && h->dmh[1].alloc(S * 64) == JSDR_OK && h->tcs.alloc(256 + FM_TABLE_SLACK) == JSDR_OK &&
+              h->dmh[0].alloc(S * 64) == JSDR_OK && h->dmh[1].alloc(S * 64) == JSDR_OK && h->tcs.alloc(2 * (256 + FM_TABLE_SLACK)) == JSDR_OK &&
               (!do_fft || (h->fft_state.alloc(S) == JSDR_OK && h->fft_tw.alloc(fft_pow2 ? (size_t)nsamples_per_frame : (size_t)65536) == JSDR_OK &&
                             h->vco_cs.alloc((size_t)h->max_ds) == JSDR_OK)) &&
               (!(do_fft && fft2x_supported(nsamples_per_frame)) ||
