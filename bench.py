@@ -408,6 +408,7 @@ def main():
     #  signal every frame, and at 2048-sample frames its own demodulator -- the oracle bit for bit, see
     #  tests/test_gpu_bpsk.py -- rarely brings a 5200-bit FEC block through; parity for that mode is the tests')
     cert = None
+    vstats = None
     if dem is not None and not a.no_validate and not (a.fft_acquire and a.bpsk_frame != 9600):
         payloads = pay.to_host(np.uint8).reshape(S, nfr, 256)
         info = dem.slot_info()
@@ -423,7 +424,12 @@ def main():
             n_failed += len(fr) - len(good)
             n_none += 0 if good else 1
             n_wrong += sum(0 if any(np.array_equal(r[2], payloads[s, f]) for f in range(nfr)) else 1 for r in good)
-        ok = n_none == 0 and n_wrong == 0
+        # tune mode: every stream must bring a frame through.  FFT-acquire mode puts a seam into the signal every frame
+        # (FUNcubeBPSKDemod.java:458-463) and loses some frames by design -- the oracle does, bit for bit (tests); there only a
+        # WRONG payload invalidates the run
+        ok = n_wrong == 0 and (n_none == 0 or a.fft_acquire)
+        vstats = {"streams": S, "streams_without_decoded_frame": n_none, "decoded_frames_matching_no_sent_payload": n_wrong,
+                  "sync_hits_whose_fec_decode_failed": n_failed}
         if not ok or n_failed:
             print(f"[bench] validation rank {rank}: {n_none} streams without a decoded frame, {n_wrong} decoded frames that "
                   f"match no sent payload, {n_failed} sync hits whose FEC decode failed (of {S} streams)", file=sys.stderr)
@@ -455,6 +461,8 @@ def main():
             "hbm_read_roofline_frac": round(total / dt * 4.0 / (N * HBM_PEAK_GBS * 1e9), 4),
             "validated": validated,
         }
+        if vstats is not None:
+            out["validation"] = vstats
         if cert is not None:
             out["certification"] = cert
         if N == 1 and not a.no_cpu_baseline:
