@@ -117,7 +117,11 @@ int jsdr_fec_encode_batch(const uint8_t *data_dev, int64_t nblocks, uint8_t *sym
  * One handle = `nstreams` independent demodulators with identical configuration that advance in
  * lock-step (stream-major batches).  nstreams=1 + receive_* is the IAudioHandler drop-in.
  *   rate, blen/size : AudioDescriptor (FUNcubeBPSKDemod.java:193-194)
- *   tuning_hz       : "bpsk-tuning" (:195), do_fft "bpsk-dofft" (:199), do_up "bpsk-upper" (:200)  */
+ *   tuning_hz       : "bpsk-tuning" (:195), do_fft "bpsk-dofft" (:199), do_up "bpsk-upper" (:200)
+ * Frames: tune mode takes any frame; FFT-acquire mode (do_fft) frames of 1024 / 2048 / 4096 / 8192 samples, n = 2^a 3^b 5^c
+ * with n % 16 == 0 up to 9600 (java-sdr's defaults 9600 / 4800) and twice such a frame (19200, the 192 kHz default).
+ * max_batch_samples bounds one batch call; the per-call result log holds max_batch/40 + 16 bits and
+ * max(8, bits/2600 + 4) FECDecode calls per stream -- a call that exceeds either flags the stream (getters fail).  */
 typedef struct jsdr_bpsk jsdr_bpsk;
 int jsdr_bpsk_create(jsdr_bpsk **h, int rate, int nsamples_per_frame, int tuning_hz, int do_fft,
                      int do_up, int nstreams, int64_t max_batch_samples);
