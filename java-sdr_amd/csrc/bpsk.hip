@@ -683,7 +683,34 @@ __device__ __forceinline__ void matched_block(const double2 *xl /* &X[s0] of thi
     }
     // phase 1: s = s0 - i, ages u+i.  main part: every output still has a tap
     const int n1 = 66 - u0 - R;
-    for (int i = 0; i < n1; i++) {
+    int i = 0;
+#ifndef JSDR_MATCHED_NO_CHUNKS
+    // eight steps at a time: their 8+R-1 taps come in with one pair of scalar loads and their eight samples with eight
+    // LDS reads in flight together -- as a plain loop the compiler reloads all R taps every other step and waits for each
+    // load on the spot (lgkmcnt counts scalar loads and LDS reads together).  Same products, same order.
+    for (; i + 8 <= n1; i += 8) {
+        double tw[8 + R - 1];
+#pragma unroll
+        for (int k = 0; k < 8 + R - 1; k++) tw[k] = f[u0 + i + k];
+        double2 v8[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v8[k] = xl[-(i + k)];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                if constexpr (FAST) {
+                    ai[r] = __builtin_fma(v8[k].x, tw[k + r], ai[r]);
+                    aq[r] = __builtin_fma(v8[k].y, tw[k + r], aq[r]);
+                } else {
+                    ai[r] += v8[k].x * tw[k + r];
+                    aq[r] += v8[k].y * tw[k + r];
+                }
+            }
+        }
+    }
+#endif
+    for (; i < n1; i++) {
         double2 v = xl[-i];
 #pragma unroll
         for (int r = 0; r < R; r++) {
@@ -700,11 +727,11 @@ __device__ __forceinline__ void matched_block(const double2 *xl /* &X[s0] of thi
     // phase 1 tail: outputs drop out from the top (age would exceed 64)
 #pragma unroll
     for (int q = 0; q < R - 1; q++) {
-        const int i = n1 + q;
-        double2 v = xl[-i];
+        const int i2 = n1 + q;
+        double2 v = xl[-i2];
 #pragma unroll
         for (int r = 0; r < R - 1 - q; r++) {
-            double t = f[u0 + i + r];
+            double t = f[u0 + i2 + r];
             if constexpr (FAST) {
                 ai[r] = __builtin_fma(v.x, t, ai[r]);
                 aq[r] = __builtin_fma(v.y, t, aq[r]);
@@ -731,7 +758,31 @@ __device__ __forceinline__ void matched_block(const double2 *xl /* &X[s0] of thi
         }
     }
     // phase 2 main: s = s0 + u0 - m, m = 0..u0-1, age = r + m
-    for (int m = 0; m < u0; m++) {
+    int m = 0;
+#ifndef JSDR_MATCHED_NO_CHUNKS
+    for (; m + 8 <= u0; m += 8) {
+        double tw[8 + R - 1];
+#pragma unroll
+        for (int k = 0; k < 8 + R - 1; k++) tw[k] = f[m + k];
+        double2 v8[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v8[k] = xl[u0 - (m + k)];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                if constexpr (FAST) {
+                    ai[r] = __builtin_fma(v8[k].x, tw[k + r], ai[r]);
+                    aq[r] = __builtin_fma(v8[k].y, tw[k + r], aq[r]);
+                } else {
+                    ai[r] += v8[k].x * tw[k + r];
+                    aq[r] += v8[k].y * tw[k + r];
+                }
+            }
+        }
+    }
+#endif
+    for (; m < u0; m++) {
         double2 v = xl[u0 - m];
 #pragma unroll
         for (int r = 0; r < R; r++) {
