@@ -22,7 +22,7 @@ STREAMS = {
     "r44k1": dict(rate=44100, tuning=12000, ic=0, qc=0, n=102400, synth=dict(seed=20020113, stream=3, noise_sigma=1500.0)),
     "r192k": dict(rate=192000, tuning=12000, ic=-5, qc=9, n=204800, synth=dict(seed=20020114, stream=4, noise_sigma=1500.0)),
 }
-FEC_CASES = ["clean", "flips200", "burst400", "soft", "flips350", "flips520", "flips700", "garbage"]
+FEC_CASES = ["clean", "flips200", "burst400", "soft", "flips350", "flips520", "flips700", "garbage", "rs8", "rs16", "rs16_0", "rs17"]
 TRACE = 2048
 
 

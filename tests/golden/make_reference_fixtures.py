@@ -52,7 +52,31 @@ def fec_blocks():
     b[rng.choice(5200, 700, replace=False)] ^= 0x80
     out["flips700"] = b
     out["garbage"] = rng.integers(0, 256, 5200, dtype=np.uint8)
+    # byte errors placed BEHIND the convolutional code: the Viterbi decoder returns exactly these bytes wrong and the RS
+    # stage has to correct them -- 8 and 16 (the limit) per code word decode, 17 in one word does not
+    for name, (n0, n1) in (("rs8", (8, 8)), ("rs16", (16, 16)), ("rs16_0", (16, 0)), ("rs17", (17, 3))):
+        out[name] = np.where(np.array(encode_with_byte_errors(pay, n0, n1, rng), np.uint8) == 1, 0xC0, 0x40).astype(np.uint8)
     return pay, sym, out
+
+
+class _ByteErrorEncoder(J.Encoder):
+    """encode_FEC40 (:677-688) whose byte stream into the scrambler / convolutional encoder carries errors the RS parity
+    does not know about (the parity is computed from the clean bytes)"""
+
+    def __init__(self, errs):
+        super().__init__()
+        self.errs = errs  # position in the 320-byte stream -> xor mask
+
+    def scramble_and_encode(self, c):
+        super().scramble_and_encode(c ^ self.errs.get(self.Nbytes, 0))
+
+
+def encode_with_byte_errors(pay, n0, n1, rng):
+    errs = {}
+    for blk, n in ((0, n0), (1, n1)):  # byte i of the stream belongs to RS word i & 1 (:617)
+        for p in rng.choice(160, n, replace=False):
+            errs[2 * int(p) + blk] = int(rng.integers(1, 256))
+    return _ByteErrorEncoder(errs).encode_FEC40([int(v) for v in pay])
 
 
 def main():

@@ -74,6 +74,8 @@ def test_fixture_corpus_covers_the_interesting_outcomes(fx):
     rcs = {n: int(fx["f_" + n + "_rc"][0]) for n in FEC_CASES}
     assert rcs["clean"] == 0 and rcs["flips200"] == 200 and rcs["burst400"] == 400 and rcs["soft"] > 0
     assert rcs["flips700"] == -1 and rcs["garbage"] == -1
+    # RS stage exercised with known error counts: 8+8 and 16+16 (the limit) byte errors decode, 17 in one word does not
+    assert rcs["rs8"] > 0 and rcs["rs16"] > 0 and rcs["rs16_0"] > 0 and rcs["rs17"] == -1
     assert int(fx["s_clean_fec_rc"][0]) >= 0 and int(fx["s_noisy_fec_rc"][0]) > 100 and int(fx["s_fail_fec_rc"][0]) == -1
 
 

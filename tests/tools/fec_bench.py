@@ -14,7 +14,15 @@ soft_clean = np.where(sym == 1, 0xC0, 0x40).astype(np.uint8)
 soft_err = soft_clean.copy()
 for i in range(64):
     soft_err[i, rng.choice(5200, 400, replace=False)] ^= 0x80
-for name, soft in (("clean", soft_clean), ("400 flips", soft_err)):
+# bursts the interleaver spreads over both RS code words: the Viterbi decoder leaves byte errors, the RS stage has to correct
+soft_rs = soft_clean.copy()
+for i in range(64):
+    for b0 in (700, 2100, 3900):
+        soft_rs[i, b0:b0 + 150] ^= 0x80
+# blocks whose two RS code words need 16 corrections each (errors placed behind the convolutional code by the fixture generator)
+FX = np.load(os.path.join(ROOT, "tests", "golden", "reference_fixtures.npz"))
+soft_rs16 = np.tile(FX["f_rs16_in"], (64, 1))
+for name, soft in (("clean", soft_clean), ("400 flips", soft_err), ("3 bursts", soft_rs), ("RS 16+16", soft_rs16)):
     for nb in (64, 256, 768, 1536, 2560, 5120):
         raws = np.tile(soft, (nb // 64, 1))
         d_raw = J.DeviceBuffer.from_host(raws)
