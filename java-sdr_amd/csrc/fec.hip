@@ -455,7 +455,7 @@ __device__ __forceinline__ int fec_decode_wave(FecLdsT<DECW> &L, int lane, unsig
         // otherwise (paths that did not merge: garbage frames) the serial chain-back below runs as before.
         bool par_ok = false;
         {
-            constexpr int SEG = 40, WARM = 64, LAST = NBITS - 7;  // bits 0..LAST
+            constexpr int SEG = 40, WARM = 128, LAST = NBITS - 7;  // bits 0..LAST (warm-up 128: blocks with ~8 % symbol errors still merge)
             static_assert(64 * SEG == LAST + 1, "64 lanes x 40 bits");
             const int seg_lo = SEG * lane;
             int st = 0, top = 0;
