@@ -650,6 +650,30 @@ __global__ void k_hist_in(HistArgs a)
     a.hist_new[(long long)s * 32 + i] = v;
 }
 
+// The 26-sample input history is kept in the form of the input that produced it (DC-corrected int16 pair in .x, or the
+// float pair's bits).  A handle fed through the other form next (receive(float[]) after int16 batches or the other way
+// round) gets it converted: int16 -> float is JavaAudio's rule; float -> int16 exists exactly when the float is some
+// (float)s/32767f (what IAudioHandler delivers, JavaAudio.java:281-288) -- anything else is reported (bad[0] != 0).
+__global__ void k_hist_convert(int2 *hist, int nstreams, int to_float, int *bad)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int s = t >> 5, i = t & 31;
+    if (s >= nstreams || i >= 26) return;
+    int2 v = hist[(long long)s * 32 + i];
+    if (to_float) {
+        const float fi = i16_to_float_java((int)(short)(v.x & 0xffff)), fq = i16_to_float_java(v.x >> 16);
+        v = make_int2(__float_as_int(fi), __float_as_int(fq));
+    } else {
+        const float fi = __int_as_float(v.x), fq = __int_as_float(v.y);
+        const int si = (int)rintf(fi * 32767.0f), sq = (int)rintf(fq * 32767.0f);
+        const bool ok = si >= -32768 && si <= 32767 && sq >= -32768 && sq <= 32767 && i16_to_float_java(si) == fi &&
+                        i16_to_float_java(sq) == fq;
+        if (!ok) atomicOr(bad, 1);
+        v = make_int2((si & 0xffff) | (sq << 16), 0);
+    }
+    hist[(long long)s * 32 + i] = v;
+}
+
 // ------------------------------------------------------------------------------------------- k_matched
 // 65-tap matched filter, summed in ring-slot order n=0..64 with tap 65-dmPos+n (:519-523).  In time
 // terms (g = global index of a 9600 Hz sample, slot(g) = (64-g) mod 65): the window [g-64, g] holds one
@@ -1620,6 +1644,8 @@ struct jsdr_bpsk {
     DevBuf<unsigned char> kvco;
     DevBuf<int2> hist_in[2];
     int hist_cur = 0;
+    bool hist_is_float = false;    // form of the samples in hist_in[hist_cur] (the input form of the call that wrote them)
+    DevBuf<int> hist_bad;          // k_hist_convert's "not an int16 sample" flag
     DevBuf<double2> dm, y[2];  // y is double-buffered: the tail of call k overlaps the front end of call k+1
     int y_cur = 0;
     // fused front end + matched filter (k_fm): the 64-sample halo lives in its own double buffer, the tuner table is
@@ -2089,6 +2115,23 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
     const long long nds = build_schedule(h, L);
     JSDR_REQUIRE(nds <= h->max_ds, "bpsk: internal: %lld decimated samples exceed capacity %lld", nds, h->max_ds);
     JSDR_REQUIRE(h->do_fft || h->mix >= 0, "bpsk: tuner phase changes sign inside a call (unsupported)");
+    if (!h->do_fft) {
+        const bool want_float = rawf_dev != nullptr;
+        if (h->n_in > 0 && want_float != h->hist_is_float) {  // the previous call came through the other input form
+            JSDR_HIP_TRY(hipMemsetAsync(h->hist_bad.p, 0, sizeof(int), st));
+            hipLaunchKernelGGL(k_hist_convert, dim3((unsigned)((h->nstreams * 32 + 255) / 256)), dim3(256), 0, st,
+                               h->hist_in[h->hist_cur].p, h->nstreams, want_float ? 1 : 0, h->hist_bad.p);
+            JSDR_LAUNCH_CHECK();
+            if (!want_float) {
+                int bad = 0;
+                JSDR_HIP_TRY(hipMemcpyAsync(&bad, h->hist_bad.p, sizeof(int), hipMemcpyDeviceToHost, st));
+                JSDR_HIP_TRY(hipStreamSynchronize(st));
+                JSDR_REQUIRE(!bad, "bpsk: int16 input after float frames whose samples are not (float)s/32767f values: the input "
+                             "history cannot be carried over");
+            }
+        }
+        h->hist_is_float = want_float;
+    }
     // fused path (k_fm): int16 input, a tuner schedule that is periodic with a period dividing the lane span (or
     // no tuner at all), 32-bit sample indices
     const int fm_rd = h->decim == 4 ? 20 : h->decim * 4;  // D * R of the k_fm instantiation
@@ -2465,7 +2508,7 @@ int jsdr_bpsk_create(jsdr_bpsk **out, int rate, int nsamples_per_frame, int tuni
               h->cnt_dec.alloc(S) == JSDR_OK && h->corr.alloc(S * (size_t)h->max_bits) == JSDR_OK &&
               h->fec_data.alloc(S * h->trig_cap * 256) == JSDR_OK && h->decoded.alloc(S * 256) == JSDR_OK &&
               h->stage_raw.alloc((size_t)nsamples_per_frame * 2) == JSDR_OK && h->ds_taps_dev.alloc(32) == JSDR_OK &&
-              h->dmh[0].alloc(S * 64) == JSDR_OK && h->dmh[1].alloc(S * 64) == JSDR_OK && h->tcs.alloc(2 * (256 + FM_TABLE_SLACK)) == JSDR_OK &&
+              h->dmh[0].alloc(S * 64) == JSDR_OK && h->dmh[1].alloc(S * 64) == JSDR_OK && h->hist_bad.alloc(1) == JSDR_OK && h->tcs.alloc(2 * (256 + FM_TABLE_SLACK)) == JSDR_OK &&
               (!do_fft || (h->fft_state.alloc(S) == JSDR_OK && h->fft_tw.alloc(fft_pow2 ? (size_t)nsamples_per_frame : (size_t)65536) == JSDR_OK &&
                             h->vco_cs.alloc((size_t)h->max_ds) == JSDR_OK)) &&
               (!(do_fft && fft2x_supported(nsamples_per_frame)) ||
@@ -2585,6 +2628,7 @@ int jsdr_bpsk_destroy(jsdr_bpsk *h)
     h->hist_in[0].release();
     h->hist_in[1].release();
     h->dm.release();
+    h->hist_bad.release();
     h->dmh[0].release();
     h->dmh[1].release();
     h->tcs.release();
@@ -2971,7 +3015,8 @@ int jsdr_bpsk_slot_info(jsdr_bpsk *h, int64_t *slot_bytes, int64_t *bits_offset,
 namespace jsdr {
 // slot = int32 header[16] | int8 bits[slot_bits] | trig_cap x {int32 rc, int32 bit_index, uint8 data[256]}
 // header: nbits, nfec, cntRaw, cntDS, cntBit, cntFEC, cntDec, dmErrBits, dmCorr, dmMaxCorr, decodeOK, overflow (a stream
-// that overflowed its per-call bit / FEC capacity: its slot is incomplete), 0...
+// that overflowed its per-call bit / FEC capacity: its slot is incomplete), uncertified (fast variant: a decision of this
+// stream could not be certified), 0...
 __global__ void k_pack_slots(unsigned char *slots, long long slot_bytes, int slot_bits, int trig_cap, const TailState *st,
                              const int *nbits, const signed char *bitlog, long long bitlog_stride, const int *trig_count,
                              const int *trig_bits, const int *fec_rc, const unsigned char *fec_data, const int *fec_last,
@@ -2996,6 +3041,7 @@ __global__ void k_pack_slots(unsigned char *slots, long long slot_bytes, int slo
             case 9: v = st[s].dmMaxCorr; break;
             case 10: v = fec_last[2 * s + 1]; break;
             case 11: v = st[s].overflow; break;
+            case 12: v = st[s].uncertified; break;
             default: v = 0;
         }
         hdr[threadIdx.x] = v;

@@ -443,3 +443,46 @@ def test_bpsk_schedule_look_ahead_for_non_periodic_tuning():
     d3, _ = run_both([iq96], 4 * c96, [c96] * 4)
     st = d3.schedule_stats()
     assert st["prefetched"] + st["computed_inline"] <= 2, st
+
+
+def test_bpsk_one_stream_fed_through_both_input_forms_alternately():
+    """the fused kernel (int16 batches) keeps the 64-sample halo of VCO-mixed samples in its own buffer, the generic
+    front end (float frames) in the dm array: a handle that is fed through both forms in turn must carry the halo
+    across every switch -- compared with one oracle that sees the same samples in order"""
+    n = 2048 * 40
+    iq = O.make_dbpsk_stream(71, 0, n, noise_sigma=500.0)[0]
+    buf = O.convert_i16(iq)
+    d = J.Bpsk(nstreams=1, max_batch_samples=2048 * 8)
+    o = O.Bpsk(trace=n // 10 + 8)
+    d_iq = J.DeviceBuffer.from_host(iq)
+    bits, tr = [], []
+    pos = 0
+    plan = [("f", 1), ("i", 3), ("f", 2), ("i", 8), ("f", 1), ("f", 1), ("i", 1), ("i", 5), ("f", 3), ("i", 8), ("f", 7)]
+    assert sum(k for _, k in plan) == 40
+    kernels = set()
+    for form, k in plan:
+        if form == "f":
+            for j in range(k):
+                d.receive(buf[2 * (pos + 2048 * j):2 * (pos + 2048 * (j + 1))])
+                bits.append(d.bits().copy())
+                tr.append(d.trace().copy())
+                kernels.add(d.front_kernel_name())
+        else:
+            d.batch_i16(d_iq.ptr + 4 * pos, 2 * n, 2048 * k)
+            bits.append(d.bits().copy())
+            tr.append(d.trace().copy())
+            kernels.add(d.front_kernel_name())
+        pos += 2048 * k
+    o.receive_i16(iq)
+    assert kernels == {"k_front", "k_fm"}
+    assert np.array_equal(np.concatenate(tr), o.trace())
+    assert np.array_equal(np.concatenate(bits), o.bits())
+    same_counters(d.counters(), o.counters())
+    same_state(d.state(), o.state())
+
+
+def test_bpsk_switching_to_int16_after_arbitrary_floats_is_refused():
+    d = J.Bpsk(nstreams=1, max_batch_samples=2048)
+    d.receive(np.full(4096, 0.123456789, np.float32))  # not a (float)s/32767f value
+    with pytest.raises(J.JsdrError):
+        d.batch_i16(J.DeviceBuffer.from_host(np.zeros(4096, np.int16)), 4096, 2048)
