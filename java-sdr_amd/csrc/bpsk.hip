@@ -2110,6 +2110,7 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
     JSDR_REQUIRE((stride_i16 & 1) == 0 && (h->nstreams == 1 || stride_i16 >= 2 * L),
                  "bpsk: stream stride %lld too small for %lld samples", stride_i16, L);
     JSDR_REQUIRE(!h->do_fft || (L % h->nsf) == 0, "bpsk: FFT-acquire mode needs whole frames (%lld %% %d != 0)", L, h->nsf);
+    JSDR_REQUIRE(h->variant == 0 || raw_dev, "bpsk: the fast variant takes int16 input (its certification pass re-reads the raw samples)");
     const int first_out = h->decim - 1 - h->dsCnt;
     const long long g_first = h->n_ds;
     const long long nds = build_schedule(h, L);

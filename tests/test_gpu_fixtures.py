@@ -187,3 +187,10 @@ def test_fast_variant_flags_a_stream_it_cannot_certify(monkeypatch):
 def test_fast_variant_is_tune_mode_only():
     with pytest.raises(J.JsdrError):
         J.Bpsk(nstreams=1, do_fft=1, variant="fast")
+
+
+def test_fast_variant_takes_int16_input_only():
+    d = J.Bpsk(nstreams=1, variant="fast")
+    with pytest.raises(J.JsdrError):
+        d.receive(np.zeros(4096, np.float32))
+    d.receive_raw(np.zeros(4096, np.int16))  # the raw (IRawHandler) form is fine
