@@ -933,6 +933,7 @@ struct FmArgs {
     long long g_first;          // global 9600 Hz index of this call's output 0
     long long tile0;            // global index of tile 0's first block (== 64 mod 65, <= g_first)
     int first_out;              // input index whose arrival completes output 0
+    int *amax;                  // FAST: [S] running maximum of |int16 sample| per stream, float bits (never reset)
 };
 
 template <int D, int R, bool MIX, bool DC, bool FAST>
@@ -963,6 +964,7 @@ __global__ __launch_bounds__(FM_THREADS, 2) void k_fm(FmArgs a)
     // become scalar loads (a plain global pointer in a kernel that also stores gives 57 vector loads per job)
     typedef const __attribute__((address_space(4))) double *const_tab_t;
     const_tab_t tb = (const_tab_t)(a.tcs + e0);  // tb[2m] = cos, tb[2m+1] = sin
+    float amx = 0.0f;  // FAST: largest |sample| this lane converts
     __syncthreads();  // sin/cos table
     // ================================================================================ front half
 #pragma unroll 1
@@ -992,7 +994,7 @@ __global__ __launch_bounds__(FM_THREADS, 2) void k_fm(FmArgs a)
                     if (m < NS) {
                         const int w = (t == 0) ? w4.x : (t == 1) ? w4.y : (t == 2) ? w4.z : w4.w;
                         double di, dq;
-                        fm_convert(w, a.ic, a.qc, DC, di, dq);
+                        fm_convert(w, a.ic, a.qc, DC, di, dq, FAST ? &amx : nullptr);
                         if constexpr (MIX) {  // :388-390 component-wise, not a complex multiply
                             di = di * tb[2 * m];
                             dq = dq * tb[2 * m + 1];
@@ -1038,8 +1040,8 @@ __global__ __launch_bounds__(FM_THREADS, 2) void k_fm(FmArgs a)
                     for (int age = 0; age < 27; age++) {
                         const int n = a.first_out + D * j - age;  // >= -26
                         double di, dq;
-                        if (n >= 0) fm_convert(raw[n], a.ic, a.qc, DC, di, dq);
-                        else fm_convert(hist[26 + n].x, 0, 0, false, di, dq);  // stored corrected
+                        if (n >= 0) fm_convert(raw[n], a.ic, a.qc, DC, di, dq, FAST ? &amx : nullptr);
+                        else fm_convert(hist[26 + n].x, 0, 0, false, di, dq, FAST ? &amx : nullptr);  // stored corrected
                         if constexpr (MIX) {
                             const double2 cs = a.tcs[(n + 26) % P];
                             di = di * cs.x;
@@ -1061,6 +1063,11 @@ __global__ __launch_bounds__(FM_THREADS, 2) void k_fm(FmArgs a)
                 X[t] = val;
             }
         }
+    }
+    if constexpr (FAST) {  // non-negative floats order like their bit patterns
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) amx = fmaxf(amx, __shfl_xor(amx, off, 64));
+        if ((threadIdx.x & 63) == 0 && amx > 0.0f) atomicMax(a.amax + s, __float_as_int(amx));
     }
     __syncthreads();
     // ---- the call's last 64 VCO-mixed samples are the next call's halo; every sample is owned by one tile
@@ -1126,7 +1133,8 @@ struct TailArgs {
     int max_bits;
     int nstreams;
     // ---- fast variant (k_tail<true>): what it takes to bound the error of (fi,fq) and to redo a sample in exact order
-    double ey;                      // bound on |fi' - fi|, |fq' - fq| of the FMA-contracted front end + matched filter
+    double ey;                      // bound on |fi' - fi|, |fq' - fq| of the FMA-contracted front end + matched filter at FULL SCALE
+    const int *amax;                // [S] largest |int16 sample| the fast kernels have converted so far (float bits): the bound scales with it
     double margin_scale;            // safety factor on the detector margins (>= 1; tests raise it to force the exact path)
     double argmax_scale;            // ... on the argmax margin (tests raise it to provoke an uncertifiable decision)
     const int *raw;                 // the call's input, as FmArgs
@@ -1278,10 +1286,12 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs a)
             emax = em > emax ? em : emax;
             // |fi|,|fq| <= sqrt(emax); u = 2^-53.  energy1: 2 sqrt2 sqrt(emax) ey + 7 u emax; through the IIR (gain 1, 3
             // roundings a link, 1/(1-K) = 200 links deep): + 1200 u emax.  di, dq: 4 sqrt(emax) ey + 7 u emax.
+            // (all linear in the input: the full-scale bound ey shrinks with the stream's largest sample so far)
             const double sq = sqrt(emax), U = 1.1102230246251565e-16;
-            m_en = a.argmax_scale * 2.0 * (2.83 * sq * a.ey + 1207.0 * U * emax);
-            m_d = a.margin_scale * (4.1 * sq * a.ey + 7.0 * U * emax);
-            m_e2 = 1.5 * m_d + 4.0e-14;
+            const double eys = a.ey * ((double)__int_as_float(a.amax[s]) * (1.0000001 / 32767.0));
+            m_en = a.argmax_scale * 2.0 * (2.83 * sq * eys + 2.0 * eys * eys + 1207.0 * U * emax);
+            m_d = a.margin_scale * (4.1 * sq * eys + 2.0 * eys * eys + 7.0 * U * emax);
+            m_e2 = 1.5 * m_d + (m_d > 0.0 ? 4.0e-14 : 0.0);
         }
         if (MB + 64 <= M_last) fetch(MB + 64);
         const int nper = (int)((M_last - MB + 1) < 64 ? (M_last - MB + 1) : 64);
@@ -1348,7 +1358,8 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs a)
                     }
                 }
                 if constexpr (CERT) {
-                    if (!(bv - sv > m_en)) uncert = 1;  // the order of the two largest is not certain
+                    // (m_en == 0: nothing but zeros has gone through the fast kernels, both variants hold the same numbers)
+                    if (!(bv - sv > m_en) && m_en > 0.0) uncert = 1;  // the order of the two largest is not certain
                 }
             }
         }
@@ -1646,6 +1657,7 @@ struct jsdr_bpsk {
     int hist_cur = 0;
     bool hist_is_float = false;    // form of the samples in hist_in[hist_cur] (the input form of the call that wrote them)
     DevBuf<int> hist_bad;          // k_hist_convert's "not an int16 sample" flag
+    DevBuf<int> amax;              // fast variant: [S] running maximum of |int16 sample| (float bits)
     DevBuf<double2> dm, y[2];  // y is double-buffered: the tail of call k overlaps the front end of call k+1
     int y_cur = 0;
     // fused front end + matched filter (k_fm): the 64-sample halo lives in its own double buffer, the tuner table is
@@ -2261,13 +2273,15 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
         ma.g_first = g_first;
         ma.tile0 = g_first - (((g_first - 64) % 65 + 65) % 65);
         ma.first_out = first_out;
+        ma.amax = h->amax.p;
         ProfScope ps(h, PK_FM, st);
         h->front_name = "k_fm";
         if (launch_fm(ma, h->decim, h->mix != 0, (ic != 0) || (qc != 0), h->variant != 0, S, st) != JSDR_OK) return JSDR_ERR;
         h->dmh_cur ^= 1;
     } else if (nds > 0) {
         ProfScope ps(h, PK_FRONT, st);
-        const bool fast = h->variant != 0;
+        const bool fast = false;  // (a fast handle whose call cannot take k_fm runs it in exact order: the amplitude the
+                                  //  fast variant's bound scales with is tracked by k_fm only)
         h->front_name = "k_front";
         switch (h->decim) {
             case 4:
@@ -2342,8 +2356,7 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
         }
         {
             ProfScope ps(h, PK_MATCHED, st);
-            if (h->variant != 0) hipLaunchKernelGGL(k_matched<true>, dim3((unsigned)ntiles, (unsigned)S), dim3(512), lds, st, ma);
-            else hipLaunchKernelGGL(k_matched<false>, dim3((unsigned)ntiles, (unsigned)S), dim3(512), lds, st, ma);
+            hipLaunchKernelGGL(k_matched<false>, dim3((unsigned)ntiles, (unsigned)S), dim3(512), lds, st, ma);
         }
         JSDR_LAUNCH_CHECK();
         ProfScope ps2(h, PK_DMHIST, st);
@@ -2372,6 +2385,7 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
         ta.max_bits = h->max_bits;
         ta.nstreams = S;
         ta.ey = h->fast_ey;
+        ta.amax = h->amax.p;
         ta.margin_scale = h->margin_scale;
         ta.argmax_scale = h->argmax_scale;
         ta.raw = fa.raw;
@@ -2509,7 +2523,7 @@ int jsdr_bpsk_create(jsdr_bpsk **out, int rate, int nsamples_per_frame, int tuni
               h->cnt_dec.alloc(S) == JSDR_OK && h->corr.alloc(S * (size_t)h->max_bits) == JSDR_OK &&
               h->fec_data.alloc(S * h->trig_cap * 256) == JSDR_OK && h->decoded.alloc(S * 256) == JSDR_OK &&
               h->stage_raw.alloc((size_t)nsamples_per_frame * 2) == JSDR_OK && h->ds_taps_dev.alloc(32) == JSDR_OK &&
-              h->dmh[0].alloc(S * 64) == JSDR_OK && h->dmh[1].alloc(S * 64) == JSDR_OK && h->hist_bad.alloc(1) == JSDR_OK && h->tcs.alloc(2 * (256 + FM_TABLE_SLACK)) == JSDR_OK &&
+              h->dmh[0].alloc(S * 64) == JSDR_OK && h->dmh[1].alloc(S * 64) == JSDR_OK && h->hist_bad.alloc(1) == JSDR_OK && h->amax.alloc(S) == JSDR_OK && h->tcs.alloc(2 * (256 + FM_TABLE_SLACK)) == JSDR_OK &&
               (!do_fft || (h->fft_state.alloc(S) == JSDR_OK && h->fft_tw.alloc(fft_pow2 ? (size_t)nsamples_per_frame : (size_t)65536) == JSDR_OK &&
                             h->vco_cs.alloc((size_t)h->max_ds) == JSDR_OK)) &&
               (!(do_fft && fft2x_supported(nsamples_per_frame)) ||
@@ -2601,7 +2615,7 @@ int jsdr_bpsk_create(jsdr_bpsk **out, int rate, int nsamples_per_frame, int tuni
               hipMemcpyToSymbol(HIP_SYMBOL(c_bpsk), &bc, sizeof(bc)) == hipSuccess &&
               hipMemcpy(h->tail.p, ts.data(), sizeof(TailState) * S, hipMemcpyHostToDevice) == hipSuccess &&
               h->hist_in[0].zero() == JSDR_OK && h->hist_in[1].zero() == JSDR_OK && h->dm.zero() == JSDR_OK &&
-              h->dmh[0].zero() == JSDR_OK && h->dmh[1].zero() == JSDR_OK && h->tcs.zero() == JSDR_OK &&
+              h->dmh[0].zero() == JSDR_OK && h->dmh[1].zero() == JSDR_OK && h->tcs.zero() == JSDR_OK && h->amax.zero() == JSDR_OK &&
               h->bitlog[0].zero() == JSDR_OK && h->bitlog[1].zero() == JSDR_OK && h->decoded.zero() == JSDR_OK &&
               h->nbits.zero() == JSDR_OK && h->trig_count.zero() == JSDR_OK && h->fec_last.zero() == JSDR_OK &&
               h->cnt_dec.zero() == JSDR_OK && h->y[0].zero() == JSDR_OK && h->y[1].zero() == JSDR_OK &&
@@ -2630,6 +2644,7 @@ int jsdr_bpsk_destroy(jsdr_bpsk *h)
     h->hist_in[1].release();
     h->dm.release();
     h->hist_bad.release();
+    h->amax.release();
     h->dmh[0].release();
     h->dmh[1].release();
     h->tcs.release();

@@ -81,7 +81,9 @@ __device__ __forceinline__ int java_short_add(int s, int corr)
 }
 
 // int16 pair -> (double)((float)s / 32767f) for I and Q (JavaAudio.java:281-288, FUNcubeBPSKDemod.java:372-373)
-__device__ __forceinline__ void fm_convert(int w, int ic, int qc, bool dc, double &di, double &dq)
+// amax (optional): running maximum of |s| over the samples converted, as a float (the fast variant scales its error
+// bound with the stream's actual input amplitude)
+__device__ __forceinline__ void fm_convert(int w, int ic, int qc, bool dc, double &di, double &dq, float *amax = nullptr)
 {
     int si = (int)(short)(w & 0xffff), sq = w >> 16;
     if (dc) {
@@ -92,6 +94,7 @@ __device__ __forceinline__ void fm_convert(int w, int ic, int qc, bool dc, doubl
     // v_pk_mul_f32 + v_pk_fma_f32 round each half exactly as the scalar instructions do
     typedef float v2f __attribute__((ext_vector_type(2)));
     const v2f a = {(float)si, (float)sq};
+    if (amax) *amax = fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), *amax);  // v_max3_f32 with |.| modifiers: one instruction
     const v2f rh = {0x1.0002p-15f, 0x1.0002p-15f}, rl = {0x1.0002p-45f, 0x1.0002p-45f};
     const v2f q = __builtin_elementwise_fma(a, rh, a * rl);
     di = (double)q.x;

@@ -162,9 +162,9 @@ def test_fast_variant_error_of_fi_fq_is_inside_the_proven_bound():
 
 
 def test_fast_variant_redoes_unsure_decisions_in_exact_order(monkeypatch):
-    """widen the detector margins by 1e12: most decisions fall inside and take the cold path (two samples recomputed
+    """widen the detector margins by 1e14: most decisions fall inside and take the cold path (two samples recomputed
     from the raw input in exact order); bits and bytes must not change"""
-    monkeypatch.setenv("JSDR_FAST_MARGIN_SCALE", "1e12")
+    monkeypatch.setenv("JSDR_FAST_MARGIN_SCALE", "1e14")
     d = _check_stream("clean", [STREAMS["clean"]["n"]], variant="fast")
     st = d.cert_stats()
     assert st["decisions_redone_exactly"] > 100 and st["streams_uncertified"] == 0, st
@@ -194,3 +194,17 @@ def test_fast_variant_takes_int16_input_only():
     with pytest.raises(J.JsdrError):
         d.receive(np.zeros(4096, np.float32))
     d.receive_raw(np.zeros(4096, np.int16))  # the raw (IRawHandler) form is fine
+
+
+def test_fast_variant_certifies_silence_and_scales_its_bound_with_the_input():
+    """an all-zero stream keeps all eight smoothed energies at exactly 0.0 in both variants: the tie is the reference's
+    tie, nothing to certify.  A quiet stream (1 % of full scale) gets margins 100x tighter than the full-scale bound."""
+    d = J.Bpsk(nstreams=2, max_batch_samples=65536, variant="fast")
+    quiet = (stream_input("clean")[:2 * 65536].astype(np.int32) // 10).astype(np.int16)
+    both = np.concatenate([np.zeros(2 * 65536, np.int16), quiet])
+    d.batch_i16(J.DeviceBuffer.from_host(both), 2 * 65536, 65536)
+    assert d.cert_stats()["streams_uncertified"] == 0
+    assert d.counters(0)["cntBit"] == 0
+    o = O.Bpsk()
+    o.receive_i16(quiet)
+    assert np.array_equal(d.bits(1), o.bits())
