@@ -934,6 +934,7 @@ struct FmArgs {
     long long tile0;            // global index of tile 0's first block (== 64 mod 65, <= g_first)
     int first_out;              // input index whose arrival completes output 0
     int *amax;                  // FAST: [S] running maximum of |int16 sample| per stream, float bits (never reset)
+    int ntiles, nstreams;       // work items = ntiles x nstreams, stream-major; the grid strides over them
 };
 
 template <int D, int R, bool MIX, bool DC, bool FAST>
@@ -945,8 +946,11 @@ __global__ __launch_bounds__(FM_THREADS, 2) void k_fm(FmArgs a)
     double2 *X = reinterpret_cast<double2 *>(smem);                    // [FM_NT]: X[t] = sample G - 64 + t
     double *sc = reinterpret_cast<double *>(smem + FM_NT * sizeof(double2));  // [512]
     for (int i = threadIdx.x; i < 512; i += FM_THREADS) sc[i] = a.sincos[i];
-    const int s = blockIdx.y;
-    const long long G = a.tile0 + (long long)(65 * FM_NB) * blockIdx.x;
+    const long long nwork = (long long)a.ntiles * a.nstreams;
+#pragma unroll 1
+    for (long long work = blockIdx.x; work < nwork; work += gridDim.x) {
+    const int s = (int)(work / a.ntiles);
+    const long long G = a.tile0 + (long long)(65 * FM_NB) * (work % a.ntiles);
     const int jrel0 = (int)(G - 64 - a.g_first);  // call-relative output index of X[0] (negative in the first tile)
     const int *raw = a.raw + (long long)s * a.stride_pairs;
     const int2 *hist = a.hist + (long long)s * 32;
@@ -1014,9 +1018,11 @@ __global__ __launch_bounds__(FM_THREADS, 2) void k_fm(FmArgs a)
                         }
                     }
                 }
+#ifndef JSDR_FM_NOPIN
 #pragma unroll
                 for (int r = 0; r < R; r++) asm volatile("" : "+v"(ai[r]), "+v"(aq[r])::"memory");  // sums are due here
                 __builtin_amdgcn_sched_barrier(0);
+#endif
             }
 #pragma unroll
             for (int r = 0; r < R; r++) {  // x HOWARD_FUDGE_FACTOR (:486), VCO mix (:515-516)
@@ -1077,7 +1083,7 @@ __global__ __launch_bounds__(FM_THREADS, 2) void k_fm(FmArgs a)
             const int j = jrel0 + t;
             if (j >= nds - 64 && j < nds && j >= 0) dmh_new[j - (nds - 64)] = X[t];
         }
-        if (blockIdx.x == 0 && nds < 64 && (int)threadIdx.x < 64 - nds) dmh_new[threadIdx.x] = dmh_old[threadIdx.x + nds];
+        if (work % a.ntiles == 0 && nds < 64 && (int)threadIdx.x < 64 - nds) dmh_new[threadIdx.x] = dmh_old[threadIdx.x + nds];
     }
     // ================================================================================ matched filter
     const int lane = threadIdx.x & 63;
@@ -1103,6 +1109,8 @@ __global__ __launch_bounds__(FM_THREADS, 2) void k_fm(FmArgs a)
             const int rel = rel0 + u0 + r;
             if (lane < FM_NB && rel >= 0 && rel < nds) y[rel] = make_double2(ai[r], aq[r]);
         }
+    }
+    __syncthreads();  // the next work item reuses the image
     }
 }
 
@@ -2070,12 +2078,21 @@ static void launch_front(const FrontArgs &fa, int nstreams, long long nds, hipSt
 
 
 template <int D, int R>
-static int launch_fm_t(const FmArgs &a, bool mix, bool dc, bool fast, int nstreams, hipStream_t st)
+static int launch_fm_t(const FmArgs &a_in, bool mix, bool dc, bool fast, int nstreams, hipStream_t st)
 {
     const size_t lds = (size_t)FM_NT * sizeof(double2) + 512 * sizeof(double);
     const long long span = 65LL * FM_NB;
-    const long long ntiles = (a.g_first + a.nds - a.tile0 + span - 1) / span;
-    const dim3 grid((unsigned)ntiles, (unsigned)nstreams), block(FM_THREADS);
+    const long long ntiles = (a_in.g_first + a_in.nds - a_in.tile0 + span - 1) / span;
+    FmArgs a = a_in;
+    a.ntiles = (int)ntiles;
+    a.nstreams = nstreams;
+    static const long long grid_cap = [] {
+        const char *e = getenv("JSDR_FM_GRID");  // tuning knob: total workgroups (default: one per tile)
+        return e ? atoll(e) : 0LL;
+    }();
+    long long gx = ntiles * nstreams;
+    if (grid_cap > 0 && gx > grid_cap) gx = grid_cap;
+    const dim3 grid((unsigned)gx), block(FM_THREADS);
 #define JSDR_FM_LAUNCH(MIX, DC, FAST)                                                                           \
     do {                                                                                                        \
         static bool attr_done = false;                                                                          \

@@ -370,6 +370,11 @@ static int fft_run(jsdr_fft *h, const void *in_dev, int in_kind, int out_kind, l
         return v > 0 ? v : 4;
     }();
     long long cap = (long long)h->num_cu * per_cu * mult;
+    static const int abs_grid = [] {
+        const char *e = getenv("JSDR_FFT_GRID_ABS");  // tuning knob: total workgroups (co-residency experiments: 2 per CU = 512)
+        return e ? atoi(e) : 0;
+    }();
+    if (abs_grid > 0) cap = abs_grid;
     int grid = (int)(groups < cap ? groups : cap);
     l.launch(a, grid, s);
     JSDR_LAUNCH_CHECK();
