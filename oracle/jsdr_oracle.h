@@ -12,8 +12,11 @@
  *
  * Parity pinning status:
  *   - FECDecoder, FUNcubeBPSKDemod (tune mode), fir, phase, sample conversion:
- *     pinned by the reference's own constant tables (digests in tests/golden) and by
- *     the internal-consistency / round-trip KATs of SURVEY.md section 8c.
+ *     pinned by an independent pure-Python restatement of the Java text whose outputs
+ *     are committed as fixtures (tests/golden/reference_fixtures.npz: bits, counters,
+ *     state doubles, FEC bytes -- this library reproduces them bit for bit), by the
+ *     reference's own constant tables (digests in tests/golden) and by the
+ *     internal-consistency / round-trip KATs of SURVEY.md section 8c.
  *   - Anything that crosses JTransforms 2.4 (FloatFFT_1D / DoubleFFT_1D, absent from
  *     /root/reference): PARITY UNPINNED -- a radix-2 FFT stands in, checked against an
  *     exact float64 DFT.
