@@ -143,7 +143,7 @@ __device__ __forceinline__ void fft_pass(const FftArgs &a, long long frame, bool
                     for (int r = 0; r < R; r++) {
                         float2 x = v[gi][cx_bitrev(r, R)];
                         db[r] = L2 * __log2f(x.x * x.x + x.y * x.y) + OFF;
-                        dst[j0 + r * P] = db[r];
+                        dst[j0 + r * P] = db[r];  // (nontemporal stores: 1.99 -> 2.39 ms, measured r02)
                     }
                     // first strict maximum of this thread's bins (fft.java:208-211): the group's maximum
                     // (fmaxf ignores NaN, like the reference's '>'), then the lowest bin that holds it
