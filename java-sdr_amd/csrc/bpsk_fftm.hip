@@ -623,9 +623,73 @@ __device__ __attribute__((noinline)) void fm_pass_t(double2 *X, const double2 *t
     __syncthreads();
 }
 
+// two consecutive passes of an odd half in one LDS round trip: fm_pass2 with the two-dimensional tables
+template <int R1, int R2, int NN, int PP>
+__device__ __attribute__((noinline)) void fm_pass2_t(double2 *X, const double2 *tw1, const double2 *tw2, int tid)
+{
+    constexpr int RR = R1 * R2;
+    constexpr int ITERS = ((NN / RR) + FM_T - 1) / FM_T;
+    constexpr int ng = NN / RR, nb1 = NN / R1, P = PP, P2 = PP * R1;
+    double2 v[ITERS][R2][R1];
+#pragma unroll
+    for (int it = 0; it < ITERS; it++) {
+        const int g = it * FM_T + tid;
+        if (g < ng) {
+            const int k1 = g % PP;
+#pragma unroll
+            for (int j2 = 0; j2 < R2; j2++) {
+                const int b1 = g + j2 * ng;
+#pragma unroll
+                for (int j1 = 0; j1 < R1; j1++) {
+                    v[it][j2][j1] = X[b1 + j1 * nb1];
+                    if (j1 >= 1) v[it][j2][j1] = cdmul(v[it][j2][j1], tw1[(j1 - 1) * P + k1]);
+                }
+                dft_r<R1>(v[it][j2]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q1 = 0; q1 < R1; q1++) {
+                const int k2 = k1 + q1 * P;
+                double2 w[R2];
+#pragma unroll
+                for (int j2 = 0; j2 < R2; j2++) {
+                    w[j2] = v[it][j2][q1];
+                    if (j2 >= 1) w[j2] = cdmul(w[j2], tw2[(j2 - 1) * P2 + k2]);
+                }
+                dft_r<R2>(w);
+#pragma unroll
+                for (int q2 = 0; q2 < R2; q2++) v[it][q2][q1] = w[q2];
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < ITERS; it++) {
+        const int g = it * FM_T + tid;
+        if (g < ng) {
+            const int k1 = g % PP;
+            double2 *z = X + ((g - k1) * RR + k1);
+#pragma unroll
+            for (int q2 = 0; q2 < R2; q2++)
+#pragma unroll
+                for (int q1 = 0; q1 < R1; q1++) z[q1 * P + q2 * P * R1] = v[it][q2][q1];
+        }
+    }
+    __syncthreads();
+}
+
 __device__ __forceinline__ void fm_forward_odd(double2 *X, const Fft2xArgs &a, int tid)
 {
     const FftmArgs &m = a.sub;
+    if (m.f.n == 9600) {  // the 192 kHz default: the 9600-point plan 4 | 4,4 | 2,3 | 5 | 5 with pass pairs, as fm_forward
+        const double2 *t = m.f.tw;
+        fm_pass_t<4>(X, t + a.tw1_off[0], 9600, 1, 0u, tid);
+        fm_pass2_t<4, 4, 9600, 4>(X, t + a.tw1_off[1], t + a.tw1_off[2], tid);
+        fm_pass2_t<2, 3, 9600, 64>(X, t + a.tw1_off[3], t + a.tw1_off[4], tid);
+        fm_pass_t<5>(X, t + a.tw1_off[5], 9600, 384, m.pmagic[5], tid);
+        fm_pass_t<5>(X, t + a.tw1_off[6], 9600, 1920, m.pmagic[6], tid);
+        return;
+    }
     int P = 1;
     for (int p = 0; p < m.np; p++) {
         const int r = m.rad[p];
@@ -713,8 +777,13 @@ __global__ __launch_bounds__(FM_T) void k_front_fft2x(Fft2xArgs aa)
         load_half(t0, 1, tf);
         fm_forward_odd(X, aa, tf);
         // ---- |X| over the band the boxcar reads (:425-427)
-        for (int i = pbase + tf; i < end - 24; i += FM_T) {
-            const double2 v = spectrum(i);
+        // (pbase is even: even bins come from the scratch, odd ones from the image -- one loop each, no per-bin branch)
+        for (int i = pbase + 2 * tf; i < end - 24; i += 2 * FM_T) {
+            const double2 v = ek[i >> 1];
+            P[i - pbase] = sqrt(v.x * v.x + v.y * v.y);
+        }
+        for (int i = pbase + 1 + 2 * tf; i < end - 24; i += 2 * FM_T) {
+            const double2 v = X[i >> 1];
             P[i - pbase] = sqrt(v.x * v.x + v.y * v.y);
         }
         __syncthreads();
@@ -801,14 +870,32 @@ __global__ __launch_bounds__(FM_T) void k_front_fft2x(Fft2xArgs aa)
         {
             long long jlo = (t0 - a.first_out + D - 1) / D;
             if (t0 <= a.first_out) jlo = 0;
+            // with an even decimation (20 at 192 kHz) every window of the call ends on the same parity (t0 is even): which
+            // of the 27 taps read the scratch and which the image is then known at compile time
+            const bool uniform_parity = (D & 1) == 0;
+            const int epar = (int)((a.first_out - t0) & 1);
             for (long long j = jlo + tf;; j += FM_T) {
                 const long long te = (long long)a.first_out + (long long)D * j;
                 if (te >= t0 + n || j >= a.nds) break;
                 const double2 cs = a.vco_cs[j];
                 const int e = (int)(te - t0);
                 double fi = 0.0;
+                if (uniform_parity && e >= 26) {
+                    if (epar) {  // e odd: taps 0,2,.. read odd samples (image), taps 1,3,.. even ones (scratch)
+                        const double2 *xo = X + (e >> 1);
+                        const double *re = r0 + ((e - 1) >> 1);
 #pragma unroll
-                for (int k = 0; k < 27; k++) fi += sample(e - k) * ds_tap(k);  // newest first (:479-483)
+                        for (int k = 0; k < 27; k++) fi += ((k & 1) ? re[-(k >> 1)] : xo[-(k >> 1)].x * norm) * ds_tap(k);
+                    } else {     // e even: taps 0,2,.. read even samples (scratch), taps 1,3,.. odd ones (image)
+                        const double *re = r0 + (e >> 1);
+                        const double2 *xo = X + ((e - 1) >> 1);
+#pragma unroll
+                        for (int k = 0; k < 27; k++) fi += ((k & 1) ? xo[-(k >> 1)].x * norm : re[-(k >> 1)]) * ds_tap(k);
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 27; k++) fi += sample(e - k) * ds_tap(k);  // newest first (:479-483)
+                }
                 const double o = fi * HOWARD;
                 dm[64 + j] = make_double2(o * cs.x, o * cs.y);  // :515-516
             }
