@@ -1157,7 +1157,7 @@ struct TailArgs {
 // g-64..g (27-tap low-pass each, :479-483, one per lane) through LDS, then the 65 products in ring-slot order (:519-523).
 // The cold path of the fast variant: only samples whose 65-sample window lies inside this call (j0 >= 7, checked by the
 // caller, keeps every input index >= 0).
-__device__ __attribute__((noinline)) double2 tail_exact_sample(const TailArgs &a, int s, long long g, double2 *dmL, int lane)
+__device__ __forceinline__ double2 tail_exact_sample(const TailArgs &a, int s, long long g, double2 *dmL, int lane)
 {
     const int *raw = a.raw + (long long)s * a.stride_pairs;
     const double HOWARD = 0.9 * 32768.0;
@@ -1481,8 +1481,14 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs a)
                             if (fabs(e2L - 100.0) <= m_e2 / a.margin_scale || (e2L > 100.0 && fabs(diL) <= m_d / a.margin_scale)) uncert = 1;
                             continue;
                         }
-                        const double2 ec = tail_exact_sample(a, s, gc, dmL, lane);
-                        const double2 ep = tail_exact_sample(a, s, gp, dmL, lane);
+                        // (one inlined instance in a two-trip loop: a call would put the kernel on the function-call ABI --
+                        //  256 VGPRs, a stack, one wave per SIMD)
+                        double2 ec = make_double2(0.0, 0.0), ep = make_double2(0.0, 0.0);
+#pragma unroll 1
+                        for (int which = 0; which < 2; which++) {
+                            const double2 r = tail_exact_sample(a, s, which ? gp : gc, dmL, lane);
+                            if (which) ep = r; else ec = r;
+                        }
                         if (lane == L) {
                             di = -((ep.x * ec.x) + (ep.y * ec.y));
                             dq = (ep.x * ec.y) - (ep.y * ec.x);
