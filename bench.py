@@ -270,8 +270,11 @@ def main():
     dem = J.Bpsk(rate=RATE, blen=4 * a.bpsk_frame, tuning=12000, do_fft=int(a.fft_acquire), nstreams=S, max_batch_samples=L,
                  variant=a.variant) if a.workload in ("pipeline", "bpsk") else None
     # the PSD kernel is HBM-bound, the demodulator FP64-issue bound: on streams of their own they share the CUs
+    # every kernel of the timed loop goes to an explicit stream (the NULL stream would serialise with blocking streams)
+    main_stream = J.Stream()
+    ms_ = main_stream.ptr
     psd_stream = J.Stream() if (fft is not None and dem is not None and a.psd_stream) else None
-    ps = psd_stream.ptr if psd_stream else None
+    ps = psd_stream.ptr if psd_stream else ms_
     fir_taps = d_fir = None
     if a.workload == "fir":
         fir_taps = J.bpsk_table(0) if a.fir_taps == 27 else (J.bpsk_table(1) if a.fir_taps == 65 else J.Fir(44100.0).weights(500, 1500))
@@ -313,14 +316,14 @@ def main():
                     wf_timer[i].stop(ps)
         if fir_taps is not None:
             if timed:
-                fir_timer[i].start(None)
-            J.fir_batch_decimate_i16(d_iq, S, 2 * L, L, fir_taps, a.fir_decim, 0.9 * 32768.0, d_fir, L // a.fir_decim)
+                fir_timer[i].start(ms_)
+            J.fir_batch_decimate_i16(d_iq, S, 2 * L, L, fir_taps, a.fir_decim, 0.9 * 32768.0, d_fir, L // a.fir_decim, stream=ms_)
             if timed:
-                fir_timer[i].stop(None)
+                fir_timer[i].stop(ms_)
         if amfm is not None:
-            amfm.batch_i16(d_iq, 2 * L, L, d_audio, 2 * L)
+            amfm.batch_i16(d_iq, 2 * L, L, d_audio, 2 * L, stream=ms_)
         if dem is not None:
-            dem.batch_i16(d_iq, 2 * L, L)
+            dem.batch_i16(d_iq, 2 * L, L, stream=ms_)
             if N > 1:
                 dem.pack_slots(slots.data_ptr(), stream=gstream.cuda_stream)
                 with torch.cuda.stream(gstream):
@@ -329,6 +332,7 @@ def main():
     def sync():
         if psd_stream is not None:
             psd_stream.sync()
+        main_stream.sync()
         if dem is not None:
             dem.sync()  # the tail / FEC of the last step run on the handle's side stream
         if N > 1:
