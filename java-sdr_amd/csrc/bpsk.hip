@@ -1315,34 +1315,43 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs a)
             const bool lane_on = lane_iir || lane_out;
             // the 64 energies this lane will fold in, fetched up front: the serial chain below then touches
             // registers only (an LDS read per step would put ~100 cycles of latency on every link of the chain)
-            double xs[64];
+#ifndef JSDR_TAIL_XS
+#define JSDR_TAIL_XS 32
+#endif
+            // (in two halves of 32: the preload is 64 VGPRs instead of 128 and the kernel fits three waves per SIMD
+            //  instead of two -- at 8192 streams the tail is throughput-, not latency-bound)
+            constexpr int XS = JSDR_TAIL_XS;
+            const int pfirst = (glane < g_first) ? 1 : 0;  // period 0 of the chunk lacks this lane's sample
 #pragma unroll
-            for (int p = 0; p < 64; p++) xs[p] = enL[p * 8 + idx] * Sc;  // the products are off the chain
-            // (pinned: left to itself the compiler sinks the reads back into the chain, one LDS wait per two steps)
+            for (int p0 = 0; p0 < 64; p0 += XS) {
+                double xs[XS];
 #pragma unroll
-            for (int p = 0; p < 64; p++) asm volatile("" : "+v"(xs[p]));
-            // only the first and the last period of a call can be partial; everywhere else, with the peak position
-            // settled (the locked demodulator), a link of the chain is one multiply and one add.  The energies go to
-            // LDS as they fall out (stores are not on the chain; a register copy of all 64 would double the kernel's
-            // footprint beside the kernels it overlaps with).
-            if (interior && spec) {
-                // lanes 0..8 only, under ONE exec mask for the whole chain (a mask per store costs an exec write and its
-                // hazard on every link); lane 8 (dmEnergyOut) stores into the rows' pad column, which nobody reads
-                if (lane <= 8) {
+                for (int p = 0; p < XS; p++) xs[p] = enL[(p0 + p) * 8 + idx] * Sc;  // the products are off the chain
+                // (pinned: left to itself the compiler sinks the reads back into the chain, one LDS wait per two steps)
 #pragma unroll
-                    for (int p = 0; p < 64; p++) {
-                        e = (e * Kc) + xs[p];  // :535 / :538
-                        eL[p][lane] = e;
+                for (int p = 0; p < XS; p++) asm volatile("" : "+v"(xs[p]));
+                // only the first and the last period of a call can be partial; everywhere else, with the peak position
+                // settled (the locked demodulator), a link of the chain is one multiply and one add.  The energies go to
+                // LDS as they fall out (stores are not on the chain; a register copy of all 64 would double the kernel's
+                // footprint beside the kernels it overlaps with).
+                if (interior && spec) {
+                    // lanes 0..8 only, under ONE exec mask for the whole chain (a mask per store costs an exec write and
+                    // its hazard on every link); lane 8 (dmEnergyOut) stores into the rows' pad column, which nobody reads
+                    if (lane <= 8) {
+#pragma unroll
+                        for (int p = 0; p < XS; p++) {
+                            e = (e * Kc) + xs[p];  // :535 / :538
+                            eL[p0 + p][lane] = e;
+                        }
                     }
-                }
-            } else {
-                const int pfirst = (glane < g_first) ? 1 : 0;  // period 0 of the chunk lacks this lane's sample
+                } else {
 #pragma unroll
-                for (int p = 0; p < 64; p++) {
-                    const double ne = (e * Kc) + xs[p];
-                    const bool ok = lane_on && (p >= pfirst) && (glane + 8 * p < g_end);
-                    if (ok) e = ne;
-                    if (lane_iir) eL[p][lane] = e;
+                    for (int p = 0; p < XS; p++) {
+                        const double ne = (e * Kc) + xs[p];
+                        const bool ok = lane_on && (p0 + p >= pfirst) && (glane + 8 * (p0 + p) < g_end);
+                        if (ok) e = ne;
+                        if (lane_iir) eL[p0 + p][lane] = e;
+                    }
                 }
             }
         }
