@@ -1585,6 +1585,68 @@ __global__ void k_sync(SyncArgs a)
     }
 }
 
+// k_sync_t: the same correlations from a TRANSPOSED image of the stream's bit log in LDS.  Window p of output b is
+// W[b + 80 n], W[p] = bitlog[1 + p]: with T[p mod 80][p div 80] = W[p] the 65 bytes of an output are CONTIGUOUS in row
+// b mod 80 from column b div 80 -- eighteen aligned dword reads, a byte alignment and seventeen v_dot4_i32_i8 against
+// the packed sync vector instead of 65 strided byte loads and 65 multiply-adds (integer arithmetic: same sums).  One
+// workgroup per stream; the row stride is 4 * odd so that the rows of 32 consecutive outputs fall on 32 different banks.
+__global__ __launch_bounds__(256) void k_sync_t(SyncArgs a, int row_stride)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    signed char *T = reinterpret_cast<signed char *>(smem);  // [80][row_stride]
+    const int s = blockIdx.x;
+    const int nb = a.nbits[s];
+    if (nb <= 0) return;
+    const signed char *W = a.bitlog + (long long)s * a.bitlog_stride + 1;
+    const int np = HIST_BITS - 1 + nb;  // W[0 .. np): the last window ends at W[nb-1 + 80*64]
+    {
+        int p = threadIdx.x, r = p % 80, q = p / 80;
+        for (; p < np; p += 256) {
+            T[r * row_stride + q] = W[p];
+            r += 256 % 80;
+            q += 256 / 80;
+            if (r >= 80) {
+                r -= 80;
+                q += 1;
+            }
+        }
+    }
+    // packed sync vector: bytes 4i .. 4i+3 (zero beyond 64)
+    int S4[17];
+#pragma unroll
+    for (int i = 0; i < 17; i++) {
+        int v = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (4 * i + k < SYNC_N) v |= ((int)c_bpsk.sync[4 * i + k] & 0xff) << (8 * k);
+        S4[i] = v;
+    }
+    __syncthreads();
+    {
+        int b = threadIdx.x, r = b % 80, q0 = b / 80;
+        for (; b < nb; b += 256) {
+            const int *row = reinterpret_cast<const int *>(T + r * row_stride + (q0 & ~3));
+            const int sh = q0 & 3;
+            int d[18];
+#pragma unroll
+            for (int i = 0; i < 18; i++) d[i] = row[i];
+            int c = 0;
+#pragma unroll
+            for (int i = 0; i < 17; i++) {
+                const int w = (int)__builtin_amdgcn_alignbyte((unsigned)d[i + 1], (unsigned)d[i], (unsigned)sh);
+                c = __builtin_amdgcn_sdot4(w, S4[i], c, false);
+            }
+            a.corr[(long long)s * a.max_bits + b] = (signed char)c;
+            r += 256 % 80;
+            q0 += 256 / 80;
+            if (r >= 80) {
+                r -= 80;
+                q0 += 1;
+            }
+        }
+    }
+}
+
 // the hits (correlation >= 45, :560) in bit order -- one wave per stream walks the correlations 64 at a time, a ballot
 // and a prefix count give every hit its slot: deterministic, and when a call holds more hits than the handle has room
 // for it is the FIRST trig_cap that are kept (the stream is flagged; the getters then fail instead of returning a
@@ -2452,7 +2514,25 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
         if (gx < 1) gx = 1;
         {
             ProfScope ps(h, PK_SYNC, ts);
-            hipLaunchKernelGGL(k_sync, dim3((unsigned)gx, (unsigned)S), dim3(256), 0, ts, sa);
+            // transposed-image kernel when the stream's log fits a workgroup's LDS (always, up to ~8M samples a call)
+            int cols = (HIST_BITS + h->max_bits + 79) / 80 + 72;  // + the 18 dwords an output reads past its first column
+            int rs = (cols + 3) & ~3;
+            if (((rs / 4) & 1) == 0) rs += 4;  // 4 * odd
+            const size_t lds = (size_t)80 * rs + 16;
+            static const bool use_t = [] {
+                const char *e = getenv("JSDR_SYNC_T");  // JSDR_SYNC_T=0: the strided kernel
+                return !e || atoi(e) != 0;
+            }();
+            if (use_t && lds <= 150 * 1024) {
+                static size_t attr_for = 0;
+                if (attr_for < lds) {
+                    JSDR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sync_t), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    attr_for = lds;
+                }
+                hipLaunchKernelGGL(k_sync_t, dim3((unsigned)S), dim3(256), lds, ts, sa, rs);
+            } else {
+                hipLaunchKernelGGL(k_sync, dim3((unsigned)gx, (unsigned)S), dim3(256), 0, ts, sa);
+            }
         }
         JSDR_LAUNCH_CHECK();
         {
