@@ -11,8 +11,9 @@
 //                 cached while the phase state repeats (it is an exact 8-cycle at 12 kHz / 96 kHz)
 //   k_front*    : int16 -> float -> double, tuner mix, 27-tap low-pass at the decimated instants
 //                 (newest-first order, :479-483), x HOWARD_FUDGE_FACTOR, VCO mix  -> dm[s][64+j]
-//                 (k_front_reg: register-staged lane windows, the default for int16 at 96 kHz; k_front_dma:
-//                 LDS image filled by LDS-DMA; k_front: generic; bpsk_fft.hip / bpsk_fftm.hip: FFT-acquire mode)
+//                 (k_fm: fused with the matched filter, the default for int16 input with a periodic tuner schedule;
+//                 k_front_reg: register-staged lane windows; k_front: generic, float input; bpsk_fft.hip /
+//                 bpsk_fftm.hip: FFT-acquire mode)
 //   k_matched   : 65-tap matched filter in RING-SLOT order with rotated taps (:519-523) -> y[s][j]=(fi,fq)
 //   k_tail      : bit-energy IIRs, peak tracking, differential slicer (:534-593) -> bits
 //   k_sync      : 65-symbol sync correlation at stride 80 over the 5200-bit window (:556-560)
@@ -307,17 +308,7 @@ __global__ __launch_bounds__(128, 4) void k_front(FrontArgs a)
     }
 }
 
-// ------------------------------------------------------------------------------------------- k_front_dma
-// The int16 fast path of k_front.  Same arithmetic, same order; what changes is how the samples reach the lanes:
-//   stage : LDS-DMA (global_load_lds): every wave instruction copies 64 consecutive raw dwords (resp. 64 tuner
-//           index bytes) straight into a LINEAR LDS image -- no VGPR round trip, no address arithmetic beyond a
-//           clamped index, ~5 VALU per element instead of ~18.
-//   walk  : lane l owns samples RD*l .. RD*l+NS-1 of the tile and reads them four at a time with ds_read_b128
-//           (lane stride RD/4 = 10 quads: a 2-way conflict, 2 LDS cycles per sample); the walk is unrolled over
-//           compile-time sample positions, newest first, exactly as front_block does.
-// DC correction cannot ride on the DMA, so it is applied in the walk (template flag).  History samples arrive
-// already corrected; they are stored "un-corrected" (minus this call's ic/qc, 16-bit wrap) so that the uniform
-// correction in the walk reproduces them.
+// lane-span geometry of the register-staged front end: a lane owns RD samples = R outputs, its window NS samples
 template <int D, int RD>
 struct FrontDmaGeom {
     static_assert(RD % D == 0 && RD % 4 == 0, "lane span: whole outputs, whole quads");
@@ -325,160 +316,15 @@ struct FrontDmaGeom {
     static constexpr int NS = RD - D + 27;
     static constexpr int NSQ = (NS + 3) / 4;
     static constexpr int NT = 64 * RD - D + 27;
-    static constexpr int NIT = (NT + 63) / 64;                 // raw: one dword (one sample) per lane per DMA
-    static constexpr int NITK = (NT + 255) / 256;              // tuner indices: one dword (four samples) per lane per DMA
-    static constexpr int RAW_DW = NIT * 64 + 64;               // linear images, whole wave instructions
-    static constexpr int K_BYTES = NITK * 256 + 64;
 };
-
-template <int D, int RD, bool MIX, bool DC>
-__global__ __launch_bounds__(128, 4) void k_front_dma(FrontArgs a)
-{
-    using G = FrontDmaGeom<D, RD>;
-    constexpr int R = G::R;
-    extern __shared__ __align__(16) unsigned char smem[];
-    double *sc = reinterpret_cast<double *>(smem);  // [512]
-    for (int i = threadIdx.x; i < 512; i += blockDim.x) sc[i] = a.sincos[i];
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
-    constexpr size_t WAVE_BYTES = (size_t)G::RAW_DW * 4 + G::K_BYTES;
-    unsigned char *wbase = smem + 512 * sizeof(double) + wave * WAVE_BYTES;
-    int *rawL = reinterpret_cast<int *>(wbase);
-    unsigned char *kL = wbase + (size_t)G::RAW_DW * 4;
-    const int s = blockIdx.y;
-    const long long ntiles = (a.nds + 64 * R - 1) / (64 * R);
-    const double HOWARD = 0.9 * 32768.0;  // :469
-    const int *raw = a.raw + (long long)s * a.stride_pairs;
-    const int2 *hist = a.hist + (long long)s * 32;
-    const int Lm1 = (int)(a.nsamples - 1);
-    for (long long tile = (long long)blockIdx.x * nwave + wave; tile < ntiles; tile += (long long)gridDim.x * nwave) {
-        const long long j0 = tile * 64 * R;
-        const int lo = a.first_out + (int)(D * j0) - 26;  // input index of tile sample 0 (call-relative, fits int)
-        // ---- stage by LDS-DMA: element e of the tile <- sample clamp(lo+e) ; linear image
-        typedef __attribute__((address_space(3))) void *lds_ptr_t;
-        typedef const __attribute__((address_space(1))) void *glb_ptr_t;
-#pragma unroll 4
-        for (int it = 0; it < G::NIT; it++) {
-            int n = lo + it * 64 + lane;
-            n = n < 0 ? 0 : (n > Lm1 ? Lm1 : n);
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(raw + n), (lds_ptr_t)(rawL + it * 64), 4, 0, 0);
-        }
-        // tuner indices, four per lane: the host lays the byte table out so that element 26+first_out is dword
-        // aligned (D*j0 is a multiple of 4), and pads it, so neither a clamp nor a byte-wide DMA is needed
-        // (a byte-wide global_load_lds still advances 4 bytes of LDS per lane)
-#pragma unroll
-        for (int it = 0; it < G::NITK; it++)
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(a.ktu + 26 + lo + it * 256 + 4 * lane),
-                                             (lds_ptr_t)(kL + it * 256), 4, 0, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        JSDR_WAVE_SYNC();
-        if (lo < 0) {  // first tile of the call: the 26 inputs before it come from the history (already corrected)
-            const int n = lo + lane;
-            if (n < 0) {
-                int w = hist[26 + n].x;
-                if constexpr (DC) {  // undo this call's correction so that the walk re-applies it
-                    int si = (int)(short)((w & 0xffff) - a.ic);
-                    int sq = (int)(short)((w >> 16) - a.qc);
-                    w = (si & 0xffff) | (sq << 16);
-                }
-                rawL[lane] = w;
-                kL[lane] = a.ktu[26 + n];
-            }
-            JSDR_WAVE_SYNC();
-        }
-        // ---- walk this lane's samples from newest to oldest
-        double ai[R], aq[R];
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-            ai[r] = 0.0;
-            aq[r] = 0.0;
-        }
-        const int4 *xq = reinterpret_cast<const int4 *>(rawL + RD * lane);
-        const unsigned *kq = reinterpret_cast<const unsigned *>(kL + RD * lane);
-        // The walk is software pipelined two quads deep: while quad q is multiplied out, the sin/cos entries of
-        // quad q-1 and the samples / tuner indices of quad q-2 are on their way from LDS.  (Per quad there are two
-        // DEPENDENT LDS round trips -- indices first, then the table entries they select -- and the kernel is
-        // latency bound: 1.81 ms at 5 workgroups per CU, 3.3 ms at 2.)  The fences keep the compiler from hoisting
-        // the whole unrolled walk's reads to the top (it spills) while leaving this much in flight.
-        int4 W[G::NSQ];
-        unsigned K[G::NSQ];
-        double CS[G::NSQ][8];
-        auto load_raw = [&](int q) {
-            W[q] = xq[q];
-            K[q] = kq[q];
-        };
-        auto load_sc = [&](int q) {
-            if constexpr (MIX) {
-#pragma unroll
-                for (int t = 0; t < 4; t++) {
-                    const int k = (K[q] >> (8 * t)) & 0xff;
-                    CS[q][2 * t] = sc[k];
-                    CS[q][2 * t + 1] = sc[256 + k];
-                }
-            }
-        };
-        load_raw(G::NSQ - 1);
-        if constexpr (G::NSQ >= 2) load_raw(G::NSQ - 2);
-        load_sc(G::NSQ - 1);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int q = G::NSQ - 1; q >= 0; q--) {
-            if (q - 2 >= 0) load_raw(q - 2);
-            if (q - 1 >= 0) load_sc(q - 1);
-            const int4 w4 = W[q];
-#pragma unroll
-            for (int t = 3; t >= 0; t--) {
-                const int m = 4 * q + t;
-                if (m < G::NS) {
-                    int w = (t == 0) ? w4.x : (t == 1) ? w4.y : (t == 2) ? w4.z : w4.w;
-                    int si = (int)(short)(w & 0xffff), sq = w >> 16;
-                    if constexpr (DC) {
-                        si = java_short_add(si, a.ic);
-                        sq = java_short_add(sq, a.qc);
-                    }
-                    double di = (double)i16_to_float_java(si);
-                    double dq = (double)i16_to_float_java(sq);
-                    if constexpr (MIX) {  // :388-390 component-wise, not a complex multiply
-                        di = di * CS[q][2 * t];
-                        dq = dq * CS[q][2 * t + 1];
-                    }
-#pragma unroll
-                    for (int r = 0; r < R; r++) {
-                        if (m >= D * r && m <= D * r + 26) {  // sample m has age D*r+26-m in the window of output r
-                            const double tp = ds_tap(D * r + 26 - m);
-                            ai[r] += di * tp;
-                            aq[r] += dq * tp;
-                        }
-                    }
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < R; r++) asm volatile("" : "+v"(ai[r]), "+v"(aq[r])::"memory");  // sums are due here
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        // ---- x HOWARD_FUDGE_FACTOR (:486), VCO mix (:515-516)
-        const long long jl = j0 + (long long)R * lane;
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-            const long long j = jl + r;
-            if (j < a.nds) {
-                const double oi = ai[r] * HOWARD, oq = aq[r] * HOWARD;
-                if (a.ds_dbg) a.ds_dbg[(long long)s * a.nds + j] = make_double2(oi, oq);
-                const int kv = a.kvco[j];
-                a.dm[(long long)s * a.dm_stride + 64 + j] = make_double2(oi * sc[kv], oq * sc[256 + kv]);
-            }
-        }
-        JSDR_WAVE_SYNC();
-    }
-}
 
 // ------------------------------------------------------------------------------------------- k_front_reg
 // The int16 fast path without an LDS image: lane l of a tile reads ITS OWN window of NS = RD-D+27 samples
 // (RD*l .. RD*l+NS-1) straight into registers with 16-byte loads, newest quad first, and walks it while the older
 // quads are still in flight (vmcnt counts them down in issue order).  The overlap of neighbouring windows (26
-// samples) is served by L1/L2, not by HBM.  Against k_front_dma: no LDS but the 4 KB sin/cos table, so occupancy
+// samples) is served by L1/L2, not by HBM.  Against an LDS image of the tile (round 1's k_front_dma): no LDS but the 4 KB sin/cos table, so occupancy
 // is set by registers alone and does not collapse when the side stream's kernels hold LDS on the same CU --
-// k_front_dma is latency bound and its time goes with 1/occupancy.  Same arithmetic, same order.
+// the LDS-image kernel was latency bound and its time went with 1/occupancy.  Same arithmetic, same order.
 // PER: the tuner index is periodic in the sample number with a period that divides the lane span RD (verified by
 // the host over every sample of the call): the (cos, sin) pair of window sample m sits at the compile-time offset m
 // from a wave-uniform base of an unwrapped table -- scalar loads and SGPR operands instead of the 1 B/sample index
@@ -1803,8 +1649,6 @@ struct jsdr_bpsk {
     long long last_nds = 0;
     int last_y = 0;
     hipStream_t last_stream = 0;
-    bool front_dma = true;  // LDS-DMA staged int16 fast path (JSDR_FRONT_DMA=0 selects the generic kernel)
-    int front_rd = 40;  // samples per lane span in k_front at 96 kHz (JSDR_FRONT_RD=80 selects the wide variant)
     // optional per-kernel HIP-event timing (bench.py's roofline leg)
     bool prof_on = false;
     struct ProfRec {
@@ -2043,42 +1887,10 @@ static void launch_front_t(const FrontArgs &fa, int nstreams, long long nds, hip
                        fa);
 }
 
-template <int D, int RD, bool MIX, bool DC>
-static void launch_front_dma_t(const FrontArgs &fa, int nstreams, long long nds, hipStream_t st)
-{
-    using G = FrontDmaGeom<D, RD>;
-    constexpr int WAVES = 2;
-    static const size_t lds_pad = [] {
-        const char *e = getenv("JSDR_FRONT_LDS_PAD");  // experiment knob: extra LDS per workgroup = lower occupancy
-        return e ? (size_t)atoi(e) : (size_t)0;
-    }();
-    const size_t lds = 512 * sizeof(double) + WAVES * ((size_t)G::RAW_DW * 4 + G::K_BYTES) + lds_pad;
-    long long ntiles = (nds + 64 * G::R - 1) / (64 * G::R);
-    // five tiles per wave: a workgroup that walks several tiles loads the 4 KB sin/cos table once for all of them
-    // (2.00 -> 1.82 ms; JSDR_FRONT_TPW overrides).  Tried and dropped: double-buffered tiles with the next tile's
-    // LDS-DMA in flight during the walk -- the halved occupancy costs far more (3.4 ms) than the latency it hides.
-    static const int tpw = [] {
-        const char *e = getenv("JSDR_FRONT_TPW");
-        const int v = e ? atoi(e) : 0;
-        return v > 0 ? v : 5;
-    }();
-    long long gx = (ntiles + (long long)WAVES * tpw - 1) / ((long long)WAVES * tpw);
-    if (gx > 2048) gx = 2048;
-    if (gx < 1) gx = 1;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_front_dma<D, RD, MIX, DC>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
-    hipLaunchKernelGGL((k_front_dma<D, RD, MIX, DC>), dim3((unsigned)gx, (unsigned)nstreams), dim3(64 * WAVES), lds, st,
-                       fa);
-}
-
 static bool front_reg_enabled()
 {
     static const bool reg = [] {
-        const char *e = getenv("JSDR_FRONT_REG");  // JSDR_FRONT_REG=0: k_front_dma / the generic kernel instead
+        const char *e = getenv("JSDR_FRONT_REG");  // JSDR_FRONT_REG=0: the generic kernel instead
         return !e || atoi(e) != 0;
     }();
     return reg;
@@ -2122,22 +1934,6 @@ static bool launch_front_reg(const FrontArgs &fa, int nstreams, long long nds, b
         else { if (dc) JSDR_REG(true, true, false, false); else JSDR_REG(true, false, false, false); }
     }
 #undef JSDR_REG
-    return true;
-}
-
-// the LDS-DMA path (JSDR_FRONT_REG=0): int16 input, 96 kHz (D=10), samples addressable with 32-bit indices
-template <int D, int RD>
-static bool launch_front_dma(const FrontArgs &fa, int nstreams, long long nds, hipStream_t st)
-{
-    if (fa.rawf || fa.nsamples > 0x3fffffffLL || fa.nsamples < 64) return false;
-    const bool dc = (fa.ic != 0) || (fa.qc != 0);
-    if (fa.mix) {
-        if (dc) launch_front_dma_t<D, RD, true, true>(fa, nstreams, nds, st);
-        else launch_front_dma_t<D, RD, true, false>(fa, nstreams, nds, st);
-    } else {
-        if (dc) launch_front_dma_t<D, RD, false, true>(fa, nstreams, nds, st);
-        else launch_front_dma_t<D, RD, false, false>(fa, nstreams, nds, st);
-    }
     return true;
 }
 
@@ -2245,8 +2041,7 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
     const bool per_ok = !h->do_fft && h->mix == 1 && h->c_tper > 0 && fm_rd % h->c_tper == 0;
     const bool fm_ok = h->use_fm && !h->do_fft && raw_dev && !rawf_dev && nds > 0 && L <= 0x3fffffffLL &&
                        (h->mix == 0 || per_ok);
-    // the byte table is shifted by 0..3 so that ktu[26 + first_out] is dword aligned (k_front_dma's dword DMA)
-    const int kshift = (4 - (first_out & 3)) & 3;  // element 26+lo = first_out + D*j0, and D*j0 is a multiple of 4
+    const int kshift = 0;
     const bool fresh = !h->cache_valid;
     if (fresh) h->ktu_uploaded = false;
     if (fresh) {
@@ -2261,10 +2056,9 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
     }
     unsigned char *kvco_p = h->kvco.p + (size_t)h->tab_cur * (size_t)h->max_ds;
     double2 *tcs_p = h->tcs.p + (size_t)h->tab_cur * (256 + FM_TABLE_SLACK);
-    // the 1 B/sample index table is only read by the kernels without the periodic table (k_front, k_front_dma,
-    // k_front_reg<PER = false>)
+    // the 1 B/sample index table is only read by the kernels without the periodic table (k_front, k_front_reg<PER = false>)
     const bool reg_will_run = front_reg_enabled() && raw_dev && !rawf_dev && L <= 0x3fffffffLL && L >= 64 &&
-                              (h->decim != 10 || (h->front_rd != 80 && h->front_dma));
+                              true;
     const bool need_ktu = !h->do_fft && !fm_ok && !(per_ok && reg_will_run) && h->mix != 0;
     if (need_ktu && (!h->ktu_uploaded || kshift != h->c_kshift)) {
         h->c_kshift = kshift;
@@ -2387,14 +2181,8 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
                 else launch_front<5, 40>(fa, S, nds, st);
                 break;
             case 10:
-                if (h->front_rd == 80)
-                    launch_front<10, 80>(fa, S, nds, st);
-                else if (h->front_dma && launch_front_reg<10, 40>(fa, S, nds, fast, st))
-                    h->front_name = "k_front_reg";
-                else if (h->front_dma && launch_front_dma<10, 40>(fa, S, nds, st))
-                    h->front_name = "k_front_dma";
-                else
-                    launch_front<10, 40>(fa, S, nds, st);
+                if (launch_front_reg<10, 40>(fa, S, nds, fast, st)) h->front_name = "k_front_reg";
+                else launch_front<10, 40>(fa, S, nds, st);
                 break;
             case 20:
                 if (launch_front_reg<20, 80>(fa, S, nds, fast, st)) h->front_name = "k_front_reg";
@@ -2614,9 +2402,7 @@ int jsdr_bpsk_create(jsdr_bpsk **out, int rate, int nsamples_per_frame, int tuni
     h->tuPhaseInc = 2.0 * JPI * (double)tuning_hz / (double)rate;  // :196
     while ((1 << h->logn) < nsamples_per_frame) h->logn++;
     if (do_fft) h->max_batch = (h->max_batch / nsamples_per_frame) * nsamples_per_frame;
-    if (const char *e = getenv("JSDR_FRONT_RD")) h->front_rd = atoi(e) == 80 ? 80 : 40;
     if (const char *e = getenv("JSDR_NO_OVERLAP")) h->overlap = atoi(e) == 0;
-    if (const char *e = getenv("JSDR_FRONT_DMA")) h->front_dma = atoi(e) != 0;
     if (const char *e = getenv("JSDR_FM")) h->use_fm = atoi(e) != 0;
     if (const char *e = getenv("JSDR_SCHED_PREFETCH")) h->prefetch_on = atoi(e) != 0;
     const size_t S = (size_t)nstreams;

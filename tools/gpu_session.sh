@@ -38,23 +38,16 @@ for step in "$@"; do
     bench_acq)   run bench_acq 400 python bench.py --workload bpsk --fft-acquire --steps 3 --warmup 1 --no-cpu-baseline ;;
     bench_acq9600) run bench_acq9600 400 python bench.py --workload bpsk --fft-acquire --bpsk-frame 9600 --steps 3 --warmup 1 --no-cpu-baseline ;;
     bench_acq_clk) JSDR_FFT_PHASECLK=1 run bench_acq_clk 400 python bench.py --workload bpsk --fft-acquire --steps 2 --warmup 1 --no-cpu-baseline ;;
-    bench_nodma) JSDR_FRONT_DMA=0 run bench_nodma 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline ;;
     bench_n2)    JSDR_BENCH_SAME_DEVICE=1 JSDR_BENCH_BACKEND=gloo run bench_n2 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 3 --warmup 1 --streams 256 ;;
-    bench_pad20) JSDR_FRONT_LDS_PAD=20000 JSDR_NO_OVERLAP=1 run bench_pad20 300 python bench.py --workload bpsk --steps 5 --warmup 2 --no-cpu-baseline ;;
-    bench_pad45) JSDR_FRONT_LDS_PAD=45000 JSDR_NO_OVERLAP=1 run bench_pad45 300 python bench.py --workload bpsk --steps 5 --warmup 2 --no-cpu-baseline ;;
-    bench_pad0) JSDR_NO_OVERLAP=1 run bench_pad0 300 python bench.py --workload bpsk --steps 5 --warmup 2 --no-cpu-baseline ;;
     bench_nofec) JSDR_EXPERIMENT_SKIP_FEC=1 run bench_nofec 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-validate ;;
     bench_reg_alone) JSDR_NO_OVERLAP=1 run bench_reg_alone 300 python bench.py --workload bpsk --steps 5 --warmup 2 --no-cpu-baseline ;;
     bench_reg) run bench_reg 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline ;;
-    tests_bpsk_reg) JSDR_FRONT_REG=0 run tests_bpsk_reg 600 python -m pytest tests/test_gpu_bpsk.py -m gpu -q -x -p no:cacheprovider --timeout 600 ;;
-    bench_dma_alone) JSDR_FRONT_REG=0 JSDR_NO_OVERLAP=1 run bench_dma_alone 300 python bench.py --workload bpsk --steps 5 --warmup 2 --no-cpu-baseline ;;
     bench_m64) JSDR_FFT_GRID_MULT=64 run bench_m64 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline ;;
     bench_m256) JSDR_FFT_GRID_MULT=256 run bench_m256 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline ;;
     bench_m16) JSDR_FFT_GRID_MULT=16 run bench_m16 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline ;;
     bench_alone_b) JSDR_LIB=$PWD/java-sdr_amd/libjsdr_hip_b.so JSDR_NO_OVERLAP=1 run bench_alone_b 300 python bench.py --workload bpsk --steps 5 --warmup 2 --no-cpu-baseline ;;
     bench_alone) JSDR_NO_OVERLAP=1 run bench_alone 300 python bench.py --workload bpsk --steps 5 --warmup 2 --no-cpu-baseline ;;
     bench_noov)  JSDR_NO_OVERLAP=1 run bench_noov 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline ;;
-    bench_rd80)  JSDR_FRONT_RD=80 run bench_rd80 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline ;;
     fec_bench)   run fec_bench 300 python tests/tools/fec_bench.py ;;
     hbm)         run hbm_build 120 hipcc --offload-arch=gfx950 -O3 -o /tmp/mb_hbm tools/microbench_hbm.hip
                  run hbm 120 /tmp/mb_hbm ;;
