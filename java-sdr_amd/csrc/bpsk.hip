@@ -817,14 +817,23 @@ __global__ __launch_bounds__(FM_THREADS, 2) void k_fm(FmArgs a)
     float amx = 0.0f;  // FAST: largest |sample| this lane converts
     __syncthreads();  // sin/cos table
     // ================================================================================ front half
+#ifdef JSDR_X_NOFRONT
+    if (a.nds < 0)
+#endif
 #pragma unroll 1
     for (int round = 0; round < ROUNDS; round++) {
         const int job = threadIdx.x + FM_THREADS * round;
         const int t0 = R * job;
         if (t0 >= FM_NT) break;
         const int j0 = jrel0 + t0;                   // first output of the job, call relative
+#ifdef JSDR_X_COAL
+        const int n0 = (a.first_out + D * (jrel0 + R * FM_THREADS * round) - 26) + 4 * (threadIdx.x);  // TIMING EXPERIMENT: wrong data
+#else
         const int n0 = a.first_out + D * j0 - 26;    // its window's first sample
-        const bool inside = j0 >= 0 && j0 + R <= nds && t0 + R <= FM_NT && n0 >= 0 && n0 + 4 * NSQ - 1 <= Lm1;
+#endif
+        // (the tile's last job owns fewer than R image slots when R does not divide FM_NT: it still takes this path and
+        // drops the surplus outputs at the store -- on the edge path it cost every tile ~7 us, 15 % of the kernel)
+        const bool inside = j0 >= 0 && j0 + R <= nds && n0 >= 0 && n0 + 4 * NSQ - 1 <= Lm1;
         if (inside) {
             int4 W[NSQ];
 #pragma unroll
@@ -846,8 +855,13 @@ __global__ __launch_bounds__(FM_THREADS, 2) void k_fm(FmArgs a)
                         double di, dq;
                         fm_convert(w, a.ic, a.qc, DC, di, dq, FAST ? &amx : nullptr);
                         if constexpr (MIX) {  // :388-390 component-wise, not a complex multiply
+#ifdef JSDR_X_TB8
+                            di = di * tb[2 * (m & 7)];
+                            dq = dq * tb[2 * (m & 7) + 1];
+#else
                             di = di * tb[2 * m];
                             dq = dq * tb[2 * m + 1];
+#endif
                         }
 #pragma unroll
                         for (int r = 0; r < R; r++) {
@@ -874,7 +888,7 @@ __global__ __launch_bounds__(FM_THREADS, 2) void k_fm(FmArgs a)
             for (int r = 0; r < R; r++) {  // x HOWARD_FUDGE_FACTOR (:486), VCO mix (:515-516)
                 const double oi = ai[r] * HOWARD, oq = aq[r] * HOWARD;
                 const int kv = a.kvco[j0 + r];
-                X[t0 + r] = make_double2(oi * sc[kv], oq * sc[256 + kv]);
+                if (FM_NT % R == 0 || t0 + r < FM_NT) X[t0 + r] = make_double2(oi * sc[kv], oq * sc[256 + kv]);
             }
         } else {
             // the call's edges (history before sample 0, the halo before output 0, the end of the data): one output
@@ -886,7 +900,9 @@ __global__ __launch_bounds__(FM_THREADS, 2) void k_fm(FmArgs a)
                 double2 val = make_double2(0.0, 0.0);
                 if (j >= -64 && j < 0) {
                     val = dmh_old[64 + j];
-                } else if (j >= 0 && j < nds) {
+                }
+#ifndef JSDR_X_NOEDGE
+                else if (j >= 0 && j < nds) {
                     double fi = 0.0, fq = 0.0;
 #pragma unroll 1
                     for (int age = 0; age < 27; age++) {
@@ -912,6 +928,7 @@ __global__ __launch_bounds__(FM_THREADS, 2) void k_fm(FmArgs a)
                     const int kv = a.kvco[j];
                     val = make_double2(oi * sc[kv], oq * sc[256 + kv]);
                 }
+#endif
                 X[t] = val;
             }
         }
@@ -938,6 +955,9 @@ __global__ __launch_bounds__(FM_THREADS, 2) void k_fm(FmArgs a)
     const double2 *xl = X + 64 + 65 * blk;            // &X[s0]
     const int rel0 = jrel0 + 64 + 65 * blk;           // call-relative index of s0
     double2 *y = a.y + (long long)s * a.y_stride;
+#ifdef JSDR_X_NOMATCHED
+    if (a.nds < 0)
+#endif
     if (wave == 0) {
         double ai[9], aq[9];
         matched_block<9, FAST>(xl, 0, ai, aq);
