@@ -759,14 +759,26 @@ __global__ __launch_bounds__(64) void k_dm_history(double2 *dm, long long dm_str
 #ifndef JSDR_FM_NB
 #define JSDR_FM_NB 62
 #endif
-enum { FM_NB = JSDR_FM_NB, FM_NT = 64 + 65 * FM_NB, FM_THREADS = 512, FM_TABLE_SLACK = 128 };
+enum { FM_NB = JSDR_FM_NB, FM_NT = 64 + 65 * FM_NB, FM_THREADS = 512, FM_TABLE_SLACK = 128, FM_EDGE = 128 };
 
+#ifdef JSDR_X_CLK  // timing experiment: s_memtime ticks (10 ns) per phase, summed over every wave of the launch
+__device__ unsigned long long g_fm_clk[256][64];  // [blockIdx & 255][phase]: same-address atomics serialise
+#define FM_CLK(i)                                                                          \
+    do {                                                                                   \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();                      \
+        clk_acc_[i] += now_ - clk_last_;                                                   \
+        clk_last_ = now_;                                                                  \
+    } while (0)
+#else
+#define FM_CLK(i) do {} while (0)
+#endif
 struct FmArgs {
     const int *raw;             // int16 pairs as dwords, [S][stride]
     long long stride_pairs;
     int nsamples;               // L
     int ic, qc;
     const int2 *hist;           // [S][32]: the 26 inputs before this call, DC-corrected int16 pairs in .x
+    const int *edges;           // [S][4 * FM_EDGE]: k_fm_edges' images of the stream around sample 0 and around the last sample
     const double2 *tcs;         // unwrapped tuner table: entry e = (cos, sin) for samples n with (n + 26) mod P == e mod P
     int tper;                   // P (1 when the tuner is off)
     const unsigned char *kvco;  // [nds] VCO table index per decimated sample
@@ -783,6 +795,38 @@ struct FmArgs {
     int ntiles, nstreams;       // work items = ntiles x nstreams, stream-major; the grid strides over them
 };
 
+// The stream's edge images for k_fm: E[0 .. 2*FM_EDGE) = samples -FM_EDGE .. FM_EDGE-1, E[2*FM_EDGE .. 4*FM_EDGE) = samples
+// L-FM_EDGE .. L+FM_EDGE-1 as raw int16 pairs: the previous call's 26 samples before sample 0 (kept DC-corrected: the
+// correction is taken off again, k_fm's conversion re-applies it -- 16-bit wrap-around both ways, so exactly the stored
+// value), zero before them and beyond the last sample.
+struct EdgeArgs {
+    const int *raw;
+    long long stride_pairs;
+    int nsamples, ic, qc, dc;
+    const int2 *hist;
+    int *edges;
+    int nstreams;
+};
+__global__ void k_fm_edges(EdgeArgs a)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int s = t / (4 * FM_EDGE), i = t % (4 * FM_EDGE);
+    if (s >= a.nstreams) return;
+    const int n = i < 2 * FM_EDGE ? i - FM_EDGE : a.nsamples - FM_EDGE + (i - 2 * FM_EDGE);
+    int w = 0;
+    if (n >= 0 && n < a.nsamples) {
+        w = a.raw[(long long)s * a.stride_pairs + n];
+    } else if (n < 0 && n >= -26) {
+        w = a.hist[(long long)s * 32 + 26 + n].x;
+        if (a.dc) {
+            const int si = (int)(short)((w & 0xffff) - a.ic);
+            const int sq = (int)(short)((w >> 16) - a.qc);
+            w = (si & 0xffff) | (sq << 16);
+        }
+    }
+    a.edges[(long long)s * (4 * FM_EDGE) + i] = w;
+}
+
 template <int D, int R, bool MIX, bool DC, bool FAST>
 __global__ __launch_bounds__(FM_THREADS, 2) void k_fm(FmArgs a)
 {
@@ -792,6 +836,9 @@ __global__ __launch_bounds__(FM_THREADS, 2) void k_fm(FmArgs a)
     double2 *X = reinterpret_cast<double2 *>(smem);                    // [FM_NT]: X[t] = sample G - 64 + t
     double *sc = reinterpret_cast<double *>(smem + FM_NT * sizeof(double2));  // [512]
     for (int i = threadIdx.x; i < 512; i += FM_THREADS) sc[i] = a.sincos[i];
+#ifdef JSDR_X_CLK
+    unsigned long long clk_acc_[6] = {0, 0, 0, 0, 0, 0}, clk_last_ = 0;
+#endif
     const long long nwork = (long long)a.ntiles * a.nstreams;
 #pragma unroll 1
     for (long long work = blockIdx.x; work < nwork; work += gridDim.x) {
@@ -799,7 +846,7 @@ __global__ __launch_bounds__(FM_THREADS, 2) void k_fm(FmArgs a)
     const long long G = a.tile0 + (long long)(65 * FM_NB) * (work % a.ntiles);
     const int jrel0 = (int)(G - 64 - a.g_first);  // call-relative output index of X[0] (negative in the first tile)
     const int *raw = a.raw + (long long)s * a.stride_pairs;
-    const int2 *hist = a.hist + (long long)s * 32;
+    const int *edges = a.edges + (long long)s * (4 * FM_EDGE);
     const double2 *dmh_old = a.dmh_old + (long long)s * 64;
     const int Lm1 = a.nsamples - 1, nds = a.nds, P = a.tper;
     const double HOWARD = 0.9 * 32768.0;  // :469
@@ -816,6 +863,9 @@ __global__ __launch_bounds__(FM_THREADS, 2) void k_fm(FmArgs a)
     const_tab_t tb = (const_tab_t)(a.tcs + e0);  // tb[2m] = cos, tb[2m+1] = sin
     float amx = 0.0f;  // FAST: largest |sample| this lane converts
     __syncthreads();  // sin/cos table
+#ifdef JSDR_X_CLK
+    clk_last_ = __builtin_amdgcn_s_memtime();
+#endif
     // ================================================================================ front half
 #ifdef JSDR_X_NOFRONT
     if (a.nds < 0)
@@ -831,14 +881,45 @@ __global__ __launch_bounds__(FM_THREADS, 2) void k_fm(FmArgs a)
 #else
         const int n0 = a.first_out + D * j0 - 26;    // its window's first sample
 #endif
-        // (the tile's last job owns fewer than R image slots when R does not divide FM_NT: it still takes this path and
-        // drops the surplus outputs at the store -- on the edge path it cost every tile ~7 us, 15 % of the kernel)
-        const bool inside = j0 >= 0 && j0 + R <= nds && n0 >= 0 && n0 + 4 * NSQ - 1 <= Lm1;
-        if (inside) {
+        // `none`: no output of the job is filtered here (the halo before output 0, slots past the call's last output).
+        // Every other job takes the same arithmetic in the same pass.  A window that reaches back into the previous
+        // call's 26 samples, or past the last sample, is read from the stream's EDGE IMAGE instead of the input -- 256
+        // samples around sample 0 (history, then input) and 256 around the last one (zero beyond), laid out by
+        // k_fm_edges before this kernel -- with the same fifteen loads; outputs that are not this call's (a job that
+        // straddles output 0 or the last output) are replaced at the store.  (These jobs used to run a
+        // one-output-at-a-time loop of dependent loads after the others had finished: one of them held its workgroup
+        // for longer than a whole regular tile takes.  The tile's last job, which owns fewer than R image slots when R
+        // does not divide FM_NT, drops the surplus at the store -- on the old edge path it cost every tile ~7 us.)
+        const bool none = j0 + R <= 0 || j0 >= nds || nds <= 0;
+        const bool regular = j0 >= 0 && j0 + R <= nds;
+        if (!none) {
             int4 W[NSQ];
+            const int *wp = raw + n0;
+            if (n0 < 0) wp = edges + (n0 + FM_EDGE);
+            else if (n0 + 4 * NSQ - 1 > Lm1) wp = edges + 2 * FM_EDGE + (n0 - (a.nsamples - FM_EDGE));
+            // the VCO table indices of the job's outputs come in WITH the window: left where they are used, after the
+            // last quad, the load was issued there and waited for on the spot -- a full memory latency at the end of
+            // every round (nothing may cross the quads' scheduling barriers, so the source order decides)
+            unsigned kv4[(R + 3) / 4];  // R byte indices, four to a register
 #pragma unroll
-            for (int q = NSQ - 1; q >= 0; q--) W[q] = *reinterpret_cast<const int4 *>(raw + n0 + 4 * q);
+            for (int k = 0; k < (R + 3) / 4; k++) kv4[k] = 0;
+            if (regular) {
+#pragma unroll
+                for (int r = 0; r < R; r++) kv4[r / 4] |= (unsigned)a.kvco[j0 + r] << (8 * (r % 4));
+            } else {
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const int j = j0 + r;
+                    kv4[r / 4] |= (unsigned)a.kvco[j < 0 ? 0 : (j >= nds ? nds - 1 : j)] << (8 * (r % 4));
+                }
+            }
+#pragma unroll
+            for (int q = NSQ - 1; q >= 0; q--) W[q] = *reinterpret_cast<const int4 *>(wp + 4 * q);
+#ifndef JSDR_FM_NOPIN
+            __builtin_amdgcn_sched_barrier(0);
+#endif
             double ai[R], aq[R];
+            double vc[R], vs[R];  // the outputs' VCO (cos, sin): LDS reads issued under the last quad's arithmetic
 #pragma unroll
             for (int r = 0; r < R; r++) {
                 ai[r] = 0.0;
@@ -847,6 +928,14 @@ __global__ __launch_bounds__(FM_THREADS, 2) void k_fm(FmArgs a)
 #pragma unroll
             for (int q = NSQ - 1; q >= 0; q--) {
                 const int4 w4 = W[q];
+                if (q == 0) {
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        const int kv = (kv4[r / 4] >> (8 * (r % 4))) & 0xff;
+                        vc[r] = sc[kv];
+                        vs[r] = sc[256 + kv];
+                    }
+                }
 #pragma unroll
                 for (int t = 3; t >= 0; t--) {
                     const int m = 4 * q + t;
@@ -855,13 +944,8 @@ __global__ __launch_bounds__(FM_THREADS, 2) void k_fm(FmArgs a)
                         double di, dq;
                         fm_convert(w, a.ic, a.qc, DC, di, dq, FAST ? &amx : nullptr);
                         if constexpr (MIX) {  // :388-390 component-wise, not a complex multiply
-#ifdef JSDR_X_TB8
-                            di = di * tb[2 * (m & 7)];
-                            dq = dq * tb[2 * (m & 7) + 1];
-#else
                             di = di * tb[2 * m];
                             dq = dq * tb[2 * m + 1];
-#endif
                         }
 #pragma unroll
                         for (int r = 0; r < R; r++) {
@@ -881,55 +965,43 @@ __global__ __launch_bounds__(FM_THREADS, 2) void k_fm(FmArgs a)
 #ifndef JSDR_FM_NOPIN
 #pragma unroll
                 for (int r = 0; r < R; r++) asm volatile("" : "+v"(ai[r]), "+v"(aq[r])::"memory");  // sums are due here
+                if constexpr (FAST) asm volatile("" : "+v"(amx));  // (or the maxima sink to the end of the round with all 114 floats alive)
                 __builtin_amdgcn_sched_barrier(0);
 #endif
             }
+            if (regular) {
 #pragma unroll
-            for (int r = 0; r < R; r++) {  // x HOWARD_FUDGE_FACTOR (:486), VCO mix (:515-516)
-                const double oi = ai[r] * HOWARD, oq = aq[r] * HOWARD;
-                const int kv = a.kvco[j0 + r];
-                if (FM_NT % R == 0 || t0 + r < FM_NT) X[t0 + r] = make_double2(oi * sc[kv], oq * sc[256 + kv]);
+                for (int r = 0; r < R; r++) {  // x HOWARD_FUDGE_FACTOR (:486), VCO mix (:515-516)
+                    const double oi = ai[r] * HOWARD, oq = aq[r] * HOWARD;
+                    if (FM_NT % R == 0 || t0 + r < FM_NT) X[t0 + r] = make_double2(oi * vc[r], oq * vs[r]);
+                }
+            } else {  // a job that straddles output 0 or the call's last output: one or two per stream and call
+                double oi[R], oq[R];
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    oi[r] = ai[r] * HOWARD * vc[r];
+                    oq[r] = aq[r] * HOWARD * vs[r];
+                }
+#pragma unroll 1
+                for (int r = 0; r < R; r++) {
+                    const int t = t0 + r, j = j0 + r;
+                    double2 val = make_double2(0.0, 0.0);
+                    if (j >= 0 && j < nds) {
+                        // (run-time r: a select chain, not an indexed register file)
+                        val.x = r == 0 ? oi[0] : r == 1 ? oi[1] : r == 2 ? oi[2] : r == 3 ? oi[3] : oi[R - 1];
+                        val.y = r == 0 ? oq[0] : r == 1 ? oq[1] : r == 2 ? oq[2] : r == 3 ? oq[3] : oq[R - 1];
+                    } else if (j >= -64 && j < 0) {
+                        val = dmh_old[64 + j];
+                    }
+                    if (t < FM_NT) X[t] = val;
+                }
             }
         } else {
-            // the call's edges (history before sample 0, the halo before output 0, the end of the data): one output
-            // at a time, run-time indices; a handful of jobs per stream and call
 #pragma unroll 1
             for (int r = 0; r < R; r++) {
                 const int t = t0 + r, j = j0 + r;
-                if (t >= FM_NT) break;
-                double2 val = make_double2(0.0, 0.0);
-                if (j >= -64 && j < 0) {
-                    val = dmh_old[64 + j];
-                }
-#ifndef JSDR_X_NOEDGE
-                else if (j >= 0 && j < nds) {
-                    double fi = 0.0, fq = 0.0;
-#pragma unroll 1
-                    for (int age = 0; age < 27; age++) {
-                        const int n = a.first_out + D * j - age;  // >= -26
-                        double di, dq;
-                        if (n >= 0) fm_convert(raw[n], a.ic, a.qc, DC, di, dq, FAST ? &amx : nullptr);
-                        else fm_convert(hist[26 + n].x, 0, 0, false, di, dq, FAST ? &amx : nullptr);  // stored corrected
-                        if constexpr (MIX) {
-                            const double2 cs = a.tcs[(n + 26) % P];
-                            di = di * cs.x;
-                            dq = dq * cs.y;
-                        }
-                        const double tp = c_bpsk.ds_taps[age];
-                        if constexpr (FAST) {
-                            fi = __builtin_fma(di, tp, fi);
-                            fq = __builtin_fma(dq, tp, fq);
-                        } else {
-                            fi += di * tp;
-                            fq += dq * tp;
-                        }
-                    }
-                    const double oi = fi * HOWARD, oq = fq * HOWARD;
-                    const int kv = a.kvco[j];
-                    val = make_double2(oi * sc[kv], oq * sc[256 + kv]);
-                }
-#endif
-                X[t] = val;
+                const double2 val = (j >= -64 && j < 0) ? dmh_old[64 + j] : make_double2(0.0, 0.0);
+                if (t < FM_NT) X[t] = val;
             }
         }
     }
@@ -938,7 +1010,9 @@ __global__ __launch_bounds__(FM_THREADS, 2) void k_fm(FmArgs a)
         for (int off = 32; off >= 1; off >>= 1) amx = fmaxf(amx, __shfl_xor(amx, off, 64));
         if ((threadIdx.x & 63) == 0 && amx > 0.0f) atomicMax(a.amax + s, __float_as_int(amx));
     }
+    FM_CLK(1);  // front half
     __syncthreads();
+    FM_CLK(3);  // barrier after the front half
     // ---- the call's last 64 VCO-mixed samples are the next call's halo; every sample is owned by one tile
     if (jrel0 + FM_NT > nds - 64) {  // uniform
         double2 *dmh_new = a.dmh_new + (long long)s * 64;
@@ -976,8 +1050,14 @@ __global__ __launch_bounds__(FM_THREADS, 2) void k_fm(FmArgs a)
             if (lane < FM_NB && rel >= 0 && rel < nds) y[rel] = make_double2(ai[r], aq[r]);
         }
     }
+    FM_CLK(4);  // matched half
     __syncthreads();  // the next work item reuses the image
+    FM_CLK(5);  // barrier after the matched half
     }
+#ifdef JSDR_X_CLK
+    if ((threadIdx.x & 63) == 0)
+        for (int i = 0; i < 6; i++) atomicAdd(&g_fm_clk[blockIdx.x & 255][(threadIdx.x >> 6) * 8 + i], clk_acc_[i]);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------- k_tail
@@ -1609,6 +1689,7 @@ struct jsdr_bpsk {
     bool hist_is_float = false;    // form of the samples in hist_in[hist_cur] (the input form of the call that wrote them)
     DevBuf<int> hist_bad;          // k_hist_convert's "not an int16 sample" flag
     DevBuf<int> amax;              // fast variant: [S] running maximum of |int16 sample| (float bits)
+    DevBuf<int> fm_edges;          // k_fm: [S][4 * FM_EDGE] the stream around sample 0 and around the last sample (k_fm_edges)
     DevBuf<double2> dm, y[2];  // y is double-buffered: the tail of call k overlaps the front end of call k+1
     int y_cur = 0;
     // fused front end + matched filter (k_fm): the 64-sample halo lives in its own double buffer, the tuner table is
@@ -2169,6 +2250,7 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
         ma.ic = ic;
         ma.qc = qc;
         ma.hist = fa.hist;
+        ma.edges = h->fm_edges.p;
         ma.tcs = tcs_p;
         ma.tper = h->mix ? h->c_tper : 1;
         ma.kvco = kvco_p;
@@ -2182,6 +2264,20 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
         ma.tile0 = g_first - (((g_first - 64) % 65 + 65) % 65);
         ma.first_out = first_out;
         ma.amax = h->amax.p;
+        {
+            EdgeArgs ea;
+            ea.raw = fa.raw;
+            ea.stride_pairs = fa.stride_pairs;
+            ea.nsamples = (int)L;
+            ea.ic = ic;
+            ea.qc = qc;
+            ea.dc = (ic != 0) || (qc != 0);
+            ea.hist = fa.hist;
+            ea.edges = h->fm_edges.p;
+            ea.nstreams = S;
+            hipLaunchKernelGGL(k_fm_edges, dim3((unsigned)(((long long)S * 4 * FM_EDGE + 255) / 256)), dim3(256), 0, st, ea);
+            JSDR_LAUNCH_CHECK();
+        }
         ProfScope ps(h, PK_FM, st);
         h->front_name = "k_fm";
         if (launch_fm(ma, h->decim, h->mix != 0, (ic != 0) || (qc != 0), h->variant != 0, S, st) != JSDR_OK) return JSDR_ERR;
@@ -2441,7 +2537,7 @@ int jsdr_bpsk_create(jsdr_bpsk **out, int rate, int nsamples_per_frame, int tuni
               h->cnt_dec.alloc(S) == JSDR_OK && h->corr.alloc(S * (size_t)h->max_bits) == JSDR_OK &&
               h->fec_data.alloc(S * h->trig_cap * 256) == JSDR_OK && h->decoded.alloc(S * 256) == JSDR_OK &&
               h->stage_raw.alloc((size_t)nsamples_per_frame * 2) == JSDR_OK && h->ds_taps_dev.alloc(32) == JSDR_OK &&
-              h->dmh[0].alloc(S * 64) == JSDR_OK && h->dmh[1].alloc(S * 64) == JSDR_OK && h->hist_bad.alloc(1) == JSDR_OK && h->amax.alloc(S) == JSDR_OK && h->tcs.alloc(2 * (256 + FM_TABLE_SLACK)) == JSDR_OK &&
+              h->dmh[0].alloc(S * 64) == JSDR_OK && h->dmh[1].alloc(S * 64) == JSDR_OK && h->hist_bad.alloc(1) == JSDR_OK && h->amax.alloc(S) == JSDR_OK && h->fm_edges.alloc(S * 4 * FM_EDGE) == JSDR_OK && h->tcs.alloc(2 * (256 + FM_TABLE_SLACK)) == JSDR_OK &&
               (!do_fft || (h->fft_state.alloc(S) == JSDR_OK && h->fft_tw.alloc(fft_pow2 ? (size_t)nsamples_per_frame : (size_t)65536) == JSDR_OK &&
                             h->vco_cs.alloc((size_t)h->max_ds) == JSDR_OK)) &&
               (!(do_fft && fft2x_supported(nsamples_per_frame)) ||
@@ -2563,6 +2659,7 @@ int jsdr_bpsk_destroy(jsdr_bpsk *h)
     h->dm.release();
     h->hist_bad.release();
     h->amax.release();
+    h->fm_edges.release();
     h->dmh[0].release();
     h->dmh[1].release();
     h->tcs.release();
@@ -2595,6 +2692,29 @@ int jsdr_bpsk_destroy(jsdr_bpsk *h)
     h->fft2x_ek.release();
     h->fft2x_r0.release();
     h->vco_cs.release();
+#ifdef JSDR_X_CLK
+    {
+        static unsigned long long cc[256][64];
+        if (hipMemcpyFromSymbol(cc, HIP_SYMBOL(g_fm_clk), sizeof(cc)) == hipSuccess) {
+            static const char *nm[6] = {"-", "front half", "-", "barrier front", "matched", "barrier matched"};
+            for (int i = 0; i < 6; i++) {
+                if (i == 0 || i == 2) continue;
+                fprintf(stderr, "k_fm clk %-16s", nm[i]);
+                for (int w = 0; w < 8; w++) {
+                    unsigned long long c = 0, tot = 0;
+                    for (int b = 0; b < 256; b++) {
+                        c += cc[b][w * 8 + i];
+                        for (int k = 0; k < 6; k++) tot += cc[b][w * 8 + k];
+                    }
+                    fprintf(stderr, " w%d %5.1f%%", w, 100.0 * c / (tot ? tot : 1));
+                }
+                fprintf(stderr, "\n");
+            }
+            memset(cc, 0, sizeof(cc));
+            hipMemcpyToSymbol(HIP_SYMBOL(g_fm_clk), cc, sizeof(cc));
+        }
+    }
+#endif
     if (h->phase_clk.p) {
         static const char *const names_p2[8] = {"load+scatter", "forward FFT", "|X|", "boxcar+argmax", "centre-bin rule",
                                                 "gather/zero", "inverse FFT", "scale+RxDownSample"};
