@@ -751,8 +751,16 @@ __global__ __launch_bounds__(64) void k_dm_history(double2 *dm, long long dm_str
 //            OWN 57-sample window with 4-byte aligned 16-byte loads, newest quad first, converts I and Q of a
 //            sample together (packed FP32: the same IEEE operations as the scalar form, two per instruction) and
 //            walks newest -> oldest with the R accumulator pairs in registers (:479-483).  The halo is recomputed
-//            (1.6 %); before the call's first sample it comes from the 64 samples the previous call saved.
+//            (1.6 %); before the call's first sample it comes from the 64 samples the previous call saved.  Windows
+//            that reach into the previous call's 26 samples or past the last sample are read from the stream's edge
+//            images (k_fm_edges) with the same loads, so every job -- edge or not -- takes the same arithmetic in the
+//            same pass; the VCO table indices come in with the window and their table reads are issued under the last
+//            quad's arithmetic.
 //   matched: as k_matched, from the LDS image.
+// Where the time goes (2048 streams x 2^20 samples, alone, tools/build_define.sh with -DJSDR_X_NOFRONT / _NOMATCHED /
+// _CLK): front half 2.15 ms + matched half 2.12 ms = the kernel's 4.3-4.4 ms; the matched half issues FP64 at ~95 % of
+// the chip's measured rate, the front half at ~80 % (1.94 ms with its window loads replaced by constants: the loads'
+// latency costs a tenth of it); coalesced window addresses or a register-resident tuner table change nothing.
 // Every floating-point operation and its order are those of k_front_reg + k_matched (FAST = false), so (fi,fq)
 // stay bit-identical to the reference.  Used when the input is int16, the tuner schedule is periodic with a period
 // that divides the lane span (or the tuner is off, tuning <= 0); everything else takes the three-kernel path.
@@ -876,11 +884,7 @@ __global__ __launch_bounds__(FM_THREADS, 2) void k_fm(FmArgs a)
         const int t0 = R * job;
         if (t0 >= FM_NT) break;
         const int j0 = jrel0 + t0;                   // first output of the job, call relative
-#ifdef JSDR_X_COAL
-        const int n0 = (a.first_out + D * (jrel0 + R * FM_THREADS * round) - 26) + 4 * (threadIdx.x);  // TIMING EXPERIMENT: wrong data
-#else
         const int n0 = a.first_out + D * j0 - 26;    // its window's first sample
-#endif
         // `none`: no output of the job is filtered here (the halo before output 0, slots past the call's last output).
         // Every other job takes the same arithmetic in the same pass.  A window that reaches back into the previous
         // call's 26 samples, or past the last sample, is read from the stream's EDGE IMAGE instead of the input -- 256
