@@ -1159,12 +1159,21 @@ __device__ __forceinline__ double2 tail_exact_sample(const TailArgs &a, int s, l
 template <bool CERT>
 __global__ __launch_bounds__(64) void k_tail(TailArgs a)
 {
-    __shared__ double2 yL[512];        // [period*8 + bitPos]
-    __shared__ double enL[512];
+    // (fi,fq) of the chunk's 64 samples at the bit position the peak tracker holds when the chunk starts -- the
+    // differential detector's inputs while the demodulator is locked; a decision anywhere else (acquisition, a moving
+    // peak) reads its sample from y.  The whole chunk (8 KB) used to sit here: with 10 KB instead of 17 KB a CU holds
+    // sixteen of these one-wave workgroups instead of nine, and the kernel is occupancy x latency bound.
+    __shared__ double2 ydL[64];        // [period]
+    __shared__ double enL[512];        // [period*8 + bitPos]
     __shared__ double eL[64][9];       // dmEnergy[c] after each period (row padded: conflict-free column walk)
     __shared__ unsigned char maskL[64];
     __shared__ short declist[136];
     __shared__ double2 dmL[CERT ? 66 : 1];
+#ifdef JSDR_X_TAIL_PAD  // timing experiment: a larger LDS footprint (fewer tail waves beside k_fm)
+    __shared__ int padL[JSDR_X_TAIL_PAD];
+    if (a.nstreams < 0) padL[threadIdx.x] = 1;
+    if (a.nstreams < -1) a.st[0].cntBit = padL[threadIdx.x + 1];
+#endif
     const int lane = threadIdx.x;
     const int s = blockIdx.x;
     if (s >= a.nstreams) return;
@@ -1222,12 +1231,15 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs a)
 
     for (long long MB = M_first; MB <= M_last && a.nds > 0; MB += 64) {
         // ---------------- stage the prefetched chunk, start fetching the next one
+        const int v = peakPos;
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-            yL[k * 64 + lane] = pre[k];
+            if ((lane & 7) == v) ydL[k * 8 + (lane >> 3)] = pre[k];  // sample k*64 + lane = period k*8 + lane/8, position lane%8
             enL[k * 64 + lane] = pre[k].x * pre[k].x + pre[k].y * pre[k].y;  // :534
         }
         JSDR_WAVE_SYNC();
+        const double2 *ychunk = y + (8 * MB - g_first);  // sample i of the chunk (only in-range samples are ever decisions)
+        auto ysample = [&](int pos) { return (pos & 7) == v ? ydL[pos >> 3] : ychunk[pos]; };
         double m_en = 0.0, m_d = 0.0, m_e2 = 0.0;  // this chunk's margins
         if constexpr (CERT) {
             double em = 0.0;
@@ -1255,7 +1267,6 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs a)
         const int nper = (int)((M_last - MB + 1) < 64 ? (M_last - MB + 1) : 64);
         const bool interior = (8 * MB >= g_first) && (8 * (MB + 64) <= g_end);  // every sample of all 64 periods is in range (uniform)
         // ---------------- serial IIRs, speculating that the peak position stays at v
-        const int v = peakPos;
         const bool spec = (newPeak == peakPos);
         const double e_in = e;
         {
@@ -1266,10 +1277,10 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs a)
             // the 64 energies this lane will fold in, fetched up front: the serial chain below then touches
             // registers only (an LDS read per step would put ~100 cycles of latency on every link of the chain)
 #ifndef JSDR_TAIL_XS
-#define JSDR_TAIL_XS 32
+#define JSDR_TAIL_XS 16
 #endif
-            // (in two halves of 32: the preload is 64 VGPRs instead of 128 and the kernel fits three waves per SIMD
-            //  instead of two -- at 8192 streams the tail is throughput-, not latency-bound)
+            // (in four parts of 16: the preload is 32 VGPRs instead of 128 and the kernel fits four waves per SIMD
+            //  instead of two -- at 8192 streams the tail is occupancy x latency bound)
             constexpr int XS = JSDR_TAIL_XS;
             const int pfirst = (glane < g_first) ? 1 : 0;  // period 0 of the chunk lacks this lane's sample
 #pragma unroll
@@ -1412,8 +1423,8 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs a)
             const bool have = d < nd;
             double2 cur = make_double2(0.0, 0.0), prv = make_double2(lastI, lastQ);
             if (have) {
-                cur = yL[fastd ? 8 * d + v : (int)declist[d]];
-                if (d > 0) prv = yL[fastd ? 8 * (d - 1) + v : (int)declist[d - 1]];
+                cur = fastd ? ydL[d] : ysample((int)declist[d]);
+                if (d > 0) prv = fastd ? ydL[d - 1] : ysample((int)declist[d - 1]);
             }
             double di = -((prv.x * cur.x) + (prv.y * cur.y));
             double dq = (prv.x * cur.y) - (prv.y * cur.x);

@@ -118,7 +118,6 @@ int fec_prepare() { return upload_tables(); }
 
 // ----------------------------------------------------------------------------------------------
 // LDS work area of one wave
-enum { METS_CHUNK = 512 };
 // DECW = NBITS+2: the decision words live in LDS (31.5 KB per block).  DECW = DECW_WORK: they live in a global
 // scratch area and LDS keeps only the work area behind them (16.2 KB per block): the demodulator's FEC kernel runs
 // under the throughput kernels of the next call, where every LDS byte it holds is a workgroup of theirs that
@@ -126,11 +125,21 @@ enum { METS_CHUNK = 512 };
 enum { DECW_LDS = NBITS + 2, DECW_WORK = (SYMPBLOCK + 7) / 8 + 6, DEC_SCRATCH_WORDS = ((NBITS + 2 + 63) / 64) * 64 };
 template <int DECW>
 struct FecLdsT {
-    unsigned char raw[SYMPBLOCK];       // soft symbols in
+    // The demodulator's instance (decision words in global scratch) decodes HARD decisions: one bit per symbol instead
+    // of a soft byte, and a shorter branch-metric chunk -- 8.6 KB of LDS per block instead of 16.2, so that a CU holds
+    // nineteen of these one-wave workgroups instead of ten (the kernel is occupancy x latency bound).
+    static constexpr bool HARD = DECW != NBITS + 2;
+    static constexpr int METS = HARD ? 128 : 512;
+    unsigned char raw[HARD ? ((SYMPBLOCK + 63) / 64) * 8 : SYMPBLOCK];  // soft symbols in (HARD: bit i of the array = symbol i is a 1)
+    __device__ __forceinline__ int sym(int i) const
+    {
+        if constexpr (HARD) return ((reinterpret_cast<const unsigned *>(raw)[i >> 5] >> (i & 31)) & 1u) ? 0xc0 : 0x40;
+        else return raw[i];
+    }
     unsigned long long dec[DECW];       // decisions per step (== the reference's pp[2k], pp[2k+1]); once the
                                         // chain-back is done the same bytes hold the RS work arrays, then the
                                         // re-encoded symbols (fec_enc())
-    short mets[METS_CHUNK][4];          // branch metrics of the current chunk of trellis steps
+    short mets[METS][4];                // branch metrics of the current chunk of trellis steps
     unsigned char alpha_to[256];
     unsigned char index_of[256];
     unsigned char vit[320];             // Viterbi output / scrambled byte stream
@@ -388,12 +397,13 @@ __device__ __forceinline__ int fec_decode_wave(FecLdsT<DECW> &L, int lane, unsig
         int metric = (lane == 0) ? 0 : -999999;
         const int src_lo = lane >> 1, src_hi = (lane >> 1) + 32;
         unsigned dlo = 0, dhi = 0;  // DEC_GLOBAL: lane (k & 63) collects the word of step k; flushed every 64 steps
+        constexpr int METS_CHUNK = FecLdsT<DECW>::METS;
         for (int k0 = 0; k0 < NBITS; k0 += METS_CHUNK) {
             const int kn = (NBITS - k0) < METS_CHUNK ? (NBITS - k0) : METS_CHUNK;
             for (int kk = lane; kk < kn; kk += 64) {
                 const int j0 = 2 * (k0 + kk), j1 = j0 + 1;
-                const int y0 = L.raw[(j0 % COLUMNS) * ROWS + (j0 / COLUMNS + 1)];
-                const int y1 = L.raw[(j1 % COLUMNS) * ROWS + (j1 / COLUMNS + 1)];
+                const int y0 = L.sym((j0 % COLUMNS) * ROWS + (j0 / COLUMNS + 1));
+                const int y1 = L.sym((j1 % COLUMNS) * ROWS + (j1 / COLUMNS + 1));
 #pragma unroll
                 for (int i = 0; i < 4; i++)
                     L.mets[kk][i] = (short)(c_fec.mettab[(i >> 1) & 1][y0] + c_fec.mettab[i & 1][y1]);
@@ -562,7 +572,7 @@ __device__ __forceinline__ int fec_decode_wave(FecLdsT<DECW> &L, int lane, unsig
     int errs = 0;
     {
         const unsigned char *enc = fec_enc(L);
-        for (int i = lane; i < SYMPBLOCK; i += 64) errs += (enc[i] != (L.raw[i] >> 7)) ? 1 : 0;
+        for (int i = lane; i < SYMPBLOCK; i += 64) errs += (enc[i] != (L.sym(i) >> 7)) ? 1 : 0;
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) errs += __shfl_xor(errs, off, 64);
@@ -635,7 +645,12 @@ __global__ __launch_bounds__(64) void k_fec_bpsk(BpskFecArgs a)
     if (t >= nt) return;
     fec_lds_init(L, lane);
     const signed char *win = a.bitlog + (long long)s * a.bitlog_stride + (a.trig_bits[s * a.max_trig + t] + 1);
-    for (int i = lane; i < SYMPBLOCK; i += 64) L.raw[i] = (win[i] == 1) ? 0xc0 : 0x40;
+    // hard decisions, one bit per symbol: 64 symbols per ballot, lane 0 files the word
+    for (int i0 = 0; i0 < SYMPBLOCK; i0 += 64) {
+        const int i = i0 + lane;
+        const unsigned long long m = __ballot(i < SYMPBLOCK && win[i < SYMPBLOCK ? i : SYMPBLOCK - 1] == 1);
+        if (lane == 0) reinterpret_cast<unsigned long long *>(L.raw)[i0 >> 6] = m;
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
