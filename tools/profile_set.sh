@@ -1,0 +1,54 @@
+#!/bin/bash
+# tools/profile_set.sh <tag> -- one gpurun call that takes the judged evidence set on the current code and leaves
+# ready-to-commit summaries under gpurun_out/<tag>_*: the default bench line, rocprofv3 kernel stats of the same
+# command, the two separate PMC passes (FETCH_SIZE, WRITE_SIZE -> pmc_traffic.json), and the other workloads' lines.
+#   gpurun --timeout 1100 -- 'bash tools/profile_set.sh r02_j'       then:  cp gpurun_out/r02_j_* profiles/
+set -u
+T=${1:-rXX}
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+O=$PWD/gpurun_out
+line() { grep '^{"metric' "$1" | tail -1; }
+step() { # name timeout cmd...
+  local name=$1 to=$2; shift 2
+  echo "=== $name: $*" | tee -a $O/session.log
+  timeout -k 10 "$to" "$@" > "$O/${T}_$name.log" 2>&1
+  local rc=$?
+  echo "=== $name rc=$rc" | tee -a $O/session.log
+  if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "TIMEOUT in $name: stopping" | tee -a $O/session.log; exit 99; fi
+  if grep -q "Memory access fault" "$O/${T}_$name.log"; then echo "GPU FAULT in $name: stopping" | tee -a $O/session.log; exit 98; fi
+}
+step bench 400 python bench.py
+line $O/${T}_bench.log > $O/${T}_bench.json
+rm -rf $O/prof_$T $O/pmc_rd_$T $O/pmc_wr_$T
+step prof 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$T -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline
+line $O/${T}_prof.log > $O/${T}_bench_under_rocprof.json
+cp "$(find $O/prof_$T -name '*kernel_stats.csv' | head -1)" $O/${T}_kernel_stats.csv
+step pmc_rd 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_rd_$T -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-validate
+step pmc_wr 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_wr_$T -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-validate
+python tools/pmc_traffic.py $O/pmc_rd_$T $O/pmc_wr_$T $O/${T}_pmc_traffic.json 8589934592 > /dev/null
+python - "$O" "$T" <<'PY'
+import collections, csv, glob, sys
+O, T = sys.argv[1], sys.argv[2]
+for tag, ctr in (("rd", "FETCH_SIZE"), ("wr", "WRITE_SIZE")):
+    acc = collections.defaultdict(list)
+    for f in glob.glob(f"{O}/pmc_{tag}_{T}/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == ctr:
+                acc[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
+    with open(f"{O}/{T}_pmc_{tag}.csv", "w") as o:
+        o.write("kernel,counter,launches,mean_value_KiB\n")
+        for k in sorted(acc):
+            o.write(f'"{k}",{ctr},{len(acc[k])},{sum(acc[k]) / len(acc[k]):.1f}\n')
+PY
+B="--no-cpu-baseline"
+step b_bpsk 300 python bench.py --workload bpsk $B;                      line $O/${T}_b_bpsk.log > $O/${T}_b_bpsk.json
+step b_bpsk_fast 300 python bench.py --workload bpsk --variant fast $B;  line $O/${T}_b_bpsk_fast.log > $O/${T}_b_bpsk_fast.json
+step b_pipe_fast 300 python bench.py --variant fast $B;                  line $O/${T}_b_pipe_fast.log > $O/${T}_b_pipe_fast.json
+step b_fft 300 python bench.py --workload fft $B;                        line $O/${T}_b_fft.log > $O/${T}_b_fft.json
+step b_fir 300 python bench.py --workload fir $B;                        line $O/${T}_b_fir.log > $O/${T}_b_fir.json
+step b_1k 300 python bench.py --streams 1024 $B;                         line $O/${T}_b_1k.log > $O/${T}_b_1k.json
+step b_acq 300 python bench.py --workload bpsk --fft-acquire --streams 1024 $B;                    line $O/${T}_b_acq.log > $O/${T}_b_acq.json
+step b_acq9600 300 python bench.py --workload bpsk --fft-acquire --bpsk-frame 9600 --streams 1024 $B;  line $O/${T}_b_acq9600.log > $O/${T}_b_acq9600.json
+rm -f $O/${T}_*.log.tmp
+echo "profile set $T done" | tee -a $O/session.log
