@@ -29,7 +29,7 @@ samples = int(sys.argv[4]) if len(sys.argv) > 4 else 1024 * 1048576  # IQ sample
 fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
 write = per_kernel(sys.argv[2], "WRITE_SIZE")
 out = {"_samples_per_launch": samples, "_note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (tools/gpu_session.sh pmc_rd pmc_wr), "
-                "bench.py --steps 2 --warmup 1, S=1024 x L=2^20.  Counter unit = KiB.  Per MI355X_MICROARCH.md the gfx950 "
+                "bench.py --steps 2 --warmup 1, per launch of _samples_per_launch IQ samples.  Counter unit = KiB.  Per MI355X_MICROARCH.md the gfx950 "
                 "FETCH_SIZE reports half the bytes of coalesced streaming reads: hbm_bytes = 2*FETCH + WRITE "
                 "(calibration: k_synth_dbpsk writes exactly 4.295e9 B; k_fft reads 4.295e9 B of int16 IQ)."}
 for k in sorted(set(fetch) | set(write)):
