@@ -129,6 +129,10 @@ def test_bpsk_dc_correction_is_applied_like_javaaudio():
     iq, _, _ = O.make_dbpsk_stream(5, 0, n)
     run_both([iq], n, [n], ic=1234, qc=-4321)
     run_both([iq], n, [n], ic=40000, qc=-40000)  # (short) cast of the correction wraps
+    # across calls: the 26 history samples are kept corrected, the first windows of a call read them through the
+    # edge image with the correction taken off and re-applied (k_fm_edges), also for calls shorter than a window
+    run_both([iq], n, [n // 3, 7, 30, n - n // 3 - 37], ic=1234, qc=-4321)
+    run_both([iq], n, [4096, 1, 20000, n - 24097], ic=-32768, qc=32767)
 
 
 def test_bpsk_fec_errors_and_failed_decode_keep_previous_payload():
