@@ -64,12 +64,43 @@ __device__ __forceinline__ void store_lds(float2 *dst, const float2 *v, int j0, 
     ((dst[lds_pad(j0 + Rs * p)] = v[cx_bitrev(Rs, R)]), ...);
 }
 
+// A frame's first-pass inputs as they come from memory: one (I,Q) int16 pair or one float pair per point.  They are
+// fetched ONE FRAME AHEAD, just before the previous frame's last pass: that pass holds one small butterfly at a time
+// (registers to spare), and a load issued before the PSD stores does not queue behind them -- loads and stores share
+// the in-order vmcnt counter, so a frame's loads issued after the previous frame's stores waited for those stores'
+// acknowledgements first (measured on 2048 streams: 4.02 ms, without the loads 3.41, without the stores 3.36, without
+// both 2.76: memory time simply added to the arithmetic).
+template <int IN>
+struct RawPoint {
+    using type = int;
+};
+template <>
+struct RawPoint<IN_F32> {
+    using type = float2;
+};
+template <int N, int T, int IN, int R>
+__device__ __forceinline__ void fft_fetch(const FftArgs &a, long long frame, int tid, typename RawPoint<IN>::type (&w)[R])
+{
+    constexpr int NB = N / R;
+    static_assert(NB == T, "one first-pass butterfly per thread");
+    const typename RawPoint<IN>::type *src = reinterpret_cast<const typename RawPoint<IN>::type *>(a.in) + frame * N;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+#ifdef JSDR_X_FFT_NOLOAD  // timing experiment: no input loads (wrong data)
+        if constexpr (IN == IN_I16) w[r] = (tid + r * NB) * 2654435761u + (int)(size_t)src;
+        else w[r] = make_float2((float)(tid + r), (float)(size_t)src);
+#else
+        w[r] = src[tid + r * NB];
+#endif
+    }
+}
+
 // One Stockham pass of one frame by T threads.  Each thread owns ITERS = (N/R)/T butterflies, loads
 // them all (global for the first pass, LDS otherwise), transforms in registers, and only after a
 // barrier (every load of the in-place image has landed) writes its outputs.
-template <int N, int T, int IN, int OUT, int R, int P, bool FIRST, bool LAST>
+template <int N, int T, int IN, int OUT, int R, int P, bool FIRST, bool LAST, class RAW = int>
 __device__ __forceinline__ void fft_pass(const FftArgs &a, long long frame, bool active, int tid, float2 *buf,
-                                         const float2 *tab, Best &best)
+                                         const float2 *tab, Best &best, const RAW *raw = nullptr)
 {
     constexpr int NB = N / R;
     static_assert(NB % T == 0, "butterflies per pass must be a multiple of the threads per frame");
@@ -86,10 +117,7 @@ __device__ __forceinline__ void fft_pass(const FftArgs &a, long long frame, bool
             if constexpr (FIRST) {
                 if (active) {
                     if constexpr (IN == IN_I16) {
-                        const int *src = reinterpret_cast<const int *>(a.in) + frame * N;
-                        int w[R];
-#pragma unroll
-                        for (int r = 0; r < R; r++) w[r] = src[b + r * NB];
+                        const RAW *w = raw;
                         if ((a.ic | a.qc) == 0) {  // uniform: no DC correction (the usual case), two adds per sample less
 #pragma unroll
                             for (int r = 0; r < R; r++)
@@ -104,9 +132,8 @@ __device__ __forceinline__ void fft_pass(const FftArgs &a, long long frame, bool
                             }
                         }
                     } else {
-                        const float2 *src = reinterpret_cast<const float2 *>(a.in) + frame * N;
 #pragma unroll
-                        for (int r = 0; r < R; r++) v[gi][r] = src[b + r * NB];
+                        for (int r = 0; r < R; r++) v[gi][r] = raw[r];
                     }
                 } else {
 #pragma unroll
@@ -143,7 +170,9 @@ __device__ __forceinline__ void fft_pass(const FftArgs &a, long long frame, bool
                     for (int r = 0; r < R; r++) {
                         float2 x = v[gi][cx_bitrev(r, R)];
                         db[r] = L2 * __log2f(x.x * x.x + x.y * x.y) + OFF;
+#ifndef JSDR_X_FFT_NOSTORE  // timing experiment: no PSD stores (the argmax keeps the arithmetic alive)
                         dst[j0 + r * P] = db[r];  // (nontemporal stores: 1.99 -> 2.39 ms, measured r02)
+#endif
                     }
                     // first strict maximum of this thread's bins (fft.java:208-211): the group's maximum
                     // (fmaxf ignores NaN, like the reference's '>'), then the lowest bin that holds it
@@ -164,24 +193,36 @@ __device__ __forceinline__ void fft_pass(const FftArgs &a, long long frame, bool
     if constexpr (!LAST) __syncthreads();
 }
 
-// One frame, executed by T threads (tid in [0,T)).  `active` false => keep barriers, skip memory.
+// One frame, executed by T threads (tid in [0,T)).  `raw` holds the frame's first-pass inputs (fft_fetch); before the
+// last pass the NEXT frame's inputs are fetched into it.
 template <int N, int T, int IN, int OUT, int R0, int R1, int R2, int R3>
-__device__ __forceinline__ void fft_frame(const FftArgs &a, long long frame, bool active, int tid, float2 *buf,
-                                          const float2 *tw_lds, float *red_val, int *red_idx, int frame_in_block)
+__device__ __forceinline__ void fft_frame(const FftArgs &a, long long frame, long long next, int tid, float2 *buf,
+                                          const float2 *tw_lds, float *red_val, int *red_idx, int frame_in_block,
+                                          typename RawPoint<IN>::type (&raw)[R0])
 {
+    using RAW = typename RawPoint<IN>::type;
+    constexpr bool active = true;
     constexpr int NPASS = (R1 == 1) ? 1 : (R2 == 1) ? 2 : (R3 == 1) ? 3 : 4;
+    static_assert(NPASS >= 2, "the first pass must not be the last");
     static_assert(R0 * R1 * R2 * R3 == N, "radix plan must multiply to N");
     Best best;
     best.v = -3.402823466e+38f;
     best.k = 0x7fffffff;
     constexpr int O1 = 0, O2 = tw_size(R0, R1), O3 = O2 + tw_size(R0 * R1, R2);
-    fft_pass<N, T, IN, OUT, R0, 1, true, NPASS == 1>(a, frame, active, tid, buf, tw_lds, best);
-    if constexpr (NPASS >= 2)
-        fft_pass<N, T, IN, OUT, R1, R0, false, NPASS == 2>(a, frame, active, tid, buf, tw_lds + O1, best);
-    if constexpr (NPASS >= 3)
+    fft_pass<N, T, IN, OUT, R0, 1, true, false, RAW>(a, frame, active, tid, buf, tw_lds, best, raw);
+    // (unconditional: a workgroup's last frame fetches itself again -- with a branch around the loads the compiler cannot
+    //  count what is in flight at the loop head and waits for everything, the previous frame's stores included)
+    auto prefetch = [&] { fft_fetch<N, T, IN, R0>(a, next, tid, raw); };
+    if constexpr (NPASS == 2) prefetch();
+    fft_pass<N, T, IN, OUT, R1, R0, false, NPASS == 2>(a, frame, active, tid, buf, tw_lds + O1, best);
+    if constexpr (NPASS >= 3) {
+        if constexpr (NPASS == 3) prefetch();
         fft_pass<N, T, IN, OUT, R2, R0 * R1, false, NPASS == 3>(a, frame, active, tid, buf, tw_lds + O2, best);
-    if constexpr (NPASS >= 4)
+    }
+    if constexpr (NPASS >= 4) {
+        prefetch();
         fft_pass<N, T, IN, OUT, R3, R0 * R1 * R2, false, NPASS == 4>(a, frame, active, tid, buf, tw_lds + O3, best);
+    }
 
     if constexpr (OUT == OUT_PSD) {
         // first strict maximum (fft.java:208-211): highest value, lowest bin on ties; none if all -inf
@@ -253,8 +294,12 @@ __global__ __launch_bounds__(T *FPB, (N == 2048 ? 4 : 1)) void k_fft(FftArgs a)
         long long f = g * FPB + fib;
         return f < a.nframes ? f : a.nframes - 1;
     };
+    typename RawPoint<IN>::type raw[R0];
+    if ((long long)blockIdx.x < ngroups) fft_fetch<N, T, IN, R0>(a, frame_of(blockIdx.x), tid, raw);
     for (long long g = blockIdx.x; g < ngroups; g += gridDim.x) {
-        fft_frame<N, T, IN, OUT, R0, R1, R2, R3>(a, frame_of(g), true, tid, buf, tw_lds, red_val, red_idx, fib);
+        const long long gn = g + gridDim.x;
+        fft_frame<N, T, IN, OUT, R0, R1, R2, R3>(a, frame_of(g), frame_of(gn < ngroups ? gn : g), tid, buf, tw_lds, red_val,
+                                                 red_idx, fib, raw);
         __syncthreads();
     }
 }

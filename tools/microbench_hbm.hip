@@ -39,6 +39,57 @@ __global__ __launch_bounds__(256, 4) void k_fftshape(const int *__restrict__ in,
         for (int r = 0; r < 8; r++) dst[128 + tid + r * 256] = (float)v[8 + r];
     }
 }
+// the same traffic with wide accesses: 16-byte loads (four per thread and frame), 8-byte stores (frames are 2050 floats
+// apart: 8-byte aligned only) or 16-byte stores (misaligned on odd frames)
+template <int SW>
+__global__ __launch_bounds__(256, 4) void k_fftshape_wide(const int *__restrict__ in, float *__restrict__ out, long long nframes)
+{
+    const int fib = threadIdx.x >> 7, tid = threadIdx.x & 127;
+    const long long ngroups = nframes / 2;
+    for (long long g = blockIdx.x; g < ngroups; g += gridDim.x) {
+        const long long frame = 2 * g + fib;
+        const int4 *src = reinterpret_cast<const int4 *>(in + frame * 2048);
+        float *dst = out + frame * 2050;
+        int4 v[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) v[r] = src[tid + r * 128];
+        if constexpr (SW == 2) {
+            float2 *d2 = reinterpret_cast<float2 *>(dst);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                d2[2 * (tid + r * 128)] = make_float2((float)v[r].x, (float)v[r].y);
+                d2[2 * (tid + r * 128) + 1] = make_float2((float)v[r].z, (float)v[r].w);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                float4 o = make_float4((float)v[r].x, (float)v[r].y, (float)v[r].z, (float)v[r].w);
+                __builtin_memcpy(dst + 4 * (tid + r * 128), &o, 16);
+            }
+        }
+    }
+}
+// dword loads, wide stores / wide loads, dword stores: which side matters
+__global__ __launch_bounds__(256, 4) void k_fftshape_wl(const int *__restrict__ in, float *__restrict__ out, long long nframes)
+{
+    const int fib = threadIdx.x >> 7, tid = threadIdx.x & 127;
+    const long long ngroups = nframes / 2;
+    for (long long g = blockIdx.x; g < ngroups; g += gridDim.x) {
+        const long long frame = 2 * g + fib;
+        const int4 *src = reinterpret_cast<const int4 *>(in + frame * 2048);
+        float *dst = out + frame * 2050;
+        int4 v[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) v[r] = src[tid + r * 128];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            dst[tid + (4 * r) * 128] = (float)v[r].x;
+            dst[tid + (4 * r + 1) * 128] = (float)v[r].y;
+            dst[tid + (4 * r + 2) * 128] = (float)v[r].z;
+            dst[tid + (4 * r + 3) * 128] = (float)v[r].w;
+        }
+    }
+}
 int main()
 {
     const long long n = 1ll << 30;
@@ -67,5 +118,11 @@ int main()
     time("copy x16 in flight, 4096", [&] { hipLaunchKernelGGL(k_copy_u<16>, dim3(4096), dim3(256), 0, 0, in, out, n); });
     time("k_fft shape, grid 4096", [&] { hipLaunchKernelGGL(k_fftshape, dim3(4096), dim3(256), 0, 0, in, out, n / 2048); });
     time("k_fft shape, grid 262144", [&] { hipLaunchKernelGGL(k_fftshape, dim3(262144), dim3(256), 0, 0, in, out, n / 2048); });
+    time("k_fft shape x4 ld, x2 st, 262144", [&] { hipLaunchKernelGGL(k_fftshape_wide<2>, dim3(262144), dim3(256), 0, 0, in, out, n / 2048); });
+    time("k_fft shape x4 ld, x4 st, 262144", [&] { hipLaunchKernelGGL(k_fftshape_wide<4>, dim3(262144), dim3(256), 0, 0, in, out, n / 2048); });
+    time("k_fft shape x4 ld, x1 st, 262144", [&] { hipLaunchKernelGGL(k_fftshape_wl, dim3(262144), dim3(256), 0, 0, in, out, n / 2048); });
+    time("k_fft shape x4 ld, x2 st, 4096", [&] { hipLaunchKernelGGL(k_fftshape_wide<2>, dim3(4096), dim3(256), 0, 0, in, out, n / 2048); });
+    time("k_fft shape x1 ld, x1 st, 16384", [&] { hipLaunchKernelGGL(k_fftshape, dim3(16384), dim3(256), 0, 0, in, out, n / 2048); });
+    time("k_fft shape x4 ld, x2 st, 16384", [&] { hipLaunchKernelGGL(k_fftshape_wide<2>, dim3(16384), dim3(256), 0, 0, in, out, n / 2048); });
     return 0;
 }
