@@ -1164,8 +1164,12 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs a)
     // peak) reads its sample from y.  The whole chunk (8 KB) used to sit here: with 10 KB instead of 17 KB a CU holds
     // sixteen of these one-wave workgroups instead of nine, and the kernel is occupancy x latency bound.
     __shared__ double2 ydL[64];        // [period]
-    __shared__ double enL[512];        // [period*8 + bitPos]
-    __shared__ double eL[64][9];       // dmEnergy[c] after each period (row padded: conflict-free column walk)
+    // The chains' work area, in place: before the chain row p holds its INPUTS -- energy1 x 1/200 of the period's eight
+    // samples (the products are taken lane-parallel when the chunk is staged, not by the nine chain lanes one at a time)
+    // and, in the pad column, energy1 x 1/800 of the sample at position v for dmEnergyOut -- and afterwards dmEnergy[c]
+    // after that period (a chain has its 16 inputs in registers before it overwrites their rows).  Row padded: a
+    // conflict-free column walk.  6 KB of LDS a workgroup (it was 17 KB): twenty of them on a CU.
+    __shared__ double eL[64][9];
     __shared__ unsigned char maskL[64];
     __shared__ short declist[136];
     __shared__ double2 dmL[CERT ? 66 : 1];
@@ -1211,7 +1215,7 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs a)
     const double K2 = 1.0 - 1.0 / 800.0, S2 = 1.0 / 800.0;  // BIT_SMOOTH2 (:90)
     // lanes 0..7 carry dmEnergy[lane], lane 8 carries dmEnergyOut
     double e = (lane < 8) ? sp->dmEnergy[lane] : sp->dmEnergyOut;
-    const double Kc = (lane < 8) ? K1 : K2, Sc = (lane < 8) ? S1 : S2;
+    const double Kc = (lane < 8) ? K1 : K2;
     int peakPos = __builtin_amdgcn_readfirstlane(sp->peakPos);
     int newPeak = __builtin_amdgcn_readfirstlane(sp->newPeak);
     double lastI = sp->lastI, lastQ = sp->lastQ, energy1 = sp->energy1, energy2 = sp->energy2;
@@ -1233,9 +1237,13 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs a)
         // ---------------- stage the prefetched chunk, start fetching the next one
         const int v = peakPos;
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            if ((lane & 7) == v) ydL[k * 8 + (lane >> 3)] = pre[k];  // sample k*64 + lane = period k*8 + lane/8, position lane%8
-            enL[k * 64 + lane] = pre[k].x * pre[k].x + pre[k].y * pre[k].y;  // :534
+        for (int k = 0; k < 8; k++) {  // sample k*64 + lane = period k*8 + lane/8, position lane%8
+            const double en = pre[k].x * pre[k].x + pre[k].y * pre[k].y;  // :534
+            eL[k * 8 + (lane >> 3)][lane & 7] = en * S1;
+            if ((lane & 7) == v) {
+                ydL[k * 8 + (lane >> 3)] = pre[k];
+                eL[k * 8 + (lane >> 3)][8] = en * S2;
+            }
         }
         JSDR_WAVE_SYNC();
         const double2 *ychunk = y + (8 * MB - g_first);  // sample i of the chunk (only in-range samples are ever decisions)
@@ -1271,23 +1279,24 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs a)
         const double e_in = e;
         {
             const int idx = (lane < 8) ? lane : v;
+            const int col = (lane < 8) ? lane : 8;
             const long long glane = 8 * MB + idx;
             const bool lane_iir = lane < 8, lane_out = (lane == 8) && spec;
             const bool lane_on = lane_iir || lane_out;
             // the 64 energies this lane will fold in, fetched up front: the serial chain below then touches
             // registers only (an LDS read per step would put ~100 cycles of latency on every link of the chain)
 #ifndef JSDR_TAIL_XS
-#define JSDR_TAIL_XS 16
+#define JSDR_TAIL_XS 8
 #endif
-            // (in four parts of 16: the preload is 32 VGPRs instead of 128 and the kernel fits four waves per SIMD
-            //  instead of two -- at 8192 streams the tail is occupancy x latency bound)
+            // (a few at a time: the preload is 16 VGPRs instead of 128 -- at 8192 streams the tail is occupancy x latency
+            //  bound, and what counts is how many of these one-wave workgroups a CU holds)
             constexpr int XS = JSDR_TAIL_XS;
             const int pfirst = (glane < g_first) ? 1 : 0;  // period 0 of the chunk lacks this lane's sample
 #pragma unroll
             for (int p0 = 0; p0 < 64; p0 += XS) {
                 double xs[XS];
 #pragma unroll
-                for (int p = 0; p < XS; p++) xs[p] = enL[(p0 + p) * 8 + idx] * Sc;  // the products are off the chain
+                for (int p = 0; p < XS; p++) xs[p] = eL[p0 + p][col];  // (the x S products were taken at staging)
                 // (pinned: left to itself the compiler sinks the reads back into the chain, one LDS wait per two steps)
 #pragma unroll
                 for (int p = 0; p < XS; p++) asm volatile("" : "+v"(xs[p]));
@@ -1405,8 +1414,12 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs a)
                 // dmEnergyOut (:538) over the decisions in time order: the products x*S2 lane-parallel, the chain
                 // e = e*K2 + (x*S2) on broadcast values, in the reference's operation order
                 double xa = 0.0, xb = 0.0;
-                if (lane < nd) xa = enL[declist[lane]] * S2;
-                if (lane + 64 < nd) xb = enL[declist[lane + 64]] * S2;
+                auto en_of = [&](int pos) {  // energy1 of the chunk's sample pos, as :534 forms it
+                    const double2 q = ysample(pos);
+                    return q.x * q.x + q.y * q.y;
+                };
+                if (lane < nd) xa = en_of(declist[lane]) * S2;
+                if (lane + 64 < nd) xb = en_of(declist[lane + 64]) * S2;
                 double eo = __shfl(e_in, 8, 64);
                 for (int d = 0; d < nd; d++) {  // d is uniform: v_readlane, no LDS round trip on the chain
                     const double xs = (d < 64) ? xa : xb;
@@ -1488,13 +1501,12 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs a)
                 }
             }
         }
-        // energy1 = that of the last sample processed (:534)
-        {
-            long long glast = 8 * (MB + nper - 1) + 7;
-            if (glast >= g_end) glast = g_end - 1;
-            energy1 = enL[(int)(glast - 8 * MB)];
-        }
         JSDR_WAVE_SYNC();
+    }
+    // energy1 = that of the last sample processed (:534)
+    if (a.nds > 0) {
+        const double2 q = y[a.nds - 1];
+        energy1 = q.x * q.x + q.y * q.y;
     }
     // ---------------- write back
     const bool any_uncert = CERT && (__ballot(uncert != 0) != 0ull);
