@@ -785,7 +785,6 @@ struct FmArgs {
     long long stride_pairs;
     int nsamples;               // L
     int ic, qc;
-    const int2 *hist;           // [S][32]: the 26 inputs before this call, DC-corrected int16 pairs in .x
     const int *edges;           // [S][4 * FM_EDGE]: k_fm_edges' images of the stream around sample 0 and around the last sample
     const double2 *tcs;         // unwrapped tuner table: entry e = (cos, sin) for samples n with (n + 26) mod P == e mod P
     int tper;                   // P (1 when the tuner is off)
@@ -1173,11 +1172,6 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs a)
     __shared__ unsigned char maskL[64];
     __shared__ short declist[136];
     __shared__ double2 dmL[CERT ? 66 : 1];
-#ifdef JSDR_X_TAIL_PAD  // timing experiment: a larger LDS footprint (fewer tail waves beside k_fm)
-    __shared__ int padL[JSDR_X_TAIL_PAD];
-    if (a.nstreams < 0) padL[threadIdx.x] = 1;
-    if (a.nstreams < -1) a.st[0].cntBit = padL[threadIdx.x + 1];
-#endif
     const int lane = threadIdx.x;
     const int s = blockIdx.x;
     if (s >= a.nstreams) return;
@@ -2276,7 +2270,6 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
         ma.nsamples = (int)L;
         ma.ic = ic;
         ma.qc = qc;
-        ma.hist = fa.hist;
         ma.edges = h->fm_edges.p;
         ma.tcs = tcs_p;
         ma.tper = h->mix ? h->c_tper : 1;
