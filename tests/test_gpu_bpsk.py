@@ -135,6 +135,30 @@ def test_bpsk_dc_correction_is_applied_like_javaaudio():
     run_both([iq], n, [4096, 1, 20000, n - 24097], ic=-32768, qc=32767)
 
 
+@pytest.mark.parametrize("seed", range(16))
+def test_bpsk_random_call_patterns_rates_and_corrections(seed):
+    """seeded sweep over what decides which samples a call's first and last windows see: call lengths around the
+    window sizes (26 / 27-tap window, 57-sample lane window, 60-sample quad span, the 64-sample halo), every rate,
+    periodic and non-periodic tunings, DC correction on and off -- bits, (fi,fq), state and FEC against the oracle"""
+    rng = np.random.default_rng(1000 + seed)
+    rate, tunings = [(96000, [12000, 24000, 10000, 0]), (48000, [12000, 9000]), (44100, [8000]),
+                     (192000, [12000, 24000])][seed % 4]
+    tuning = tunings[(seed // 4) % len(tunings)]
+    n = int(rng.integers(50000, 90000)) * (rate // 9600) // 10
+    small = [1, 2, 9, 10, 11, 25, 26, 27, 28, 39, 40, 41, 56, 57, 58, 59, 60, 61, 63, 64, 65, 79, 80, 81, 127, 128, 640, 641]
+    chunks, left = [], n
+    while left > 0:
+        L = int(rng.choice(small)) if rng.random() < 0.6 else int(rng.integers(1000, 30000))
+        L = min(L, left)
+        chunks.append(L)
+        left -= L
+    carrier = (tuning if tuning > 0 else 0) + 1200.0
+    iq, _, _ = O.make_dbpsk_stream(70 + seed, 0, n, rate=rate, carrier_hz=carrier, noise_sigma=700.0)
+    noise = rng.integers(-30000, 30000, 2 * n).astype(np.int16)
+    ic, qc = (0, 0) if seed % 2 == 0 else (int(rng.integers(-40000, 40000)), int(rng.integers(-40000, 40000)))
+    run_both([iq, noise], n, chunks, rate=rate, tuning=tuning, ic=ic, qc=qc)
+
+
 def test_bpsk_fec_errors_and_failed_decode_keep_previous_payload():
     """two frames; the second is corrupted beyond repair -> rc=-1, decoded[] keeps frame 0's bytes"""
     n = 2 * 416000 + 30000
