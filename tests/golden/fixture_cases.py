@@ -36,3 +36,26 @@ def stream_input(name):
                                         noise_sigma=s["noise_sigma"])
     assert raw.size == 2 * p["n"], (name, raw.size)
     return raw
+
+
+# ---- FFT-acquire mode (tests/golden/fftmode_fixtures.npz, make_fftmode_fixtures.py): frame = samples per receive()
+FFT_STREAMS = {
+    "sine": dict(rate=96000, frame=2048, do_up=0, n=4096, synth=None),
+    "clean": dict(rate=96000, frame=2048, do_up=0, n=65536, synth=dict(seed=20020121, stream=3, noise_sigma=300.0, carrier=13200.0)),
+    "noisy": dict(rate=96000, frame=2048, do_up=0, n=49152, synth=dict(seed=20020122, stream=1, noise_sigma=3000.0, carrier=13200.0)),
+    "upper": dict(rate=96000, frame=2048, do_up=1, n=49152, synth=dict(seed=20020123, stream=2, noise_sigma=600.0, carrier=30000.0)),
+    "f4096": dict(rate=96000, frame=4096, do_up=0, n=65536, synth=dict(seed=20020124, stream=4, noise_sigma=600.0, carrier=13200.0)),
+    "f1024": dict(rate=48000, frame=1024, do_up=0, n=32768, synth=dict(seed=20020125, stream=6, noise_sigma=600.0, carrier=6000.0)),
+}
+
+
+def fft_stream_input(name):
+    p = FFT_STREAMS[name]
+    if p["synth"] is None:
+        raw = np.fromfile(os.path.join(HERE, "sine4410.raw"), dtype="<i2")
+    else:
+        s = p["synth"]
+        raw, _, _ = O.make_dbpsk_stream(s["seed"], s["stream"], p["n"], rate=p["rate"], carrier_hz=s["carrier"], amp=3000,
+                                        noise_sigma=s["noise_sigma"])
+    assert raw.size == 2 * p["n"], (name, raw.size)
+    return raw

@@ -431,7 +431,7 @@ def _sbyte16(v):
 
 # ------------------------------------------------------------------------------------- FUNcubeBPSKDemod.java
 class Demod:
-    """tune-mode receive chain (:366-397, :466-595); doFFT is not restated here (it crosses JTransforms)"""
+    """tune-mode receive chain (:366-397, :466-595); the FFT-acquire front end (:399-464) is DemodFFT below"""
 
     DOWN_SAMPLE_FILTER_SIZE = 27
     MATCHED_FILTER_SIZE = 65
@@ -589,3 +589,119 @@ class Demod:
 
     def istate(self):
         return [self.dsPos, self.dsCnt, self.dmPos, self.dmBitPos, self.dmPeakPos, self.dmNewPeak]
+
+
+# ------------------------------------------------------------------------------------- doBufferFFT (:399-464)
+def fft_radix2_dit(a, n, inverse, scale, w):
+    """The transform this project DEFINES in place of JTransforms' DoubleFFT_1D.complexForward / complexInverse(a, true)
+    (FUNcubeBPSKDemod.java:422-423, :459; JTransforms 2.4 is a Maven dependency whose source is not in the reference
+    tree, so its own rounding is unknowable): radix-2 decimation in time on interleaved (re, im) doubles --
+      bit-reversal permutation, then log2(n) stages of butterflies  t = w b ; a' = a + t ; b' = a - t
+      with  tr = wr br - wi bi ,  ti = wr bi + wi br  (every product and every sum rounded on its own),
+      w = table entry j n/(2 half) for butterfly j of a stage of half-width `half`, conjugated for the inverse,
+      the inverse scaled by the product with 1/n afterwards.
+    Written from that definition (oracle/o_fft.c's header comment), not from the C code.  `w` = the twiddle table as DATA."""
+    bits = n.bit_length() - 1
+    assert 1 << bits == n
+    for i in range(n):
+        j = int(format(i, "0%db" % bits)[::-1], 2) if bits else 0
+        if j > i:
+            a[2 * i], a[2 * j] = a[2 * j], a[2 * i]
+            a[2 * i + 1], a[2 * j + 1] = a[2 * j + 1], a[2 * i + 1]
+    half = 1
+    while half < n:
+        step = n // (2 * half)
+        for base in range(0, n, 2 * half):
+            for j in range(half):
+                wr = w[2 * (j * step)]
+                wi = w[2 * (j * step) + 1]
+                if inverse:
+                    wi = -wi
+                ia = base + j
+                ib = ia + half
+                br = a[2 * ib]
+                bi = a[2 * ib + 1]
+                tr = wr * br - wi * bi
+                ti = wr * bi + wi * br
+                ar = a[2 * ia]
+                ai = a[2 * ia + 1]
+                a[2 * ia] = ar + tr
+                a[2 * ia + 1] = ai + ti
+                a[2 * ib] = ar - tr
+                a[2 * ib + 1] = ai - ti
+        half *= 2
+    if inverse and scale:
+        norm = 1.0 / float(n)
+        for i in range(2 * n):
+            a[i] *= norm
+
+
+def _f32(x):
+    return float(np.float32(x))
+
+
+class DemodFFT(Demod):
+    """receive() with bpsk-dofft set: doBufferFFT (:399-464) in front of the same RxDownSample / RxDemodulate chain.
+    `samples` complex samples per call (blen/4 of the reference's byte buffer), `twiddles` the table of fft_radix2_dit."""
+
+    # :399-402 -- float expressions, widened to double when the static finals are initialised
+    CFREQ_INV_AVERAGE_FACTOR = _f32(np.float32(1.0) - (np.float32(2.0) / np.float32(1 + 1)))
+    CFREQ_AVERAGE_FACTOR = _f32(np.float32(2.0) / np.float32(1 + 1))
+    PSD_INV_AVERAGE_FACTOR = _f32(np.float32(1.0) - (np.float32(2.0) / np.float32(10 + 1)))
+    PSD_AVERAGE_FACTOR = _f32(np.float32(2.0) / np.float32(10 + 1))
+
+    def __init__(self, samples, twiddles, rate=96000, tuning=12000, do_up=False, trace_cap=0):
+        super().__init__(rate=rate, tuning=tuning, trace_cap=trace_cap)
+        self.samples = samples
+        self.w = twiddles
+        self.doUp = do_up
+        self.avePeakPower = 0.0
+        self.aveCentreBin = 0.0
+        self.centreBin = 0
+        self.centre_log = []  # observation only: centreBin after every call
+
+    def receive(self, buf):
+        """:357-363 with doFFT: one call = one frame of `samples` complex samples"""
+        assert len(buf) == 2 * self.samples
+        self.doBufferFFT(buf)
+
+    def doBufferFFT(self, buf):
+        samples = self.samples
+        fftFwd = [0.0] * (2 * samples)
+        fftRev = [0.0] * (2 * samples)
+        psd = [0.0] * samples
+        avePsd = [0.0] * samples
+        for n in range(samples):
+            fftFwd[2 * n] = buf[2 * n]      # (double)buf[n*2]: the float's value
+            fftFwd[2 * n + 1] = buf[2 * n + 1]
+        fft_radix2_dit(fftFwd, samples, False, False, self.w)  # :422-423
+        for i in range(samples // 2):  # :425-427
+            psd[i] = math.sqrt(fftFwd[2 * i] * fftFwd[2 * i] + fftFwd[2 * i + 1] * fftFwd[2 * i + 1])
+        maxBin = 0.0
+        binPos = -1
+        beg = samples // 4 if self.doUp else 0
+        end = samples // 2 if self.doUp else samples // 4
+        for i in range(beg + 75, end - 75):  # :433-443
+            acc = 0.0
+            for j in range(i - 50, i + 50):
+                acc += psd[j]
+            avePsd[i] = acc
+            if maxBin < acc:
+                maxBin = acc
+                binPos = i
+        if self.centreBin < 0:
+            self.centreBin = 0
+        if self.centreBin > end - 1:
+            self.centreBin = end - 1
+        self.avePeakPower = (self.PSD_AVERAGE_FACTOR * avePsd[self.centreBin]) + (self.PSD_INV_AVERAGE_FACTOR * self.avePeakPower)
+        if maxBin > (self.avePeakPower / 4) * 5 and binPos > 0:  # :447
+            self.aveCentreBin = (self.CFREQ_AVERAGE_FACTOR * float(binPos)) + (self.CFREQ_INV_AVERAGE_FACTOR * self.aveCentreBin)
+            self.centreBin = int(self.aveCentreBin + 1.0)  # (int) of a positive double truncates
+        if self.centreBin < 102:
+            self.centreBin = 102
+        self.centre_log.append(self.centreBin)
+        lo = 2 * (self.centreBin - 102)
+        fftRev[0:2 * 204] = fftFwd[lo:lo + 2 * 204]  # :458
+        fft_radix2_dit(fftRev, samples, True, True, self.w)  # :459
+        for i in range(samples):
+            self.RxDownSample(fftRev[2 * i], fftRev[2 * i])  # "yes it drops Q component.."

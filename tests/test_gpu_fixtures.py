@@ -208,3 +208,43 @@ def test_fast_variant_certifies_silence_and_scales_its_bound_with_the_input():
     o = O.Bpsk()
     o.receive_i16(quiet)
     assert np.array_equal(d.bits(1), o.bits())
+
+
+# ------------------------------------------------------------------ FFT-acquire mode against the Python restatement
+from fixture_cases import FFT_STREAMS, fft_stream_input  # noqa: E402
+
+FXF = np.load(os.path.join(HERE, "golden", "fftmode_fixtures.npz"))
+
+
+@pytest.mark.parametrize("name", list(FFT_STREAMS))
+@pytest.mark.parametrize("whole", [True, False])
+def test_hip_fft_acquire_equals_python_restatement(name, whole):
+    """bpsk-dofft: doBufferFFT restated from the Java text (tests/golden/java_restatement.DemodFFT) around the transform
+    this project defines in JTransforms' place -- bits, counters, the centre bin, avePeakPower / aveCentreBin and every
+    other state double, the (fi,fq) trace; frame by frame (the plugin's receive cadence) and as one batch call"""
+    p = FFT_STREAMS[name]
+    raw = fft_stream_input(name)
+    k = "x_" + name + "_"
+    assert hashlib.sha256(raw.tobytes()).digest() == FXF[k + "sha256"].tobytes()
+    n = p["frame"]
+    chunks = [p["n"]] if whole else [n] * (p["n"] // n)
+    d = J.Bpsk(rate=p["rate"], blen=4 * n, tuning=12000, do_fft=1, do_up=p["do_up"], nstreams=1, max_batch_samples=max(chunks))
+    d_iq = J.DeviceBuffer.from_host(raw)
+    bits, trace, centre = [], [], []
+    pos = 0
+    for L in chunks:
+        d.batch_i16(d_iq.ptr + 4 * pos, 2 * p["n"], L, 0, 0)
+        bits.append(d.bits(0).copy())
+        trace.append(d.trace(0).copy())
+        centre.append(d.counters(0)["centreBin"])
+        pos += L
+    c = d.counters(0)
+    assert [c[m] for m in CN] == [int(v) for v in FXF[k + "counters"][:9]]
+    assert np.array_equal(np.concatenate(bits), FXF[k + "bits"])
+    if whole:
+        assert centre[-1] == int(FXF[k + "centre"][-1])
+    else:
+        assert centre == [int(v) for v in FXF[k + "centre"]]
+    keep = [1, 2, 3, 4, 5, 6, 7] + list(range(8, 18))
+    assert d.state(0)[keep].tobytes() == FXF[k + "state"][keep].tobytes()
+    assert np.concatenate(trace)[:1024].tobytes() == FXF[k + "trace"].tobytes()

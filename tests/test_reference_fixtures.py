@@ -96,3 +96,61 @@ def test_fft_acquire_at_2048_sample_frames_never_finds_sync():
     f = O.Bpsk(rate=96000, blen=38400, size=4, tuning=12000, do_fft=1)
     f.receive_i16(iq[:2 * n])
     assert f.counters()["cntDec"] == 1
+
+
+# ------------------------------------------------------------------ FFT-acquire mode (bpsk-dofft), :399-464
+from fixture_cases import FFT_STREAMS, fft_stream_input  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def fxf():
+    return np.load(os.path.join(HERE, "golden", "fftmode_fixtures.npz"))
+
+
+@pytest.mark.parametrize("name", list(FFT_STREAMS))
+def test_oracle_fft_acquire_equals_python_restatement(fxf, name):
+    """doBufferFFT restated from the Java text (java_restatement.DemodFFT) around the transform this project defines in
+    JTransforms' place: the C oracle must give the same centre bin after every frame, the same bits, counters and state
+    doubles (avePeakPower and aveCentreBin included), bit for bit"""
+    p = FFT_STREAMS[name]
+    raw = fft_stream_input(name)
+    k = "x_" + name + "_"
+    assert hashlib.sha256(raw.tobytes()).digest() == fxf[k + "sha256"].tobytes(), "input generator changed"
+    n = p["frame"]
+    d = O.Bpsk(rate=p["rate"], blen=4 * n, size=4, tuning=12000, do_fft=1, do_up=p["do_up"], trace=1024)
+    centre = []
+    for f in range(p["n"] // n):
+        d.receive_i16(raw[2 * n * f:2 * n * (f + 1)], 0, 0)
+        centre.append(d.counters()["centreBin"])
+    assert centre == [int(v) for v in fxf[k + "centre"]]
+    c = d.counters()
+    got = [c[m] for m in ("cntRaw", "cntDS", "cntBit", "cntFEC", "cntDec", "dmErrBits", "dmCorr", "dmMaxCorr", "decodeOK")]
+    assert got == [int(v) for v in fxf[k + "counters"][:9]]
+    assert np.array_equal(d.bits(), fxf[k + "bits"])
+    st = d.state()
+    keep = [1, 2, 3, 4, 5, 6, 7] + list(range(8, 18))  # (tuPhase is not advanced in this mode)
+    assert st[keep].tobytes() == fxf[k + "state"][keep].tobytes()
+    assert np.array_equal(d.istate(), fxf[k + "istate"])
+    assert d.trace()[:1024].tobytes() == fxf[k + "trace"].tobytes()
+
+
+def test_fft_twiddle_table_is_cos_sin_to_the_last_bit_or_one(fxf):
+    """the table of the defined transform (cosl / sinl of the long-double angle, rounded once; exact on the axes) against
+    the correctly rounded cos / sin of the exact angle 2 pi k / n: equal, or one unit in the last place apart"""
+    from fractions import Fraction
+
+    import java_restatement as JR
+
+    pi = Fraction(314159265358979323846264338327950288419716939937510582097494459230781640628620899, 10 ** 80)
+    for n in (1024, 2048, 4096):
+        w = O.fft_twiddles_f64(n)
+        assert np.array_equal(w, fxf[f"twiddles_{n}"])
+        off = 0
+        for kk in range(0, n // 2, 7):  # a seventh of the table keeps the exact arithmetic short
+            ang = 2 * pi * kk / n
+            s, c = JR._sincos_exact(ang)
+            for got, want in ((w[2 * kk], c), (w[2 * kk + 1], -s)):
+                if got != want:
+                    off += 1
+                    assert abs(got - want) <= np.spacing(abs(want)), (n, kk, got, want)
+        assert off <= 4, (n, off)
