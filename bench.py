@@ -404,7 +404,12 @@ def main():
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "avg_launch_ms": round(dom_ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes),
-                "kernels_ms_per_step": {k: round(v[0] / v[1], 4) for k, v in sorted(kern.items())}}
+                "kernels_ms_per_step": {k: round(v[0] / v[1], 4) for k, v in sorted(kern.items())},
+                # every critical-path kernel against the same roofline (the dominant one is the slowest AS MEASURED, i.e.
+                # with whatever the side stream's kernels took from it)
+                "per_kernel": {k: {"avg_launch_ms": round(v[0] / v[1], 4), "algorithmic_bytes_per_launch": int(v[2] * S * L),
+                                   "frac": round(v[2] * S * L / (v[0] / v[1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                               for k, v in sorted(main.items()) if v[0] > 0}}
 
     # ---- validation outside the timed region: every sampled stream decodes what it was sent
     validated = None
