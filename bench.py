@@ -409,7 +409,7 @@ def main():
                 # with whatever the side stream's kernels took from it)
                 "per_kernel": {k: {"avg_launch_ms": round(v[0] / v[1], 4), "algorithmic_bytes_per_launch": int(v[2] * S * L),
                                    "frac": round(v[2] * S * L / (v[0] / v[1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-                               for k, v in sorted(main.items()) if v[0] > 0}}
+                               for k, v in sorted(main.items()) if v[0] / v[1] > 0.05 * dom_ms}}  # (not the helper kernels)
 
     # ---- validation outside the timed region: every sampled stream decodes what it was sent
     validated = None
