@@ -1681,6 +1681,15 @@ struct Schedule {
     std::vector<double2> tcs;
 };
 
+struct SnapPack {
+    TailState t;
+    int last[2];
+    int cdec, nbits, centreBin, pad;
+    double avePeakPower, aveCentreBin;
+    unsigned char decoded[256];
+    signed char bits[512];
+};
+
 struct jsdr_bpsk {
     int rate = 0, nsf = 0, tuning = 0, do_fft = 0, do_up = 0, nstreams = 0, decim = 0;
     long long max_batch = 0, max_ds = 0;
@@ -1710,6 +1719,7 @@ struct jsdr_bpsk {
     bool hist_is_float = false;    // form of the samples in hist_in[hist_cur] (the input form of the call that wrote them)
     DevBuf<int> hist_bad;          // k_hist_convert's "not an int16 sample" flag
     DevBuf<int> amax;              // fast variant: [S] running maximum of |int16 sample| (float bits)
+    DevBuf<SnapPack> snap_dev;     // receive(): the packed results of the call, fetched in one copy (k_snapshot_pack)
     DevBuf<int> fm_edges;          // k_fm: [S][4 * FM_EDGE] the stream around sample 0 and around the last sample (k_fm_edges)
     DevBuf<double2> dm, y[2];  // y is double-buffered: the tail of call k overlaps the front end of call k+1
     int y_cur = 0;
@@ -2557,7 +2567,7 @@ int jsdr_bpsk_create(jsdr_bpsk **out, int rate, int nsamples_per_frame, int tuni
               h->cnt_dec.alloc(S) == JSDR_OK && h->corr.alloc(S * (size_t)h->max_bits) == JSDR_OK &&
               h->fec_data.alloc(S * h->trig_cap * 256) == JSDR_OK && h->decoded.alloc(S * 256) == JSDR_OK &&
               h->stage_raw.alloc((size_t)nsamples_per_frame * 2) == JSDR_OK && h->ds_taps_dev.alloc(32) == JSDR_OK &&
-              h->dmh[0].alloc(S * 64) == JSDR_OK && h->dmh[1].alloc(S * 64) == JSDR_OK && h->hist_bad.alloc(1) == JSDR_OK && h->amax.alloc(S) == JSDR_OK && h->fm_edges.alloc(S * 4 * FM_EDGE) == JSDR_OK && h->tcs.alloc(2 * (256 + FM_TABLE_SLACK)) == JSDR_OK &&
+              h->dmh[0].alloc(S * 64) == JSDR_OK && h->dmh[1].alloc(S * 64) == JSDR_OK && h->hist_bad.alloc(1) == JSDR_OK && h->amax.alloc(S) == JSDR_OK && h->fm_edges.alloc(S * 4 * FM_EDGE) == JSDR_OK && h->snap_dev.alloc(1) == JSDR_OK && h->tcs.alloc(2 * (256 + FM_TABLE_SLACK)) == JSDR_OK &&
               (!do_fft || (h->fft_state.alloc(S) == JSDR_OK && h->fft_tw.alloc(fft_pow2 ? (size_t)nsamples_per_frame : (size_t)65536) == JSDR_OK &&
                             h->vco_cs.alloc((size_t)h->max_ds) == JSDR_OK)) &&
               (!(do_fft && fft2x_supported(nsamples_per_frame)) ||
@@ -2680,6 +2690,7 @@ int jsdr_bpsk_destroy(jsdr_bpsk *h)
     h->hist_bad.release();
     h->amax.release();
     h->fm_edges.release();
+    h->snap_dev.release();
     h->dmh[0].release();
     h->dmh[1].release();
     h->tcs.release();
@@ -2790,22 +2801,92 @@ int jsdr_bpsk_receive_f32(jsdr_bpsk *h, const float *iq_host)
     return publish_snapshot(h);
 }
 
+// ---- the 1-stream receive() forms publish their results for a concurrent reader (jsdr_bpsk_snapshot_read).  What the
+// four getters behind the snapshot fetch with eleven small blocking copies (each a round trip to the device: ~130 us of
+// a 290 us receive) is packed by ONE tiny kernel at the end of the side stream's work and comes back in ONE copy.
+__global__ void k_snapshot_pack(SnapPack *out, const TailState *st, const int *fec_last, const int *cnt_dec, const int *nbits,
+                                const FftFrontState *fs, const unsigned char *decoded, const signed char *bits_new)
+{
+    const int i = threadIdx.x;
+    if (i == 0) {
+        out->t = st[0];
+        out->last[0] = fec_last[0];
+        out->last[1] = fec_last[1];
+        out->cdec = cnt_dec[0];
+        out->nbits = nbits[0];
+        out->centreBin = fs ? fs[0].centreBin : 0;
+        out->pad = 0;
+        out->avePeakPower = fs ? fs[0].avePeakPower : 0.0;
+        out->aveCentreBin = fs ? fs[0].aveCentreBin : 0.0;
+    }
+    if (i < 256) out->decoded[i] = decoded[i];
+    const int nb = nbits[0];
+    for (int k = i; k < 512; k += blockDim.x) out->bits[k] = k < nb ? bits_new[k] : (signed char)0;
+}
+
+static void counters_from(const jsdr_bpsk *h, const TailState &t, const int last[2], int cdec, int centreBin, int32_t *out)
+{
+    out[0] = (int32_t)h->n_in;
+    out[1] = (int32_t)h->n_ds;
+    out[2] = t.cntBit;
+    out[3] = t.cntFEC;
+    out[4] = cdec;
+    out[5] = last[0];
+    out[6] = t.dmCorr;
+    out[7] = t.dmMaxCorr;
+    out[8] = last[1];
+    out[9] = h->do_fft ? centreBin : 0;
+}
+
+static void state_from(const jsdr_bpsk *h, const TailState &t, double avePeakPower, double aveCentreBin, double *out)
+{
+    out[0] = h->tuPhase;
+    out[1] = h->vcoPhase;
+    // dmBitPhase (:501,:581-584): k steps of +1/9600 from 0.0 within the current bit, replayed exactly
+    double ph = 0.0;
+    for (int i = 0; i < (int)(h->n_ds & 7); i++) ph += 1.0 / (double)9600;
+    out[2] = ph;
+    out[3] = t.dmEnergyOut;
+    out[4] = t.energy1;
+    out[5] = t.energy2;
+    out[6] = h->do_fft ? avePeakPower : 0.0;
+    out[7] = h->do_fft ? aveCentreBin : 0.0;
+    for (int i = 0; i < 8; i++) out[8 + i] = t.dmEnergy[i];
+    out[16] = t.lastI;
+    out[17] = t.lastQ;
+}
+
 static int publish_snapshot(jsdr_bpsk *h)
 {
+    // pack on the stream the call's last kernels ran on, fetch once
+    hipStream_t ts = (h->overlap && h->tail_stream) ? h->tail_stream : h->last_stream;
+    hipLaunchKernelGGL(k_snapshot_pack, dim3(1), dim3(256), 0, ts, h->snap_dev.p, h->tail.p, h->fec_last.p, h->cnt_dec.p,
+                       h->nbits.p, h->do_fft ? h->fft_state.p : (const FftFrontState *)nullptr, h->decoded.p,
+                       h->bitlog[h->bitlog_cur].p + HIST_BITS);
+    JSDR_LAUNCH_CHECK();
+    SnapPack pk;
+    JSDR_HIP_TRY(hipMemcpyAsync(&pk, h->snap_dev.p, sizeof(pk), hipMemcpyDeviceToHost, ts));
+    if (sync_last(h) != JSDR_OK) return JSDR_ERR;
+    JSDR_HIP_TRY(hipStreamSynchronize(ts));
+    // what the getters refuse, the snapshot refuses (check_overflow)
+    JSDR_REQUIRE(!pk.t.overflow, "receive: stream 0 exceeded its per-call capacity (%d bits / %d FEC calls per call of at most %lld samples)",
+                 h->max_bits, h->trig_cap, h->max_batch);
+    JSDR_REQUIRE(h->variant == 0 || !pk.t.uncertified, "receive: stream 0: the fast variant could not certify a slicer decision (inside "
+                 "its error margin and not recomputable in exact order); run this stream with JSDR_VARIANT_EXACT");
     const int cur = h->snap_cur.load(std::memory_order_relaxed);
     const int w = cur == 0 ? 1 : 0;  // the copy no reader is directed to
     h->snap_seq[w].fetch_add(1, std::memory_order_acq_rel);  // odd: writing
     jsdr_bpsk_snapshot &sn = h->snap[w];
-    int nb = 0;
-    int rc = jsdr_bpsk_get_counters(h, 0, sn.counters);
-    if (rc == JSDR_OK) rc = jsdr_bpsk_get_state(h, 0, sn.state);
-    if (rc == JSDR_OK) rc = jsdr_bpsk_get_decoded(h, 0, sn.decoded);
-    if (rc == JSDR_OK) rc = jsdr_bpsk_get_bits(h, 0, sn.bits, (int)sizeof(sn.bits), &nb);
-    sn.nbits = nb;
+    counters_from(h, pk.t, pk.last, pk.cdec, pk.centreBin, sn.counters);
+    state_from(h, pk.t, pk.avePeakPower, pk.aveCentreBin, sn.state);
+    memcpy(sn.decoded, pk.decoded, 256);
+    static_assert(sizeof(sn.bits) == sizeof(pk.bits), "snapshot bit capacity");
+    memcpy(sn.bits, pk.bits, sizeof(sn.bits));
+    sn.nbits = pk.nbits;
     sn.frames = ++h->snap_count;
     h->snap_seq[w].fetch_add(1, std::memory_order_release);  // even: complete
-    if (rc == JSDR_OK) h->snap_cur.store(w, std::memory_order_release);
-    return rc;
+    h->snap_cur.store(w, std::memory_order_release);
+    return JSDR_OK;
 }
 
 static int sync_last(jsdr_bpsk *h)
@@ -2844,21 +2925,13 @@ int jsdr_bpsk_get_counters(jsdr_bpsk *h, int stream, int32_t out[JSDR_BPSK_NCOUN
     JSDR_HIP_TRY(hipMemcpy(last, h->fec_last.p + 2 * stream, sizeof(last), hipMemcpyDeviceToHost));
     JSDR_HIP_TRY(hipMemcpy(&cdec, h->cnt_dec.p + stream, sizeof(int), hipMemcpyDeviceToHost));
     if (check_overflow(h, stream, "jsdr_bpsk_get_counters") != JSDR_OK) return JSDR_ERR;
-    out[0] = (int32_t)h->n_in;
-    out[1] = (int32_t)h->n_ds;
-    out[2] = t.cntBit;
-    out[3] = t.cntFEC;
-    out[4] = cdec;
-    out[5] = last[0];
-    out[6] = t.dmCorr;
-    out[7] = t.dmMaxCorr;
-    out[8] = last[1];
-    out[9] = 0;
+    int centreBin = 0;
     if (h->do_fft) {
         FftFrontState fs;
         JSDR_HIP_TRY(hipMemcpy(&fs, h->fft_state.p + stream, sizeof(fs), hipMemcpyDeviceToHost));
-        out[9] = fs.centreBin;
+        centreBin = fs.centreBin;
     }
+    counters_from(h, t, last, cdec, centreBin, out);
     return JSDR_OK;
 }
 
@@ -2930,26 +3003,14 @@ int jsdr_bpsk_get_state(jsdr_bpsk *h, int stream, double out[18])
     if (sync_last(h) != JSDR_OK) return JSDR_ERR;
     TailState t;
     JSDR_HIP_TRY(hipMemcpy(&t, h->tail.p + stream, sizeof(t), hipMemcpyDeviceToHost));
-    out[0] = h->tuPhase;
-    out[1] = h->vcoPhase;
-    // dmBitPhase (:501,:581-584): k steps of +1/9600 from 0.0 within the current bit, replayed exactly
-    double ph = 0.0;
-    for (int i = 0; i < (int)(h->n_ds & 7); i++) ph += 1.0 / (double)9600;
-    out[2] = ph;
-    out[3] = t.dmEnergyOut;
-    out[4] = t.energy1;
-    out[5] = t.energy2;
-    out[6] = 0.0;
-    out[7] = 0.0;
+    double app = 0.0, acb = 0.0;
     if (h->do_fft) {
         FftFrontState fs;
         JSDR_HIP_TRY(hipMemcpy(&fs, h->fft_state.p + stream, sizeof(fs), hipMemcpyDeviceToHost));
-        out[6] = fs.avePeakPower;
-        out[7] = fs.aveCentreBin;
+        app = fs.avePeakPower;
+        acb = fs.aveCentreBin;
     }
-    for (int i = 0; i < 8; i++) out[8 + i] = t.dmEnergy[i];
-    out[16] = t.lastI;
-    out[17] = t.lastQ;
+    state_from(h, t, app, acb, out);
     return JSDR_OK;
 }
 
