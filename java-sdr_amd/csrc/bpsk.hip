@@ -1163,12 +1163,14 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs a)
     // peak) reads its sample from y.  The whole chunk (8 KB) used to sit here: with 10 KB instead of 17 KB a CU holds
     // sixteen of these one-wave workgroups instead of nine, and the kernel is occupancy x latency bound.
     __shared__ double2 ydL[64];        // [period]
-    // The chains' work area, in place: before the chain row p holds its INPUTS -- energy1 x 1/200 of the period's eight
-    // samples (the products are taken lane-parallel when the chunk is staged, not by the nine chain lanes one at a time)
-    // and, in the pad column, energy1 x 1/800 of the sample at position v for dmEnergyOut -- and afterwards dmEnergy[c]
-    // after that period (a chain has its 16 inputs in registers before it overwrites their rows).  Row padded: a
-    // conflict-free column walk.  6 KB of LDS a workgroup (it was 17 KB): twenty of them on a CU.
-    __shared__ double eL[64][9];
+    // The chains' work area, in place and ROW PER CHAIN: before the chain, row c < 8 holds the inputs of dmEnergy[c] --
+    // energy1 x 1/200 of the sample at bit position c of every period (the products are taken lane-parallel when the chunk
+    // is staged, not by the nine chain lanes one at a time) -- and row 8 energy1 x 1/800 of the sample at position v, for
+    // dmEnergyOut; afterwards dmEnergy[c] after every period (a chain has the inputs of its next eight links in registers
+    // before it overwrites them).  A chain lane reads and writes ITS row two periods per LDS instruction: the kernel is
+    // bound by the number of LDS instructions its twenty waves per CU issue (SQ counters: half of a wave's life spent
+    // waiting on lgkmcnt), and one 8-byte access per link in each direction was most of them.  6 KB a workgroup.
+    __shared__ __align__(16) double eT[9][72];  // [chain][period]; 72: rows 16-byte aligned, two-way conflicts at worst
     __shared__ unsigned char maskL[64];
     __shared__ short declist[136];
     __shared__ double2 dmL[CERT ? 66 : 1];
@@ -1233,10 +1235,10 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs a)
 #pragma unroll
         for (int k = 0; k < 8; k++) {  // sample k*64 + lane = period k*8 + lane/8, position lane%8
             const double en = pre[k].x * pre[k].x + pre[k].y * pre[k].y;  // :534
-            eL[k * 8 + (lane >> 3)][lane & 7] = en * S1;
+            eT[lane & 7][k * 8 + (lane >> 3)] = en * S1;
             if ((lane & 7) == v) {
                 ydL[k * 8 + (lane >> 3)] = pre[k];
-                eL[k * 8 + (lane >> 3)][8] = en * S2;
+                eT[8][k * 8 + (lane >> 3)] = en * S2;
             }
         }
         JSDR_WAVE_SYNC();
@@ -1290,7 +1292,11 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs a)
             for (int p0 = 0; p0 < 64; p0 += XS) {
                 double xs[XS];
 #pragma unroll
-                for (int p = 0; p < XS; p++) xs[p] = eL[p0 + p][col];  // (the x S products were taken at staging)
+                for (int p = 0; p < XS; p += 2) {  // (the x S products were taken at staging)
+                    const double2 x2 = *reinterpret_cast<const double2 *>(&eT[col][p0 + p]);
+                    xs[p] = x2.x;
+                    xs[p + 1] = x2.y;
+                }
                 // (pinned: left to itself the compiler sinks the reads back into the chain, one LDS wait per two steps)
 #pragma unroll
                 for (int p = 0; p < XS; p++) asm volatile("" : "+v"(xs[p]));
@@ -1303,9 +1309,10 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs a)
                     // its hazard on every link); lane 8 (dmEnergyOut) stores into the rows' pad column, which nobody reads
                     if (lane <= 8) {
 #pragma unroll
-                        for (int p = 0; p < XS; p++) {
-                            e = (e * Kc) + xs[p];  // :535 / :538
-                            eL[p0 + p][lane] = e;
+                        for (int p = 0; p < XS; p += 2) {
+                            const double e0 = (e * Kc) + xs[p];  // :535 / :538
+                            e = (e0 * Kc) + xs[p + 1];
+                            *reinterpret_cast<double2 *>(&eT[lane][p0 + p]) = make_double2(e0, e);
                         }
                     }
                 } else {
@@ -1314,7 +1321,7 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs a)
                         const double ne = (e * Kc) + xs[p];
                         const bool ok = lane_on && (p0 + p >= pfirst) && (glane + 8 * (p0 + p) < g_end);
                         if (ok) e = ne;
-                        if (lane_iir) eL[p0 + p][lane] = e;
+                        if (lane_iir) eT[lane][p0 + p] = e;
                     }
                 }
             }
@@ -1325,11 +1332,11 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs a)
         if (lane < nper) {
             const long long g7 = 8 * (MB + lane) + 7;
             if (g7 >= g_first && g7 < g_end) {
-                double bv = eL[lane][0], sv = -1.0e300;
+                double bv = eT[0][lane], sv = -1.0e300;
                 np = 0;
 #pragma unroll
                 for (int c = 1; c < 8; c++) {
-                    double ov = eL[lane][c];
+                    double ov = eT[c][lane];
                     if (ov > bv) {  // strict: the first maximum wins
                         sv = bv;
                         bv = ov;
