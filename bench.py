@@ -7,7 +7,9 @@ One STEP = one pass of the hot path over one HBM-resident batch of synthetic inp
     S streams x L int16 IQ samples (96 kHz FUNcube-style DBPSK carrying valid FEC frames, generated on
     the device) -> fft.java waterfall PSD of every 2048-sample frame  +  FUNcubeBPSKDemod (tuner, 27-tap
     /10, VCO, 65-tap matched filter, slicer, sync correlation) + FECDecoder of every synchronised frame.
-N > 1: one rank per GPU (torch.distributed, backend nccl == RCCL).  Default = BASELINE config 5 as SURVEY.md 8d
+N > 1: one rank per GPU (torch.distributed, backend nccl == RCCL); started either under torch.distributed.run (WORLD_SIZE
+set) or from the bare command, in which case this process spawns one fresh child per rank before it touches the GPU.
+Default = BASELINE config 5 as SURVEY.md 8d
 defines it: --total-streams 8192 FIXED and sharded contiguously over the ranks (8192 / N streams per rank,
 "scaling": "strong"; the N=1 line runs all 8192 streams, 32 GiB of IQ, on one GPU).  --streams S gives S streams
 per rank instead ("scaling": "weak").  Every step ends with one all-gather of the fixed-size per-stream result
@@ -41,6 +43,19 @@ DEMOD_MODES = {"raw": 1, "am": 2, "nfm": 3, "wfm": 4}
 N_FFT = 2048
 RATE = 96000
 SEED = 20020109
+SEED_TONES = 20020107
+# measured FP64 issue rate of the box, separately rounded v_mul_f64 + v_add_f64 (tools/microbench_fp64.hip,
+# profiles/r01_fp64_microbench.txt: 31.22 T lane-ops/s); the exact-order demodulator's floor
+FP64_ISSUE_TOPS = 31.2
+# separately rounded FP64 operations per 9600 Hz sample of the exact-order chain: 27 taps x 2 rails x (mul + add) = 108
+# (FUNcubeBPSKDemod.java:479-483) + 65 x 2 x 2 = 260 (:519-523)
+FP64_OPS_PER_DS_SAMPLE = {"k_fm": 368.0, "k_front_reg": 108.0, "k_front": 108.0, "k_matched": 260.0}
+# what binds each kernel, from the measurements cited in DESIGN.md 3 (not from the roofline arithmetic)
+KERNEL_BOUND = {"k_fft": "hbm", "k_fir_batch": "hbm", "k_waterfall": "hbm", "k_fm": "fp64-issue", "k_front_reg": "fp64-issue",
+                "k_front": "fp64-issue", "k_matched": "fp64-issue", "k_front_fft": "valu-issue", "k_front_fftm": "valu-issue",
+                "k_front_fft2x": "valu-issue", "k_acq_fwd": "valu-issue", "k_acq_inv": "valu-issue", "k_tail": "lds-issue/latency",
+                "k_sync_t": "latency", "k_sync": "latency", "k_sync_fin": "latency", "k_fec_bpsk": "latency",
+                "k_demod_front": "valu-issue", "k_demod_fused": "valu-issue", "k_demod_out": "hbm", "k_demod_mean": "latency"}
 
 
 def parse():
@@ -94,6 +109,59 @@ def make_inputs(J, S, L, stream0):
     return d_iq, pay, nfr
 
 
+def make_tone_frames(J, nframes, frame0=0):
+    """per 2048-sample frame 1-3 complex tones (hash-chosen bin, amplitude 0.08-0.4 FS, random
+    phase) + noise of sigma 0.01 FS (4-term Irwin-Hall on a counter hash), clipped to int16, seed 20020107; on the device"""
+    ct, _ = J.binding.synth_carrier_tables(21100)  # x amp/256, amp in 32..159: 0.08 .. 0.4 of full scale
+    gain = int(round(0.01 * 32767.0 * 32768.0 / 37837.0))  # noise_from_hash: sigma = 37837 * gain / 32768 int16 units
+    d_iq = J.DeviceBuffer(nframes * N_FFT * 4)
+    key = J.binding.synth_mix64(SEED_TONES)
+    J.synth_tones(d_iq, frame0, nframes, N_FFT, J.DeviceBuffer.from_host(ct), gain, key)
+    J.binding.stream_sync(None)
+    return d_iq
+
+
+def validate_fft(J, d_iq, d_psd, nframes, rate):
+    """sampled frames of the batch against the oracle's fft.receive (fft.java:190-228): amplitude within 1e-5 of the frame
+    peak, and the reported maximum is the first strict maximum of the kernel's own PSD with the reference's Hz rule
+    (:208-221).  Outside the timed region; the oracle only checks."""
+    import oracle_lib as O
+    idx = sorted(set(int(v) for v in np.linspace(0, nframes - 1, 48)))
+    worst = 0.0
+    for f in idx:
+        raw = d_iq.to_host(np.int16, 2 * N_FFT, offset_bytes=f * N_FFT * 4)
+        psd = d_psd.to_host(np.float32, N_FFT + 2, offset_bytes=f * (N_FFT + 2) * 4)
+        ref = O.fft_receive(O.convert_i16(raw), rate)
+        lin_g = 10.0 ** (psd[:N_FFT].astype(np.float64) / 20)
+        lin_r = 10.0 ** (ref[:N_FFT].astype(np.float64) / 20)
+        worst = max(worst, float(np.abs(lin_g - lin_r).max() / lin_r.max()))
+        k = int(np.argmax(psd[:N_FFT]))  # numpy: first maximal element == strict '<' running maximum (fft.java:208-211)
+        pbin = 2 * k
+        hz = pbin * rate // (2 * N_FFT) if pbin < N_FFT else -((2 * N_FFT - pbin) * rate // (2 * N_FFT))
+        if psd[N_FFT + 1] != psd[k] or psd[N_FFT] != np.float32(hz):
+            return False, {"frames_checked": len(idx), "first_bad_frame": f, "why": "argmax / Hz rule"}
+        # the oracle's maximum is the same bin, or a bin within float32 rounding of it (mirror tones: SURVEY 7 hard part 6)
+        kr = int(np.argmax(ref[:N_FFT]))
+        if kr != k and abs(float(ref[kr]) - float(ref[k])) > 1e-3:
+            return False, {"frames_checked": len(idx), "first_bad_frame": f, "why": "maximum bin differs from the oracle's"}
+    return worst <= 1e-5, {"frames_checked": len(idx), "worst_amplitude_error_over_frame_peak": worst}
+
+
+def validate_fir(J, d_iq, d_fir, S, L, taps, decim, scale):
+    """sampled streams of the batch against the oracle's RxDownSample operator (FUNcubeBPSKDemod.java:466-492): every
+    output of the stream bit-identical.  Outside the timed region."""
+    import oracle_lib as O
+    no = L // decim
+    idx = sorted(set(int(v) for v in np.linspace(0, S - 1, 6)))
+    for st in idx:
+        raw = d_iq.to_host(np.int16, 2 * L, offset_bytes=st * L * 4)
+        got = d_fir.to_host(np.float64, 2 * no, offset_bytes=st * no * 16).reshape(no, 2)
+        want = O.fir_decimate(raw, taps, decim, scale)
+        if got.tobytes() != want.tobytes():
+            return False, {"streams_checked": len(idx), "first_bad_stream": st}
+    return True, {"streams_checked": len(idx), "outputs_per_stream": no}
+
+
 def usable_cores():
     """threads this process may really run at once: affinity mask, capped by the cgroup CPU quota (a GPU box
     shows all host cores but grants a share of them)"""
@@ -121,8 +189,13 @@ def cpu_baseline(workload, L, seconds):
     import oracle_lib as O
     cores = usable_cores()
     Lc = min(L, 1048576)
-    streams = [O.make_dbpsk_stream(SEED, s, Lc)[0] for s in range(cores)]
     nframes = Lc // N_FFT
+    if workload == "fft":  # config 2's tone frames, the generator's CPU twin
+        ct = O.synth_tables(21100)[0]
+        gain = int(round(0.01 * 32767.0 * 32768.0 / 37837.0))
+        streams = [O.synth_tones(s * nframes, nframes, N_FFT, ct, gain, O.mix64(SEED_TONES)) for s in range(cores)]
+    else:
+        streams = [O.make_dbpsk_stream(SEED, s, Lc)[0] for s in range(cores)]
     psd = np.empty(N_FFT + 2, np.float32)
 
     def one_pass(s, dem):
@@ -215,6 +288,42 @@ def backend_text():
     return ("RCCL" if b == "nccl" else b) + (", rehearsal: all ranks on device 0" if same else "")
 
 
+def launch_ranks(N):
+    """`python bench.py --gpus N` without a launcher: start N fresh child processes, one per rank (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* as torch.distributed.run would set them), BEFORE anything in this process has touched the GPU
+    (no exec from a process that has).  Rank 0's stdout (the JSON line) is relayed; every other rank's goes to stderr.
+    Returns the exit code: 0 only when every rank ended with 0."""
+    import socket
+    import subprocess
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(N):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(N), LOCAL_WORLD_SIZE=str(N),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL needs it on this driver
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    pending = dict(enumerate(procs))
+    while pending:
+        for r, p in list(pending.items()):
+            code = p.poll()
+            if code is None:
+                continue
+            del pending[r]
+            if code != 0:
+                print(f"[bench] rank {r} exited with {code}", file=sys.stderr)
+                rc = rc or (code if code > 0 else 1)
+                for q in pending.values():  # a rank is gone: the others would wait in a collective for ever
+                    q.terminate()
+        time.sleep(0.05)
+    return rc
+
+
 def main():
     a = parse()
     knobs = sorted(k for k in os.environ if k.startswith("JSDR_EXPERIMENT_"))
@@ -227,8 +336,12 @@ def main():
     dist = None
     torch = None
     if N > 1:
+        if "WORLD_SIZE" not in os.environ:
+            # the bare command (`python bench.py --gpus N`): this process has made no GPU call yet and never will --
+            # it starts one fresh child per rank and relays rank 0's JSON line
+            raise SystemExit(launch_ranks(N))
         if world != N:
-            raise SystemExit(f"--gpus {N} needs WORLD_SIZE={N} (launch with torch.distributed.run); got {world}")
+            raise SystemExit(f"--gpus {N} under a launcher needs WORLD_SIZE={N}; got {world}")
         import torch  # noqa: F811  (first, so libjsdr_hip.so binds to the same HIP runtime)
         import torch.distributed as dist  # noqa: F811
         # rehearsal knobs for a 1-GPU box (never set by the driver): JSDR_BENCH_SAME_DEVICE=1 maps every rank to
@@ -263,8 +376,13 @@ def main():
     elif L % N_FFT:
         raise SystemExit("--samples must be a multiple of 2048")
     stream0, _ = SH.shard_streams(N * S, N, rank)  # contiguous shards: rank order == global stream order
-    d_iq, pay, nfr = make_inputs(J, S, L, stream0)
     nframes = S * L // N_FFT
+    if a.workload == "fft":
+        if N * nframes < 262144:
+            print(f"[bench] note: {N * nframes} frames; SURVEY 8d config 2 asks for >= 262144", file=sys.stderr)
+        d_iq, pay, nfr = make_tone_frames(J, nframes, rank * nframes), None, 0
+    else:
+        d_iq, pay, nfr = make_inputs(J, S, L, stream0)
     fft = J.Fft(N_FFT, RATE) if a.workload in ("pipeline", "fft") else None
     d_psd = J.DeviceBuffer(nframes * (N_FFT + 2) * 4) if fft else None
     dem = J.Bpsk(rate=RATE, blen=4 * a.bpsk_frame, tuning=12000, do_fft=int(a.fft_acquire), nstreams=S, max_batch_samples=L,
@@ -386,7 +504,7 @@ def main():
                 kern[front_name if name == "k_front" else name] = (ms, cnt, BYTES_PER_SAMPLE["bpsk"])
     # the dominant kernel is taken on the critical path: the tail / sync / FEC kernels run on the handle's side
     # stream under the next step's throughput kernels (their times are listed, they do not bound the step)
-    SIDE = ("k_tail", "k_sync", "k_sync_fin", "k_fec_bpsk", "k_fec_fin")
+    SIDE = ("k_tail", "k_sync", "k_sync_t", "k_sync_fin", "k_fec_bpsk", "k_fec_fin")
     main = {k: v for k, v in kern.items() if k not in SIDE or a.fft_acquire}
     dom = max(main, key=lambda k: main[k][0])
     dom_ms = kern[dom][0] / kern[dom][1]
@@ -394,6 +512,8 @@ def main():
     achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
     traffic = None
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if a.fft_acquire and os.path.exists(os.path.join(ROOT, "profiles", f"pmc_traffic_acq{a.bpsk_frame}.json")):
+        pmc = os.path.join(ROOT, "profiles", f"pmc_traffic_acq{a.bpsk_frame}.json")
     if os.path.exists(pmc):
         try:
             tab = json.load(open(pmc))
@@ -401,15 +521,32 @@ def main():
             traffic = int(per * (S * L) / tab.get("_samples_per_launch", 1024 * 1048576)) if per else None
         except Exception:
             traffic = None
+    nds_per_launch = S * (L // (RATE // 9600))  # 9600 Hz samples one launch of the demodulator's kernels covers
+
+    def kernel_entry(k, v):
+        ms = v[0] / v[1]
+        e = {"avg_launch_ms": round(ms, 4), "algorithmic_bytes_per_launch": int(v[2] * S * L),
+             "frac": round(v[2] * S * L / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "bound": KERNEL_BOUND.get(k, "hbm")}
+        if k in FP64_OPS_PER_DS_SAMPLE and a.variant == "exact":
+            # the exact-order FIRs cannot be contracted: their separately rounded FP64 operations against the box's
+            # measured issue rate (tools/microbench_fp64.hip, profiles/r01_fp64_microbench.txt)
+            e["fp64_issue_frac"] = round(FP64_OPS_PER_DS_SAMPLE[k] * nds_per_launch / (ms * 1e-3) / (FP64_ISSUE_TOPS * 1e12), 4)
+        return e
+
+    # "bound" stays the contract's hbm|mfma word for the roofline the fraction is taken against; what really limits
+    # the dominant kernel is "binding_limit" (and per kernel in per_kernel[...]["bound"])
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "binding_limit": KERNEL_BOUND.get(dom, "hbm"),
                 "avg_launch_ms": round(dom_ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes),
                 "kernels_ms_per_step": {k: round(v[0] / v[1], 4) for k, v in sorted(kern.items())},
                 # every critical-path kernel against the same roofline (the dominant one is the slowest AS MEASURED, i.e.
                 # with whatever the side stream's kernels took from it)
-                "per_kernel": {k: {"avg_launch_ms": round(v[0] / v[1], 4), "algorithmic_bytes_per_launch": int(v[2] * S * L),
-                                   "frac": round(v[2] * S * L / (v[0] / v[1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-                               for k, v in sorted(main.items()) if v[0] / v[1] > 0.05 * dom_ms}}  # (not the helper kernels)
+                "per_kernel": {k: kernel_entry(k, v) for k, v in sorted(kern.items())
+                               if v[0] / v[1] > 0.02 * dom_ms}}  # (not the helper kernels)
+    if a.workload in ("pipeline", "bpsk") and not a.fft_acquire:
+        roofline["note"] = ("the exact-order demodulator is FP64-issue bound, not HBM bound: see per_kernel[k_fm].fp64_issue_frac "
+                            f"(368 separately rounded operations per 9600 Hz sample against {FP64_ISSUE_TOPS} T lane-ops/s measured)")
 
     # ---- validation outside the timed region: every sampled stream decodes what it was sent
     validated = None
@@ -426,10 +563,11 @@ def main():
         blob = vslots.to_host(np.uint8).reshape(S, info["slot_bytes"])
         # EVERY stream of this rank: at least one FEC frame decoded, and every decoded frame equals a payload that was
         # sent (a sync hit on the seam where the step's input repeats may fail to decode: rc = -1, as in the reference)
-        n_none = n_wrong = n_failed = 0
+        n_none = n_wrong = n_failed = n_good = 0
         for s in range(S):
             fr = SH.unpack_slot(blob[s], info)["fec"]
             good = [r for r in fr if r[0] >= 0]
+            n_good += len(good)
             n_failed += len(fr) - len(good)
             n_none += 0 if good else 1
             n_wrong += sum(0 if any(np.array_equal(r[2], payloads[s, f]) for f in range(nfr)) else 1 for r in good)
@@ -438,13 +576,59 @@ def main():
         # WRONG payload invalidates the run
         ok = n_wrong == 0 and (n_none == 0 or a.fft_acquire)
         vstats = {"streams": S, "streams_without_decoded_frame": n_none, "decoded_frames_matching_no_sent_payload": n_wrong,
-                  "sync_hits_whose_fec_decode_failed": n_failed}
+                  "sync_hits_whose_fec_decode_failed": n_failed, "decoded_frames": n_good}
         if not ok or n_failed:
             print(f"[bench] validation rank {rank}: {n_none} streams without a decoded frame, {n_wrong} decoded frames that "
                   f"match no sent payload, {n_failed} sync hits whose FEC decode failed (of {S} streams)", file=sys.stderr)
         validated = bool(ok)
+        if a.fft_acquire and n_good < S // 2:
+            # FFT-acquire mode may lose frames by design, but a run in which (almost) nothing decodes has checked nothing
+            validated = None if n_good == 0 else False
+    elif fft is not None and dem is None and not a.no_validate:
+        validated, vstats = validate_fft(J, d_iq, d_psd, nframes, RATE)
+    elif fir_taps is not None and not a.no_validate:
+        validated, vstats = validate_fir(J, d_iq, d_fir, S, L, fir_taps, a.fir_decim, 0.9 * 32768.0)
     if dem is not None and a.variant == "fast":
         cert = dem.cert_stats()
+        if cert["streams_uncertified"] > 0 and validated:
+            # an uncertified stream's getters fail for good (include/jsdr_hip.h): its results were NOT delivered
+            validated = False
+            print(f"[bench] fast variant: {cert['streams_uncertified']} stream(s) ended uncertified -- validated: false",
+                  file=sys.stderr)
+
+    # ---- N > 1: the gathered buffer of the LAST timed step against this rank's own results
+    gather_check = None
+    if dem is not None and N > 1:
+        import hashlib
+        info = dem.slot_info()
+        sb = info["slot_bytes"]
+        own = J.DeviceBuffer(S * sb)
+        dem.pack_slots(own)
+        J.binding.stream_sync(None)
+        own_blob = own.to_host(np.uint8)
+        g = gathered.cpu().numpy().reshape(N, S * sb)
+        digests = [None] * N
+        dist.all_gather_object(digests, hashlib.sha256(own_blob.tobytes()).hexdigest())
+        seg_ok = [hashlib.sha256(g[r].tobytes()).hexdigest() == digests[r] for r in range(N)]
+        # and sampled streams of this rank's segment against the handle's getters (bits, counters, FEC results)
+        get_ok = True
+        for s_ in sorted(set(int(v) for v in np.linspace(0, S - 1, 8))):
+            u = SH.unpack_slot(g[rank][s_ * sb:(s_ + 1) * sb], info)
+            bits = dem.bits(s_)
+            c = dem.counters(s_)
+            fr = dem.fec_results(s_)
+            nb = min(len(bits), info["slot_bits"])
+            get_ok &= int(u["header"][0]) == len(bits) and np.array_equal(u["bits"][:nb], bits[:nb])
+            get_ok &= all(int(u["header"][2 + i]) == c[k] for i, k in enumerate(
+                ("cntRaw", "cntDS", "cntBit", "cntFEC", "cntDec", "dmErrBits", "dmCorr", "dmMaxCorr", "decodeOK")))
+            get_ok &= len(u["fec"]) == min(len(fr), info["nfec_max"]) and all(
+                x[0] == y[0] and x[1] == y[1] and np.array_equal(x[2], y[2]) for x, y in zip(u["fec"], fr))
+        flags = [None] * N
+        dist.all_gather_object(flags, bool(all(seg_ok) and get_ok))
+        gather_check = {"every_rank_segment_equals_that_ranks_slots": bool(all(seg_ok)),
+                        "sampled_slots_equal_getters": bool(get_ok), "all_ranks_ok": bool(all(flags))}
+        if not all(flags):
+            validated = False
 
     if rank == 0:
         total = float(N) * S * L * a.steps
@@ -472,6 +656,8 @@ def main():
         }
         if vstats is not None:
             out["validation"] = vstats
+        if gather_check is not None:
+            out["gather_check"] = gather_check
         if cert is not None:
             out["certification"] = cert
         if N == 1 and not a.no_cpu_baseline:

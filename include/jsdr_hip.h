@@ -84,6 +84,15 @@ int jsdr_fft_spectrum_f32(jsdr_fft *h, const float *iq_dev, int64_t nframes, flo
 int jsdr_phase_maxabs(const float *iq_dev, int64_t nframes, int n, float *max_dev, void *stream);
 int jsdr_phase_columns(const float *iq_dev, int n, int bx, int32_t *pix_host, float *avgi_host,
                        float *avgq_host, int cap, int *ncol);
+/* the IAudioHandler drop-in for phase.java: receive() copies the frame (phase.java:123-128) to the device and takes
+ * max|x| at once; the painter asks for `max` (:75-80) and, for its panel width, the column means (:93-116). */
+typedef struct jsdr_phase jsdr_phase;
+int jsdr_phase_create(jsdr_phase **h, int n);
+int jsdr_phase_destroy(jsdr_phase *h);
+int jsdr_phase_receive_f32(jsdr_phase *h, const float *iq_host);   /* 2n floats */
+int jsdr_phase_get_max(jsdr_phase *h, float *max_out);
+int jsdr_phase_get_columns(jsdr_phase *h, int bx, int32_t *pix_host, float *avgi_host, float *avgq_host, int cap,
+                           int *ncol);
 
 /* ------------------------------------------------------------------ fir.java
  * weights (fir.java:169-195) is setup arithmetic (host); filter (:198-211) runs on the GPU over a

@@ -256,6 +256,43 @@ def phase_columns(buf, bx):
     return pix[:k].copy(), ai[:k].copy(), aq[:k].copy()
 
 
+class Phase:
+    """phase.java as a handle (the IAudioHandler drop-in): receive() keeps the frame on the device and takes max|x|
+    (phase.java:75-80,123-128); columns(bx) are the painter's per-pixel-column means (:93-116)"""
+
+    def __init__(self, n):
+        self.n = n
+        self.h = C.c_void_p()
+        _check(lib().jsdr_phase_create(C.byref(self.h), n), "jsdr_phase_create")
+
+    def receive(self, buf):
+        buf = np.ascontiguousarray(buf, np.float32)
+        assert buf.size == 2 * self.n
+        _check(lib().jsdr_phase_receive_f32(self.h, _addr(buf)), "jsdr_phase_receive_f32")
+
+    def max(self):
+        m = C.c_float()
+        _check(lib().jsdr_phase_get_max(self.h, C.byref(m)), "jsdr_phase_get_max")
+        return np.float32(m.value)
+
+    def columns(self, bx):
+        cap = self.n + 1
+        pix = np.empty(cap, np.int32)
+        ai = np.empty(cap, np.float32)
+        aq = np.empty(cap, np.float32)
+        ncol = C.c_int()
+        _check(lib().jsdr_phase_get_columns(self.h, bx, _addr(pix), _addr(ai), _addr(aq), cap, C.byref(ncol)),
+               "jsdr_phase_get_columns")
+        k = ncol.value
+        return pix[:k].copy(), ai[:k].copy(), aq[:k].copy()
+
+    def __del__(self):
+        try:
+            lib().jsdr_phase_destroy(self.h)
+        except Exception:
+            pass
+
+
 # ------------------------------------------------------------------ fir.java
 class Fir:
     def __init__(self, rate=44100.0):

@@ -1798,9 +1798,9 @@ struct jsdr_bpsk {
     std::vector<hipEvent_t> prof_pool;
 };
 
-enum { PK_FRONT = 0, PK_HIST, PK_MATCHED, PK_DMHIST, PK_TAIL, PK_SYNC, PK_SYNCFIN, PK_FEC, PK_FM, PK_COUNT };
-static const char *const kProfNames[PK_COUNT] = {"k_front", "k_hist_in", "k_matched", "k_dm_history",
-                                                 "k_tail", "k_sync", "k_sync_fin", "k_fec_bpsk", "k_fm"};
+enum { PK_FRONT = 0, PK_HIST, PK_MATCHED, PK_DMHIST, PK_TAIL, PK_SYNC, PK_SYNCFIN, PK_FEC, PK_FM, PK_SYNCT, PK_COUNT };
+static const char *const kProfNames[PK_COUNT] = {"k_front", "k_hist_in", "k_matched", "k_dm_history", "k_tail",
+                                                 "k_sync", "k_sync_fin", "k_fec_bpsk", "k_fm", "k_sync_t"};
 
 static hipEvent_t prof_event(jsdr_bpsk *h)
 {
@@ -2454,7 +2454,6 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
         if ((long long)gx * 256 > maxnew + 255) gx = (int)((maxnew + 255) / 256);
         if (gx < 1) gx = 1;
         {
-            ProfScope ps(h, PK_SYNC, ts);
             // transposed-image kernel when the stream's log fits a workgroup's LDS (always, up to ~8M samples a call)
             int cols = (HIST_BITS + h->max_bits + 79) / 80 + 72;  // + the 18 dwords an output reads past its first column
             int rs = (cols + 3) & ~3;
@@ -2464,6 +2463,7 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
                 const char *e = getenv("JSDR_SYNC_T");  // JSDR_SYNC_T=0: the strided kernel
                 return !e || atoi(e) != 0;
             }();
+            ProfScope ps(h, (use_t && lds <= 150 * 1024) ? PK_SYNCT : PK_SYNC, ts);  // timed under the name rocprof shows
             if (use_t && lds <= 150 * 1024) {
                 static size_t attr_for = 0;
                 if (attr_for < lds) {

@@ -184,22 +184,23 @@ extern "C" int jsdr_fir_batch_decimate_i16(const int16_t *raw_dev, int nstreams,
     a.scale = scale;
     for (int i = 0; i < FIRB_MAX_TAPS; i++) a.taps[i] = i < ntaps ? taps_host[i] : 0.0;
     hipStream_t st = as_stream(stream);
-    const int key = ntaps * 100 + decim;
-    switch (key) {
-        case 2701: launch_fir_batch<27, 1, 8>(a, nstreams, st); break;
-        case 2710: launch_fir_batch<27, 10, 4>(a, nstreams, st); break;   // dsFilter at 96 kHz
-        case 2720: launch_fir_batch<27, 20, 4>(a, nstreams, st); break;   // dsFilter at 192 kHz
-        case 6501: launch_fir_batch<65, 1, 8>(a, nstreams, st); break;    // dmFilter
-        case 6510: launch_fir_batch<65, 10, 4>(a, nstreams, st); break;
-        case 6520: launch_fir_batch<65, 20, 2>(a, nstreams, st); break;
-        case 2101: launch_fir_batch<21, 1, 8>(a, nstreams, st); break;    // fir.java's 21-tap window
-        case 2110: launch_fir_batch<21, 10, 4>(a, nstreams, st); break;
-        case 2120: launch_fir_batch<21, 20, 4>(a, nstreams, st); break;
-        default: {
-            int gx = (int)((no + 255) / 256);
-            if (gx > 4096) gx = 4096;
-            hipLaunchKernelGGL(k_fir_batch_generic, dim3((unsigned)gx, (unsigned)nstreams), dim3(256), 0, st, a);
-        }
+    // the register-blocked kernels exist for exactly these (tap count, decimation) PAIRS; every other shape takes the
+    // generic kernel (a combined key such as ntaps * 100 + decim is not unique: (26, 101) would have run <27, 1>)
+    bool blocked = true;
+    if (ntaps == 27 && decim == 1) launch_fir_batch<27, 1, 8>(a, nstreams, st);
+    else if (ntaps == 27 && decim == 10) launch_fir_batch<27, 10, 4>(a, nstreams, st);   // dsFilter at 96 kHz
+    else if (ntaps == 27 && decim == 20) launch_fir_batch<27, 20, 4>(a, nstreams, st);   // dsFilter at 192 kHz
+    else if (ntaps == 65 && decim == 1) launch_fir_batch<65, 1, 8>(a, nstreams, st);     // dmFilter
+    else if (ntaps == 65 && decim == 10) launch_fir_batch<65, 10, 4>(a, nstreams, st);
+    else if (ntaps == 65 && decim == 20) launch_fir_batch<65, 20, 2>(a, nstreams, st);
+    else if (ntaps == 21 && decim == 1) launch_fir_batch<21, 1, 8>(a, nstreams, st);     // fir.java's 21-tap window
+    else if (ntaps == 21 && decim == 10) launch_fir_batch<21, 10, 4>(a, nstreams, st);
+    else if (ntaps == 21 && decim == 20) launch_fir_batch<21, 20, 4>(a, nstreams, st);
+    else blocked = false;
+    if (!blocked) {
+        int gx = (int)((no + 255) / 256);
+        if (gx > 4096) gx = 4096;
+        hipLaunchKernelGGL(k_fir_batch_generic, dim3((unsigned)gx, (unsigned)nstreams), dim3(256), 0, st, a);
     }
     JSDR_LAUNCH_CHECK();
     return JSDR_OK;

@@ -358,4 +358,68 @@ int jsdr_phase_columns(const float *iq_dev, int n, int bx, int32_t *pix_host, fl
     return rc;
 }
 
+// ---- phase.java as a handle (the IAudioHandler drop-in: one frame in per receive(), the two reductions of
+// paintComponent out): phase.java:123-128 copies the frame -- here to the device, where max|x| (:75-80) is taken at
+// once; the column means (:93-116) depend on the panel width and are computed when the painter asks.
+struct jsdr_phase {
+    int n = 0;
+    DevBuf<float> dpy;   // [2n] the frame
+    DevBuf<float> dmax;  // [1]
+    float max = -1.0f;   // phase.java:75: `float max = -1` before the first frame
+    bool have = false;
+};
+
+int jsdr_phase_create(jsdr_phase **out, int n)
+{
+    JSDR_REQUIRE(out, "jsdr_phase_create: null handle pointer");
+    *out = nullptr;
+    JSDR_REQUIRE(n > 0 && (n & 1) == 0, "jsdr_phase_create: frame of %d samples (must be positive and even)", n);
+    jsdr_phase *h = new jsdr_phase();
+    h->n = n;
+    if (h->dpy.alloc(2 * (size_t)n) != JSDR_OK || h->dmax.alloc(1) != JSDR_OK ||
+        hipMemset(h->dpy.p, 0, sizeof(float) * 2 * (size_t)n) != hipSuccess) {  // `new float[...]` is zero-filled (:23)
+        h->dpy.release();
+        h->dmax.release();
+        delete h;
+        set_error("jsdr_phase_create: no HIP device or out of device memory");
+        return JSDR_ERR;
+    }
+    *out = h;
+    return JSDR_OK;
+}
+
+int jsdr_phase_destroy(jsdr_phase *h)
+{
+    if (!h) return JSDR_OK;
+    h->dpy.release();
+    h->dmax.release();
+    delete h;
+    return JSDR_OK;
+}
+
+int jsdr_phase_receive_f32(jsdr_phase *h, const float *iq_host)
+{
+    JSDR_REQUIRE(h && iq_host, "jsdr_phase_receive_f32: null argument");
+    JSDR_HIP_TRY(hipMemcpy(h->dpy.p, iq_host, sizeof(float) * 2 * (size_t)h->n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_phase_maxabs, dim3(1), dim3(256), 0, 0, h->dpy.p, 2 * h->n, h->dmax.p);
+    JSDR_LAUNCH_CHECK();
+    JSDR_HIP_TRY(hipMemcpy(&h->max, h->dmax.p, sizeof(float), hipMemcpyDeviceToHost));
+    h->have = true;
+    return JSDR_OK;
+}
+
+int jsdr_phase_get_max(jsdr_phase *h, float *max_out)
+{
+    JSDR_REQUIRE(h && max_out, "jsdr_phase_get_max: null argument");
+    // before the first frame the reference paints a zero-filled dpy: max = 0
+    *max_out = h->have ? h->max : 0.0f;
+    return JSDR_OK;
+}
+
+int jsdr_phase_get_columns(jsdr_phase *h, int bx, int32_t *pix_host, float *avgi_host, float *avgq_host, int cap, int *ncol)
+{
+    JSDR_REQUIRE(h, "jsdr_phase_get_columns: null handle");
+    return jsdr_phase_columns(h->dpy.p, h->n, bx, pix_host, avgi_host, avgq_host, cap, ncol);
+}
+
 }  // extern "C"

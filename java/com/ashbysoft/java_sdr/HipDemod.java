@@ -49,8 +49,10 @@ public class HipDemod implements IAudioHandler, IPublishListener {
         audio = aud;
         AudioDescriptor ad = aud.getAudioDescriptor();
         int n = ad.blen / ad.size;
-        if (handle != 0)
-            HipNative.demodDestroy(handle);
+        long old = handle;
+        handle = 0;  // a failed create below (exception) must not leave the freed pointer behind
+        if (old != 0)
+            HipNative.demodDestroy(old);
         handle = HipNative.demodCreate(ad.rate, n);
         bbf = new byte[4 * n];
         HipNative.demodConfigure(handle, mode, dofir, dodwn, doagc);
@@ -114,9 +116,10 @@ public class HipDemod implements IAudioHandler, IPublishListener {
         if (audio != null)
             audio.remHandler(this);
         publish.unlisten(this);
-        if (handle != 0)
-            HipNative.demodDestroy(handle);
+        long old = handle;
         handle = 0;
+        if (old != 0)
+            HipNative.demodDestroy(old);
         logger.statusMsg("demod: closed");
     }
 }

@@ -17,9 +17,13 @@ public class HipFUNcubeBPSKDemod implements IAudioHandler, IRawHandler, IPublish
     private long handle;
     private int tuning;
     private boolean doFFT, doUp;
-    private final int[] counters = new int[10];
+    // results of the last completed receive(), refreshed through HipNative.bpskSnapshot -- a lock-free host-side read
+    // (no device call), so the painting thread never waits for the GPU and never blocks the audio thread
+    private final Object resultLock = new Object();
+    private final int[] counters = new int[11];   // ten counters + the number of bits sliced in that frame
     private final byte[] decoded = new byte[256];
     private final double[] state = new double[18];
+    private final byte[] bits = new byte[512];
 
     public HipFUNcubeBPSKDemod(int idx, IConfig cfg, IPublish pub, ILogger log, IUIHost hst, IAudio aud) {
         this(idx, cfg, pub, log, hst, aud, false);
@@ -58,8 +62,11 @@ public class HipFUNcubeBPSKDemod implements IAudioHandler, IRawHandler, IPublish
         tuning = config.getIntConfig(name + "-" + CFG_TUNING, 12000);
         doFFT = 0 != config.getIntConfig(name + "-" + CFG_DOFFT, 0);
         doUp = 0 != config.getIntConfig(name + "-" + CFG_UPPER, 0);
-        if (handle != 0)
-            HipNative.bpskDestroy(handle);
+        long old = handle;
+        handle = 0;  // bpskCreate throws when it fails (a frame FFT-acquire mode does not support, no device memory):
+                     // the freed pointer must not stay behind for a later getter, close() or setup()
+        if (old != 0)
+            HipNative.bpskDestroy(old);
         handle = HipNative.bpskCreate(ad.rate, ad.blen / ad.size, tuning, doFFT ? 1 : 0, doUp ? 1 : 0);
         if (rawPath)
             audio.addRawHandler(this);
@@ -78,43 +85,69 @@ public class HipFUNcubeBPSKDemod implements IAudioHandler, IRawHandler, IPublish
     }
 
     private void afterFrame() {
-        HipNative.bpskCounters(handle, counters);
+        int centre;
+        synchronized (resultLock) {
+            HipNative.bpskSnapshot(handle, counters, state, decoded, bits);
+            centre = counters[9];
+        }
         if (doFFT) {  // :455-456
             publish.setPublish(name + "-bpsk-tune", -1);
-            publish.setPublish(name + "-bpsk-centre", counters[9]);
+            publish.setPublish(name + "-bpsk-centre", centre);
         } else {      // :377-378
             publish.setPublish(name + "-bpsk-centre", -1);
             publish.setPublish(name + "-bpsk-tune", tuning);
         }
-        if (counters[8] != 0)
-            HipNative.bpskDecoded(handle, decoded);
     }
+
+    // The getters below serve the painting thread (FUNcubeBPSKDemod.java:220-228,331-337).  They take only resultLock,
+    // never this object's monitor, which the audio thread holds for the whole of receive(): a repaint never waits for
+    // the GPU, and never delays the audio loop.
 
     /** cntRaw,cntDS,cntBit,cntFEC,cntDec,dmErrBits,dmCorr,dmMaxCorr,decodeOK,centreBin */
-    public synchronized int[] getCounters() {
-        return counters.clone();
+    public int[] getCounters() {
+        synchronized (resultLock) {
+            return java.util.Arrays.copyOf(counters, 10);
+        }
     }
 
-    public synchronized boolean isDecodeOK() {
-        return counters[8] != 0;
+    public boolean isDecodeOK() {
+        synchronized (resultLock) {
+            return counters[8] != 0;
+        }
     }
 
-    public synchronized byte[] getDecoded() {
-        return decoded.clone();
+    /** decoded[] (:111): the last successfully decoded frame */
+    public byte[] getDecoded() {
+        synchronized (resultLock) {
+            return decoded.clone();
+        }
     }
 
-    /** bits sliced during the last frame, +1/-1 */
-    public synchronized byte[] getBits() {
-        byte[] tmp = new byte[4096];
-        int n = HipNative.bpskBits(handle, tmp);
-        byte[] out = new byte[Math.min(n, tmp.length)];
-        System.arraycopy(tmp, 0, out, 0, out.length);
-        return out;
+    /** bits sliced during the last frame, +1/-1 -- the first 512 of them (a 2048-sample frame slices about 25, the
+     *  default 9600-sample frame 120; getAllBits() has no such limit) */
+    public byte[] getBits() {
+        synchronized (resultLock) {
+            return java.util.Arrays.copyOf(bits, Math.min(counters[10], bits.length));
+        }
     }
 
-    public synchronized double[] getState() {
-        HipNative.bpskState(handle, state);
-        return state.clone();
+    /** every bit of the last frame whatever its size; a device call, so it takes the receive() monitor: for the audio
+     *  thread or a test, not for the painter */
+    public synchronized byte[] getAllBits() {
+        int n;
+        synchronized (resultLock) {
+            n = counters[10];
+        }
+        byte[] out = new byte[Math.max(n, 1)];
+        int got = HipNative.bpskBits(handle, out);
+        return java.util.Arrays.copyOf(out, Math.max(0, Math.min(got, out.length)));
+    }
+
+    /** tuPhase,vcoPhase,dmBitPhase,dmEnergyOut,energy1,energy2,avePeakPower,aveCentreBin,dmEnergy[8],dmLastIQ[2] */
+    public double[] getState() {
+        synchronized (resultLock) {
+            return state.clone();
+        }
     }
 
     public synchronized void close() {
@@ -123,9 +156,10 @@ public class HipFUNcubeBPSKDemod implements IAudioHandler, IRawHandler, IPublish
             audio.remRawHandler(this);
         }
         publish.unlisten(this);
-        if (handle != 0)
-            HipNative.bpskDestroy(handle);
+        long old = handle;
         handle = 0;
+        if (old != 0)
+            HipNative.bpskDestroy(old);
         logger.statusMsg(name + ": closed");
     }
 }

@@ -37,8 +37,10 @@ public class HipFft implements IAudioHandler, IRawHandler, IPublishListener {
         audio = aud;
         AudioDescriptor ad = aud.getAudioDescriptor();
         int n = ad.blen / ad.size;
-        if (handle != 0)
-            HipNative.fftDestroy(handle);
+        long old = handle;
+        handle = 0;  // a failed create below (exception) must not leave the freed pointer behind
+        if (old != 0)
+            HipNative.fftDestroy(old);
         handle = HipNative.fftCreate(n, ad.rate);
         psd = new float[n + 2];
         if (rawPath)
@@ -64,8 +66,9 @@ public class HipFft implements IAudioHandler, IRawHandler, IPublishListener {
             audio.remRawHandler(this);
         }
         publish.unlisten(this);
-        if (handle != 0)
-            HipNative.fftDestroy(handle);
+        long old = handle;
         handle = 0;
+        if (old != 0)
+            HipNative.fftDestroy(old);
     }
 }

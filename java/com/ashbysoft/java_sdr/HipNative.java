@@ -1,6 +1,10 @@
 // HipNative.java -- the native methods of libjsdr_jni.so (jni/jsdr_jni.c), which forwards to libjsdr_hip.so
 // (include/jsdr_hip.h).  One class holds them all; the plugin classes Hip* call nothing else.
 //
+// Every receive checks the array lengths against the frame size its handle was created with and throws
+// IllegalArgumentException on a mismatch (a buffer of the old geometry around an "audio-change"); a failed native call
+// throws IllegalStateException with the library's message.  Handle 0 is "no handle" and is rejected everywhere.
+//
 // Not part of the reference: these sources are what a java-sdr maintainer adds next to fft.java / demod.java /
 // FUNcubeBPSKDemod.java to put the MI355X path behind the unchanged IAudioHandler / IRawHandler surface
 // (IAudioHandler.java:3-6, IRawHandler.java:3-6, jsdr.java:475-483).  Compiled where a JDK exists (see jni/Makefile);
@@ -28,14 +32,16 @@ final class HipNative {
     static native void bpskDestroy(long h);
     static native void bpskReceive(long h, float[] buf);
     static native void bpskReceiveRaw(long h, byte[] raw, int ic, int qc);
-    /** cntRaw,cntDS,cntBit,cntFEC,cntDec,dmErrBits,dmCorr,dmMaxCorr,decodeOK,centreBin (:110-115,:405,:498) */
-    static native void bpskCounters(long h, int[] out10);
-    /** decoded[] (:111): the last successfully decoded 256-byte frame */
-    static native void bpskDecoded(long h, byte[] out256);
-    /** bits sliced during the last receive(), +1/-1 each; returns their number (at most out.length are copied) */
+    /** Results of the last COMPLETED receive(), callable from any thread (no lock, no device call): the Swing thread
+     *  paints these while the audio thread is inside the next receive (:220-228,331-337).
+     *  counters11 = cntRaw,cntDS,cntBit,cntFEC,cntDec,dmErrBits,dmCorr,dmMaxCorr,decodeOK,centreBin (:110-115,:405,:498)
+     *  + the number of bits sliced in that frame; state18 = tuPhase,vcoPhase,dmBitPhase,dmEnergyOut,energy1,energy2,
+     *  avePeakPower,aveCentreBin,dmEnergy[8],dmLastIQ[2]; decoded256 = decoded[] (:111); bits512 = the frame's first 512
+     *  bits, +1/-1.  Returns the number of frames received so far; 0 = none yet, arrays untouched. */
+    static native long bpskSnapshot(long h, int[] counters11, double[] state18, byte[] decoded256, byte[] bits512);
+    /** every bit sliced during the last receive(), +1/-1 each; returns their number (at most out.length are copied).
+     *  A device call: for the thread that calls receive(). */
     static native int bpskBits(long h, byte[] out);
-    /** tuPhase,vcoPhase,dmBitPhase,dmEnergyOut,energy1,energy2,avePeakPower,aveCentreBin,dmEnergy[8],dmLastIQ[2] */
-    static native void bpskState(long h, double[] out18);
 
     // ---- FECDecoder.java:703-852
     /** returns -1 or the channel error count; out256 is written only when both RS words decode (:780) */
@@ -51,4 +57,15 @@ final class HipNative {
     static native void demodReceive(long h, float[] buf, byte[] bbf);
     /** the `max` and `avg` fields after the last frame (:465-467) */
     static native void demodFrameStats(long h, float[] out2);
+
+    // ---- phase.java:75-80,93-116,123-128
+    static native long phaseCreate(int n);
+    static native void phaseDestroy(long h);
+    /** receive(): buf = 2n floats; the frame is kept on the device and max|x| (:75-80) taken at once */
+    static native void phaseReceive(long h, float[] buf);
+    /** `max` of the last frame (:75-80); 0 before the first one (a zero-filled dpy) */
+    static native float phaseMaxabs(long h);
+    /** per-pixel-column means of I and Q for a panel bx pixels wide (:93-116): pix[c], avgi[c], avgq[c]; arrays of at
+     *  least n+1 elements; returns the number of columns */
+    static native int phaseColumns(long h, int bx, int[] pix, float[] avgi, float[] avgq);
 }

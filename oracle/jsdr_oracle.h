@@ -63,6 +63,9 @@ void jo_fir_weights(jo_fir_t *f, int f1, int f2, float sample_rate); /* :169-195
 int  jo_fir_filter(jo_fir_t *f, int in);                         /* :198-211 */
 void jo_fir_complex_gen(int sig[2], int wav[2], float sample_rate); /* :221-228 */
 void jo_fir_complex_mod(const int s1[2], const int s2[2], int out[2]); /* :214-218 */
+/* FUNcubeBPSKDemod.java:466-492 as an operator: any tap count <= 128, any decimation; out = interleaved (fi,fq) */
+int64_t jo_fir_decimate(const int16_t *raw, int64_t nsamples, const double *taps, int ntaps, int decim, double scale,
+                        double *out);
 
 /* ---- phase.java:75-116 --------------------------------------------------------- */
 float jo_phase_maxabs(const float *dpy, int len);                /* :75-80 */

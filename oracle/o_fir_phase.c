@@ -128,3 +128,40 @@ int jo_phase_columns(const float *dpy, int len, int bx, int *pix_out, float *avg
     }
     return ncol;
 }
+
+/* FUNcubeBPSKDemod.java:466-492 (RxDownSample) as a stand-alone operator, generalised over tap count and decimation --
+ * BASELINE config 3's "FIR + decimate over an IQ batch".  The reference's own state machine, not a closed form: a ring of
+ * `ntaps` (I,Q) doubles written at dsPos, dsPos walking DOWN and wrapping; every `decim`-th sample the sum over ring
+ * slots n = 0..ntaps-1 of dsBuf[(n+dsPos)%ntaps]*taps[n] (newest sample first, product and sum rounded separately),
+ * times `scale` (HOWARD_FUDGE_FACTOR at :487).  The samples are JavaAudio's floats (JavaAudio.java:276-293) widened to
+ * double, as RxMixTuner hands them over when the tuner is off (:395-396); the ring starts cleared (:467).
+ * Returns the number of (fi,fq) pairs written to out (interleaved doubles). */
+int64_t jo_fir_decimate(const int16_t *raw, int64_t nsamples, const double *taps, int ntaps, int decim, double scale,
+                        double *out)
+{
+    double ds_i[128], ds_q[128];
+    if (ntaps < 1 || ntaps > 128 || decim < 1) return -1;
+    for (int n = 0; n < ntaps; n++) ds_i[n] = ds_q[n] = 0.0;
+    const float fmax = (float)32767;
+    int dsPos = ntaps - 1, dsCnt = 0;
+    int64_t no = 0;
+    for (int64_t t = 0; t < nsamples; t++) {
+        ds_i[dsPos] = (double)((float)raw[2 * t] / fmax);
+        ds_q[dsPos] = (double)((float)raw[2 * t + 1] / fmax);
+        if (++dsCnt >= decim) {
+            double fi = 0.0, fq = 0.0;
+            for (int n = 0; n < ntaps; n++) {
+                int dsi = (n + dsPos) % ntaps;
+                fi += ds_i[dsi] * taps[n];
+                fq += ds_q[dsi] * taps[n];
+            }
+            dsCnt = 0;
+            out[2 * no] = fi * scale;
+            out[2 * no + 1] = fq * scale;
+            no++;
+        }
+        dsPos--;
+        if (dsPos < 0) dsPos = ntaps - 1;
+    }
+    return no;
+}

@@ -76,6 +76,8 @@ def _proto(L):
     L.jo_fir_filter.argtypes = [vp, C.c_int]
     L.jo_fir_complex_gen.argtypes = [vp, vp, C.c_float]
     L.jo_fir_complex_mod.argtypes = [vp, vp, vp]
+    L.jo_fir_decimate.argtypes = [vp, C.c_int64, vp, C.c_int, C.c_int, C.c_double, vp]
+    L.jo_fir_decimate.restype = C.c_int64
     L.jo_phase_maxabs.restype = C.c_float
     L.jo_phase_maxabs.argtypes = [vp, C.c_int]
     L.jo_phase_columns.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp]
@@ -185,6 +187,17 @@ def fir_complex_gen(freq, count, rate=44100.0, start=0):
         out[i, 0] = sig[0]
         out[i, 1] = sig[1]
     return out
+
+
+def fir_decimate(raw, taps, decim, scale):
+    """RxDownSample as an operator (FUNcubeBPSKDemod.java:466-492) over int16 IQ: [n // decim, 2] doubles"""
+    raw = np.ascontiguousarray(raw, np.int16)
+    taps = np.ascontiguousarray(taps, np.float64)
+    n = raw.size // 2
+    out = np.empty((max(n // decim, 1), 2), np.float64)
+    no = lib().jo_fir_decimate(ptr(raw), n, ptr(taps), taps.size, decim, float(scale), ptr(out))
+    assert no == n // decim, (no, n, decim)
+    return out[:no]
 
 
 def fir_complex_mod(a, b):

@@ -1,0 +1,45 @@
+"""GPU: `python bench.py --gpus 2` from the BARE command (no torch.distributed.run) -- the launcher inside bench.py starts
+one fresh child per rank.  On the one-GPU box both ranks share device 0 and gloo stands in for RCCL (the rehearsal knobs
+bench.py documents); what is checked is the N > 1 code path itself: shard -> demodulate -> pack -> all-gather, every
+rank's segment of `gathered` equal to that rank's own slots, sampled slots equal to the handle's getters, and every
+stream's payload validated."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(extra, env_extra):
+    env = dict(os.environ, **env_extra)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, env=env, capture_output=True, text=True,
+                       timeout=560)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
+    return r, lines
+
+
+def test_bare_command_two_ranks_gather_is_checked():
+    r, lines = run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--streams", "48", "--samples", "1048576",
+                          "--no-cpu-baseline"], {"JSDR_BENCH_SAME_DEVICE": "1", "JSDR_BENCH_BACKEND": "gloo"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert len(lines) == 1, (r.stdout[-2000:], r.stderr[-2000:])
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["total_streams"] == 96 and out["scaling"] == "weak"
+    assert out["validated"] is True, out
+    g = out["gather_check"]
+    assert g["every_rank_segment_equals_that_ranks_slots"] and g["sampled_slots_equal_getters"] and g["all_ranks_ok"], g
+    assert out["roofline"]["per_kernel"]["k_fm"]["bound"] == "fp64-issue"
+    assert 0.0 < out["roofline"]["per_kernel"]["k_fm"]["fp64_issue_frac"] < 1.0
+
+
+def test_bare_command_fails_when_a_rank_fails():
+    # 7 streams do not split over 2 ranks: every rank exits with an error, and so must the launcher
+    r, lines = run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0", "--total-streams", "7", "--no-cpu-baseline"],
+                         {"JSDR_BENCH_SAME_DEVICE": "1", "JSDR_BENCH_BACKEND": "gloo"})
+    assert r.returncode != 0 and not lines

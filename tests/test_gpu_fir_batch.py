@@ -7,8 +7,9 @@ import pytest
 import java_sdr_amd as J
 import oracle_lib as O
 
+from fir_defs import HOWARD, py_fir
+
 pytestmark = pytest.mark.gpu
-HOWARD = 0.9 * 32768.0
 
 
 def gpu_fir(iq_streams, n, taps, decim, scale):
@@ -19,26 +20,6 @@ def gpu_fir(iq_streams, n, taps, decim, scale):
     got = J.fir_batch_decimate_i16(d_iq, S, 2 * n, n, taps, decim, scale, d_out, max(no, 1))
     assert got == no
     return d_out.to_host(np.float64).reshape(S, max(no, 1), 2)[:, :no]
-
-
-def py_fir(iq, taps, decim, scale):
-    """the definition, in Python floats (IEEE doubles, no FMA): newest sample first"""
-    x = O.convert_i16(iq).astype(np.float64).reshape(-1, 2)
-    n = x.shape[0]
-    out = []
-    for j in range(n // decim):
-        newest = decim * (j + 1) - 1
-        fi = fq = 0.0
-        for a, t in enumerate(taps):
-            k = newest - a
-            if k >= 0:
-                fi += float(x[k, 0]) * float(t)
-                fq += float(x[k, 1]) * float(t)
-            else:
-                fi += 0.0 * float(t)
-                fq += 0.0 * float(t)
-        out.append((fi * scale, fq * scale))
-    return np.array(out, np.float64).reshape(-1, 2)
 
 
 @pytest.mark.parametrize("rate,decim", [(96000, 10), (192000, 20), (48000, 5), (44100, 4)])
@@ -57,9 +38,11 @@ def test_fir_batch_equals_the_oracles_downsampler(rate, decim):
         assert got[s].tobytes() == want.tobytes(), (rate, s)
 
 
-@pytest.mark.parametrize("ntaps,decim", [(65, 1), (65, 10), (65, 20), (21, 1), (21, 10), (27, 1), (33, 3), (128, 7), (1, 1)])
+@pytest.mark.parametrize("ntaps,decim", [(65, 1), (65, 10), (65, 20), (21, 1), (21, 10), (27, 1), (33, 3), (128, 7), (1, 1),
+                                         (26, 101), (20, 110), (20, 120), (64, 110)])  # the last four: pairs whose
+# ntaps * 100 + decim collides with a register-blocked kernel's key -- they must take the generic kernel
 def test_fir_batch_other_taps_and_decimations_against_the_definition(ntaps, decim):
-    n = 2500
+    n = 2500 + 3 * decim
     rng = np.random.default_rng(ntaps * 100 + decim)
     iq = rng.integers(-32768, 32768, 2 * n).astype(np.int16)
     if ntaps == 65:
@@ -71,6 +54,25 @@ def test_fir_batch_other_taps_and_decimations_against_the_definition(ntaps, deci
     got = gpu_fir([iq, iq[::-1].copy()], n, taps, decim, 1.25)
     assert got[0].tobytes() == py_fir(iq, taps, decim, 1.25).tobytes()
     assert got[1].tobytes() == py_fir(iq[::-1].copy(), taps, decim, 1.25).tobytes()
+
+
+@pytest.mark.parametrize("ntaps,decim", [(65, 10), (65, 1), (21, 1), (21, 10), (27, 10), (65, 20)])
+def test_fir_batch_config3_shape_one_million_samples_by_four_streams(ntaps, decim):
+    """BASELINE config 3: "65-tap low-pass + decimate over 1 M-sample IQ batch" -- the register-blocked kernels across
+    every workgroup boundary of a 2^20-sample stream, four streams (DBPSK, noise, full-scale square wave, a ramp),
+    every output bit-identical to the oracle's RxDownSample operator (jo_fir_decimate, pinned on the CPU by
+    tests/test_fir_decimate_oracle.py)"""
+    n = 1 << 20
+    rng = np.random.default_rng(ntaps * 7 + decim)
+    sq = np.where((np.arange(2 * n) // 14) % 2 == 0, 32767, -32768).astype(np.int16)
+    ramp = (np.arange(2 * n) * 37 % 65536 - 32768).astype(np.int16)
+    streams = [O.make_dbpsk_stream(5, 2, n)[0], rng.integers(-32768, 32768, 2 * n).astype(np.int16), sq, ramp]
+    taps = O.bpsk_table(1)[:65] if ntaps == 65 else (O.bpsk_table(0) if ntaps == 27 else O.Fir().weights(500, 1500, 44100.0))
+    got = gpu_fir(streams, n, taps, decim, HOWARD)
+    for s, iq in enumerate(streams):
+        want = O.fir_decimate(iq, taps, decim, HOWARD)
+        assert got[s].shape == want.shape
+        assert got[s].tobytes() == want.tobytes(), (ntaps, decim, s, int(np.argmax((got[s] != want).any(axis=1))))
 
 
 def test_fir_batch_api_errors_and_empty():

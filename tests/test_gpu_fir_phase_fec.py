@@ -47,6 +47,23 @@ def test_fir_complex_gen_and_mod():
 
 
 # ------------------------------------------------------------------ phase.java
+def test_phase_handle_is_the_drop_in_form(golden_dir):
+    """jsdr_phase_* (what HipPhase.java binds): frame by frame, max and column means equal the oracle's"""
+    raw = np.fromfile(os.path.join(golden_dir, "sine4410.raw"), dtype="<i2")
+    buf = O.convert_i16(raw)
+    p = J.Phase(2048)
+    assert p.max() == 0.0  # the reference paints a zero-filled dpy before the first frame (phase.java:23,75-80)
+    for f in range(2):
+        fr = buf[4096 * f:4096 * (f + 1)]
+        p.receive(fr)
+        assert p.max() == O.phase_maxabs(fr)
+        for bx in (0, 1, 200, 317, 2048, 5000):
+            pg, po = p.columns(bx), O.phase_columns(fr, bx)
+            assert all(np.array_equal(a, b) for a, b in zip(pg, po)), (f, bx)
+    with pytest.raises(J.JsdrError):
+        J.Phase(0)
+
+
 def test_phase_maxabs_and_columns(golden_dir):
     raw = np.fromfile(os.path.join(golden_dir, "sine4410.raw"), dtype="<i2")
     buf = O.convert_i16(raw)

@@ -43,7 +43,7 @@ def jni_functions():
 
 def test_every_native_method_has_its_jni_function_and_vice_versa():
     nat, jni = native_methods(), jni_functions()
-    assert len(nat) == 19
+    assert len(nat) == 22
     assert set(nat) == set(jni)
     for name, nargs in nat.items():
         assert jni[name] == nargs + 2, (name, nargs, jni[name])  # JNIEnv*, jclass + the Java arguments
@@ -52,7 +52,7 @@ def test_every_native_method_has_its_jni_function_and_vice_versa():
 def test_plugin_classes_call_only_declared_native_methods():
     nat = native_methods()
     used = set()
-    for fn in ("HipFft.java", "HipFUNcubeBPSKDemod.java", "HipDemod.java"):
+    for fn in ("HipFft.java", "HipFUNcubeBPSKDemod.java", "HipDemod.java", "HipPhase.java"):
         src = strip_comments(open(os.path.join(JDIR, fn)).read())
         used |= set(re.findall(r"HipNative\.(\w+)\s*\(", src))
     assert used and used <= set(nat), used - set(nat)
@@ -83,7 +83,8 @@ def test_plugin_classes_keep_the_reference_surface():
     fft = strip_comments(open(os.path.join(JDIR, "HipFft.java")).read())
     bpsk = strip_comments(open(os.path.join(JDIR, "HipFUNcubeBPSKDemod.java")).read())
     dem = strip_comments(open(os.path.join(JDIR, "HipDemod.java")).read())
-    for src in (fft, bpsk, dem):
+    pha = strip_comments(open(os.path.join(JDIR, "HipPhase.java")).read())
+    for src in (fft, bpsk, dem, pha):
         assert "package com.ashbysoft.java_sdr;" in src
         assert re.search(r"implements\s+IAudioHandler", src)
         assert "public synchronized void receive(float[] buf)" in src
@@ -92,6 +93,7 @@ def test_plugin_classes_keep_the_reference_surface():
     for src in (fft, bpsk):
         assert "IRawHandler" in src and "public synchronized void receive(byte[] raw)" in src
     assert re.search(r"public HipFft\(IConfig \w+, IPublish \w+, ILogger \w+, IUIHost \w+, IAudio \w+\)", fft)
+    assert re.search(r"public HipPhase\(IConfig \w+, IPublish \w+, ILogger \w+, IUIHost \w+, IAudio \w+\)", pha)  # jsdr.java:475
     assert re.search(r"public HipDemod\(IConfig \w+, IPublish \w+, ILogger \w+, IUIHost \w+, IAudio \w+\)", dem)
     assert re.search(r"public HipFUNcubeBPSKDemod\(int \w+, IConfig \w+, IPublish \w+, ILogger \w+, IUIHost \w+, IAudio \w+\)", bpsk)
     for key in ('"bpsk-tuning"', '"bpsk-dofft"', '"bpsk-upper"', '"-bpsk-centre"', '"-bpsk-tune"'):
@@ -99,3 +101,35 @@ def test_plugin_classes_keep_the_reference_surface():
     for key in ('"demod-filter-low"', '"demod-filter-high"', '"demod-mode"', '"demod-fir-enable"', '"demod-agc-enable"'):
         assert key in dem, key
     assert '"fft-psd"' in fft
+
+
+def test_shim_never_calls_the_device_inside_a_critical_region_and_checks_lengths():
+    """no GetPrimitiveArrayCritical around GPU calls (the JNI specification forbids blocking there); every
+    receive compares the Java array's length with the handle's frame before it copies"""
+    src = strip_comments(open(SHIM).read())
+    assert "GetPrimitiveArrayCritical" not in src
+    for fn in ("fftReceive", "fftReceiveRaw", "bpskReceive", "bpskReceiveRaw", "demodReceive", "phaseReceive"):
+        body = src[src.index(PREFIX + fn + "("):]
+        body = body[:body.index("\n}\n")]
+        assert "bad_length(" in body and "null_handle(" in body, fn
+        assert body.index("bad_length(") < body.index("ArrayRegion("), fn
+    assert "IllegalArgumentException" in src
+
+
+def test_java_handles_are_zeroed_before_a_create_that_may_throw():
+    """setup() must not keep a freed native pointer when the following create throws"""
+    for fn, kind in (("HipFft.java", "fft"), ("HipFUNcubeBPSKDemod.java", "bpsk"), ("HipDemod.java", "demod"),
+                     ("HipPhase.java", "phase")):
+        src = strip_comments(open(os.path.join(JDIR, fn)).read())
+        setup = src[src.index("void setup(IAudio"):]
+        setup = setup[:setup.index("\n    }\n")]
+        assert setup.index("handle = 0;") < setup.index("HipNative.%sDestroy(old)" % kind) < setup.index("HipNative.%sCreate(" % kind), fn
+        assert "HipNative.%sDestroy(handle)" % kind not in src, fn
+
+
+def test_painter_getters_use_the_lock_free_snapshot():
+    src = strip_comments(open(os.path.join(JDIR, "HipFUNcubeBPSKDemod.java")).read())
+    assert "HipNative.bpskSnapshot(" in src
+    for getter in ("getCounters", "getState", "getDecoded", "getBits", "isDecodeOK"):
+        m = re.search(r"public (synchronized )?[\w\[\]]+ %s\(" % getter, src)
+        assert m and not m.group(1), getter  # not on the receive() monitor
