@@ -835,7 +835,10 @@ __global__ void k_fm_edges(EdgeArgs a)
 }
 
 template <int D, int R, bool MIX, bool DC, bool FAST>
-__global__ __launch_bounds__(FM_THREADS, 2) void k_fm(FmArgs a)
+#ifndef JSDR_FM_MINWAVES
+#define JSDR_FM_MINWAVES 2
+#endif
+__global__ __launch_bounds__(FM_THREADS, JSDR_FM_MINWAVES) void k_fm(FmArgs a)
 {
     constexpr int RD = D * R, NS = RD - D + 27, NSQ = (NS + 3) / 4;
     constexpr int JOBS = (FM_NT + R - 1) / R, ROUNDS = (JOBS + FM_THREADS - 1) / FM_THREADS;

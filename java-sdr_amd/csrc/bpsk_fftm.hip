@@ -119,6 +119,160 @@ __device__ __attribute__((noinline)) void fm_pass(double2 *X, const double2 *tw,
     __syncthreads();
 }
 
+// The LAST pass of the inverse transform: RxDownSample reads nothing but re/n (FUNcubeBPSKDemod.java:461-463), so only the
+// real part of every output is formed (the imaginary halves of the 5-point butterfly -- a third of its operations --
+// have no reader and are not computed) and it is stored already scaled: X[i].x = re * (1/n), once per sample instead of
+// once per tap that reads it.  Same operands, same operations, same order for everything that IS computed.
+template <int NN, int PP>
+__device__ __attribute__((noinline)) void fm_pass5_real(double2 *X, const double2 *tw, double norm, int tid)
+{
+    constexpr int R = 5, nb = NN / R, ITERS = (nb + FM_T - 1) / FM_T;
+    double o[ITERS][R];
+#pragma unroll
+    for (int it = 0; it < ITERS; it++) {
+        const int b = it * FM_T + tid;
+        if (b < nb) {
+            const int k = b % PP;
+            double2 v[R];
+#pragma unroll
+            for (int j = 0; j < R; j++) {
+                v[j] = X[b + j * nb];
+                if (j >= 1) v[j] = cdmul(v[j], tw[k * j]);
+            }
+            dft_r<R>(v);
+#pragma unroll
+            for (int q = 0; q < R; q++) o[it][q] = v[q].x * norm;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < ITERS; it++) {
+        const int b = it * FM_T + tid;
+        if (b < nb) {
+            const int k = b % PP;
+            const int j0 = (b - k) * R + k;
+#pragma unroll
+            for (int q = 0; q < R; q++) X[j0 + q * PP].x = o[it][q];
+        }
+    }
+    __syncthreads();
+}
+
+// The LAST pass of the forward transform: of the n bins only those the front end can read are formed -- |X| over
+// [beg+24, end-24) (:425-427, the boxcar's reach) and the 204 bins around a centre bin (:458), which the rule and its
+// clamps keep in [102, end-1] (:444-453): everything below end + 102, end = n/4 (lower band) or n/2 (upper band).  A
+// butterfly whose only needed output is q = 0 forms (x0 + a1) + a2 alone (32 of its 72 operations); all others run in
+// full and store what is read.
+template <int NN, int PP>
+__device__ __attribute__((noinline)) void fm_pass5_band(double2 *X, const double2 *tw, int do_up, int tid)
+{
+    constexpr int R = 5, nb = NN / R, ITERS = (nb + FM_T - 1) / FM_T;
+    static_assert(PP == nb, "the last pass: one butterfly per k");
+    const int need_end = (do_up ? NN / 2 : NN / 4) + 102;  // bins [0, need_end) are read
+    double2 v[ITERS][R];
+    unsigned need[ITERS];
+#pragma unroll
+    for (int it = 0; it < ITERS; it++) {
+        const int b = it * FM_T + tid;  // == k
+        need[it] = 0u;
+        if (b < nb) {
+#pragma unroll
+            for (int q = 0; q < R; q++) {
+                const int bin = b + q * PP;
+                if (bin < need_end) need[it] |= 1u << q;
+            }
+#pragma unroll
+            for (int j = 0; j < R; j++) {
+                v[it][j] = X[b + j * nb];
+                if (j >= 1) v[it][j] = cdmul(v[it][j], tw[b * j]);
+            }
+            if (need[it] & ~1u) {
+                dft_r<R>(v[it]);
+            } else {
+                // output 0 alone, as dft_r<5> forms it: (x0 + a1) + a2 with a1 = v1 + v4, a2 = v2 + v3
+                const double2 a1 = cdadd(v[it][1], v[it][4]), a2 = cdadd(v[it][2], v[it][3]);
+                v[it][0] = make_double2((v[it][0].x + a1.x) + a2.x, (v[it][0].y + a1.y) + a2.y);
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < ITERS; it++) {
+        const int b = it * FM_T + tid;
+        if (b < nb) {
+#pragma unroll
+            for (int q = 0; q < R; q++)
+                if (need[it] & (1u << q)) X[b + q * PP] = v[it][q];
+        }
+    }
+    __syncthreads();
+}
+
+// The first THREE passes (4, 4, 4) of the inverse transform of the default frames, straight from the gathered bins.
+// After them the image holds C = n/64 blocks of 64: block m = the 64-point transform of z[m + C i], i < 64, of which only
+// z[m] (i = 0), z[m + C] (i = 1, if m + C < 204) and z[m + 2C] (i = 2, if m + 2C < 204) are not the zeroed array's.  An
+// input that is alone in its butterfly passes through it unchanged (a + 0 = a; 0 * w = 0), so passes 1 and 2 only copy,
+// and in pass 3 butterfly k < 16 of block m takes v0 = z[m], v1 = z[m + C] T64[k], v2 = z[m + 2C] T64[2k], v3 = 0:
+//     a = v0 + v2, b = v0 - v2, c = d = v1:   out[k] = a + c, out[k+32] = a - c, out[k+16] = b - i d, out[k+48] = b + i d
+// -- the operations the three general passes perform on these operands, minus the ones whose second operand is a zero of
+// the zeroed array.  (Those return their first operand; only the SIGN of an exact zero can differ from the general
+// passes' -- a sum of zeros -- and a zero's sign reaches nothing RxDownSample computes: its accumulators start at +0.0 and
+// x + (+-0) = x.)  Replaces fm_first_from_bins + fm_pass2<4,4>: one LDS round trip and two thirds of a transform's
+// radix-4 arithmetic less per frame.  z = conj of the spectrum bin (the inverse is conj o forward o conj).
+template <int NN>
+__device__ __attribute__((noinline)) void fm_inv_blocks(double2 *X, const double2 *t64, int first_bin, int tid)
+{
+    constexpr int C = NN / 64, NITEM = C * 16, ITERS = (NITEM + FM_T - 1) / FM_T;
+    static_assert(3 * C > 204, "at most three of a block's 64 inputs come from the 204 bins");
+    double2 z0[ITERS], z1[ITERS], z2[ITERS];
+#pragma unroll
+    for (int it = 0; it < ITERS; it++) {
+        const int id = it * FM_T + tid;
+        const int m = id >> 4;
+        z0[it] = z1[it] = z2[it] = make_double2(0.0, 0.0);
+        if (id < NITEM) {
+            const double2 a = X[first_bin + m];
+            z0[it] = make_double2(a.x, -a.y);
+            if (m + C < 204) {
+                const double2 b = X[first_bin + m + C];
+                z1[it] = make_double2(b.x, -b.y);
+            }
+            if (m + 2 * C < 204) {
+                const double2 c = X[first_bin + m + 2 * C];
+                z2[it] = make_double2(c.x, -c.y);
+            }
+        }
+    }
+    __syncthreads();  // every bin is in registers before the image is overwritten
+#pragma unroll
+    for (int it = 0; it < ITERS; it++) {
+        const int id = it * FM_T + tid;
+        if (id < NITEM) {
+            const int m = id >> 4, k = id & 15;
+            double2 a = z0[it], b = z0[it];
+            if (m + 2 * C < 204) {
+                const double2 v2 = cdmul(z2[it], t64[2 * k]);
+                a = cdadd(z0[it], v2);
+                b = cdsub(z0[it], v2);
+            }
+            double2 *o = X + (64 * m + k);
+            if (m + C < 204) {
+                const double2 v1 = cdmul(z1[it], t64[k]);
+                o[0] = cdadd(a, v1);
+                o[32] = cdsub(a, v1);
+                o[16] = make_double2(b.x + v1.y, b.y - v1.x);
+                o[48] = make_double2(b.x - v1.y, b.y + v1.x);
+            } else {
+                o[0] = a;
+                o[32] = a;
+                o[16] = b;
+                o[48] = b;
+            }
+        }
+    }
+    __syncthreads();
+}
+
 // TWO consecutive Stockham passes (radix R1 at stride P, then R2 at stride P*R1) in one LDS round trip.  The R1*R2
 // points of a group are closed under both passes: group g = m0*P + k1 (k1 < P) takes the R2 first-pass butterflies
 // b1 = g + j2*(n/(R1 R2)) -- their outputs q1 feed the R1 second-pass butterflies b2 = m0*P*R1 + (k1 + q1*P), which
@@ -281,22 +435,41 @@ __device__ __forceinline__ const double2 *fm_table(const double2 *twL, const Fft
 }
 
 // first_done: the caller has already run the first pass (fm_first_from_*, default frames only)
-__device__ __forceinline__ void fm_forward(double2 *X, const double2 *twL, const FftmArgs &a, int tid, bool first_done)
+// mode (default frames): FM_FULL the whole transform; FM_FWD_BAND the forward transform of the front end, last pass
+// restricted to the bins that are read (do_up says which band); FM_INV_REAL the inverse transform after fm_inv_blocks
+// (passes 1-3 done), last pass real parts only, scaled by norm
+enum { FM_FULL = 0, FM_FWD_BAND = 1, FM_INV_REAL = 2 };
+__device__ __forceinline__ void fm_forward(double2 *X, const double2 *twL, const FftmArgs &a, int tid, bool first_done,
+                                           int mode = FM_FULL, int do_up = 0, double norm = 1.0)
 {
     // the reference's two default frames: the plan is known (fftm_radices: 4,4,4,2,3,5,5 / 4,4,4,3,5,5)
     if (a.f.n == 9600) {
-        if (!first_done) fm_pass<4, 9600, 1>(X, fm_table(twL, a, 0, 1), 9600, 1, 0u, tid);
-        fm_pass2<4, 4, 9600, 4>(X, fm_table(twL, a, 1, 4), fm_table(twL, a, 2, 16), 9600, 4, 0u, tid);
+        if (mode != FM_INV_REAL) {
+            if (!first_done) fm_pass<4, 9600, 1>(X, fm_table(twL, a, 0, 1), 9600, 1, 0u, tid);
+            fm_pass2<4, 4, 9600, 4>(X, fm_table(twL, a, 1, 4), fm_table(twL, a, 2, 16), 9600, 4, 0u, tid);
+        }
         fm_pass2<2, 3, 9600, 64>(X, fm_table(twL, a, 3, 64), fm_table(twL, a, 4, 128), 9600, 64, 0u, tid);
         fm_pass<5, 9600, 384>(X, fm_table(twL, a, 5, 384), 9600, 384, 0u, tid);
-        fm_pass<5, 9600, 1920>(X, fm_table(twL, a, 6, 1920), 9600, 1920, 0u, tid);
+        if (mode == FM_FWD_BAND)
+            fm_pass5_band<9600, 1920>(X, fm_table(twL, a, 6, 1920), do_up, tid);
+        else if (mode == FM_INV_REAL)
+            fm_pass5_real<9600, 1920>(X, fm_table(twL, a, 6, 1920), norm, tid);
+        else
+            fm_pass<5, 9600, 1920>(X, fm_table(twL, a, 6, 1920), 9600, 1920, 0u, tid);
         return;
     }
     if (a.f.n == 4800) {
-        if (!first_done) fm_pass<4, 4800, 1>(X, fm_table(twL, a, 0, 1), 4800, 1, 0u, tid);
-        fm_pass2<4, 4, 4800, 4>(X, fm_table(twL, a, 1, 4), fm_table(twL, a, 2, 16), 4800, 4, 0u, tid);
+        if (mode != FM_INV_REAL) {
+            if (!first_done) fm_pass<4, 4800, 1>(X, fm_table(twL, a, 0, 1), 4800, 1, 0u, tid);
+            fm_pass2<4, 4, 4800, 4>(X, fm_table(twL, a, 1, 4), fm_table(twL, a, 2, 16), 4800, 4, 0u, tid);
+        }
         fm_pass2<3, 5, 4800, 64>(X, fm_table(twL, a, 3, 64), fm_table(twL, a, 4, 192), 4800, 64, 0u, tid);
-        fm_pass<5, 4800, 960>(X, fm_table(twL, a, 5, 960), 4800, 960, 0u, tid);
+        if (mode == FM_FWD_BAND)
+            fm_pass5_band<4800, 960>(X, fm_table(twL, a, 5, 960), do_up, tid);
+        else if (mode == FM_INV_REAL)
+            fm_pass5_real<4800, 960>(X, fm_table(twL, a, 5, 960), norm, tid);
+        else
+            fm_pass<5, 4800, 960>(X, fm_table(twL, a, 5, 960), 4800, 960, 0u, tid);
         return;
     }
     int P = 1;
@@ -432,7 +605,7 @@ __global__ __launch_bounds__(FM_T) void k_front_fftm(FftmArgs aa)
             __syncthreads();
         }
         PHASE(0)
-        fm_forward(X, twL, aa, tf, fused_first);  // :422-423
+        fm_forward(X, twL, aa, tf, fused_first, fused_first ? FM_FWD_BAND : FM_FULL, a.do_up);  // :422-423
         PHASE(1)
         // ---- |X| (:425-427) over the band the boxcar reads
         for (int i = pbase + tf; i < end - 24; i += FM_T) {
@@ -506,25 +679,30 @@ __global__ __launch_bounds__(FM_T) void k_front_fftm(FftmArgs aa)
         PHASE(2)
         // ---- 204 bins around the centre to bin 0 of a zeroed array (:458), inverse transform (:459) as
         // conj o forward o conj; only real parts are read afterwards, so the closing conjugation is dropped
-        double2 keep = make_double2(0.0, 0.0);
-        if (tf < 204) keep = X[centreBin - 102 + tf];
-        __syncthreads();
         if (fused_first) {
-            const double2 in0 = (tf < 204) ? make_double2(keep.x, -keep.y) : make_double2(0.0, -0.0);
+            // default frames: passes 1-3 straight from the bins, last pass real parts only and already scaled by 1/n
+            const double2 *t64 = fm_table(twL, aa, 2, 16);
             if (n == 9600)
-                fm_first_from_bins<9600>(X, in0, tf);
+                fm_inv_blocks<9600>(X, t64, centreBin - 102, tf);
             else
-                fm_first_from_bins<4800>(X, in0, tf);
+                fm_inv_blocks<4800>(X, t64, centreBin - 102, tf);
+            PHASE(3)
+            fm_forward(X, twL, aa, tf, true, FM_INV_REAL, 0, norm);
         } else {
+            double2 keep = make_double2(0.0, 0.0);
+            if (tf < 204) keep = X[centreBin - 102 + tf];
+            __syncthreads();
             for (int i = tf; i < n; i += FM_T) X[i] = make_double2(0.0, -0.0);  // conj of the zeroed array: -0.0 imaginary parts
             __syncthreads();
             if (tf < 204) X[tf] = make_double2(keep.x, -keep.y);
             __syncthreads();
+            PHASE(3)
+            fm_forward(X, twL, aa, tf, false);
+            for (int i = tf; i < n; i += FM_T) X[i].x = X[i].x * norm;  // re = X.x / n (:462)
+            __syncthreads();
         }
-        PHASE(3)
-        fm_forward(X, twL, aa, tf, fused_first);
         PHASE(4)
-        if (tf < 26) hist[26 + tf] = X[tf].x * norm;
+        if (tf < 26) hist[26 + tf] = X[tf].x;
         __syncthreads();
         // ---- RxDownSample(re, re) (:461-463, :470-492): outputs whose window ends inside this frame
         {
@@ -539,7 +717,7 @@ __global__ __launch_bounds__(FM_T) void k_front_fftm(FftmArgs aa)
                 if (e >= 26) {  // all but the first three windows of a frame: no history, constant offsets
                     const double2 *w = X + e;
 #pragma unroll
-                    for (int k = 0; k < 27; k++) fi += (w[-k].x * norm) * ds_tap(k);  // newest first (:479-483); re = X.x / n (:462)
+                    for (int k = 0; k < 27; k++) fi += w[-k].x * ds_tap(k);  // newest first (:479-483)
                 } else {
                     const double *w = hist + 26 + e;  // the first three windows of a frame: history, then the frame's head
 #pragma unroll
@@ -550,7 +728,7 @@ __global__ __launch_bounds__(FM_T) void k_front_fftm(FftmArgs aa)
             }
         }
         double hnew = 0.0;
-        if (tf < 26) hnew = X[n - 26 + tf].x * norm;
+        if (tf < 26) hnew = X[n - 26 + tf].x;
         __syncthreads();
         if (tf < 26) hist[tf] = hnew;
         __syncthreads();
