@@ -123,7 +123,8 @@ __device__ __attribute__((noinline)) void fm_pass(double2 *X, const double2 *tw,
 // real part of every output is formed (the imaginary halves of the 5-point butterfly -- a third of its operations --
 // have no reader and are not computed) and it is stored already scaled: X[i].x = re * (1/n), once per sample instead of
 // once per tap that reads it.  Same operands, same operations, same order for everything that IS computed.
-template <int NN, int PP>
+// TT: the two-dimensional tables of an odd half (fm_pass_t): tw[(j-1) P + k] instead of tw[k j]
+template <int NN, int PP, bool TT = false>
 __device__ __attribute__((noinline)) void fm_pass5_real(double2 *X, const double2 *tw, double norm, int tid)
 {
     constexpr int R = 5, nb = NN / R, ITERS = (nb + FM_T - 1) / FM_T;
@@ -137,7 +138,7 @@ __device__ __attribute__((noinline)) void fm_pass5_real(double2 *X, const double
 #pragma unroll
             for (int j = 0; j < R; j++) {
                 v[j] = X[b + j * nb];
-                if (j >= 1) v[j] = cdmul(v[j], tw[k * j]);
+                if (j >= 1) v[j] = cdmul(v[j], TT ? tw[(j - 1) * PP + k] : tw[k * j]);
             }
             dft_r<R>(v);
 #pragma unroll
@@ -160,15 +161,15 @@ __device__ __attribute__((noinline)) void fm_pass5_real(double2 *X, const double
 
 // The LAST pass of the forward transform: of the n bins only those the front end can read are formed -- |X| over
 // [beg+24, end-24) (:425-427, the boxcar's reach) and the 204 bins around a centre bin (:458), which the rule and its
-// clamps keep in [102, end-1] (:444-453): everything below end + 102, end = n/4 (lower band) or n/2 (upper band).  A
+// clamps keep in [102, end-1] (:444-453): everything below need_end = end + 102, end = n/4 (lower band) or n/2 (upper).  A
 // butterfly whose only needed output is q = 0 forms (x0 + a1) + a2 alone (32 of its 72 operations); all others run in
 // full and store what is read.
-template <int NN, int PP>
-__device__ __attribute__((noinline)) void fm_pass5_band(double2 *X, const double2 *tw, int do_up, int tid)
+// need_end: outputs [0, need_end) of THIS transform are read (a half transform of a 2 m frame holds every second bin)
+template <int NN, int PP, bool TT = false>
+__device__ __attribute__((noinline)) void fm_pass5_band(double2 *X, const double2 *tw, int need_end, int tid)
 {
     constexpr int R = 5, nb = NN / R, ITERS = (nb + FM_T - 1) / FM_T;
     static_assert(PP == nb, "the last pass: one butterfly per k");
-    const int need_end = (do_up ? NN / 2 : NN / 4) + 102;  // bins [0, need_end) are read
     double2 v[ITERS][R];
     unsigned need[ITERS];
 #pragma unroll
@@ -184,7 +185,7 @@ __device__ __attribute__((noinline)) void fm_pass5_band(double2 *X, const double
 #pragma unroll
             for (int j = 0; j < R; j++) {
                 v[it][j] = X[b + j * nb];
-                if (j >= 1) v[it][j] = cdmul(v[it][j], tw[b * j]);
+                if (j >= 1) v[it][j] = cdmul(v[it][j], TT ? tw[(j - 1) * PP + b] : tw[b * j]);
             }
             if (need[it] & ~1u) {
                 dft_r<R>(v[it]);
@@ -219,8 +220,12 @@ __device__ __attribute__((noinline)) void fm_pass5_band(double2 *X, const double
 // passes' -- a sum of zeros -- and a zero's sign reaches nothing RxDownSample computes: its accumulators start at +0.0 and
 // x + (+-0) = x.)  Replaces fm_first_from_bins + fm_pass2<4,4>: one LDS round trip and two thirds of a transform's
 // radix-4 arithmetic less per frame.  z = conj of the spectrum bin (the inverse is conj o forward o conj).
-template <int NN>
-__device__ __attribute__((noinline)) void fm_inv_blocks(double2 *X, const double2 *t64, int first_bin, int tid)
+// src / CONJ: where the 204 values z[0..203] come from -- the spectrum image itself (conjugated on the way, CONJ) or a
+// small array of already conjugated values beside the image.  tw1[k * s1], tw2[k * s2]: the pass-3 twiddles of inputs
+// 1 and 2 -- T64[k], T64[2k] for a transform with the ordinary tables, U[k], U[16 + k] for an odd half's (fm_pass_t).
+template <int NN, bool CONJ>
+__device__ __attribute__((noinline)) void fm_inv_blocks(double2 *X, const double2 *src, const double2 *tw1, int s1,
+                                                         const double2 *tw2, int s2, int tid)
 {
     constexpr int C = NN / 64, NITEM = C * 16, ITERS = (NITEM + FM_T - 1) / FM_T;
     static_assert(3 * C > 204, "at most three of a block's 64 inputs come from the 204 bins");
@@ -231,15 +236,15 @@ __device__ __attribute__((noinline)) void fm_inv_blocks(double2 *X, const double
         const int m = id >> 4;
         z0[it] = z1[it] = z2[it] = make_double2(0.0, 0.0);
         if (id < NITEM) {
-            const double2 a = X[first_bin + m];
-            z0[it] = make_double2(a.x, -a.y);
+            const double2 a = src[m];
+            z0[it] = make_double2(a.x, CONJ ? -a.y : a.y);
             if (m + C < 204) {
-                const double2 b = X[first_bin + m + C];
-                z1[it] = make_double2(b.x, -b.y);
+                const double2 b = src[m + C];
+                z1[it] = make_double2(b.x, CONJ ? -b.y : b.y);
             }
             if (m + 2 * C < 204) {
-                const double2 c = X[first_bin + m + 2 * C];
-                z2[it] = make_double2(c.x, -c.y);
+                const double2 c = src[m + 2 * C];
+                z2[it] = make_double2(c.x, CONJ ? -c.y : c.y);
             }
         }
     }
@@ -251,13 +256,13 @@ __device__ __attribute__((noinline)) void fm_inv_blocks(double2 *X, const double
             const int m = id >> 4, k = id & 15;
             double2 a = z0[it], b = z0[it];
             if (m + 2 * C < 204) {
-                const double2 v2 = cdmul(z2[it], t64[2 * k]);
+                const double2 v2 = cdmul(z2[it], tw2[k * s2]);
                 a = cdadd(z0[it], v2);
                 b = cdsub(z0[it], v2);
             }
             double2 *o = X + (64 * m + k);
             if (m + C < 204) {
-                const double2 v1 = cdmul(z1[it], t64[k]);
+                const double2 v1 = cdmul(z1[it], tw1[k * s1]);
                 o[0] = cdadd(a, v1);
                 o[32] = cdsub(a, v1);
                 o[16] = make_double2(b.x + v1.y, b.y - v1.x);
@@ -436,11 +441,11 @@ __device__ __forceinline__ const double2 *fm_table(const double2 *twL, const Fft
 
 // first_done: the caller has already run the first pass (fm_first_from_*, default frames only)
 // mode (default frames): FM_FULL the whole transform; FM_FWD_BAND the forward transform of the front end, last pass
-// restricted to the bins that are read (do_up says which band); FM_INV_REAL the inverse transform after fm_inv_blocks
+// restricted to the outputs [0, need_end) that are read; FM_INV_REAL the inverse transform after fm_inv_blocks
 // (passes 1-3 done), last pass real parts only, scaled by norm
 enum { FM_FULL = 0, FM_FWD_BAND = 1, FM_INV_REAL = 2 };
 __device__ __forceinline__ void fm_forward(double2 *X, const double2 *twL, const FftmArgs &a, int tid, bool first_done,
-                                           int mode = FM_FULL, int do_up = 0, double norm = 1.0)
+                                           int mode = FM_FULL, int need_end = 0, double norm = 1.0)
 {
     // the reference's two default frames: the plan is known (fftm_radices: 4,4,4,2,3,5,5 / 4,4,4,3,5,5)
     if (a.f.n == 9600) {
@@ -451,7 +456,7 @@ __device__ __forceinline__ void fm_forward(double2 *X, const double2 *twL, const
         fm_pass2<2, 3, 9600, 64>(X, fm_table(twL, a, 3, 64), fm_table(twL, a, 4, 128), 9600, 64, 0u, tid);
         fm_pass<5, 9600, 384>(X, fm_table(twL, a, 5, 384), 9600, 384, 0u, tid);
         if (mode == FM_FWD_BAND)
-            fm_pass5_band<9600, 1920>(X, fm_table(twL, a, 6, 1920), do_up, tid);
+            fm_pass5_band<9600, 1920>(X, fm_table(twL, a, 6, 1920), need_end, tid);
         else if (mode == FM_INV_REAL)
             fm_pass5_real<9600, 1920>(X, fm_table(twL, a, 6, 1920), norm, tid);
         else
@@ -465,7 +470,7 @@ __device__ __forceinline__ void fm_forward(double2 *X, const double2 *twL, const
         }
         fm_pass2<3, 5, 4800, 64>(X, fm_table(twL, a, 3, 64), fm_table(twL, a, 4, 192), 4800, 64, 0u, tid);
         if (mode == FM_FWD_BAND)
-            fm_pass5_band<4800, 960>(X, fm_table(twL, a, 5, 960), do_up, tid);
+            fm_pass5_band<4800, 960>(X, fm_table(twL, a, 5, 960), need_end, tid);
         else if (mode == FM_INV_REAL)
             fm_pass5_real<4800, 960>(X, fm_table(twL, a, 5, 960), norm, tid);
         else
@@ -605,7 +610,7 @@ __global__ __launch_bounds__(FM_T) void k_front_fftm(FftmArgs aa)
             __syncthreads();
         }
         PHASE(0)
-        fm_forward(X, twL, aa, tf, fused_first, fused_first ? FM_FWD_BAND : FM_FULL, a.do_up);  // :422-423
+        fm_forward(X, twL, aa, tf, fused_first, fused_first ? FM_FWD_BAND : FM_FULL, end + 102);  // :422-423; bins < end + 102 are read
         PHASE(1)
         // ---- |X| (:425-427) over the band the boxcar reads
         for (int i = pbase + tf; i < end - 24; i += FM_T) {
@@ -683,9 +688,9 @@ __global__ __launch_bounds__(FM_T) void k_front_fftm(FftmArgs aa)
             // default frames: passes 1-3 straight from the bins, last pass real parts only and already scaled by 1/n
             const double2 *t64 = fm_table(twL, aa, 2, 16);
             if (n == 9600)
-                fm_inv_blocks<9600>(X, t64, centreBin - 102, tf);
+                fm_inv_blocks<9600, true>(X, X + (centreBin - 102), t64, 1, t64, 2, tf);
             else
-                fm_inv_blocks<4800>(X, t64, centreBin - 102, tf);
+                fm_inv_blocks<4800, true>(X, X + (centreBin - 102), t64, 1, t64, 2, tf);
             PHASE(3)
             fm_forward(X, twL, aa, tf, true, FM_INV_REAL, 0, norm);
         } else {
@@ -856,16 +861,24 @@ __device__ __attribute__((noinline)) void fm_pass2_t(double2 *X, const double2 *
     __syncthreads();
 }
 
-__device__ __forceinline__ void fm_forward_odd(double2 *X, const Fft2xArgs &a, int tid)
+__device__ __forceinline__ void fm_forward_odd(double2 *X, const Fft2xArgs &a, int tid, int mode = FM_FULL, int need_end = 0,
+                                               double norm = 1.0)
 {
     const FftmArgs &m = a.sub;
     if (m.f.n == 9600) {  // the 192 kHz default: the 9600-point plan 4 | 4,4 | 2,3 | 5 | 5 with pass pairs, as fm_forward
         const double2 *t = m.f.tw;
-        fm_pass_t<4>(X, t + a.tw1_off[0], 9600, 1, 0u, tid);
-        fm_pass2_t<4, 4, 9600, 4>(X, t + a.tw1_off[1], t + a.tw1_off[2], tid);
+        if (mode != FM_INV_REAL) {
+            fm_pass_t<4>(X, t + a.tw1_off[0], 9600, 1, 0u, tid);
+            fm_pass2_t<4, 4, 9600, 4>(X, t + a.tw1_off[1], t + a.tw1_off[2], tid);
+        }
         fm_pass2_t<2, 3, 9600, 64>(X, t + a.tw1_off[3], t + a.tw1_off[4], tid);
         fm_pass_t<5>(X, t + a.tw1_off[5], 9600, 384, m.pmagic[5], tid);
-        fm_pass_t<5>(X, t + a.tw1_off[6], 9600, 1920, m.pmagic[6], tid);
+        if (mode == FM_FWD_BAND)
+            fm_pass5_band<9600, 1920, true>(X, t + a.tw1_off[6], need_end, tid);
+        else if (mode == FM_INV_REAL)
+            fm_pass5_real<9600, 1920, true>(X, t + a.tw1_off[6], norm, tid);
+        else
+            fm_pass_t<5>(X, t + a.tw1_off[6], 9600, 1920, m.pmagic[6], tid);
         return;
     }
     int P = 1;
@@ -894,6 +907,8 @@ __global__ __launch_bounds__(FM_T) void k_front_fft2x(Fft2xArgs aa)
     double *hist = reinterpret_cast<double *>(X + m);    // [64]: [0,26) the previous frame's last 26 scaled samples
     double *redv = hist + 64;
     int *redi = reinterpret_cast<int *>(redv + 16);
+    double2 *zb = reinterpret_cast<double2 *>(redi + 16);  // [204] the gathered bins, conjugated (default frame only)
+    const bool pruned = (m == 9600);  // the 192 kHz default: pruned passes (fm_inv_blocks, fm_pass5_band / _real)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int s = blockIdx.x;
     const int beg = a.do_up ? n / 4 : 0;
@@ -946,14 +961,16 @@ __global__ __launch_bounds__(FM_T) void k_front_fft2x(Fft2xArgs aa)
         int tf = tid;
         asm volatile("" : "+v"(tf));
         // ---- forward, even bins
+        // bins below end + 102 are read (see fm_pass5_band): even bin 2 i <=> output i of this half
+        const int need_even = (end + 102 + 1) / 2, need_odd = (end + 102) / 2;
         load_half(t0, 0, tf);
-        fm_forward(X, nullptr, aa.sub, tf, false);
-        for (int i = tf; i < nek; i += FM_T) ek[i] = X[i];
+        fm_forward(X, nullptr, aa.sub, tf, false, pruned ? FM_FWD_BAND : FM_FULL, need_even);
+        for (int i = tf; i < (pruned ? need_even : nek); i += FM_T) ek[i] = X[i];
         __threadfence_block();
         __syncthreads();
         // ---- forward, odd bins
         load_half(t0, 1, tf);
-        fm_forward_odd(X, aa, tf);
+        fm_forward_odd(X, aa, tf, pruned ? FM_FWD_BAND : FM_FULL, need_odd);
         // ---- |X| over the band the boxcar reads (:425-427)
         // (pbase is even: even bins come from the scratch, odd ones from the image -- one loop each, no per-bin branch)
         for (int i = pbase + 2 * tf; i < end - 24; i += 2 * FM_T) {
@@ -1032,19 +1049,38 @@ __global__ __launch_bounds__(FM_T) void k_front_fft2x(Fft2xArgs aa)
         }
         __syncthreads();
         const double2 Z = make_double2(0.0, -0.0);
-        // even output samples: first-pass sums z[b] + z[b + m], z[b + m] being the zeroed array's
-        for (int b = tf; b < m; b += FM_T) X[b] = cdadd(b < 204 ? keep : Z, Z);
-        __syncthreads();
-        fm_forward(X, nullptr, aa.sub, tf, false);
-        for (int i = tf; i < m; i += FM_T) r0[i] = X[i].x * norm;  // re = X.x / n (:462), sample 2 i
-        __threadfence_block();
-        __syncthreads();
-        // odd output samples: first-pass differences
-        for (int b = tf; b < m; b += FM_T) X[b] = cdsub(b < 204 ? keep : Z, Z);
-        __syncthreads();
-        fm_forward_odd(X, aa, tf);
+        if (pruned) {
+            // The radix-2 first pass leaves z[b] + Z = z[b] in the even half and z[b] - Z = z[b] in the odd one (b < 204, zeros
+            // elsewhere): both halves start from the same 204 values, and their first three passes come straight from
+            // them (fm_inv_blocks) -- the even half with the 9600-point tables, the odd one with its own
+            if (tf < 204) zb[tf] = keep;
+            __syncthreads();
+            const double2 *t64 = aa.sub.f.tw + aa.sub.tw_off[2];
+            fm_inv_blocks<9600, false>(X, zb, t64, 1, t64, 2, tf);
+            fm_forward(X, nullptr, aa.sub, tf, true, FM_INV_REAL, 0, norm);
+            for (int i = tf; i < m; i += FM_T) r0[i] = X[i].x;  // re = X.x / n (:462), sample 2 i
+            __threadfence_block();
+            __syncthreads();
+            const double2 *u64 = aa.sub.f.tw + aa.tw1_off[2];  // [(j-1) 16 + k]
+            fm_inv_blocks<9600, false>(X, zb, u64, 1, u64 + 16, 1, tf);
+            fm_forward_odd(X, aa, tf, FM_INV_REAL, 0, norm);
+        } else {
+            // even output samples: first-pass sums z[b] + z[b + m], z[b + m] being the zeroed array's
+            for (int b = tf; b < m; b += FM_T) X[b] = cdadd(b < 204 ? keep : Z, Z);
+            __syncthreads();
+            fm_forward(X, nullptr, aa.sub, tf, false);
+            for (int i = tf; i < m; i += FM_T) r0[i] = X[i].x * norm;  // re = X.x / n (:462), sample 2 i
+            __threadfence_block();
+            __syncthreads();
+            // odd output samples: first-pass differences
+            for (int b = tf; b < m; b += FM_T) X[b] = cdsub(b < 204 ? keep : Z, Z);
+            __syncthreads();
+            fm_forward_odd(X, aa, tf);
+            for (int i = tf; i < m; i += FM_T) X[i].x = X[i].x * norm;  // re = X.x / n (:462), sample 2 i + 1
+            __syncthreads();
+        }
         // ---- RxDownSample(re, re) (:461-463, :470-492): sample t of the frame = r0[t/2] (t even) or X[t/2].x / n (t odd)
-        auto sample = [&](int t) -> double { return t < 0 ? hist[26 + t] : ((t & 1) ? X[t >> 1].x * norm : r0[t >> 1]); };
+        auto sample = [&](int t) -> double { return t < 0 ? hist[26 + t] : ((t & 1) ? X[t >> 1].x : r0[t >> 1]); };
         {
             long long jlo = (t0 - a.first_out + D - 1) / D;
             if (t0 <= a.first_out) jlo = 0;
@@ -1063,12 +1099,12 @@ __global__ __launch_bounds__(FM_T) void k_front_fft2x(Fft2xArgs aa)
                         const double2 *xo = X + (e >> 1);
                         const double *re = r0 + ((e - 1) >> 1);
 #pragma unroll
-                        for (int k = 0; k < 27; k++) fi += ((k & 1) ? re[-(k >> 1)] : xo[-(k >> 1)].x * norm) * ds_tap(k);
+                        for (int k = 0; k < 27; k++) fi += ((k & 1) ? re[-(k >> 1)] : xo[-(k >> 1)].x) * ds_tap(k);
                     } else {     // e even: taps 0,2,.. read even samples (scratch), taps 1,3,.. odd ones (image)
                         const double *re = r0 + (e >> 1);
                         const double2 *xo = X + ((e - 1) >> 1);
 #pragma unroll
-                        for (int k = 0; k < 27; k++) fi += ((k & 1) ? xo[-(k >> 1)].x * norm : re[-(k >> 1)]) * ds_tap(k);
+                        for (int k = 0; k < 27; k++) fi += ((k & 1) ? xo[-(k >> 1)].x : re[-(k >> 1)]) * ds_tap(k);
                     }
                 } else {
 #pragma unroll
@@ -1244,7 +1280,7 @@ int launch_front_fft2x(const FftFrontArgs &a, int np, const int *rad, const int 
     aa.r0 = r0;
     aa.ek_stride = (long long)fft2x_scratch_ek(a.n);
     aa.r0_stride = (long long)fft2x_scratch_r0(a.n);
-    const size_t lds = sizeof(double2) * (size_t)(a.n / 2) + sizeof(double) * (64 + 16) + sizeof(int) * 16 + 64;
+    const size_t lds = sizeof(double2) * (size_t)(a.n / 2) + sizeof(double) * (64 + 16) + sizeof(int) * 16 + sizeof(double2) * 204 + 64;
     const bool f32 = a.rawf != nullptr;
     static size_t attr_for[2] = {0, 0};
     if (attr_for[f32] < lds) {
