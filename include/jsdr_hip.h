@@ -148,6 +148,20 @@ int jsdr_bpsk_set_variant(jsdr_bpsk *h, int variant);
  * fail), and the bound on |fi' - fi|, |fq' - fq| the margins are built on.  In FAST mode the input buffer of a batch
  * call must stay unmodified until the next jsdr_bpsk_sync() / getter: the certification pass may re-read it. */
 int jsdr_bpsk_cert_stats(jsdr_bpsk *h, int64_t *redone, int64_t *uncertified_streams, double *ey);
+/* FAST, the contract for a drop-in: a stream whose 8-way energy argmax (FUNcubeBPSKDemod.java:586-592) falls inside the
+ * error margin cannot be decided without the exact IIR history and is marked UNCERTIFIED by the call in which that
+ * happens.  The mark is sticky: from that call on every getter of that stream (counters, bits, fec, decoded, trace,
+ * state), the snapshot and receive_*() of a 1-stream handle return JSDR_ERR with a message that says so, and the
+ * result slot's header[12] is 1 -- a wrong bit is never delivered, and neither is a silent gap.  Measured rate on the
+ * benchmark's streams: about 1 stream in 8192 per 1.4e9 bit periods; a stream that carried signal and then
+ * goes silent for ~5 s also ends here (its energies decay below the margin, which scales with the largest sample seen).
+ * What the caller does: jsdr_bpsk_uncertified_streams() lists the stream ids after a call (count > 0 <=> some results
+ * of that call were withheld); those streams are re-run on a JSDR_VARIANT_EXACT handle -- from the start of the stream,
+ * or from the flagged call on an exact handle that was fed the same earlier input -- which decides the same near-tie by
+ * the reference's own arithmetic (tests/test_gpu_fixtures.py::test_fast_variant_uncertified_streams_are_listed_and_
+ * recovered_on_an_exact_handle).  There is no automatic fallback: it would need the exact state kept beside the fast
+ * one for every stream, i.e. the exact variant's cost.  ids: ascending, at most cap; *count: all of them. */
+int jsdr_bpsk_uncertified_streams(jsdr_bpsk *h, int32_t *ids, int cap, int *count);
 /* receive(float[]) / raw form for stream 0 of a 1-stream handle (:357-364) */
 int jsdr_bpsk_receive_f32(jsdr_bpsk *h, const float *iq_host);
 int jsdr_bpsk_receive_i16(jsdr_bpsk *h, const int16_t *raw_host, int ic, int qc);

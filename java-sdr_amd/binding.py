@@ -432,6 +432,14 @@ class Bpsk:
         _check(lib().jsdr_bpsk_cert_stats(self.h, C.byref(r), C.byref(u), C.byref(e)), "jsdr_bpsk_cert_stats")
         return dict(decisions_redone_exactly=r.value, streams_uncertified=u.value, fi_fq_error_bound=e.value)
 
+    def uncertified_streams(self):
+        """fast variant: ids of the streams whose results are withheld (jsdr_hip.h); [] for the exact variant"""
+        n = C.c_int()
+        _check(lib().jsdr_bpsk_uncertified_streams(self.h, None, 0, C.byref(n)), "jsdr_bpsk_uncertified_streams")
+        ids = np.empty(max(n.value, 1), np.int32)
+        _check(lib().jsdr_bpsk_uncertified_streams(self.h, _addr(ids), n.value, C.byref(n)), "jsdr_bpsk_uncertified_streams")
+        return [int(v) for v in ids[:n.value]]
+
     def schedule_stats(self):
         a, b = C.c_int64(), C.c_int64()
         _check(lib().jsdr_bpsk_schedule_stats(self.h, C.byref(a), C.byref(b)), "jsdr_bpsk_schedule_stats")

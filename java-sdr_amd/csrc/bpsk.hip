@@ -3102,6 +3102,30 @@ int jsdr_bpsk_cert_stats(jsdr_bpsk *h, int64_t *redone, int64_t *uncertified_str
     return JSDR_OK;
 }
 
+// fast variant: WHICH streams are uncertified (ascending ids, at most cap of them; *count = how many there are in all).
+// The flag is set by the call in which the uncertifiable decision fell and stays set: the results of that call and of
+// every later one are withheld for that stream (its getters fail).  What a caller does with the list: run those streams
+// -- from the first sample of the flagged call on an exact handle that has seen the same earlier input, or from the start
+// of the stream -- with JSDR_VARIANT_EXACT, which decides the same near-tie by the reference's own arithmetic.
+int jsdr_bpsk_uncertified_streams(jsdr_bpsk *h, int32_t *ids, int cap, int *count)
+{
+    JSDR_REQUIRE(h && count, "jsdr_bpsk_uncertified_streams: null argument");
+    JSDR_REQUIRE(cap == 0 || ids, "jsdr_bpsk_uncertified_streams: null id buffer");
+    *count = 0;
+    if (h->variant == 0) return JSDR_OK;  // the exact variant certifies nothing and withholds nothing
+    if (sync_last(h) != JSDR_OK) return JSDR_ERR;
+    std::vector<TailState> ts((size_t)h->nstreams);
+    JSDR_HIP_TRY(hipMemcpy(ts.data(), h->tail.p, sizeof(TailState) * ts.size(), hipMemcpyDeviceToHost));
+    int n = 0;
+    for (int s = 0; s < h->nstreams; s++)
+        if (ts[(size_t)s].uncertified) {
+            if (n < cap) ids[n] = s;
+            n++;
+        }
+    *count = n;
+    return JSDR_OK;
+}
+
 int jsdr_bpsk_schedule_stats(jsdr_bpsk *h, int64_t *computed_inline, int64_t *prefetched)
 {
     JSDR_REQUIRE(h, "jsdr_bpsk_schedule_stats: null handle");

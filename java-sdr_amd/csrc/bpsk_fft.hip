@@ -83,6 +83,51 @@ __device__ __forceinline__ void dit_stages(double2 (&v)[1 << G], int j, const do
     }
 }
 
+// The first three stages (wings 1, 2, 4) of the FORWARD transform on a group of eight converted int16 samples, with the
+// multiplications by the trivial twiddles 1 = (1, -0) and -i = (0, -1) of the table not performed:
+//     w = 1 :  t = b                     w = -i :  t = (b.y, -b.x)
+// instead of tr = wr*br - wi*bi, ti = wr*bi + wi*br.  Same results to the last bit, signs of zeros included, because no
+// value in this network is ever -0.0: a converted int16 sample is never -0.0 ((float)0/32767f = +0.0f), and a sum or a
+// difference is -0.0 only if an operand already is.  With that, for w = 1 the products wi*bi = -0*bi and wi*br are zeros
+// that leave br and bi unchanged; for w = -i, tr = (+-0) + bi = bi exactly (bi = +0 gives +0 either way), and ti = (+-0) - br
+// differs from -br at most in the sign of a zero -- which a + t and a - t (a never -0.0) absorb.  Twelve of the twenty
+// butterflies of a group are trivial: 60 of its 200 operations.  (Float input may hold -0.0f and takes dit_stages.)
+__device__ __forceinline__ void dit_first3_i16(double2 (&v)[8], const double2 *__restrict__ tsg)
+{
+    auto bf1 = [](double2 &a, double2 &b) {  // w = 1
+        const double2 x = a, y = b;
+        a = make_double2(x.x + y.x, x.y + y.y);
+        b = make_double2(x.x - y.x, x.y - y.y);
+    };
+    auto bfi = [](double2 &a, double2 &b) {  // w = -i: t = (b.y, -b.x)
+        const double2 x = a, y = b;
+        a = make_double2(x.x + y.y, x.y - y.x);
+        b = make_double2(x.x - y.y, x.y + y.x);
+    };
+    auto bfw = [](double2 &a, double2 &b, const double2 w) {  // the oracle's butterfly
+        const double2 x = a, y = b;
+        const double p1 = w.x * y.x, p2 = w.y * y.y, p3 = w.x * y.y, p4 = w.y * y.x;
+        const double tr = p1 - p2, ti = p3 + p4;
+        a = make_double2(x.x + tr, x.y + ti);
+        b = make_double2(x.x - tr, x.y - ti);
+    };
+    // wing 1: twiddle Ts[0] = 1
+    bf1(v[0], v[1]);
+    bf1(v[2], v[3]);
+    bf1(v[4], v[5]);
+    bf1(v[6], v[7]);
+    // wing 2: Ts[1] = 1, Ts[2] = -i
+    bf1(v[0], v[2]);
+    bfi(v[1], v[3]);
+    bf1(v[4], v[6]);
+    bfi(v[5], v[7]);
+    // wing 4: Ts[3] = 1, Ts[4] = W8, Ts[5] = -i, Ts[6] = W8^3
+    bf1(v[0], v[4]);
+    bfw(v[1], v[5], tsg[4]);
+    bfi(v[2], v[6]);
+    bfw(v[3], v[7], tsg[6]);
+}
+
 // one LDS round trip: G stages starting at wing HALF0 over the whole frame.  REAL_OUT: scale and store only
 // the real part (last pass of the inverse transform; :462 reads nothing else).
 template <int G, int HALF0, bool INVERSE, int LOGN, bool REAL_OUT>
@@ -252,7 +297,10 @@ __global__ __launch_bounds__(256, (LOGN <= 11 ? 4 : (LOGN == 12 ? 2 : 1))) void 
                             pre[c][m] = raw[t];
                     }
                 }
-                dit_stages<3, 1, false, true>(v, 0, TsL, tsg);
+                if (F32IN)
+                    dit_stages<3, 1, false, true>(v, 0, TsL, tsg);
+                else
+                    dit_first3_i16(v, tsg);
 #pragma unroll
                 for (int m = 0; m < 8; m++) X[xpad(8 * q + m)] = v[m];
             }

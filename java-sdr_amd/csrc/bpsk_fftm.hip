@@ -19,6 +19,14 @@
 
 namespace jsdr {
 
+// timing probe only (never in the product build): the passes without their workgroup barriers -- wrong data, unchanged
+// addresses -- to see what lock-step at the barriers costs
+#ifdef JSDR_X_NOBAR
+#define FM_PASS_SYNC() __builtin_amdgcn_wave_barrier()
+#else
+#define FM_PASS_SYNC() __syncthreads()
+#endif
+
 constexpr int FM_T = 768;
 constexpr int FM_NMAX = 9600;
 constexpr int FM_MAXPASS = 12;
@@ -105,7 +113,7 @@ __device__ __attribute__((noinline)) void fm_pass(double2 *X, const double2 *tw,
             dft_r<R>(v[it]);
         }
     }
-    __syncthreads();
+    FM_PASS_SYNC();
 #pragma unroll
     for (int it = 0; it < ITERS; it++) {
         const int b = it * FM_T + tid;
@@ -116,7 +124,7 @@ __device__ __attribute__((noinline)) void fm_pass(double2 *X, const double2 *tw,
             for (int q = 0; q < R; q++) X[j0 + q * P] = v[it][q];
         }
     }
-    __syncthreads();
+    FM_PASS_SYNC();
 }
 
 // The LAST pass of the inverse transform: RxDownSample reads nothing but re/n (FUNcubeBPSKDemod.java:461-463), so only the
@@ -145,7 +153,7 @@ __device__ __attribute__((noinline)) void fm_pass5_real(double2 *X, const double
             for (int q = 0; q < R; q++) o[it][q] = v[q].x * norm;
         }
     }
-    __syncthreads();
+    FM_PASS_SYNC();
 #pragma unroll
     for (int it = 0; it < ITERS; it++) {
         const int b = it * FM_T + tid;
@@ -156,7 +164,7 @@ __device__ __attribute__((noinline)) void fm_pass5_real(double2 *X, const double
             for (int q = 0; q < R; q++) X[j0 + q * PP].x = o[it][q];
         }
     }
-    __syncthreads();
+    FM_PASS_SYNC();
 }
 
 // The LAST pass of the forward transform: of the n bins only those the front end can read are formed -- |X| over
@@ -196,7 +204,7 @@ __device__ __attribute__((noinline)) void fm_pass5_band(double2 *X, const double
             }
         }
     }
-    __syncthreads();
+    FM_PASS_SYNC();
 #pragma unroll
     for (int it = 0; it < ITERS; it++) {
         const int b = it * FM_T + tid;
@@ -206,7 +214,7 @@ __device__ __attribute__((noinline)) void fm_pass5_band(double2 *X, const double
                 if (need[it] & (1u << q)) X[b + q * PP] = v[it][q];
         }
     }
-    __syncthreads();
+    FM_PASS_SYNC();
 }
 
 // The first THREE passes (4, 4, 4) of the inverse transform of the default frames, straight from the gathered bins.
@@ -248,7 +256,7 @@ __device__ __attribute__((noinline)) void fm_inv_blocks(double2 *X, const double
             }
         }
     }
-    __syncthreads();  // every bin is in registers before the image is overwritten
+    FM_PASS_SYNC();  // every bin is in registers before the image is overwritten
 #pragma unroll
     for (int it = 0; it < ITERS; it++) {
         const int id = it * FM_T + tid;
@@ -275,7 +283,7 @@ __device__ __attribute__((noinline)) void fm_inv_blocks(double2 *X, const double
             }
         }
     }
-    __syncthreads();
+    FM_PASS_SYNC();
 }
 
 // TWO consecutive Stockham passes (radix R1 at stride P, then R2 at stride P*R1) in one LDS round trip.  The R1*R2
@@ -325,7 +333,7 @@ __device__ __attribute__((noinline)) void fm_pass2(double2 *X, const double2 *tw
             }
         }
     }
-    __syncthreads();
+    FM_PASS_SYNC();
 #pragma unroll
     for (int it = 0; it < ITERS; it++) {
         const int g = it * FM_T + tid;
@@ -338,7 +346,7 @@ __device__ __attribute__((noinline)) void fm_pass2(double2 *X, const double2 *tw
                 for (int q1 = 0; q1 < R1; q1++) z[q1 * P + q2 * P * R1] = v[it][q2][q1];
         }
     }
-    __syncthreads();
+    FM_PASS_SYNC();
 }
 
 // The first pass stores X[4b + q]: lane stride 4 slots, so the 8 lanes of a 16-byte-store group share two bank groups

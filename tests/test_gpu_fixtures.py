@@ -184,6 +184,34 @@ def test_fast_variant_flags_a_stream_it_cannot_certify(monkeypatch):
             getter(0)
 
 
+def test_fast_variant_uncertified_streams_are_listed_and_recovered_on_an_exact_handle(monkeypatch):
+    """the drop-in contract of the fast variant (include/jsdr_hip.h): a stream it cannot certify is LISTED after the call,
+    its results are withheld, and running that stream's input on an exact handle gives the reference's bits, counters
+    and FEC bytes for the call"""
+    monkeypatch.setenv("JSDR_FAST_ARGMAX_SCALE", "1e14")  # every argmax falls inside the (widened) margin
+    p = STREAMS["clean"]
+    n = 458752
+    raw = stream_input("clean")[:2 * n]
+    quiet = np.zeros(2 * n, np.int16)  # silence: all eight energies exactly 0.0 in both variants, nothing to certify
+    d = J.Bpsk(rate=p["rate"], blen=8192, tuning=p["tuning"], nstreams=3, max_batch_samples=n, variant="fast")
+    d_in = J.DeviceBuffer.from_host(np.concatenate([raw, quiet, raw]))
+    d.batch_i16(d_in, 2 * n, n)
+    flagged = d.uncertified_streams()
+    assert flagged == [0, 2] and d.cert_stats()["streams_uncertified"] == 2
+    assert len(d.bits(1)) == 0  # the certified stream's results ARE delivered
+    monkeypatch.delenv("JSDR_FAST_ARGMAX_SCALE")
+    ex = J.Bpsk(rate=p["rate"], blen=8192, tuning=p["tuning"], nstreams=len(flagged), max_batch_samples=n, variant="exact")
+    assert ex.uncertified_streams() == []
+    ex.batch_i16(J.DeviceBuffer.from_host(np.concatenate([raw] * len(flagged))), 2 * n, n)
+    o = O.Bpsk(rate=p["rate"], blen=8192, tuning=p["tuning"])
+    o.receive_i16(raw)
+    for i in range(len(flagged)):
+        assert np.array_equal(ex.bits(i), o.bits())
+        assert ex.counters(i)["cntBit"] == o.counters()["cntBit"]
+        fg, fo = ex.fec_results(i), o.fec_results()
+        assert len(fg) == len(fo) and all(a[0] == b[0] and np.array_equal(a[2], b[2]) for a, b in zip(fg, fo))
+
+
 def test_fast_variant_is_tune_mode_only():
     with pytest.raises(J.JsdrError):
         J.Bpsk(nstreams=1, do_fft=1, variant="fast")
