@@ -18,7 +18,7 @@ step() { # name timeout cmd...
   if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "TIMEOUT in $name: stopping" | tee -a $O/session.log; exit 99; fi
   if grep -q "Memory access fault" "$O/${T}_$name.log"; then echo "GPU FAULT in $name: stopping" | tee -a $O/session.log; exit 98; fi
 }
-step bench 400 python bench.py
+step bench 500 python bench.py --steps 20 --warmup 5
 line $O/${T}_bench.log > $O/${T}_bench.json
 rm -rf $O/prof_$T $O/pmc_rd_$T $O/pmc_wr_$T
 step prof 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$T -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline
@@ -50,5 +50,14 @@ step b_fir 300 python bench.py --workload fir $B;                        line $O
 step b_1k 300 python bench.py --streams 1024 $B;                         line $O/${T}_b_1k.log > $O/${T}_b_1k.json
 step b_acq 300 python bench.py --workload bpsk --fft-acquire --streams 1024 $B;                    line $O/${T}_b_acq.log > $O/${T}_b_acq.json
 step b_acq9600 300 python bench.py --workload bpsk --fft-acquire --bpsk-frame 9600 --streams 1024 $B;  line $O/${T}_b_acq9600.log > $O/${T}_b_acq9600.json
+step b_acq19200 300 python bench.py --workload bpsk --fft-acquire --bpsk-frame 19200 --streams 1024 $B;  line $O/${T}_b_acq19200.log > $O/${T}_b_acq19200.json
+# FFT-acquire at the reference's default frame, all 8192 streams, every stream validated by payload
+step b_acq9600_8k 500 python bench.py --workload bpsk --fft-acquire --bpsk-frame 9600 $B;  line $O/${T}_b_acq9600_8k.log > $O/${T}_b_acq9600_8k.json
+step b_fir65 300 python bench.py --workload fir --fir-taps 65 --streams 1024 $B;  line $O/${T}_b_fir65.log > $O/${T}_b_fir65.json
+step b_fir65_1 300 python bench.py --workload fir --fir-taps 65 --fir-decim 1 --streams 1024 $B;  line $O/${T}_b_fir65_1.log > $O/${T}_b_fir65_1.json
+# the N > 1 path from the bare command on this one-GPU box: two ranks on device 0, gloo in RCCL's place (rehearsal knobs)
+JSDR_BENCH_SAME_DEVICE=1 JSDR_BENCH_BACKEND=gloo step b_n2_rehearsal 400 python bench.py --gpus 2 --streams 512 --steps 5 --warmup 2 $B
+line $O/${T}_b_n2_rehearsal.log > $O/${T}_b_n2_rehearsal.json
+step latency 200 python tools/latency_bench.py; cp $O/${T}_latency.log $O/${T}_single_stream_latency.txt
 rm -f $O/${T}_*.log.tmp
 echo "profile set $T done" | tee -a $O/session.log
