@@ -757,6 +757,10 @@ __global__ __launch_bounds__(64) void k_dm_history(double2 *dm, long long dm_str
 //            same pass; the VCO table indices come in with the window and their table reads are issued under the last
 //            quad's arithmetic.
 //   matched: as k_matched, from the LDS image.
+// (Compile-time timing probes, never defined in the product build (java-sdr_amd/build.py): each of them only REMOVES
+// work -- a half of the kernel, a load, a store, a barrier -- and none changes an address that is still accessed; the
+// one probe that did (JSDR_X_COAL, round 2) faulted and was deleted.  A probe that needs "wrong data" keeps the
+// kernel's own bounds.)
 // Where the time goes (2048 streams x 2^20 samples, alone, tools/build_define.sh with -DJSDR_X_NOFRONT / _NOMATCHED /
 // _CLK): front half 2.15 ms + matched half 2.12 ms = the kernel's 4.3-4.4 ms; the matched half issues FP64 at ~95 % of
 // the chip's measured rate, the front half at ~80 % (1.94 ms with its window loads replaced by constants: the loads'
@@ -2499,8 +2503,7 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
         fa2.nstreams = S;
         fa2.dec_scratch = h->fec_scratch.p;
         ProfScope ps(h, PK_FEC, ts);
-        static const bool skip_fec = getenv("JSDR_EXPERIMENT_SKIP_FEC") != nullptr;  // timing experiment only
-        if (!skip_fec && launch_fec_bpsk(fa2, ts) != JSDR_OK) return JSDR_ERR;
+        if (launch_fec_bpsk(fa2, ts) != JSDR_OK) return JSDR_ERR;
     }
     if (h->overlap) {
         JSDR_HIP_TRY(hipEventRecord(h->ev_tail_done[yb], ts));

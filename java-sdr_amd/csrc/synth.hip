@@ -1,6 +1,7 @@
 // synth.hip -- on-device synthetic IQ generators (bench / tests).  NOT part of the reference: java-sdr's
 // only signal source is a sound card.  Integer arithmetic on a counter-based hash, bit-identical to
-// oracle/o_synth.c by construction (tests/test_gpu_synth.py), so that multi-GB inputs never cross PCIe.
+// oracle/o_synth.c by construction (tests/test_gpu_fir_phase_fec.py::test_synth_generators_bit_identical_to_oracle), so
+// that multi-GB inputs never cross PCIe.
 #include "common.h"
 
 namespace jsdr {

@@ -39,7 +39,6 @@ for step in "$@"; do
     bench_acq9600) run bench_acq9600 400 python bench.py --workload bpsk --fft-acquire --bpsk-frame 9600 --steps 3 --warmup 1 --no-cpu-baseline ;;
     bench_acq_clk) JSDR_FFT_PHASECLK=1 run bench_acq_clk 400 python bench.py --workload bpsk --fft-acquire --steps 2 --warmup 1 --no-cpu-baseline ;;
     bench_n2)    JSDR_BENCH_SAME_DEVICE=1 JSDR_BENCH_BACKEND=gloo run bench_n2 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 3 --warmup 1 --streams 256 ;;
-    bench_nofec) JSDR_EXPERIMENT_SKIP_FEC=1 run bench_nofec 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-validate ;;
     bench_reg_alone) JSDR_NO_OVERLAP=1 run bench_reg_alone 300 python bench.py --workload bpsk --steps 5 --warmup 2 --no-cpu-baseline ;;
     bench_reg) run bench_reg 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline ;;
     bench_m64) JSDR_FFT_GRID_MULT=64 run bench_m64 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline ;;
