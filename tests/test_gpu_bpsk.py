@@ -321,6 +321,24 @@ def test_bpsk_fft_mode_at_the_fcd_pro_plus_default_frame_19200():
     run_both([iq], 15360 * 6, [15360 * 2, 15360 * 4], rate=rate, do_fft=1, blen=4 * 15360)
 
 
+@pytest.mark.parametrize("blen,rate,do_up,carrier", [(38400, 96000, 0, 23300.0), (38400, 96000, 1, 47100.0), (38400, 96000, 1, 24300.0),
+                                                     (19200, 48000, 1, 23300.0), (19200, 48000, 0, 11300.0),
+                                                     (76800, 192000, 0, 47300.0), (76800, 192000, 1, 95100.0)])
+def test_bpsk_fft_mode_default_frames_carrier_at_the_band_edges(blen, rate, do_up, carrier):
+    """round 3's pruned passes (bpsk_fftm.hip: fm_pass5_band forms only the bins below end + 102, fm_inv_blocks builds the
+    inverse's first three passes from the 204 gathered bins): a carrier near the edges of the searched band puts the
+    gathered bins at the rim of what is formed; a noise-only stream lets the centre bin wander; every trace, state double
+    and bit must still equal the oracle's"""
+    nsf = blen // 4
+    n = nsf * 12
+    iq = O.make_dbpsk_stream(83, 0, n, rate=rate, carrier_hz=carrier, noise_sigma=500.0)[0]
+    rng = np.random.default_rng(int(carrier) + do_up)
+    noise = rng.integers(-15000, 15000, 2 * n).astype(np.int16)
+    d, oracles = run_both([iq, noise], n, [nsf * 5, nsf * 7], rate=rate, do_fft=1, do_up=do_up, blen=blen)
+    # the carrier at the rim of the band was acquired (the boxcar search stops 75 bins short of the band's edges, :433-443)
+    assert abs(oracles[0].counters()["centreBin"] - carrier / (rate / nsf)) <= 60
+
+
 def test_bpsk_fft_mode_other_mixed_radix_frames():
     """frames of 2^a 3^b 5^c samples other than the two defaults go through the run-time (unspecialised) Stockham passes
     and pass pairs: 7680 = 4.4.4.4.2.3.5 -> [4][4,4][4,2][3,5], 1440 = 4.4.2.3.3.5 -> [4][4,2][3][3,5], 1200 = 4.4.3.5.5"""
