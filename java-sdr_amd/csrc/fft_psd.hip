@@ -171,7 +171,8 @@ __device__ __forceinline__ void fft_pass(const FftArgs &a, long long frame, bool
                         float2 x = v[gi][cx_bitrev(r, R)];
                         db[r] = L2 * __log2f(x.x * x.x + x.y * x.y) + OFF;
 #ifndef JSDR_X_FFT_NOSTORE  // timing experiment: no PSD stores (the argmax keeps the arithmetic alive)
-                        dst[j0 + r * P] = db[r];  // (nontemporal stores: 1.99 -> 2.39 ms, measured r02)
+                        dst[j0 + r * P] = db[r];  // (nontemporal stores: 1.99 -> 2.39 ms, measured r02; 8-byte stores through a DPP
+                                                  //  exchange between neighbouring lanes: 15.5 -> 16.1 ms at 8192 streams, r03)
 #endif
                     }
                     // first strict maximum of this thread's bins (fft.java:208-211): the group's maximum
