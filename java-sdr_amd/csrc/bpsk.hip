@@ -838,6 +838,46 @@ __global__ void k_fm_edges(EdgeArgs a)
     a.edges[(long long)s * (4 * FM_EDGE) + i] = w;
 }
 
+// k_fm_edges and k_hist_in in ONE launch (the k_fm path): both only read the call's input and the previous call's history,
+// and write disjoint buffers (the edge images, the next call's history) -- one dependent launch less per call.
+__global__ void k_fm_prep(EdgeArgs e, HistArgs hi)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nedge = e.nstreams * 4 * FM_EDGE;
+    if (t < nedge) {
+        const int s = t / (4 * FM_EDGE), i = t % (4 * FM_EDGE);
+        const int n = i < 2 * FM_EDGE ? i - FM_EDGE : e.nsamples - FM_EDGE + (i - 2 * FM_EDGE);
+        int w = 0;
+        if (n >= 0 && n < e.nsamples) {
+            w = e.raw[(long long)s * e.stride_pairs + n];
+        } else if (n < 0 && n >= -26) {
+            w = e.hist[(long long)s * 32 + 26 + n].x;
+            if (e.dc) {
+                const int si = (int)(short)((w & 0xffff) - e.ic);
+                const int sq = (int)(short)((w >> 16) - e.qc);
+                w = (si & 0xffff) | (sq << 16);
+            }
+        }
+        e.edges[(long long)s * (4 * FM_EDGE) + i] = w;
+        return;
+    }
+    // ---- k_hist_in's part (int16 input only on this path)
+    const int u = t - nedge;
+    const int s = u >> 5, i = u & 31;
+    if (s >= hi.nstreams || i >= 26) return;
+    const long long n = hi.nsamples - 26 + i;
+    int2 v;
+    if (n < 0) {
+        v = hi.hist_old[(long long)s * 32 + (26 + n)];
+    } else {
+        const int w = hi.raw[(long long)s * hi.stride_pairs + n];
+        const int si = java_short_add((int)(short)(w & 0xffff), hi.ic);
+        const int sq = java_short_add(w >> 16, hi.qc);
+        v = make_int2((si & 0xffff) | (sq << 16), 0);
+    }
+    hi.hist_new[(long long)s * 32 + i] = v;
+}
+
 template <int D, int R, bool MIX, bool DC, bool FAST>
 #ifndef JSDR_FM_MINWAVES
 #define JSDR_FM_MINWAVES 2
@@ -1571,13 +1611,29 @@ __global__ void k_sync(SyncArgs a)
 // b mod 80 from column b div 80 -- eighteen aligned dword reads, a byte alignment and seventeen v_dot4_i32_i8 against
 // the packed sync vector instead of 65 strided byte loads and 65 multiply-adds (integer arithmetic: same sums).  One
 // workgroup per stream; the row stride is 4 * odd so that the rows of 32 consecutive outputs fall on 32 different banks.
-__global__ __launch_bounds__(256) void k_sync_t(SyncArgs a, int row_stride)
+// Its first wave then orders the hits and leaves dmCorr / dmMaxCorr (sync_fin_wave below; a kernel of its own until
+// round 3: one dependent launch less per call): the workgroup's correlations are read back from global memory behind a
+// device-scope release / acquire pair around the barrier.
+struct SyncFinArgs {
+    int *trig_count, *trig_bits;
+    int trig_cap;
+    TailState *st;
+    int fuse;  // 1: this kernel orders the hits itself (short calls: one dependent launch less); 0: k_sync_fin follows --
+               // for a long call the scan is a chain of L2 round trips that one wave walks while the workgroup's LDS
+               // image and its other three waves' registers stay allocated (measured at 8192 x 2^20: the step +4 ms)
+};
+__device__ __forceinline__ void sync_fin_wave(int s, int lane, int nb, const signed char *c, int *trig_count, int *trig_bits,
+                                              int trig_cap, TailState *st);
+__global__ __launch_bounds__(256) void k_sync_t(SyncArgs a, int row_stride, SyncFinArgs f)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     signed char *T = reinterpret_cast<signed char *>(smem);  // [80][row_stride]
     const int s = blockIdx.x;
     const int nb = a.nbits[s];
-    if (nb <= 0) return;
+    if (nb <= 0) {  // no new bit: no hit, dmCorr / dmMaxCorr stay (what sync_fin_wave does with nb = 0)
+        if (f.fuse && threadIdx.x == 0) f.trig_count[s] = 0;
+        return;
+    }
     const signed char *W = a.bitlog + (long long)s * a.bitlog_stride + 1;
     const int np = HIST_BITS - 1 + nb;  // W[0 .. np): the last window ends at W[nb-1 + 80*64]
     {
@@ -1626,6 +1682,13 @@ __global__ __launch_bounds__(256) void k_sync_t(SyncArgs a, int row_stride)
             }
         }
     }
+    if (!f.fuse) return;  // (uniform)
+    __threadfence();  // release: every wave's correlations are visible device-wide ...
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        __threadfence();  // ... acquire: and read from there, not from a stale L1 line
+        sync_fin_wave(s, (int)threadIdx.x, nb, a.corr + (long long)s * a.max_bits, f.trig_count, f.trig_bits, f.trig_cap, f.st);
+    }
 }
 
 // the hits (correlation >= 45, :560) in bit order -- one wave per stream walks the correlations 64 at a time, a ballot
@@ -1633,13 +1696,9 @@ __global__ __launch_bounds__(256) void k_sync_t(SyncArgs a, int row_stride)
 // for it is the FIRST trig_cap that are kept (the stream is flagged; the getters then fail instead of returning a
 // truncated result).  Then dmCorr / dmMaxCorr exactly as the serial loop leaves them (:556-572): after a hit dmMaxCorr
 // restarts from 0 (:567) and immediately takes that bit's correlation (:571-572).
-__global__ __launch_bounds__(64) void k_sync_fin(const int *nbits, const signed char *corr, int max_bits, int *trig_count,
-                                                 int *trig_bits, int trig_cap, TailState *st, int nstreams)
+__device__ __forceinline__ void sync_fin_wave(int s, int lane, int nb, const signed char *c, int *trig_count, int *trig_bits,
+                                              int trig_cap, TailState *st)
 {
-    const int s = blockIdx.x, lane = threadIdx.x;
-    if (s >= nstreams) return;
-    const int nb = nbits[s];
-    const signed char *c = corr + (long long)s * max_bits;
     int nt = 0, last_hit = -1;
     for (int b0 = 0; b0 < nb; b0 += 64) {
         const int b = b0 + lane;
@@ -1673,6 +1732,15 @@ __global__ __launch_bounds__(64) void k_sync_fin(const int *nbits, const signed 
         }
         trig_count[s] = nt;
     }
+}
+
+// after the strided k_sync (the fallback for calls whose bit log does not fit a workgroup's LDS); k_sync_t does this itself
+__global__ __launch_bounds__(64) void k_sync_fin(const int *nbits, const signed char *corr, int max_bits, int *trig_count,
+                                                 int *trig_bits, int trig_cap, TailState *st, int nstreams)
+{
+    const int s = blockIdx.x, lane = threadIdx.x;
+    if (s >= nstreams) return;
+    sync_fin_wave(s, lane, nbits[s], corr + (long long)s * max_bits, trig_count, trig_bits, trig_cap, st);
 }
 
 }  // namespace jsdr
@@ -1778,6 +1846,14 @@ struct jsdr_bpsk {
     DevBuf<signed char> corr;
     DevBuf<unsigned char> fec_data, decoded;
     DevBuf<unsigned long long> fec_scratch;  // Viterbi decision words of every (stream, hit) block
+    DevBuf<int> fec_done;                    // [S] k_fec_bpsk's per-stream count of finished blocks (zero between launches)
+    // receive_*() of a 1-stream handle: every host<->device copy of the call goes through ONE pinned arena (the frame in,
+    // the schedule's tables when they change, the packed results out).  A copy from / to pageable memory is staged by the
+    // runtime and costs a multiple of the transfer; the arena is reused every call, which is safe because receive()
+    // synchronises before it returns.  Batch calls (asynchronous, caller-owned streams) keep the pageable path.
+    unsigned char *pin = nullptr;
+    size_t pin_bytes = 0, pin_off = 0;
+    bool pin_call = false;
     DevBuf<int> stage_raw;  // one frame for receive_*()
     DevBuf<FftFrontState> fft_state;  // FFT-acquire mode only
     DevBuf<double2> fft_tw;
@@ -2149,6 +2225,22 @@ static int launch_fm(const FmArgs &a, int decim, bool mix, bool dc, bool fast, i
 static int sync_last(jsdr_bpsk *h);
 static int publish_snapshot(jsdr_bpsk *h);
 
+// host -> device copy of a call's input or tables: through the pinned arena inside receive_*(), pageable otherwise
+static int h2d_call(jsdr_bpsk *h, void *dst_dev, const void *src_host, size_t bytes, hipStream_t st)
+{
+    if (h->pin_call && h->pin) {
+        const size_t off = (h->pin_off + 63) & ~(size_t)63;
+        if (off + bytes <= h->pin_bytes) {
+            memcpy(h->pin + off, src_host, bytes);
+            h->pin_off = off + bytes;
+            JSDR_HIP_TRY(hipMemcpyAsync(dst_dev, h->pin + off, bytes, hipMemcpyHostToDevice, st));
+            return JSDR_OK;
+        }
+    }
+    JSDR_HIP_TRY(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, st));
+    return JSDR_OK;
+}
+
 static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev, long long stride_i16, long long L,
                     int ic, int qc, hipStream_t st)
 {
@@ -2208,20 +2300,20 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
     const bool need_ktu = !h->do_fft && !fm_ok && !(per_ok && reg_will_run) && h->mix != 0;
     if (need_ktu && (!h->ktu_uploaded || kshift != h->c_kshift)) {
         h->c_kshift = kshift;
-        JSDR_HIP_TRY(hipMemcpyAsync(h->ktu.p + kshift, h->h_ktu.data(), (size_t)L + 26, hipMemcpyHostToDevice, st));
+        if (h2d_call(h, h->ktu.p + kshift, h->h_ktu.data(), (size_t)L + 26, st) != JSDR_OK) return JSDR_ERR;
         h->ktu_uploaded = true;
     }
     if (fresh) {
         if (nds > 0)
-            JSDR_HIP_TRY(hipMemcpyAsync(kvco_p, h->h_kvco.data(), (size_t)nds, hipMemcpyHostToDevice, st));
+            if (h2d_call(h, kvco_p, h->h_kvco.data(), (size_t)nds, st) != JSDR_OK) return JSDR_ERR;
         if (nds > 0 && h->do_fft) {
             h->h_vco_cs.resize((size_t)nds);
             for (long long j = 0; j < nds; j++)
                 h->h_vco_cs[(size_t)j] = make_double2(h->h_sincos[h->h_kvco[(size_t)j]], h->h_sincos[256 + h->h_kvco[(size_t)j]]);
-            JSDR_HIP_TRY(hipMemcpyAsync(h->vco_cs.p, h->h_vco_cs.data(), sizeof(double2) * (size_t)nds, hipMemcpyHostToDevice, st));
+            if (h2d_call(h, h->vco_cs.p, h->h_vco_cs.data(), sizeof(double2) * (size_t)nds, st) != JSDR_OK) return JSDR_ERR;
         }
         if (h->c_tper > 0)
-            JSDR_HIP_TRY(hipMemcpyAsync(tcs_p, h->h_tcs.data(), sizeof(double2) * h->h_tcs.size(), hipMemcpyHostToDevice, st));
+            if (h2d_call(h, tcs_p, h->h_tcs.data(), sizeof(double2) * h->h_tcs.size(), st) != JSDR_OK) return JSDR_ERR;
         // the host vectors must stay untouched until the copies ran; pageable memcpyAsync stages
         // synchronously, so they are safe to reuse on return
         h->cache_valid = true;
@@ -2256,6 +2348,7 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
     fa.first_out = first_out;
     fa.tcs = per_ok ? tcs_p : nullptr;
     fa.tper = h->c_tper;
+    bool hist_done = false;  // the next call's input history has been written (k_fm_prep does it in the k_fm path)
     if (h->do_fft) {
         FftFrontArgs xa;
         xa.raw = fa.raw;
@@ -2319,8 +2412,20 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
             ea.hist = fa.hist;
             ea.edges = h->fm_edges.p;
             ea.nstreams = S;
-            hipLaunchKernelGGL(k_fm_edges, dim3((unsigned)(((long long)S * 4 * FM_EDGE + 255) / 256)), dim3(256), 0, st, ea);
+            HistArgs ha;  // the next call's 26-sample input history, in the same launch (k_hist_in's work)
+            ha.raw = fa.raw;
+            ha.rawf = nullptr;
+            ha.stride_pairs = fa.stride_pairs;
+            ha.nsamples = L;
+            ha.ic = ic;
+            ha.qc = qc;
+            ha.hist_old = h->hist_in[h->hist_cur].p;
+            ha.hist_new = h->hist_in[h->hist_cur ^ 1].p;
+            ha.nstreams = S;
+            ProfScope psh(h, PK_HIST, st);
+            hipLaunchKernelGGL(k_fm_prep, dim3((unsigned)(((long long)S * (4 * FM_EDGE + 32) + 255) / 256)), dim3(256), 0, st, ea, ha);
             JSDR_LAUNCH_CHECK();
+            hist_done = true;
         }
         ProfScope ps(h, PK_FM, st);
         h->front_name = "k_fm";
@@ -2352,7 +2457,8 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
         }
         JSDR_LAUNCH_CHECK();
     }
-    if (!h->do_fft) {
+    if (!h->do_fft && hist_done) h->hist_cur ^= 1;
+    if (!h->do_fft && !hist_done) {
         HistArgs ha;
         ha.raw = fa.raw;
         ha.rawf = fa.rawf;
@@ -2477,18 +2583,31 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
                     JSDR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sync_t), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                     attr_for = lds;
                 }
-                hipLaunchKernelGGL(k_sync_t, dim3((unsigned)S), dim3(256), lds, ts, sa, rs);
+                SyncFinArgs sf;
+                sf.trig_count = h->trig_count.p;
+                sf.trig_bits = h->trig_bits.p;
+                sf.trig_cap = h->trig_cap;
+                sf.st = h->tail.p;
+                // (the hand-over inside the workgroup is a device-scope release / acquire pair: an L2 write-back per
+                //  workgroup on this multi-XCD part -- nothing for one stream, a tax beside the PSD kernel for thousands)
+                sf.fuse = (S == 1 && nds <= 16384) ? 1 : 0;  // at most ~2000 new bits: the scan is a few dozen iterations
+                hipLaunchKernelGGL(k_sync_t, dim3((unsigned)S), dim3(256), lds, ts, sa, rs, sf);
+                JSDR_LAUNCH_CHECK();
+                if (!sf.fuse) {
+                    ProfScope ps2(h, PK_SYNCFIN, ts);
+                    hipLaunchKernelGGL(k_sync_fin, dim3((unsigned)S), dim3(64), 0, ts, h->nbits.p, h->corr.p, h->max_bits,
+                                       h->trig_count.p, h->trig_bits.p, h->trig_cap, h->tail.p, S);
+                    JSDR_LAUNCH_CHECK();
+                }
             } else {
                 hipLaunchKernelGGL(k_sync, dim3((unsigned)gx, (unsigned)S), dim3(256), 0, ts, sa);
+                JSDR_LAUNCH_CHECK();
+                ProfScope ps2(h, PK_SYNCFIN, ts);
+                hipLaunchKernelGGL(k_sync_fin, dim3((unsigned)S), dim3(64), 0, ts, h->nbits.p, h->corr.p, h->max_bits,
+                                   h->trig_count.p, h->trig_bits.p, h->trig_cap, h->tail.p, S);
+                JSDR_LAUNCH_CHECK();
             }
         }
-        JSDR_LAUNCH_CHECK();
-        {
-            ProfScope ps(h, PK_SYNCFIN, ts);
-            hipLaunchKernelGGL(k_sync_fin, dim3((unsigned)S), dim3(64), 0, ts, h->nbits.p, h->corr.p, h->max_bits,
-                               h->trig_count.p, h->trig_bits.p, h->trig_cap, h->tail.p, S);
-        }
-        JSDR_LAUNCH_CHECK();
         BpskFecArgs fa2;
         fa2.bitlog = h->bitlog[h->bitlog_cur].p;
         fa2.bitlog_stride = h->bitlog_stride;
@@ -2502,6 +2621,8 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
         fa2.cnt_dec = h->cnt_dec.p;
         fa2.nstreams = S;
         fa2.dec_scratch = h->fec_scratch.p;
+        fa2.done = h->fec_done.p;
+        fa2.fuse = (S == 1) ? 1 : 0;
         ProfScope ps(h, PK_FEC, ts);
         if (launch_fec_bpsk(fa2, ts) != JSDR_OK) return JSDR_ERR;
     }
@@ -2561,6 +2682,9 @@ int jsdr_bpsk_create(jsdr_bpsk **out, int rate, int nsamples_per_frame, int tuni
     h->tuPhaseInc = 2.0 * JPI * (double)tuning_hz / (double)rate;  // :196
     while ((1 << h->logn) < nsamples_per_frame) h->logn++;
     if (do_fft) h->max_batch = (h->max_batch / nsamples_per_frame) * nsamples_per_frame;
+    // one stream (the receive() drop-in): nothing of another stream to run beside the tail, and the hop to the side
+    // stream costs a cross-stream event per call
+    if (nstreams == 1) h->overlap = false;
     if (const char *e = getenv("JSDR_NO_OVERLAP")) h->overlap = atoi(e) == 0;
     if (const char *e = getenv("JSDR_FM")) h->use_fm = atoi(e) != 0;
     if (const char *e = getenv("JSDR_SCHED_PREFETCH")) h->prefetch_on = atoi(e) != 0;
@@ -2575,7 +2699,7 @@ int jsdr_bpsk_create(jsdr_bpsk **out, int rate, int nsamples_per_frame, int tuni
               h->bitlog[0].alloc(S * (size_t)h->bitlog_stride) == JSDR_OK &&
               h->bitlog[1].alloc(S * (size_t)h->bitlog_stride) == JSDR_OK && h->nbits.alloc(S) == JSDR_OK &&
               h->trig_count.alloc(S) == JSDR_OK && h->trig_bits.alloc(S * h->trig_cap) == JSDR_OK &&
-              h->fec_scratch.alloc(S * h->trig_cap * (size_t)fec_dec_scratch_words()) == JSDR_OK &&
+              h->fec_scratch.alloc(S * h->trig_cap * (size_t)fec_dec_scratch_words()) == JSDR_OK && h->fec_done.alloc(S) == JSDR_OK &&
               h->fec_rc.alloc(S * h->trig_cap) == JSDR_OK && h->fec_last.alloc(S * 2) == JSDR_OK &&
               h->cnt_dec.alloc(S) == JSDR_OK && h->corr.alloc(S * (size_t)h->max_bits) == JSDR_OK &&
               h->fec_data.alloc(S * h->trig_cap * 256) == JSDR_OK && h->decoded.alloc(S * 256) == JSDR_OK &&
@@ -2586,6 +2710,19 @@ int jsdr_bpsk_create(jsdr_bpsk **out, int rate, int nsamples_per_frame, int tuni
               (!(do_fft && fft2x_supported(nsamples_per_frame)) ||
                (h->fft2x_ek.alloc(S * fft2x_scratch_ek(nsamples_per_frame)) == JSDR_OK &&
                 h->fft2x_r0.alloc(S * fft2x_scratch_r0(nsamples_per_frame)) == JSDR_OK));
+    if (ok && nstreams == 1) {
+        // [frame | ktu | kvco | vco_cs | tcs] + alignment slack, then the SnapPack slot (not handed out by h2d_call)
+        const size_t need = sizeof(float) * 2 * (size_t)nsamples_per_frame + ((size_t)h->max_batch + 26) + (size_t)h->max_ds +
+                            (do_fft ? sizeof(double2) * (size_t)h->max_ds : 0) + sizeof(double2) * (256 + FM_TABLE_SLACK) + 8 * 64;
+        const size_t arena = (need + 63) & ~(size_t)63;
+        void *pp = nullptr;
+        if (arena <= ((size_t)8 << 20) && hipHostMalloc(&pp, arena + sizeof(SnapPack), hipHostMallocDefault) == hipSuccess) {
+            h->pin = static_cast<unsigned char *>(pp);
+            h->pin_bytes = arena;
+        } else {
+            (void)hipGetLastError();  // no pinned memory: the pageable path serves
+        }
+    }
     if (!ok) {
         jsdr_bpsk_destroy(h);
         return JSDR_ERR;
@@ -2674,7 +2811,7 @@ int jsdr_bpsk_create(jsdr_bpsk **out, int rate, int nsamples_per_frame, int tuni
               h->hist_in[0].zero() == JSDR_OK && h->hist_in[1].zero() == JSDR_OK && h->dm.zero() == JSDR_OK &&
               h->dmh[0].zero() == JSDR_OK && h->dmh[1].zero() == JSDR_OK && h->tcs.zero() == JSDR_OK && h->amax.zero() == JSDR_OK &&
               h->bitlog[0].zero() == JSDR_OK && h->bitlog[1].zero() == JSDR_OK && h->decoded.zero() == JSDR_OK &&
-              h->nbits.zero() == JSDR_OK && h->trig_count.zero() == JSDR_OK && h->fec_last.zero() == JSDR_OK &&
+              h->nbits.zero() == JSDR_OK && h->trig_count.zero() == JSDR_OK && h->fec_last.zero() == JSDR_OK && h->fec_done.zero() == JSDR_OK &&
               h->cnt_dec.zero() == JSDR_OK && h->y[0].zero() == JSDR_OK && h->y[1].zero() == JSDR_OK &&
               hipStreamCreateWithFlags(&h->tail_stream, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreateWithFlags(&h->ev_matched, hipEventDisableTiming) == hipSuccess &&
@@ -2729,6 +2866,9 @@ int jsdr_bpsk_destroy(jsdr_bpsk *h)
     h->corr.release();
     h->fec_data.release();
     h->fec_scratch.release();
+    h->fec_done.release();
+    if (h->pin) (void)hipHostFree(h->pin);
+    h->pin = nullptr;
     h->decoded.release();
     h->stage_raw.release();
     h->fft_state.release();
@@ -2797,10 +2937,15 @@ int jsdr_bpsk_receive_i16(jsdr_bpsk *h, const int16_t *raw_host, int ic, int qc)
     JSDR_REQUIRE(h && raw_host, "jsdr_bpsk_receive_i16: null argument");
     JSDR_REQUIRE(h->nstreams == 1, "jsdr_bpsk_receive_i16: handle has %d streams; receive() is the 1-stream form",
                  h->nstreams);
-    JSDR_HIP_TRY(hipMemcpy(h->stage_raw.p, raw_host, sizeof(int16_t) * 2 * (size_t)h->nsf, hipMemcpyHostToDevice));
-    if (bpsk_run(h, reinterpret_cast<const int16_t *>(h->stage_raw.p), nullptr, 2LL * h->nsf, h->nsf, ic, qc, 0) != JSDR_OK)
-        return JSDR_ERR;
-    return publish_snapshot(h);
+    h->pin_call = true;
+    h->pin_off = 0;
+    int rc = h2d_call(h, h->stage_raw.p, raw_host, sizeof(int16_t) * 2 * (size_t)h->nsf, 0);
+    if (rc == JSDR_OK)
+        rc = bpsk_run(h, reinterpret_cast<const int16_t *>(h->stage_raw.p), nullptr, 2LL * h->nsf, h->nsf, ic, qc, 0);
+    if (rc == JSDR_OK) rc = publish_snapshot(h);  // synchronises: the arena is free again
+    else (void)hipDeviceSynchronize();            // (a failed call: nothing may still be reading the arena)
+    h->pin_call = false;
+    return rc;
 }
 
 int jsdr_bpsk_receive_f32(jsdr_bpsk *h, const float *iq_host)
@@ -2808,10 +2953,14 @@ int jsdr_bpsk_receive_f32(jsdr_bpsk *h, const float *iq_host)
     JSDR_REQUIRE(h && iq_host, "jsdr_bpsk_receive_f32: null argument");
     JSDR_REQUIRE(h->nstreams == 1, "jsdr_bpsk_receive_f32: handle has %d streams; receive() is the 1-stream form",
                  h->nstreams);
-    JSDR_HIP_TRY(hipMemcpy(h->stage_raw.p, iq_host, sizeof(float) * 2 * (size_t)h->nsf, hipMemcpyHostToDevice));
-    if (bpsk_run(h, nullptr, reinterpret_cast<const float *>(h->stage_raw.p), 2LL * h->nsf, h->nsf, 0, 0, 0) != JSDR_OK)
-        return JSDR_ERR;
-    return publish_snapshot(h);
+    h->pin_call = true;
+    h->pin_off = 0;
+    int rc = h2d_call(h, h->stage_raw.p, iq_host, sizeof(float) * 2 * (size_t)h->nsf, 0);
+    if (rc == JSDR_OK) rc = bpsk_run(h, nullptr, reinterpret_cast<const float *>(h->stage_raw.p), 2LL * h->nsf, h->nsf, 0, 0, 0);
+    if (rc == JSDR_OK) rc = publish_snapshot(h);
+    else (void)hipDeviceSynchronize();
+    h->pin_call = false;
+    return rc;
 }
 
 // ---- the 1-stream receive() forms publish their results for a concurrent reader (jsdr_bpsk_snapshot_read).  What the
@@ -2877,10 +3026,13 @@ static int publish_snapshot(jsdr_bpsk *h)
                        h->nbits.p, h->do_fft ? h->fft_state.p : (const FftFrontState *)nullptr, h->decoded.p,
                        h->bitlog[h->bitlog_cur].p + HIST_BITS);
     JSDR_LAUNCH_CHECK();
-    SnapPack pk;
-    JSDR_HIP_TRY(hipMemcpyAsync(&pk, h->snap_dev.p, sizeof(pk), hipMemcpyDeviceToHost, ts));
+    SnapPack pk_stack;
+    // (the arena's last slot: reserved at create, never handed out by h2d_call)
+    SnapPack *pkp = h->pin ? reinterpret_cast<SnapPack *>(h->pin + h->pin_bytes) : &pk_stack;
+    JSDR_HIP_TRY(hipMemcpyAsync(pkp, h->snap_dev.p, sizeof(SnapPack), hipMemcpyDeviceToHost, ts));
     if (sync_last(h) != JSDR_OK) return JSDR_ERR;
     JSDR_HIP_TRY(hipStreamSynchronize(ts));
+    const SnapPack &pk = *pkp;
     // what the getters refuse, the snapshot refuses (check_overflow)
     JSDR_REQUIRE(!pk.t.overflow, "receive: stream 0 exceeded its per-call capacity (%d bits / %d FEC calls per call of at most %lld samples)",
                  h->max_bits, h->trig_cap, h->max_batch);

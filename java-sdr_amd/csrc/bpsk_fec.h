@@ -20,6 +20,11 @@ struct BpskFecArgs {
     int *cnt_dec;               // [nstreams] cntDec (:569)
     int nstreams;
     unsigned long long *dec_scratch;  // [nstreams][max_trig][fec_dec_scratch_words()] Viterbi decision words
+    int *done;                  // [nstreams] blocks of the stream that have finished in this launch; zero before and after
+    int fuse;                   // 1: the stream's last block runs stage 2 itself (one launch less: the 1-stream receive() form);
+                                // 0: k_fec_fin follows -- the hand-over needs a DEVICE-scope release per block, which on this
+                                // multi-XCD part writes the XCD's L2 back: 20 000 of them beside the PSD kernel cost the
+                                // 8192-stream step 1.8 ms (measured, one session)
 };
 
 int launch_fec_bpsk(const BpskFecArgs &a, hipStream_t st);

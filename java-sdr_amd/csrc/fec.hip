@@ -631,8 +631,36 @@ __global__ __launch_bounds__(64) void k_fec_encode(const unsigned char *__restri
     }
 }
 
-// BPSK hook, stage 1: one wave per (stream, sync hit).  Build the soft block from the +1/-1/0 bit history
-// (FUNcubeBPSKDemod.java:562-564) and decode; payload (on success) and rc go to the per-hit log.
+// stage 2 of the BPSK hook, per stream, in hit order: a successful decode replaces decoded[] (:565-569); a failed one
+// leaves it (FECDecoder.java:780), and its log entry shows the bytes the demodulator still holds.  One wave.
+__device__ __forceinline__ void fec_bpsk_fin(const BpskFecArgs &a, int s, int nt, int lane)
+{
+    unsigned char *dst = a.decoded + (long long)s * 256;
+    unsigned cur = reinterpret_cast<unsigned *>(dst)[lane];  // 256 bytes = one dword per lane
+    int ndec = 0, lastrc = 0;
+    for (int t = 0; t < nt; t++) {
+        unsigned *logd = reinterpret_cast<unsigned *>(a.fec_data + ((long long)s * a.max_trig + t) * 256);
+        const int r = a.fec_rc[s * a.max_trig + t];
+        if (r >= 0) {
+            cur = logd[lane];
+            ndec++;
+        } else {
+            logd[lane] = cur;
+        }
+        lastrc = r;
+    }
+    reinterpret_cast<unsigned *>(dst)[lane] = cur;
+    if (lane == 0) {
+        a.last[2 * s] = lastrc;
+        a.last[2 * s + 1] = lastrc < 0 ? 0 : 1;
+        a.cnt_dec[s] += ndec;
+    }
+}
+
+// BPSK hook: one wave per (stream, sync hit).  Build the hard-decision block from the +1/-1/0 bit history
+// (FUNcubeBPSKDemod.java:562-564) and decode; payload (on success) and rc go to the per-hit log.  The block that
+// finishes LAST for its stream (a device-scope counter per stream; release / acquire fences around it) then runs stage 2
+// for that stream when a.fuse is set (short single-stream calls: one dependent launch less); otherwise k_fec_fin does.
 __global__ __launch_bounds__(64) void k_fec_bpsk(BpskFecArgs a)
 {
     __shared__ FecLdsT<DECW_WORK> L;
@@ -659,10 +687,19 @@ __global__ __launch_bounds__(64) void k_fec_bpsk(BpskFecArgs a)
     if (r >= 0)
         for (int i = lane; i < 256; i += 64) logd[i] = L.data[i];
     if (lane == 0) a.fec_rc[s * a.max_trig + t] = r;
+    if (!a.fuse) return;  // (uniform) k_fec_fin follows
+    // ---- the stream's last block to get here runs stage 2
+    __threadfence();  // release: this block's log entry is visible device-wide before the count goes up
+    int prev = 0;
+    if (lane == 0) prev = atomicAdd(a.done + s, 1);
+    prev = __shfl(prev, 0, 64);
+    if (prev == nt - 1) {
+        __threadfence();  // acquire: the other blocks' log entries
+        fec_bpsk_fin(a, s, nt, lane);
+        if (lane == 0) a.done[s] = 0;  // ready for the next launch
+    }
 }
 
-// stage 2: per stream, in hit order: a successful decode replaces decoded[] (:565-569); a failed one leaves it
-// (FECDecoder.java:780), and its log entry shows the bytes the demodulator still holds.
 __global__ __launch_bounds__(256) void k_fec_fin(BpskFecArgs a)
 {
     const int s = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -670,26 +707,7 @@ __global__ __launch_bounds__(256) void k_fec_fin(BpskFecArgs a)
     int nt = a.trig_count[s];
     if (nt > a.max_trig) nt = a.max_trig;
     if (nt <= 0) return;
-    unsigned char *dst = a.decoded + (long long)s * 256;
-    unsigned cur = reinterpret_cast<unsigned *>(dst)[lane];  // 256 bytes = one dword per lane
-    int ndec = 0, lastrc = 0;
-    for (int t = 0; t < nt; t++) {
-        unsigned *logd = reinterpret_cast<unsigned *>(a.fec_data + ((long long)s * a.max_trig + t) * 256);
-        const int r = a.fec_rc[s * a.max_trig + t];
-        if (r >= 0) {
-            cur = logd[lane];
-            ndec++;
-        } else {
-            logd[lane] = cur;
-        }
-        lastrc = r;
-    }
-    reinterpret_cast<unsigned *>(dst)[lane] = cur;
-    if (lane == 0) {
-        a.last[2 * s] = lastrc;
-        a.last[2 * s + 1] = lastrc < 0 ? 0 : 1;
-        a.cnt_dec[s] += ndec;
-    }
+    fec_bpsk_fin(a, s, nt, lane);
 }
 
 int fec_dec_scratch_words() { return DEC_SCRATCH_WORDS; }
@@ -699,8 +717,10 @@ int launch_fec_bpsk(const BpskFecArgs &a, hipStream_t st)
     if (upload_tables() != JSDR_OK) return JSDR_ERR;
     hipLaunchKernelGGL(k_fec_bpsk, dim3((unsigned)a.nstreams, (unsigned)a.max_trig), dim3(64), 0, st, a);
     JSDR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_fec_fin, dim3((unsigned)((a.nstreams + 3) / 4)), dim3(256), 0, st, a);
-    JSDR_LAUNCH_CHECK();
+    if (!a.fuse) {
+        hipLaunchKernelGGL(k_fec_fin, dim3((unsigned)((a.nstreams + 3) / 4)), dim3(256), 0, st, a);
+        JSDR_LAUNCH_CHECK();
+    }
     return JSDR_OK;
 }
 
