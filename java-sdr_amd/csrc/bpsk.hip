@@ -878,7 +878,10 @@ __global__ void k_fm_prep(EdgeArgs e, HistArgs hi)
     hi.hist_new[(long long)s * 32 + i] = v;
 }
 
-template <int D, int R, bool MIX, bool DC, bool FAST>
+// SMALL: the instantiation for SHORT calls (at most FM_THREADS outputs: the receive() form) -- the matched half as one
+// output per thread; a kernel of its own so that its loop does not sit in the batch kernel's register allocation (as a
+// run-time branch it cost the batch kernel its fourth wave per SIMD: 123 -> 131 VGPRs, 16.8 -> 20.1 ms at 8192 streams)
+template <int D, int R, bool MIX, bool DC, bool FAST, bool SMALL = false>
 #ifndef JSDR_FM_MINWAVES
 #define JSDR_FM_MINWAVES 2
 #endif
@@ -1079,6 +1082,44 @@ __global__ __launch_bounds__(FM_THREADS, JSDR_FM_MINWAVES) void k_fm(FmArgs a)
     const double2 *xl = X + 64 + 65 * blk;            // &X[s0]
     const int rel0 = jrel0 + 64 + 65 * blk;           // call-relative index of s0
     double2 *y = a.y + (long long)s * a.y_stride;
+    if constexpr (SMALL) {
+        // A SHORT call (the receive() form: 205 outputs of a 2048-sample frame): one output per thread, the reference's
+        // ring-slot order (:519-523) as a per-thread loop over the image -- (s0, s0-1, .., g-64) then (g, .., s0+1) with
+        // s0 = g - u the sample in ring slot 0 -- instead of the lane-per-block mapping, whose eight waves each walk all
+        // 65 taps for 62 blocks of which a short call fills four (19 us of a 70 us receive).  Same operands, same order:
+        // the same doubles (this is tail_exact_sample's second half).
+        const int rel = (int)threadIdx.x, t = rel - jrel0;
+        if (rel < nds && t >= 64 && t < FM_NT) {
+            const long long g = a.g_first + rel;
+            const int u = (int)(((g - 64) % 65 + 65) % 65);
+            const double2 *xg = X + t;  // &X[g]
+            const double *f = c_bpsk.dm_taps;
+            double yi = 0.0, yq = 0.0;
+            for (int i = 0; i <= 64 - u; i++) {  // s0, s0-1, .., g-64: ages u .. 64
+                const double2 x = xg[-(u + i)];
+                const double tp = f[u + i];
+                if constexpr (FAST) {
+                    yi = __builtin_fma(x.x, tp, yi);
+                    yq = __builtin_fma(x.y, tp, yq);
+                } else {
+                    yi += x.x * tp;
+                    yq += x.y * tp;
+                }
+            }
+            for (int m = 0; m < u; m++) {        // g, g-1, .., s0+1: ages 0 .. u-1
+                const double2 x = xg[-m];
+                const double tp = f[m];
+                if constexpr (FAST) {
+                    yi = __builtin_fma(x.x, tp, yi);
+                    yq = __builtin_fma(x.y, tp, yq);
+                } else {
+                    yi += x.x * tp;
+                    yq += x.y * tp;
+                }
+            }
+            y[rel] = make_double2(yi, yq);
+        }
+    } else {
 #ifdef JSDR_X_NOMATCHED
     if (a.nds < 0)
 #endif
@@ -1099,6 +1140,7 @@ __global__ __launch_bounds__(FM_THREADS, JSDR_FM_MINWAVES) void k_fm(FmArgs a)
             const int rel = rel0 + u0 + r;
             if (lane < FM_NB && rel >= 0 && rel < nds) y[rel] = make_double2(ai[r], aq[r]);
         }
+    }
     }
     FM_CLK(4);  // matched half
     __syncthreads();  // the next work item reuses the image
@@ -1854,6 +1896,7 @@ struct jsdr_bpsk {
     unsigned char *pin = nullptr;
     size_t pin_bytes = 0, pin_off = 0;
     bool pin_call = false;
+    bool snap_fused = false;  // the last call's k_fec_bpsk packed the snapshot itself (receive() of a 1-stream handle)
     DevBuf<int> stage_raw;  // one frame for receive_*()
     DevBuf<FftFrontState> fft_state;  // FFT-acquire mode only
     DevBuf<double2> fft_tw;
@@ -2198,7 +2241,20 @@ static int launch_fm_t(const FmArgs &a_in, bool mix, bool dc, bool fast, int nst
         }                                                                                                       \
         hipLaunchKernelGGL((k_fm<D, R, MIX, DC, FAST>), grid, block, lds, st, a);                               \
     } while (0)
-    if (fast) {
+#define JSDR_FM_LAUNCH_SMALL(MIX, DC)                                                                           \
+    do {                                                                                                        \
+        static bool attr_done = false;                                                                          \
+        if (!attr_done) {                                                                                       \
+            JSDR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fm<D, R, MIX, DC, false, true>),  \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));            \
+            attr_done = true;                                                                                   \
+        }                                                                                                       \
+        hipLaunchKernelGGL((k_fm<D, R, MIX, DC, false, true>), grid, block, lds, st, a);                        \
+    } while (0)
+    if (!fast && a.nds <= FM_THREADS && ntiles == 1) {  // a short call (receive()): the one-output-per-thread matched half
+        if (mix) { if (dc) JSDR_FM_LAUNCH_SMALL(true, true); else JSDR_FM_LAUNCH_SMALL(true, false); }
+        else { if (dc) JSDR_FM_LAUNCH_SMALL(false, true); else JSDR_FM_LAUNCH_SMALL(false, false); }
+    } else if (fast) {
         if (mix) { if (dc) JSDR_FM_LAUNCH(true, true, true); else JSDR_FM_LAUNCH(true, false, true); }
         else { if (dc) JSDR_FM_LAUNCH(false, true, true); else JSDR_FM_LAUNCH(false, false, true); }
     } else {
@@ -2206,6 +2262,7 @@ static int launch_fm_t(const FmArgs &a_in, bool mix, bool dc, bool fast, int nst
         else { if (dc) JSDR_FM_LAUNCH(false, true, false); else JSDR_FM_LAUNCH(false, false, false); }
     }
 #undef JSDR_FM_LAUNCH
+#undef JSDR_FM_LAUNCH_SMALL
     JSDR_LAUNCH_CHECK();
     return JSDR_OK;
 }
@@ -2623,6 +2680,30 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
         fa2.dec_scratch = h->fec_scratch.p;
         fa2.done = h->fec_done.p;
         fa2.fuse = (S == 1) ? 1 : 0;
+        fa2.ncopy = 0;
+        h->snap_fused = false;
+        if (S == 1 && h->pin_call) {  // receive(): the snapshot is packed by the block that completes the FEC work
+            SnapPack *sp = h->snap_dev.p;
+            auto add = [&](const void *src, void *dst, size_t bytes) {
+                fa2.csrc[fa2.ncopy] = static_cast<const unsigned char *>(src);
+                fa2.cdst[fa2.ncopy] = static_cast<unsigned char *>(dst);
+                fa2.cbytes[fa2.ncopy] = (int)bytes;
+                fa2.ncopy++;
+            };
+            add(h->tail.p, &sp->t, sizeof(TailState));
+            add(h->fec_last.p, sp->last, 2 * sizeof(int));
+            add(h->cnt_dec.p, &sp->cdec, sizeof(int));
+            add(h->nbits.p, &sp->nbits, sizeof(int));
+            if (h->do_fft) {
+                add(&h->fft_state.p->centreBin, &sp->centreBin, sizeof(int));
+                add(&h->fft_state.p->avePeakPower, &sp->avePeakPower, 2 * sizeof(double));  // avePeakPower, aveCentreBin
+            }
+            add(h->decoded.p, sp->decoded, 256);
+            // the call's bits: what the log holds behind the history (the host clears the snapshot's bytes beyond nbits)
+            const long long have = h->bitlog_stride - HIST_BITS;
+            add(h->bitlog[h->bitlog_cur].p + HIST_BITS, sp->bits, (size_t)(have < 512 ? have : 512));
+            h->snap_fused = true;
+        }
         ProfScope ps(h, PK_FEC, ts);
         if (launch_fec_bpsk(fa2, ts) != JSDR_OK) return JSDR_ERR;
     }
@@ -2955,8 +3036,43 @@ int jsdr_bpsk_receive_f32(jsdr_bpsk *h, const float *iq_host)
                  h->nstreams);
     h->pin_call = true;
     h->pin_off = 0;
-    int rc = h2d_call(h, h->stage_raw.p, iq_host, sizeof(float) * 2 * (size_t)h->nsf, 0);
-    if (rc == JSDR_OK) rc = bpsk_run(h, nullptr, reinterpret_cast<const float *>(h->stage_raw.p), 2LL * h->nsf, h->nsf, 0, 0, 0);
+    // What IAudioHandler delivers are (float)s / 32767f values of DC-corrected shorts (JavaAudio.java:281-288).  When every
+    // sample of the frame IS such a value -- checked here, on the host, with the same float division -- the frame goes
+    // through the int16 kernels (k_fm: two launches instead of four, half the bytes up): same doubles, the two input
+    // forms are bit-identical by construction (test_bpsk_one_stream_fed_through_both_input_forms_alternately).  Any other
+    // float takes the float kernels as before.
+    const size_t nfl = 2 * (size_t)h->nsf;
+    static const bool route = [] {
+        const char *e = getenv("JSDR_F32_AS_I16");  // JSDR_F32_AS_I16=0: float frames always take the float kernels (tests)
+        return !e || atoi(e) != 0;
+    }();
+    bool as_i16 = route && h->variant == 0 && h->pin && (h->n_in == 0 || !h->hist_is_float) && nfl * sizeof(int16_t) <= h->pin_bytes;
+    if (as_i16) {
+        int16_t *q = reinterpret_cast<int16_t *>(h->pin);  // the arena's head: the frame's slot
+        unsigned bad = 0;
+        for (size_t i = 0; i < nfl; i++) {
+            const float f = iq_host[i];
+            float v = f * 32767.0f;
+            v = v > 32767.0f ? 32767.0f : (v < -32768.0f ? -32768.0f : v);  // (also sends NaN to a value that fails the check)
+            const int sv = (int)__builtin_rintf(v);
+            const float back = (float)sv / 32767.0f;
+            unsigned bf, bb;  // compared as bit patterns: -0.0f is NOT the conversion of any short, and stays a float
+            memcpy(&bf, &f, 4);
+            memcpy(&bb, &back, 4);
+            bad |= bf ^ bb;
+            q[i] = (int16_t)sv;
+        }
+        as_i16 = bad == 0;
+    }
+    int rc;
+    if (as_i16) {
+        h->pin_off = nfl * sizeof(int16_t);
+        JSDR_HIP_TRY(hipMemcpyAsync(h->stage_raw.p, h->pin, nfl * sizeof(int16_t), hipMemcpyHostToDevice, 0));
+        rc = bpsk_run(h, reinterpret_cast<const int16_t *>(h->stage_raw.p), nullptr, 2LL * h->nsf, h->nsf, 0, 0, 0);
+    } else {
+        rc = h2d_call(h, h->stage_raw.p, iq_host, sizeof(float) * 2 * (size_t)h->nsf, 0);
+        if (rc == JSDR_OK) rc = bpsk_run(h, nullptr, reinterpret_cast<const float *>(h->stage_raw.p), 2LL * h->nsf, h->nsf, 0, 0, 0);
+    }
     if (rc == JSDR_OK) rc = publish_snapshot(h);
     else (void)hipDeviceSynchronize();
     h->pin_call = false;
@@ -3022,16 +3138,26 @@ static int publish_snapshot(jsdr_bpsk *h)
 {
     // pack on the stream the call's last kernels ran on, fetch once
     hipStream_t ts = (h->overlap && h->tail_stream) ? h->tail_stream : h->last_stream;
-    hipLaunchKernelGGL(k_snapshot_pack, dim3(1), dim3(256), 0, ts, h->snap_dev.p, h->tail.p, h->fec_last.p, h->cnt_dec.p,
-                       h->nbits.p, h->do_fft ? h->fft_state.p : (const FftFrontState *)nullptr, h->decoded.p,
-                       h->bitlog[h->bitlog_cur].p + HIST_BITS);
-    JSDR_LAUNCH_CHECK();
+    if (!h->snap_fused) {
+        hipLaunchKernelGGL(k_snapshot_pack, dim3(1), dim3(256), 0, ts, h->snap_dev.p, h->tail.p, h->fec_last.p, h->cnt_dec.p,
+                           h->nbits.p, h->do_fft ? h->fft_state.p : (const FftFrontState *)nullptr, h->decoded.p,
+                           h->bitlog[h->bitlog_cur].p + HIST_BITS);
+        JSDR_LAUNCH_CHECK();
+    }
     SnapPack pk_stack;
     // (the arena's last slot: reserved at create, never handed out by h2d_call)
     SnapPack *pkp = h->pin ? reinterpret_cast<SnapPack *>(h->pin + h->pin_bytes) : &pk_stack;
     JSDR_HIP_TRY(hipMemcpyAsync(pkp, h->snap_dev.p, sizeof(SnapPack), hipMemcpyDeviceToHost, ts));
     if (sync_last(h) != JSDR_OK) return JSDR_ERR;
     JSDR_HIP_TRY(hipStreamSynchronize(ts));
+    if (h->snap_fused) {  // what k_snapshot_pack does on the device: no FFT state in tune mode, no bytes beyond the call's bits
+        if (!h->do_fft) {
+            pkp->centreBin = 0;
+            pkp->avePeakPower = 0.0;
+            pkp->aveCentreBin = 0.0;
+        }
+        for (int k = pkp->nbits < 0 ? 0 : pkp->nbits; k < 512; k++) pkp->bits[k] = 0;
+    }
     const SnapPack &pk = *pkp;
     // what the getters refuse, the snapshot refuses (check_overflow)
     JSDR_REQUIRE(!pk.t.overflow, "receive: stream 0 exceeded its per-call capacity (%d bits / %d FEC calls per call of at most %lld samples)",

@@ -25,6 +25,12 @@ struct BpskFecArgs {
                                 // 0: k_fec_fin follows -- the hand-over needs a DEVICE-scope release per block, which on this
                                 // multi-XCD part writes the XCD's L2 back: 20 000 of them beside the PSD kernel cost the
                                 // 8192-stream step 1.8 ms (measured, one session)
+    // fuse only: byte copies the block that completes the stream's FEC work performs afterwards (the 1-stream receive()
+    // packs its result snapshot this way: what used to be one more dependent launch)
+    int ncopy;
+    const unsigned char *csrc[8];
+    unsigned char *cdst[8];
+    int cbytes[8];
 };
 
 int launch_fec_bpsk(const BpskFecArgs &a, hipStream_t st);

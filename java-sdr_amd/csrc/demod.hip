@@ -526,6 +526,8 @@ struct jsdr_demod {
     float wfir[21] = {0};
     float phi = 0.0f, car = 0.0f;
     DevBuf<float2> hist[2], lilq[2];
+    PinnedStage pin;        // receive(): [frame in | audio out]
+    bool pin_tried = false;
     int cur = 0;
     // carrier tables, double-buffered: call k fills set k&1 on the copy stream while call k-1's kernels still read
     // the other one (no bubble between calls for the host's phase recurrence and its upload)
@@ -755,6 +757,7 @@ int jsdr_demod_destroy(jsdr_demod *h)
 {
     if (!h) return JSDR_OK;
     (void)hipDeviceSynchronize();
+    h->pin.release();
     for (int k = 0; k < 2; k++) {
         h->hist[k].release();
         h->lilq[k].release();
@@ -876,11 +879,29 @@ int jsdr_demod_receive_f32(jsdr_demod *h, const float *buf_host, int16_t *audio_
 {
     JSDR_REQUIRE(h && buf_host && audio_host, "jsdr_demod_receive_f32: null argument");
     JSDR_REQUIRE(h->nstreams == 1, "jsdr_demod_receive_f32: the frame-by-frame form needs a 1-stream handle");
-    JSDR_HIP_TRY(hipMemcpy(h->stage_in.p, buf_host, sizeof(float) * 2 * (size_t)h->n, hipMemcpyHostToDevice));
+    const size_t in_bytes = sizeof(float) * 2 * (size_t)h->n, out_bytes = sizeof(int) * (size_t)h->n;
+    if (!h->pin_tried) {  // the first receive() of the handle (PinnedStage, common.h)
+        h->pin.alloc(in_bytes + out_bytes);
+        h->pin_tried = true;
+    }
+    if (h->pin.p) {
+        memcpy(h->pin.p, buf_host, in_bytes);
+        JSDR_HIP_TRY(hipMemcpyAsync(h->stage_in.p, h->pin.p, in_bytes, hipMemcpyHostToDevice, 0));
+        if (demod_run<true>(h, nullptr, h->stage_in.p, 2 * (int64_t)h->n, h->n, 0, 0, reinterpret_cast<int16_t *>(h->stage_out.p),
+                            2 * (int64_t)h->n, 0) != JSDR_OK) {
+            (void)hipDeviceSynchronize();
+            return JSDR_ERR;
+        }
+        JSDR_HIP_TRY(hipMemcpyAsync(h->pin.p + in_bytes, h->stage_out.p, out_bytes, hipMemcpyDeviceToHost, 0));
+        JSDR_HIP_TRY(hipStreamSynchronize(0));
+        memcpy(audio_host, h->pin.p + in_bytes, out_bytes);
+        return JSDR_OK;
+    }
+    JSDR_HIP_TRY(hipMemcpy(h->stage_in.p, buf_host, in_bytes, hipMemcpyHostToDevice));
     if (demod_run<true>(h, nullptr, h->stage_in.p, 2 * (int64_t)h->n, h->n, 0, 0, reinterpret_cast<int16_t *>(h->stage_out.p),
                         2 * (int64_t)h->n, 0) != JSDR_OK)
         return JSDR_ERR;
-    JSDR_HIP_TRY(hipMemcpy(audio_host, h->stage_out.p, sizeof(int) * (size_t)h->n, hipMemcpyDeviceToHost));
+    JSDR_HIP_TRY(hipMemcpy(audio_host, h->stage_out.p, out_bytes, hipMemcpyDeviceToHost));
     return JSDR_OK;
 }
 

@@ -657,6 +657,12 @@ __device__ __forceinline__ void fec_bpsk_fin(const BpskFecArgs &a, int s, int nt
     }
 }
 
+__device__ __forceinline__ void fec_post_copies(const BpskFecArgs &a, int lane)
+{
+    for (int c = 0; c < a.ncopy; c++)
+        for (int i = lane; i < a.cbytes[c]; i += 64) a.cdst[c][i] = a.csrc[c][i];
+}
+
 // BPSK hook: one wave per (stream, sync hit).  Build the hard-decision block from the +1/-1/0 bit history
 // (FUNcubeBPSKDemod.java:562-564) and decode; payload (on success) and rc go to the per-hit log.  The block that
 // finishes LAST for its stream (a device-scope counter per stream; release / acquire fences around it) then runs stage 2
@@ -670,7 +676,10 @@ __global__ __launch_bounds__(64) void k_fec_bpsk(BpskFecArgs a)
     const int s = blockIdx.x, t = blockIdx.y;
     int nt = a.trig_count[s];
     if (nt > a.max_trig) nt = a.max_trig;
-    if (t >= nt) return;
+    if (t >= nt) {
+        if (a.fuse && nt == 0 && t == 0) fec_post_copies(a, lane);  // no hit in this call: nothing to wait for
+        return;
+    }
     fec_lds_init(L, lane);
     const signed char *win = a.bitlog + (long long)s * a.bitlog_stride + (a.trig_bits[s * a.max_trig + t] + 1);
     // hard decisions, one bit per symbol: 64 symbols per ballot, lane 0 files the word
@@ -697,6 +706,8 @@ __global__ __launch_bounds__(64) void k_fec_bpsk(BpskFecArgs a)
         __threadfence();  // acquire: the other blocks' log entries
         fec_bpsk_fin(a, s, nt, lane);
         if (lane == 0) a.done[s] = 0;  // ready for the next launch
+        FEC_WAVE_SYNC();  // stage 2's stores (other lanes') before the copies read them
+        fec_post_copies(a, lane);
     }
 }
 

@@ -369,6 +369,8 @@ struct jsdr_fft {
     DevBuf<float2> tw;
     DevBuf<unsigned char> in_stage;  // one frame, for the host-buffer receive() forms
     DevBuf<float> out_stage;
+    PinnedStage pin;                 // [frame in (8 n bytes) | psd out (4 (n + 2) bytes)] for the receive() forms
+    bool pin_lazy_done = false;      // the stage is allocated at the first receive()
     int num_cu = 256;
     bool mixed = false;  // non power-of-two frame: fft_mixed.hip
     MixedPlan mplan;
@@ -512,6 +514,7 @@ int jsdr_fft_destroy(jsdr_fft *h)
     h->tw.release();
     h->in_stage.release();
     h->out_stage.release();
+    h->pin.release();
     delete h;
     return JSDR_OK;
 }
@@ -532,22 +535,46 @@ int jsdr_fft_spectrum_f32(jsdr_fft *h, const float *iq_dev, int64_t nframes, flo
     return fft_run(h, iq_dev, IN_F32, OUT_SPEC, nframes, 0, 0, spec_dev, as_stream(stream));
 }
 
+// one frame from / to host buffers: through the handle's pinned stage when it has one (PinnedStage, common.h)
+static int fft_receive(jsdr_fft *h, const void *in_host, size_t in_bytes, int in_kind, int ic, int qc, float *psd_host)
+{
+    const size_t out_bytes = sizeof(float) * ((size_t)h->n + 2), in_room = (size_t)h->n * 8;
+    if (h->pin.p && h->pin.bytes >= in_room + out_bytes) {
+        memcpy(h->pin.p, in_host, in_bytes);
+        JSDR_HIP_TRY(hipMemcpyAsync(h->in_stage.p, h->pin.p, in_bytes, hipMemcpyHostToDevice, 0));
+        if (fft_run(h, h->in_stage.p, in_kind, OUT_PSD, 1, ic, qc, h->out_stage.p, 0) != JSDR_OK) {
+            (void)hipDeviceSynchronize();
+            return JSDR_ERR;
+        }
+        JSDR_HIP_TRY(hipMemcpyAsync(h->pin.p + in_room, h->out_stage.p, out_bytes, hipMemcpyDeviceToHost, 0));
+        JSDR_HIP_TRY(hipStreamSynchronize(0));
+        memcpy(psd_host, h->pin.p + in_room, out_bytes);
+        return JSDR_OK;
+    }
+    JSDR_HIP_TRY(hipMemcpy(h->in_stage.p, in_host, in_bytes, hipMemcpyHostToDevice));
+    if (fft_run(h, h->in_stage.p, in_kind, OUT_PSD, 1, ic, qc, h->out_stage.p, 0) != JSDR_OK) return JSDR_ERR;
+    JSDR_HIP_TRY(hipMemcpy(psd_host, h->out_stage.p, out_bytes, hipMemcpyDeviceToHost));
+    return JSDR_OK;
+}
+
 int jsdr_fft_receive_f32(jsdr_fft *h, const float *iq_host, float *psd_host)
 {
     JSDR_REQUIRE(h && iq_host && psd_host, "jsdr_fft_receive_f32: null argument");
-    JSDR_HIP_TRY(hipMemcpy(h->in_stage.p, iq_host, sizeof(float) * 2 * (size_t)h->n, hipMemcpyHostToDevice));
-    if (fft_run(h, h->in_stage.p, IN_F32, OUT_PSD, 1, 0, 0, h->out_stage.p, 0) != JSDR_OK) return JSDR_ERR;
-    JSDR_HIP_TRY(hipMemcpy(psd_host, h->out_stage.p, sizeof(float) * ((size_t)h->n + 2), hipMemcpyDeviceToHost));
-    return JSDR_OK;
+    if (!h->pin_lazy_done && !h->pin.p) {  // the first receive() of a handle: batch-only handles never pin anything
+        h->pin.alloc((size_t)h->n * 8 + sizeof(float) * ((size_t)h->n + 2));
+        h->pin_lazy_done = true;
+    }
+    return fft_receive(h, iq_host, sizeof(float) * 2 * (size_t)h->n, IN_F32, 0, 0, psd_host);
 }
 
 int jsdr_fft_receive_i16(jsdr_fft *h, const int16_t *raw_host, int ic, int qc, float *psd_host)
 {
     JSDR_REQUIRE(h && raw_host && psd_host, "jsdr_fft_receive_i16: null argument");
-    JSDR_HIP_TRY(hipMemcpy(h->in_stage.p, raw_host, sizeof(int16_t) * 2 * (size_t)h->n, hipMemcpyHostToDevice));
-    if (fft_run(h, h->in_stage.p, IN_I16, OUT_PSD, 1, ic, qc, h->out_stage.p, 0) != JSDR_OK) return JSDR_ERR;
-    JSDR_HIP_TRY(hipMemcpy(psd_host, h->out_stage.p, sizeof(float) * ((size_t)h->n + 2), hipMemcpyDeviceToHost));
-    return JSDR_OK;
+    if (!h->pin_lazy_done && !h->pin.p) {
+        h->pin.alloc((size_t)h->n * 8 + sizeof(float) * ((size_t)h->n + 2));
+        h->pin_lazy_done = true;
+    }
+    return fft_receive(h, raw_host, sizeof(int16_t) * 2 * (size_t)h->n, IN_I16, ic, qc, psd_host);
 }
 
 }  // extern "C"
