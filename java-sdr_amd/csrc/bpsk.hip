@@ -840,10 +840,25 @@ __global__ void k_fm_edges(EdgeArgs a)
 
 // k_fm_edges and k_hist_in in ONE launch (the k_fm path): both only read the call's input and the previous call's history,
 // and write disjoint buffers (the edge images, the next call's history) -- one dependent launch less per call.
-__global__ void k_fm_prep(EdgeArgs e, HistArgs hi)
+// ... and, in the receive() form, the schedule's tables: they travel behind the frame in ONE host->device copy and are put
+// where the kernels read them here (two byte ranges at most: the VCO indices and the unwrapped tuner table).
+struct ScatterArgs {
+    const unsigned char *src[2];
+    unsigned char *dst[2];
+    int bytes[2];
+};
+__global__ void k_fm_prep(EdgeArgs e, HistArgs hi, ScatterArgs sc)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int nedge = e.nstreams * 4 * FM_EDGE;
+    {
+        const int v = t - nedge - 32 * e.nstreams;
+        if (v >= 0) {
+            if (v < sc.bytes[0]) sc.dst[0][v] = sc.src[0][v];
+            else if (v - sc.bytes[0] < sc.bytes[1]) sc.dst[1][v - sc.bytes[0]] = sc.src[1][v - sc.bytes[0]];
+            return;
+        }
+    }
     if (t < nedge) {
         const int s = t / (4 * FM_EDGE), i = t % (4 * FM_EDGE);
         const int n = i < 2 * FM_EDGE ? i - FM_EDGE : e.nsamples - FM_EDGE + (i - 2 * FM_EDGE);
@@ -1896,6 +1911,8 @@ struct jsdr_bpsk {
     unsigned char *pin = nullptr;
     size_t pin_bytes = 0, pin_off = 0;
     bool pin_call = false;
+    size_t rx_frame_bytes = 0;  // receive(): the frame sits at the arena's head and has not been sent yet (bpsk_run sends it,
+                                // with the schedule's tables behind it in the SAME copy when they changed)
     bool snap_fused = false;  // the last call's k_fec_bpsk packed the snapshot itself (receive() of a 1-stream handle)
     DevBuf<int> stage_raw;  // one frame for receive_*()
     DevBuf<FftFrontState> fft_state;  // FFT-acquire mode only
@@ -2360,7 +2377,37 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
         if (h2d_call(h, h->ktu.p + kshift, h->h_ktu.data(), (size_t)L + 26, st) != JSDR_OK) return JSDR_ERR;
         h->ktu_uploaded = true;
     }
-    if (fresh) {
+    ScatterArgs sc;
+    memset(&sc, 0, sizeof(sc));
+    bool tables_sent = false;
+    if (h->rx_frame_bytes) {
+        // receive(): the frame is at the arena's head.  When the call takes k_fm and its tables changed, they ride behind
+        // the frame in the same copy and k_fm_prep scatters them (three copies were ~10 us each of a 70 us call)
+        size_t total = h->rx_frame_bytes;
+        const size_t o1 = (total + 63) & ~(size_t)63;
+        const size_t tcs_bytes = h->c_tper > 0 ? sizeof(double2) * h->h_tcs.size() : 0;
+        const size_t o2 = (o1 + (size_t)nds + 63) & ~(size_t)63;
+        if (fm_ok && fresh && nds > 0 && o2 + tcs_bytes <= h->pin_bytes && o2 + tcs_bytes <= h->stage_raw.n * sizeof(int)) {
+            unsigned char *dev = reinterpret_cast<unsigned char *>(h->stage_raw.p);
+            memcpy(h->pin + o1, h->h_kvco.data(), (size_t)nds);
+            sc.src[0] = dev + o1;
+            sc.dst[0] = kvco_p;
+            sc.bytes[0] = (int)nds;
+            if (tcs_bytes) {
+                memcpy(h->pin + o2, h->h_tcs.data(), tcs_bytes);
+                sc.src[1] = dev + o2;
+                sc.dst[1] = reinterpret_cast<unsigned char *>(tcs_p);
+                sc.bytes[1] = (int)tcs_bytes;
+            }
+            total = o2 + tcs_bytes;
+            h->pin_off = total;
+            tables_sent = true;
+        }
+        JSDR_HIP_TRY(hipMemcpyAsync(h->stage_raw.p, h->pin, total, hipMemcpyHostToDevice, st));
+        h->rx_frame_bytes = 0;
+    }
+    if (fresh && tables_sent) h->cache_valid = true;
+    if (fresh && !tables_sent) {
         if (nds > 0)
             if (h2d_call(h, kvco_p, h->h_kvco.data(), (size_t)nds, st) != JSDR_OK) return JSDR_ERR;
         if (nds > 0 && h->do_fft) {
@@ -2480,7 +2527,8 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
             ha.hist_new = h->hist_in[h->hist_cur ^ 1].p;
             ha.nstreams = S;
             ProfScope psh(h, PK_HIST, st);
-            hipLaunchKernelGGL(k_fm_prep, dim3((unsigned)(((long long)S * (4 * FM_EDGE + 32) + 255) / 256)), dim3(256), 0, st, ea, ha);
+            hipLaunchKernelGGL(k_fm_prep, dim3((unsigned)(((long long)S * (4 * FM_EDGE + 32) + sc.bytes[0] + sc.bytes[1] + 255) / 256)),
+                               dim3(256), 0, st, ea, ha, sc);
             JSDR_LAUNCH_CHECK();
             hist_done = true;
         }
@@ -2784,7 +2832,9 @@ int jsdr_bpsk_create(jsdr_bpsk **out, int rate, int nsamples_per_frame, int tuni
               h->fec_rc.alloc(S * h->trig_cap) == JSDR_OK && h->fec_last.alloc(S * 2) == JSDR_OK &&
               h->cnt_dec.alloc(S) == JSDR_OK && h->corr.alloc(S * (size_t)h->max_bits) == JSDR_OK &&
               h->fec_data.alloc(S * h->trig_cap * 256) == JSDR_OK && h->decoded.alloc(S * 256) == JSDR_OK &&
-              h->stage_raw.alloc((size_t)nsamples_per_frame * 2) == JSDR_OK && h->ds_taps_dev.alloc(32) == JSDR_OK &&
+              // (one frame; a 1-stream handle's receive() sends the schedule's tables behind it in the same copy)
+              h->stage_raw.alloc((size_t)nsamples_per_frame * 2 + (nstreams == 1 ? ((size_t)h->max_ds + sizeof(double2) * (256 + FM_TABLE_SLACK) + 256) / 4 : 0)) == JSDR_OK &&
+              h->ds_taps_dev.alloc(32) == JSDR_OK &&
               h->dmh[0].alloc(S * 64) == JSDR_OK && h->dmh[1].alloc(S * 64) == JSDR_OK && h->hist_bad.alloc(1) == JSDR_OK && h->amax.alloc(S) == JSDR_OK && h->fm_edges.alloc(S * 4 * FM_EDGE) == JSDR_OK && h->snap_dev.alloc(1) == JSDR_OK && h->tcs.alloc(2 * (256 + FM_TABLE_SLACK)) == JSDR_OK &&
               (!do_fft || (h->fft_state.alloc(S) == JSDR_OK && h->fft_tw.alloc(fft_pow2 ? (size_t)nsamples_per_frame : (size_t)65536) == JSDR_OK &&
                             h->vco_cs.alloc((size_t)h->max_ds) == JSDR_OK)) &&
@@ -3020,9 +3070,18 @@ int jsdr_bpsk_receive_i16(jsdr_bpsk *h, const int16_t *raw_host, int ic, int qc)
                  h->nstreams);
     h->pin_call = true;
     h->pin_off = 0;
-    int rc = h2d_call(h, h->stage_raw.p, raw_host, sizeof(int16_t) * 2 * (size_t)h->nsf, 0);
+    int rc = JSDR_OK;
+    const size_t fb = sizeof(int16_t) * 2 * (size_t)h->nsf;
+    if (h->pin && fb <= h->pin_bytes) {  // the frame waits at the arena's head: bpsk_run sends it (with the tables, if new)
+        memcpy(h->pin, raw_host, fb);
+        h->pin_off = fb;
+        h->rx_frame_bytes = fb;
+    } else {
+        rc = h2d_call(h, h->stage_raw.p, raw_host, fb, 0);
+    }
     if (rc == JSDR_OK)
         rc = bpsk_run(h, reinterpret_cast<const int16_t *>(h->stage_raw.p), nullptr, 2LL * h->nsf, h->nsf, ic, qc, 0);
+    h->rx_frame_bytes = 0;
     if (rc == JSDR_OK) rc = publish_snapshot(h);  // synchronises: the arena is free again
     else (void)hipDeviceSynchronize();            // (a failed call: nothing may still be reading the arena)
     h->pin_call = false;
@@ -3067,8 +3126,9 @@ int jsdr_bpsk_receive_f32(jsdr_bpsk *h, const float *iq_host)
     int rc;
     if (as_i16) {
         h->pin_off = nfl * sizeof(int16_t);
-        JSDR_HIP_TRY(hipMemcpyAsync(h->stage_raw.p, h->pin, nfl * sizeof(int16_t), hipMemcpyHostToDevice, 0));
+        h->rx_frame_bytes = nfl * sizeof(int16_t);  // sent by bpsk_run
         rc = bpsk_run(h, reinterpret_cast<const int16_t *>(h->stage_raw.p), nullptr, 2LL * h->nsf, h->nsf, 0, 0, 0);
+        h->rx_frame_bytes = 0;
     } else {
         rc = h2d_call(h, h->stage_raw.p, iq_host, sizeof(float) * 2 * (size_t)h->nsf, 0);
         if (rc == JSDR_OK) rc = bpsk_run(h, nullptr, reinterpret_cast<const float *>(h->stage_raw.p), 2LL * h->nsf, h->nsf, 0, 0, 0);
