@@ -1911,6 +1911,8 @@ struct jsdr_bpsk {
     unsigned char *pin = nullptr;
     size_t pin_bytes = 0, pin_off = 0;
     bool pin_call = false;
+    bool vco_cs_in_blob = false;  // FFT-acquire mode: the current schedule's VCO factors sit behind the frame in stage_raw
+    size_t vco_cs_blob_off = 0;
     size_t rx_frame_bytes = 0;  // receive(): the frame sits at the arena's head and has not been sent yet (bpsk_run sends it,
                                 // with the schedule's tables behind it in the SAME copy when they changed)
     bool snap_fused = false;  // the last call's k_fec_bpsk packed the snapshot itself (receive() of a 1-stream handle)
@@ -2403,6 +2405,20 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
             h->pin_off = total;
             tables_sent = true;
         }
+        else if (h->do_fft && fresh && nds > 0) {
+            // FFT-acquire mode: the VCO factors of the call's outputs (the only table its front end reads) behind the frame
+            const size_t ov = (total + 63) & ~(size_t)63, vb = sizeof(double2) * (size_t)nds;
+            if (ov + vb <= h->pin_bytes && ov + vb <= h->stage_raw.n * sizeof(int)) {
+                double2 *dst = reinterpret_cast<double2 *>(h->pin + ov);
+                for (long long j = 0; j < nds; j++)
+                    dst[j] = make_double2(h->h_sincos[h->h_kvco[(size_t)j]], h->h_sincos[256 + h->h_kvco[(size_t)j]]);
+                total = ov + vb;
+                h->pin_off = total;
+                h->vco_cs_in_blob = true;
+                h->vco_cs_blob_off = ov;
+                tables_sent = true;
+            }
+        }
         JSDR_HIP_TRY(hipMemcpyAsync(h->stage_raw.p, h->pin, total, hipMemcpyHostToDevice, st));
         h->rx_frame_bytes = 0;
     }
@@ -2411,6 +2427,7 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
         if (nds > 0)
             if (h2d_call(h, kvco_p, h->h_kvco.data(), (size_t)nds, st) != JSDR_OK) return JSDR_ERR;
         if (nds > 0 && h->do_fft) {
+            h->vco_cs_in_blob = false;
             h->h_vco_cs.resize((size_t)nds);
             for (long long j = 0; j < nds; j++)
                 h->h_vco_cs[(size_t)j] = make_double2(h->h_sincos[h->h_kvco[(size_t)j]], h->h_sincos[256 + h->h_kvco[(size_t)j]]);
@@ -2466,7 +2483,8 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
         xa.do_up = h->do_up;
         xa.decim = h->decim;
         xa.first_out = first_out;
-        xa.vco_cs = h->vco_cs.p;
+        xa.vco_cs = h->vco_cs_in_blob ? reinterpret_cast<const double2 *>(reinterpret_cast<const unsigned char *>(h->stage_raw.p) + h->vco_cs_blob_off)
+                                      : h->vco_cs.p;
         xa.tw = h->fft_tw.p;
         xa.st = h->fft_state.p;
         xa.dm = h->dm.p;
@@ -2833,7 +2851,7 @@ int jsdr_bpsk_create(jsdr_bpsk **out, int rate, int nsamples_per_frame, int tuni
               h->cnt_dec.alloc(S) == JSDR_OK && h->corr.alloc(S * (size_t)h->max_bits) == JSDR_OK &&
               h->fec_data.alloc(S * h->trig_cap * 256) == JSDR_OK && h->decoded.alloc(S * 256) == JSDR_OK &&
               // (one frame; a 1-stream handle's receive() sends the schedule's tables behind it in the same copy)
-              h->stage_raw.alloc((size_t)nsamples_per_frame * 2 + (nstreams == 1 ? ((size_t)h->max_ds + sizeof(double2) * (256 + FM_TABLE_SLACK) + 256) / 4 : 0)) == JSDR_OK &&
+              h->stage_raw.alloc((size_t)nsamples_per_frame * 2 + (nstreams == 1 ? ((do_fft ? sizeof(double2) : 1) * (size_t)h->max_ds + sizeof(double2) * (256 + FM_TABLE_SLACK) + 256) / 4 : 0)) == JSDR_OK &&
               h->ds_taps_dev.alloc(32) == JSDR_OK &&
               h->dmh[0].alloc(S * 64) == JSDR_OK && h->dmh[1].alloc(S * 64) == JSDR_OK && h->hist_bad.alloc(1) == JSDR_OK && h->amax.alloc(S) == JSDR_OK && h->fm_edges.alloc(S * 4 * FM_EDGE) == JSDR_OK && h->snap_dev.alloc(1) == JSDR_OK && h->tcs.alloc(2 * (256 + FM_TABLE_SLACK)) == JSDR_OK &&
               (!do_fft || (h->fft_state.alloc(S) == JSDR_OK && h->fft_tw.alloc(fft_pow2 ? (size_t)nsamples_per_frame : (size_t)65536) == JSDR_OK &&
