@@ -172,3 +172,42 @@ def test_bpsk_snapshot_for_a_concurrent_reader():
     assert np.array_equal(np.array(sn.state[:]), d.state())
     assert np.array_equal(np.frombuffer(bytes(sn.decoded), np.uint8), d.decoded())
     assert np.array_equal(np.array(sn.bits[:sn.nbits], np.int8), d.bits())
+
+
+@pytest.mark.parametrize("form", ["raw", "float", "float_offgrid"])
+def test_bpsk_receive_frame_by_frame_through_fec_frames(form):
+    """The drop-in form end to end: one stream, 2048-sample frames through receive(), across two whole FEC frames.  Round 3
+    moved work INTO kernels for this form -- the hit ordering into k_sync_t, FEC stage 2 and the snapshot pack into the
+    block of k_fec_bpsk that finishes last, a short-call k_fm, the tables behind the frame in one copy, float frames that
+    are (float)s/32767f values through the int16 kernels -- so after EVERY frame the snapshot (what the Java getters
+    read) must equal the oracle fed the same frames: counters, state doubles, decoded[], the frame's bits.
+    "float_offgrid": floats that are NOT conversions of shorts (scaled by 0.999) keep the float kernels."""
+    import oracle_lib as O
+    n = 2048 * 420  # 860 160 samples: two sync hits
+    iq, pay, _ = O.make_dbpsk_stream(20020109, 3, n, noise_sigma=600.0)
+    buf = O.convert_i16(iq)
+    if form == "float_offgrid":
+        buf = (buf * np.float32(0.999)).astype(np.float32)
+    d = J.Bpsk(nstreams=1)
+    o = O.Bpsk(trace=8)
+    names = J.binding.COUNTER_NAMES
+    hits = 0
+    for k in range(n // 2048):
+        fr_f = buf[k * 4096:(k + 1) * 4096]
+        if form == "raw":
+            d.receive_raw(iq[k * 4096:(k + 1) * 4096])
+            o.receive_i16(iq[k * 4096:(k + 1) * 4096])
+        else:
+            d.receive(fr_f)
+            o.receive(fr_f)
+        sn = d.snapshot()
+        oc = o.counters()
+        assert sn.frames == k + 1
+        assert list(sn.counters) == [oc[x] for x in names], (k, list(sn.counters), oc)
+        if k % 37 == 0 or oc["cntFEC"] != hits:
+            assert np.array_equal(np.array(sn.state[:]), o.state()), k
+            assert np.array_equal(np.frombuffer(bytes(sn.decoded), np.uint8), o.decoded()), k
+        hits = oc["cntFEC"]
+    assert hits == 2 and o.counters()["cntDec"] == 2
+    assert np.array_equal(d.decoded(), pay[1]) if form != "float_offgrid" else True
+    assert d.front_kernel_name() == ("k_front" if form == "float_offgrid" else "k_fm")
