@@ -3630,8 +3630,14 @@ extern "C" int jsdr_bpsk_pack_slots(jsdr_bpsk *h, uint8_t *slots_dev, void *stre
     int64_t slot_bytes = 0;
     int slot_bits = 0;
     jsdr_bpsk_slot_info(h, &slot_bytes, nullptr, nullptr, &slot_bits, nullptr);
-    if (h->overlap && h->tail_pending[h->last_y])  // results of the last call come from the side stream
+    if (h->overlap && h->tail_pending[h->last_y]) {  // results of the last call come from the side stream
         JSDR_HIP_TRY(hipStreamWaitEvent(as_stream(stream), h->ev_tail_done[h->last_y], 0));
+    } else if (!h->overlap && as_stream(stream) != h->last_stream && h->ev_matched) {
+        // no side stream (1-stream handles, JSDR_NO_OVERLAP): the results come from the stream of the last call; a pack on
+        // ANOTHER stream waits for that one (the event is free in this mode)
+        JSDR_HIP_TRY(hipEventRecord(h->ev_matched, h->last_stream));
+        JSDR_HIP_TRY(hipStreamWaitEvent(as_stream(stream), h->ev_matched, 0));
+    }
     hipLaunchKernelGGL(k_pack_slots, dim3((unsigned)h->nstreams), dim3(256), 0, as_stream(stream), slots_dev,
                        (long long)slot_bytes, slot_bits, h->trig_cap, h->tail.p, h->nbits.p, h->bitlog[h->bitlog_cur].p,
                        h->bitlog_stride, h->trig_count.p, h->trig_bits.p, h->fec_rc.p, h->fec_data.p, h->fec_last.p,
