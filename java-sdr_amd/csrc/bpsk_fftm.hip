@@ -40,6 +40,52 @@ struct FftmArgs {
     int lds_tw;              // the tables of the first passes, lds_tw entries in all, are copied to LDS
 };
 
+// Typed views of the LDS image and of the twiddle tables.  The passes are separate (noinline) functions: through a plain
+// `double2 *` parameter the compiler has to treat every access as a FLAT one -- a 64-bit address computation per element,
+// a null check per pointer conversion, flat loads that tie the LDS and the vector-memory counters together.  With the
+// address space in the type an access is a ds_read / ds_write on a 32-bit offset with an immediate, or a global_load.
+typedef double d2v __attribute__((ext_vector_type(2)));
+typedef float f2v __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) d2v lds_d2v;
+typedef __attribute__((address_space(3))) double lds_f64;
+typedef __attribute__((address_space(1))) const d2v gbl_d2v;
+typedef __attribute__((address_space(1))) const int gbl_i32;
+typedef __attribute__((address_space(1))) const f2v gbl_f2v;
+
+struct LdsRef {
+    lds_d2v *q;
+    __device__ __forceinline__ operator double2() const
+    {
+        const d2v v = *q;
+        return make_double2(v.x, v.y);
+    }
+    __device__ __forceinline__ void operator=(const double2 &v) const
+    {
+        d2v t;
+        t.x = v.x;
+        t.y = v.y;
+        *q = t;
+    }
+    __device__ __forceinline__ void put_x(double x) const { *reinterpret_cast<lds_f64 *>(q) = x; }
+};
+struct LdsArr {
+    lds_d2v *p;
+    __device__ __forceinline__ LdsRef operator[](int i) const { return LdsRef{p + i}; }
+    __device__ __forceinline__ LdsArr operator+(int i) const { return LdsArr{p + i}; }
+};
+struct GblArr {
+    gbl_d2v *p;
+    __device__ __forceinline__ double2 operator[](int i) const
+    {
+        const d2v v = p[i];
+        return make_double2(v.x, v.y);
+    }
+    __device__ __forceinline__ GblArr operator+(int i) const { return GblArr{p + i}; }
+};
+// (the low half of a flat address inside the LDS aperture is the LDS offset)
+__device__ __forceinline__ LdsArr lds_arr(const void *generic) { return LdsArr{(lds_d2v *)(unsigned)(unsigned long long)generic}; }
+__device__ __forceinline__ GblArr gbl_arr(const double2 *g) { return GblArr{(gbl_d2v *)(unsigned long long)g}; }
+
 __device__ __forceinline__ double2 cdadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ double2 cdsub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
 __device__ __forceinline__ double2 cdmul(double2 u, double2 w)
@@ -92,8 +138,8 @@ __device__ __forceinline__ void dft_r(double2 *v)
 // NN / PP: frame size and stride as compile-time constants for the two default frames (9600, 4800): every LDS offset
 // becomes an immediate, `b mod P` a mask or a constant multiply-high, and the butterfly count per thread is the
 // frame's, not the largest frame's.  0 = run-time values (any other supported n).
-template <int R, int NN = 0, int PP = 0>
-__device__ __attribute__((noinline)) void fm_pass(double2 *X, const double2 *tw, int n_rt, int P_rt, unsigned pmagic, int tid)
+template <int R, int NN = 0, int PP = 0, class TW = const double2 *>
+__device__ __attribute__((noinline)) void fm_pass(LdsArr X, TW tw, int n_rt, int P_rt, unsigned pmagic, int tid)
 {
     constexpr int ITERS = (((NN ? NN : FM_NMAX) / R) + FM_T - 1) / FM_T;
     const int n = NN ? NN : n_rt;
@@ -132,8 +178,8 @@ __device__ __attribute__((noinline)) void fm_pass(double2 *X, const double2 *tw,
 // have no reader and are not computed) and it is stored already scaled: X[i].x = re * (1/n), once per sample instead of
 // once per tap that reads it.  Same operands, same operations, same order for everything that IS computed.
 // TT: the two-dimensional tables of an odd half (fm_pass_t): tw[(j-1) P + k] instead of tw[k j]
-template <int NN, int PP, bool TT = false>
-__device__ __attribute__((noinline)) void fm_pass5_real(double2 *X, const double2 *tw, double norm, int tid)
+template <int NN, int PP, bool TT = false, class TW = const double2 *>
+__device__ __attribute__((noinline)) void fm_pass5_real(LdsArr X, TW tw, double norm, int tid)
 {
     constexpr int R = 5, nb = NN / R, ITERS = (nb + FM_T - 1) / FM_T;
     double o[ITERS][R];
@@ -161,7 +207,7 @@ __device__ __attribute__((noinline)) void fm_pass5_real(double2 *X, const double
             const int k = b % PP;
             const int j0 = (b - k) * R + k;
 #pragma unroll
-            for (int q = 0; q < R; q++) X[j0 + q * PP].x = o[it][q];
+            for (int q = 0; q < R; q++) X[j0 + q * PP].put_x(o[it][q]);
         }
     }
     FM_PASS_SYNC();
@@ -173,8 +219,8 @@ __device__ __attribute__((noinline)) void fm_pass5_real(double2 *X, const double
 // butterfly whose only needed output is q = 0 forms (x0 + a1) + a2 alone (32 of its 72 operations); all others run in
 // full and store what is read.
 // need_end: outputs [0, need_end) of THIS transform are read (a half transform of a 2 m frame holds every second bin)
-template <int NN, int PP, bool TT = false>
-__device__ __attribute__((noinline)) void fm_pass5_band(double2 *X, const double2 *tw, int need_end, int tid)
+template <int NN, int PP, bool TT = false, class TW = const double2 *>
+__device__ __attribute__((noinline)) void fm_pass5_band(LdsArr X, TW tw, int need_end, int tid)
 {
     constexpr int R = 5, nb = NN / R, ITERS = (nb + FM_T - 1) / FM_T;
     static_assert(PP == nb, "the last pass: one butterfly per k");
@@ -231,9 +277,8 @@ __device__ __attribute__((noinline)) void fm_pass5_band(double2 *X, const double
 // src / CONJ: where the 204 values z[0..203] come from -- the spectrum image itself (conjugated on the way, CONJ) or a
 // small array of already conjugated values beside the image.  tw1[k * s1], tw2[k * s2]: the pass-3 twiddles of inputs
 // 1 and 2 -- T64[k], T64[2k] for a transform with the ordinary tables, U[k], U[16 + k] for an odd half's (fm_pass_t).
-template <int NN, bool CONJ>
-__device__ __attribute__((noinline)) void fm_inv_blocks(double2 *X, const double2 *src, const double2 *tw1, int s1,
-                                                         const double2 *tw2, int s2, int tid)
+template <int NN, bool CONJ, class TW1, class TW2>
+__device__ __attribute__((noinline)) void fm_inv_blocks(LdsArr X, LdsArr src, TW1 tw1, int s1, TW2 tw2, int s2, int tid)
 {
     constexpr int C = NN / 64, NITEM = C * 16, ITERS = (NITEM + FM_T - 1) / FM_T;
     static_assert(3 * C > 204, "at most three of a block's 64 inputs come from the 204 bins");
@@ -268,7 +313,7 @@ __device__ __attribute__((noinline)) void fm_inv_blocks(double2 *X, const double
                 a = cdadd(z0[it], v2);
                 b = cdsub(z0[it], v2);
             }
-            double2 *o = X + (64 * m + k);
+            const LdsArr o = X + (64 * m + k);
             if (m + C < 204) {
                 const double2 v1 = cdmul(z1[it], tw1[k * s1]);
                 o[0] = cdadd(a, v1);
@@ -292,9 +337,8 @@ __device__ __attribute__((noinline)) void fm_inv_blocks(double2 *X, const double
 // write z[m0*P*R1*R2 + k1 + q1*P + q2*P*R1].  Same operands, same tables, same operation order as fm_pass<R1>
 // followed by fm_pass<R2>: only the intermediate image stays in registers (an LDS store costs 13 cycles per wave
 // instruction, and the image is written once per pass).
-template <int R1, int R2, int NN = 0, int PP = 0>
-__device__ __attribute__((noinline)) void fm_pass2(double2 *X, const double2 *tw1, const double2 *tw2, int n_rt, int P_rt,
-                                                   unsigned pmagic, int tid)
+template <int R1, int R2, int NN = 0, int PP = 0, class TW1 = const double2 *, class TW2 = const double2 *>
+__device__ __attribute__((noinline)) void fm_pass2(LdsArr X, TW1 tw1, TW2 tw2, int n_rt, int P_rt, unsigned pmagic, int tid)
 {
     constexpr int RR = R1 * R2;
     constexpr int ITERS = (((NN ? NN : FM_NMAX) / RR) + FM_T - 1) / FM_T;
@@ -339,7 +383,7 @@ __device__ __attribute__((noinline)) void fm_pass2(double2 *X, const double2 *tw
         const int g = it * FM_T + tid;
         if (g < ng) {
             const int k1 = PP ? (g % PP) : (P == 1) ? 0 : g - (int)__umulhi((unsigned)g, pmagic) * P;
-            double2 *z = X + ((g - k1) * RR + k1);
+            const LdsArr z = X + ((g - k1) * RR + k1);
 #pragma unroll
             for (int q2 = 0; q2 < R2; q2++)
 #pragma unroll
@@ -353,7 +397,7 @@ __device__ __attribute__((noinline)) void fm_pass2(double2 *X, const double2 *tw
 // (4-way conflict, 32 LDS cycles per wave store instead of 8).  Rotating which output a lane stores in which
 // instruction -- output (i + (lane >> 1)) & 3 in instruction i -- puts the 8 lanes on 8 different bank groups; the
 // rotation is two conditional-move stages over the four values.
-__device__ __forceinline__ void fm_store4_rotated(double2 *X, int b, const double2 (&v)[4], int tid)
+__device__ __forceinline__ void fm_store4_rotated(LdsArr X, int b, const double2 (&v)[4], int tid)
 {
     const int r = (tid >> 1) & 3;
     double2 w[4], t[4], u[4];
@@ -385,11 +429,13 @@ __device__ __forceinline__ void fm_store4_rotated(double2 *X, int b, const doubl
 // Same butterflies on the same operands as fm_pass<4>; what goes away is one LDS write of the whole image, one read
 // of it and two barriers per transform.
 template <int NN, bool F32IN>
-__device__ __attribute__((noinline)) void fm_first_from_raw(double2 *X, const int *raw, const float2 *rawf, int ic, int qc, int tid)
+__device__ __attribute__((noinline)) void fm_first_from_raw(LdsArr X, const int *raw_, const float2 *rawf_, int ic, int qc, int tid)
 {
     constexpr int nb = NN / 4, ITERS = (nb + FM_T - 1) / FM_T;
+    gbl_i32 *raw = (gbl_i32 *)(unsigned long long)raw_;
+    gbl_f2v *rawf = (gbl_f2v *)(unsigned long long)rawf_;
     int w[ITERS][4];
-    float2 wf[ITERS][4];
+    f2v wf[ITERS][4];
 #pragma unroll
     for (int it = 0; it < ITERS; it++) {
         int b = it * FM_T + tid;
@@ -423,7 +469,7 @@ __device__ __attribute__((noinline)) void fm_first_from_raw(double2 *X, const in
 }
 
 template <int NN>
-__device__ __attribute__((noinline)) void fm_first_from_bins(double2 *X, double2 in0, int tid)
+__device__ __attribute__((noinline)) void fm_first_from_bins(LdsArr X, double2 in0, int tid)
 {
     constexpr int nb = NN / 4, ITERS = (nb + FM_T - 1) / FM_T;
     static_assert(FM_T >= 204, "butterfly b < 204 belongs to thread b");
@@ -451,40 +497,60 @@ __device__ __forceinline__ const double2 *fm_table(const double2 *twL, const Fft
 // mode (default frames): FM_FULL the whole transform; FM_FWD_BAND the forward transform of the front end, last pass
 // restricted to the outputs [0, need_end) that are read; FM_INV_REAL the inverse transform after fm_inv_blocks
 // (passes 1-3 done), last pass real parts only, scaled by norm
+// LDSTW: the tables of the first passes are in LDS (k_front_fftm; a.lds_tw entries) -- for the default frames that is a
+// compile-time fact (launch_front_fftm refuses any other split): fftm_twiddles lays the tables out back to back,
+//   n = 9600: radices 4,4,4,2,3,5,5, lengths 4,16,64,128,384 | 1920,9600, offsets 0,4,20,84,212 | 596,2516
+//   n = 4800: radices 4,4,4,3,5,5,   lengths 4,16,64,192,960 | 4800,      offsets 0,4,20,84,276 | 1236
+constexpr int FM_LDS_TW_9600 = 596, FM_LDS_TW_4800 = 1236;
 enum { FM_FULL = 0, FM_FWD_BAND = 1, FM_INV_REAL = 2 };
-__device__ __forceinline__ void fm_forward(double2 *X, const double2 *twL, const FftmArgs &a, int tid, bool first_done,
+template <bool LDSTW>
+__device__ __forceinline__ void fm_forward(LdsArr X, const double2 *twL, const FftmArgs &a, int tid, bool first_done,
                                            int mode = FM_FULL, int need_end = 0, double norm = 1.0)
 {
+    const GblArr g = gbl_arr(a.f.tw);
     // the reference's two default frames: the plan is known (fftm_radices: 4,4,4,2,3,5,5 / 4,4,4,3,5,5)
     if (a.f.n == 9600) {
-        if (mode != FM_INV_REAL) {
-            if (!first_done) fm_pass<4, 9600, 1>(X, fm_table(twL, a, 0, 1), 9600, 1, 0u, tid);
-            fm_pass2<4, 4, 9600, 4>(X, fm_table(twL, a, 1, 4), fm_table(twL, a, 2, 16), 9600, 4, 0u, tid);
-        }
-        fm_pass2<2, 3, 9600, 64>(X, fm_table(twL, a, 3, 64), fm_table(twL, a, 4, 128), 9600, 64, 0u, tid);
-        fm_pass<5, 9600, 384>(X, fm_table(twL, a, 5, 384), 9600, 384, 0u, tid);
-        if (mode == FM_FWD_BAND)
-            fm_pass5_band<9600, 1920>(X, fm_table(twL, a, 6, 1920), need_end, tid);
-        else if (mode == FM_INV_REAL)
-            fm_pass5_real<9600, 1920>(X, fm_table(twL, a, 6, 1920), norm, tid);
+        auto head = [&](auto t) {
+            if (mode != FM_INV_REAL) {
+                if (!first_done) fm_pass<4, 9600, 1>(X, t, 9600, 1, 0u, tid);
+                fm_pass2<4, 4, 9600, 4>(X, t + 4, t + 20, 9600, 4, 0u, tid);
+            }
+            fm_pass2<2, 3, 9600, 64>(X, t + 84, t + 212, 9600, 64, 0u, tid);
+        };
+        if constexpr (LDSTW)
+            head(lds_arr(twL));
         else
-            fm_pass<5, 9600, 1920>(X, fm_table(twL, a, 6, 1920), 9600, 1920, 0u, tid);
+            head(g);
+        fm_pass<5, 9600, 384>(X, g + 596, 9600, 384, 0u, tid);
+        if (mode == FM_FWD_BAND)
+            fm_pass5_band<9600, 1920>(X, g + 2516, need_end, tid);
+        else if (mode == FM_INV_REAL)
+            fm_pass5_real<9600, 1920>(X, g + 2516, norm, tid);
+        else
+            fm_pass<5, 9600, 1920>(X, g + 2516, 9600, 1920, 0u, tid);
         return;
     }
     if (a.f.n == 4800) {
-        if (mode != FM_INV_REAL) {
-            if (!first_done) fm_pass<4, 4800, 1>(X, fm_table(twL, a, 0, 1), 4800, 1, 0u, tid);
-            fm_pass2<4, 4, 4800, 4>(X, fm_table(twL, a, 1, 4), fm_table(twL, a, 2, 16), 4800, 4, 0u, tid);
-        }
-        fm_pass2<3, 5, 4800, 64>(X, fm_table(twL, a, 3, 64), fm_table(twL, a, 4, 192), 4800, 64, 0u, tid);
-        if (mode == FM_FWD_BAND)
-            fm_pass5_band<4800, 960>(X, fm_table(twL, a, 5, 960), need_end, tid);
-        else if (mode == FM_INV_REAL)
-            fm_pass5_real<4800, 960>(X, fm_table(twL, a, 5, 960), norm, tid);
+        auto head = [&](auto t) {
+            if (mode != FM_INV_REAL) {
+                if (!first_done) fm_pass<4, 4800, 1>(X, t, 4800, 1, 0u, tid);
+                fm_pass2<4, 4, 4800, 4>(X, t + 4, t + 20, 4800, 4, 0u, tid);
+            }
+            fm_pass2<3, 5, 4800, 64>(X, t + 84, t + 276, 4800, 64, 0u, tid);
+        };
+        if constexpr (LDSTW)
+            head(lds_arr(twL));
         else
-            fm_pass<5, 4800, 960>(X, fm_table(twL, a, 5, 960), 4800, 960, 0u, tid);
+            head(g);
+        if (mode == FM_FWD_BAND)
+            fm_pass5_band<4800, 960>(X, g + 1236, need_end, tid);
+        else if (mode == FM_INV_REAL)
+            fm_pass5_real<4800, 960>(X, g + 1236, norm, tid);
+        else
+            fm_pass<5, 4800, 960>(X, g + 1236, 4800, 960, 0u, tid);
         return;
     }
+    // any other frame: run-time plan, tables wherever fm_table finds them (flat accesses)
     int P = 1;
     for (int p = 0; p < a.np;) {
         const int r = a.rad[p];
@@ -526,6 +592,7 @@ __global__ __launch_bounds__(FM_T) void k_front_fftm(FftmArgs aa)
     const FftFrontArgs &a = aa.f;
     const int n = a.n;
     double2 *X = reinterpret_cast<double2 *>(smem);      // [n]
+    const LdsArr XL = lds_arr(smem);                     // the same image for the passes (typed view)
     // [32]; during RxDownSample slots 26..51 (over the argmax scratch behind it, dead by then) hold the frame's first 26
     // scaled samples, so that a window reaching back into the previous frame is one contiguous run as well
     double *hist = reinterpret_cast<double *>(X + n);
@@ -579,9 +646,9 @@ __global__ __launch_bounds__(FM_T) void k_front_fftm(FftmArgs aa)
         asm volatile("" : "+v"(tf));
         const bool fused_first = (n == 9600 || n == 4800);
         if (n == 9600) {
-            fm_first_from_raw<9600, F32IN>(X, raw + t0, rawf + t0, a.ic, a.qc, tf);
+            fm_first_from_raw<9600, F32IN>(XL, raw + t0, rawf + t0, a.ic, a.qc, tf);
         } else if (n == 4800) {
-            fm_first_from_raw<4800, F32IN>(X, raw + t0, rawf + t0, a.ic, a.qc, tf);
+            fm_first_from_raw<4800, F32IN>(XL, raw + t0, rawf + t0, a.ic, a.qc, tf);
         } else {
             // ---- frame -> LDS, natural order (:416-421)
             {
@@ -618,7 +685,7 @@ __global__ __launch_bounds__(FM_T) void k_front_fftm(FftmArgs aa)
             __syncthreads();
         }
         PHASE(0)
-        fm_forward(X, twL, aa, tf, fused_first, fused_first ? FM_FWD_BAND : FM_FULL, end + 102);  // :422-423; bins < end + 102 are read
+        fm_forward<true>(XL, twL, aa, tf, fused_first, fused_first ? FM_FWD_BAND : FM_FULL, end + 102);  // :422-423; bins < end + 102 are read
         PHASE(1)
         // ---- |X| (:425-427) over the band the boxcar reads
         for (int i = pbase + tf; i < end - 24; i += FM_T) {
@@ -694,13 +761,13 @@ __global__ __launch_bounds__(FM_T) void k_front_fftm(FftmArgs aa)
         // conj o forward o conj; only real parts are read afterwards, so the closing conjugation is dropped
         if (fused_first) {
             // default frames: passes 1-3 straight from the bins, last pass real parts only and already scaled by 1/n
-            const double2 *t64 = fm_table(twL, aa, 2, 16);
+            const LdsArr t64 = lds_arr(twL) + 20;  // the 64-entry table of pass 3
             if (n == 9600)
-                fm_inv_blocks<9600, true>(X, X + (centreBin - 102), t64, 1, t64, 2, tf);
+                fm_inv_blocks<9600, true>(XL, XL + (centreBin - 102), t64, 1, t64, 2, tf);
             else
-                fm_inv_blocks<4800, true>(X, X + (centreBin - 102), t64, 1, t64, 2, tf);
+                fm_inv_blocks<4800, true>(XL, XL + (centreBin - 102), t64, 1, t64, 2, tf);
             PHASE(3)
-            fm_forward(X, twL, aa, tf, true, FM_INV_REAL, 0, norm);
+            fm_forward<true>(XL, twL, aa, tf, true, FM_INV_REAL, 0, norm);
         } else {
             double2 keep = make_double2(0.0, 0.0);
             if (tf < 204) keep = X[centreBin - 102 + tf];
@@ -710,7 +777,7 @@ __global__ __launch_bounds__(FM_T) void k_front_fftm(FftmArgs aa)
             if (tf < 204) X[tf] = make_double2(keep.x, -keep.y);
             __syncthreads();
             PHASE(3)
-            fm_forward(X, twL, aa, tf, false);
+            fm_forward<true>(XL, twL, aa, tf, false);
             for (int i = tf; i < n; i += FM_T) X[i].x = X[i].x * norm;  // re = X.x / n (:462)
             __syncthreads();
         }
@@ -782,7 +849,7 @@ struct Fft2xArgs {
 
 // one Stockham pass with a two-dimensional twiddle table tw[(j-1) P + k], every input j >= 1 multiplied (also at P = 1)
 template <int R>
-__device__ __attribute__((noinline)) void fm_pass_t(double2 *X, const double2 *tw, int n, int P, unsigned pmagic, int tid)
+__device__ __attribute__((noinline)) void fm_pass_t(LdsArr X, GblArr tw, int n, int P, unsigned pmagic, int tid)
 {
     constexpr int ITERS = ((FM_NMAX / R) + FM_T - 1) / FM_T;
     const int nb = n / R;
@@ -816,7 +883,7 @@ __device__ __attribute__((noinline)) void fm_pass_t(double2 *X, const double2 *t
 
 // two consecutive passes of an odd half in one LDS round trip: fm_pass2 with the two-dimensional tables
 template <int R1, int R2, int NN, int PP>
-__device__ __attribute__((noinline)) void fm_pass2_t(double2 *X, const double2 *tw1, const double2 *tw2, int tid)
+__device__ __attribute__((noinline)) void fm_pass2_t(LdsArr X, GblArr tw1, GblArr tw2, int tid)
 {
     constexpr int RR = R1 * R2;
     constexpr int ITERS = ((NN / RR) + FM_T - 1) / FM_T;
@@ -859,7 +926,7 @@ __device__ __attribute__((noinline)) void fm_pass2_t(double2 *X, const double2 *
         const int g = it * FM_T + tid;
         if (g < ng) {
             const int k1 = g % PP;
-            double2 *z = X + ((g - k1) * RR + k1);
+            const LdsArr z = X + ((g - k1) * RR + k1);
 #pragma unroll
             for (int q2 = 0; q2 < R2; q2++)
 #pragma unroll
@@ -869,12 +936,12 @@ __device__ __attribute__((noinline)) void fm_pass2_t(double2 *X, const double2 *
     __syncthreads();
 }
 
-__device__ __forceinline__ void fm_forward_odd(double2 *X, const Fft2xArgs &a, int tid, int mode = FM_FULL, int need_end = 0,
+__device__ __forceinline__ void fm_forward_odd(LdsArr X, const Fft2xArgs &a, int tid, int mode = FM_FULL, int need_end = 0,
                                                double norm = 1.0)
 {
     const FftmArgs &m = a.sub;
     if (m.f.n == 9600) {  // the 192 kHz default: the 9600-point plan 4 | 4,4 | 2,3 | 5 | 5 with pass pairs, as fm_forward
-        const double2 *t = m.f.tw;
+        const GblArr t = gbl_arr(m.f.tw);
         if (mode != FM_INV_REAL) {
             fm_pass_t<4>(X, t + a.tw1_off[0], 9600, 1, 0u, tid);
             fm_pass2_t<4, 4, 9600, 4>(X, t + a.tw1_off[1], t + a.tw1_off[2], tid);
@@ -892,7 +959,7 @@ __device__ __forceinline__ void fm_forward_odd(double2 *X, const Fft2xArgs &a, i
     int P = 1;
     for (int p = 0; p < m.np; p++) {
         const int r = m.rad[p];
-        const double2 *tw = m.f.tw + a.tw1_off[p];
+        const GblArr tw = gbl_arr(m.f.tw + a.tw1_off[p]);
         if (r == 4)
             fm_pass_t<4>(X, tw, m.f.n, P, m.pmagic[p], tid);
         else if (r == 2)
@@ -912,6 +979,7 @@ __global__ __launch_bounds__(FM_T) void k_front_fft2x(Fft2xArgs aa)
     const FftFrontArgs &a = aa.sub.f;
     const int n = aa.n, m = n / 2;
     double2 *X = reinterpret_cast<double2 *>(smem);      // [m]: one half at a time
+    const LdsArr XL = lds_arr(smem);                     // the same image for the passes (typed view)
     double *hist = reinterpret_cast<double *>(X + m);    // [64]: [0,26) the previous frame's last 26 scaled samples
     double *redv = hist + 64;
     int *redi = reinterpret_cast<int *>(redv + 16);
@@ -972,13 +1040,13 @@ __global__ __launch_bounds__(FM_T) void k_front_fft2x(Fft2xArgs aa)
         // bins below end + 102 are read (see fm_pass5_band): even bin 2 i <=> output i of this half
         const int need_even = (end + 102 + 1) / 2, need_odd = (end + 102) / 2;
         load_half(t0, 0, tf);
-        fm_forward(X, nullptr, aa.sub, tf, false, pruned ? FM_FWD_BAND : FM_FULL, need_even);
+        fm_forward<false>(XL, nullptr, aa.sub, tf, false, pruned ? FM_FWD_BAND : FM_FULL, need_even);
         for (int i = tf; i < (pruned ? need_even : nek); i += FM_T) ek[i] = X[i];
         __threadfence_block();
         __syncthreads();
         // ---- forward, odd bins
         load_half(t0, 1, tf);
-        fm_forward_odd(X, aa, tf, pruned ? FM_FWD_BAND : FM_FULL, need_odd);
+        fm_forward_odd(XL, aa, tf, pruned ? FM_FWD_BAND : FM_FULL, need_odd);
         // ---- |X| over the band the boxcar reads (:425-427)
         // (pbase is even: even bins come from the scratch, odd ones from the image -- one loop each, no per-bin branch)
         for (int i = pbase + 2 * tf; i < end - 24; i += 2 * FM_T) {
@@ -1063,27 +1131,27 @@ __global__ __launch_bounds__(FM_T) void k_front_fft2x(Fft2xArgs aa)
             // them (fm_inv_blocks) -- the even half with the 9600-point tables, the odd one with its own
             if (tf < 204) zb[tf] = keep;
             __syncthreads();
-            const double2 *t64 = aa.sub.f.tw + aa.sub.tw_off[2];
-            fm_inv_blocks<9600, false>(X, zb, t64, 1, t64, 2, tf);
-            fm_forward(X, nullptr, aa.sub, tf, true, FM_INV_REAL, 0, norm);
+            const GblArr t64 = gbl_arr(aa.sub.f.tw + aa.sub.tw_off[2]);
+            fm_inv_blocks<9600, false>(XL, lds_arr(zb), t64, 1, t64, 2, tf);
+            fm_forward<false>(XL, nullptr, aa.sub, tf, true, FM_INV_REAL, 0, norm);
             for (int i = tf; i < m; i += FM_T) r0[i] = X[i].x;  // re = X.x / n (:462), sample 2 i
             __threadfence_block();
             __syncthreads();
-            const double2 *u64 = aa.sub.f.tw + aa.tw1_off[2];  // [(j-1) 16 + k]
-            fm_inv_blocks<9600, false>(X, zb, u64, 1, u64 + 16, 1, tf);
-            fm_forward_odd(X, aa, tf, FM_INV_REAL, 0, norm);
+            const GblArr u64 = gbl_arr(aa.sub.f.tw + aa.tw1_off[2]);  // [(j-1) 16 + k]
+            fm_inv_blocks<9600, false>(XL, lds_arr(zb), u64, 1, u64 + 16, 1, tf);
+            fm_forward_odd(XL, aa, tf, FM_INV_REAL, 0, norm);
         } else {
             // even output samples: first-pass sums z[b] + z[b + m], z[b + m] being the zeroed array's
             for (int b = tf; b < m; b += FM_T) X[b] = cdadd(b < 204 ? keep : Z, Z);
             __syncthreads();
-            fm_forward(X, nullptr, aa.sub, tf, false);
+            fm_forward<false>(XL, nullptr, aa.sub, tf, false);
             for (int i = tf; i < m; i += FM_T) r0[i] = X[i].x * norm;  // re = X.x / n (:462), sample 2 i
             __threadfence_block();
             __syncthreads();
             // odd output samples: first-pass differences
             for (int b = tf; b < m; b += FM_T) X[b] = cdsub(b < 204 ? keep : Z, Z);
             __syncthreads();
-            fm_forward_odd(X, aa, tf);
+            fm_forward_odd(XL, aa, tf);
             for (int i = tf; i < m; i += FM_T) X[i].x = X[i].x * norm;  // re = X.x / n (:462), sample 2 i + 1
             __syncthreads();
         }
@@ -1212,6 +1280,12 @@ int launch_front_fftm(const FftFrontArgs &a, int np, const int *rad, const int *
             if (end == (size_t)aa.lds_tw + (size_t)P * rad[p] && end * sizeof(double2) <= room) aa.lds_tw = (int)end;  // a prefix
             P *= rad[p];
         }
+    }
+    // the default frames' kernels address their tables by compile-time offsets (fm_forward)
+    if ((a.n == 9600 && (aa.lds_tw != FM_LDS_TW_9600 || tw_off[5] != 596 || tw_off[6] != 2516)) ||
+        (a.n == 4800 && (aa.lds_tw != FM_LDS_TW_4800 || tw_off[4] != 276 || tw_off[5] != 1236))) {
+        set_error("launch_front_fftm: the twiddle tables of a default frame are not where the kernel expects them");
+        return JSDR_ERR;
     }
     const size_t lds = fixed + sizeof(double2) * (size_t)aa.lds_tw;
     const bool f32 = a.rawf != nullptr;
