@@ -337,7 +337,13 @@ __device__ __attribute__((noinline)) void fm_inv_blocks(LdsArr X, LdsArr src, TW
 // write z[m0*P*R1*R2 + k1 + q1*P + q2*P*R1].  Same operands, same tables, same operation order as fm_pass<R1>
 // followed by fm_pass<R2>: only the intermediate image stays in registers (an LDS store costs 13 cycles per wave
 // instruction, and the image is written once per pass).
-template <int R1, int R2, int NN = 0, int PP = 0, class TW1 = const double2 *, class TW2 = const double2 *>
+// the image between the fused first two passes (fm_first2_from_raw: a thread stores 16 consecutive slots) and the pass
+// pair that reads it: slot s lives at s ^ ((s >> 4) & 7) -- the stores of eight neighbouring lanes then fall into eight
+// different 16-byte bank groups, and so do the reads of eight consecutive slots (an aligned run of 8 is permuted in place)
+__device__ __forceinline__ int fm_swz(int s) { return s ^ ((s >> 4) & 7); }
+
+// SWZ_IN: the image read is the swizzled one
+template <int R1, int R2, int NN = 0, int PP = 0, bool SWZ_IN = false, class TW1 = const double2 *, class TW2 = const double2 *>
 __device__ __attribute__((noinline)) void fm_pass2(LdsArr X, TW1 tw1, TW2 tw2, int n_rt, int P_rt, unsigned pmagic, int tid)
 {
     constexpr int RR = R1 * R2;
@@ -356,7 +362,7 @@ __device__ __attribute__((noinline)) void fm_pass2(LdsArr X, TW1 tw1, TW2 tw2, i
                 const int b1 = g + j2 * ng;
 #pragma unroll
                 for (int j1 = 0; j1 < R1; j1++) {
-                    v[it][j2][j1] = X[b1 + j1 * nb1];
+                    v[it][j2][j1] = X[SWZ_IN ? fm_swz(b1 + j1 * nb1) : b1 + j1 * nb1];
                     if (j1 >= 1 && P > 1) v[it][j2][j1] = cdmul(v[it][j2][j1], tw1[k1 * j1]);
                 }
                 dft_r<R1>(v[it][j2]);
@@ -468,6 +474,61 @@ __device__ __attribute__((noinline)) void fm_first_from_raw(LdsArr X, const int 
     __syncthreads();
 }
 
+// The first TWO passes (4, 4; strides 1 and 4) of the forward transform straight from the frame's samples: group g < n/16
+// holds x[g + j2 n/16 + j1 n/4] -- four first-pass butterflies (no twiddles at stride 1), their outputs q1 through the
+// four second-pass butterflies (T16[q1 j2]) -- and stores its 16 results at slots 16 g + q1 + 4 q2 of the SWIZZLED image
+// (fm_swz).  The operations of fm_first_from_raw followed by fm_pass<4, n, 4>, on the same operands in the same order;
+// what goes away is one LDS write and one read of the whole image, two barriers, and the first pass's rotated stores.
+template <int NN, bool F32IN, class TW2>
+__device__ __attribute__((noinline)) void fm_first2_from_raw(LdsArr X, const int *raw_, const float2 *rawf_, int ic, int qc, TW2 tw2,
+                                                              int tid)
+{
+    constexpr int ng = NN / 16, nb1 = NN / 4;
+    static_assert(ng <= FM_T, "one group per thread");
+    gbl_i32 *raw = (gbl_i32 *)(unsigned long long)raw_;
+    gbl_f2v *rawf = (gbl_f2v *)(unsigned long long)rawf_;
+    const int g = tid < ng ? tid : ng - 1;
+    int w[4][4];
+    f2v wf[4][4];
+#pragma unroll
+    for (int j2 = 0; j2 < 4; j2++)
+#pragma unroll
+        for (int j1 = 0; j1 < 4; j1++) {
+            if (F32IN)
+                wf[j2][j1] = rawf[g + j2 * ng + j1 * nb1];
+            else
+                w[j2][j1] = raw[g + j2 * ng + j1 * nb1];
+        }
+    if (tid < ng) {
+        double2 v[4][4];
+#pragma unroll
+        for (int j2 = 0; j2 < 4; j2++) {
+#pragma unroll
+            for (int j1 = 0; j1 < 4; j1++) {
+                if (F32IN)
+                    v[j2][j1] = make_double2((double)wf[j2][j1].x, (double)wf[j2][j1].y);
+                else
+                    v[j2][j1] = make_double2((double)i16_to_float_java(java_short_add((int)(short)(w[j2][j1] & 0xffff), ic)),
+                                             (double)i16_to_float_java(java_short_add(w[j2][j1] >> 16, qc)));
+            }
+            dft_r<4>(v[j2]);
+        }
+#pragma unroll
+        for (int q1 = 0; q1 < 4; q1++) {
+            double2 u[4];
+#pragma unroll
+            for (int j2 = 0; j2 < 4; j2++) {
+                u[j2] = v[j2][q1];
+                if (j2 >= 1) u[j2] = cdmul(u[j2], tw2[q1 * j2]);
+            }
+            dft_r<4>(u);
+#pragma unroll
+            for (int q2 = 0; q2 < 4; q2++) X[fm_swz(16 * tid + q1 + 4 * q2)] = u[q2];
+        }
+    }
+    __syncthreads();
+}
+
 template <int NN>
 __device__ __attribute__((noinline)) void fm_first_from_bins(LdsArr X, double2 in0, int tid)
 {
@@ -510,6 +571,17 @@ __device__ __forceinline__ void fm_forward(LdsArr X, const double2 *twL, const F
     const GblArr g = gbl_arr(a.f.tw);
     // the reference's two default frames: the plan is known (fftm_radices: 4,4,4,2,3,5,5 / 4,4,4,3,5,5)
     if (a.f.n == 9600) {
+        if constexpr (LDSTW) {
+            if (mode == FM_FWD_BAND && first_done) {
+                // k_front_fftm's forward transform: passes 1-2 came from fm_first2_from_raw (swizzled image); the other
+                // five go as 4,2 | 3,5 | 5 -- three LDS round trips, 1200 / 640 / 1920 work items for the 768 threads
+                const LdsArr t = lds_arr(twL);
+                fm_pass2<4, 2, 9600, 16, true>(X, t + 20, t + 84, 9600, 16, 0u, tid);
+                fm_pass2<3, 5, 9600, 128>(X, t + 212, g + 596, 9600, 128, 0u, tid);
+                fm_pass5_band<9600, 1920>(X, g + 2516, need_end, tid);
+                return;
+            }
+        }
         auto head = [&](auto t) {
             if (mode != FM_INV_REAL) {
                 if (!first_done) fm_pass<4, 9600, 1>(X, t, 9600, 1, 0u, tid);
@@ -646,7 +718,7 @@ __global__ __launch_bounds__(FM_T) void k_front_fftm(FftmArgs aa)
         asm volatile("" : "+v"(tf));
         const bool fused_first = (n == 9600 || n == 4800);
         if (n == 9600) {
-            fm_first_from_raw<9600, F32IN>(XL, raw + t0, rawf + t0, a.ic, a.qc, tf);
+            fm_first2_from_raw<9600, F32IN>(XL, raw + t0, rawf + t0, a.ic, a.qc, lds_arr(twL) + 4, tf);
         } else if (n == 4800) {
             fm_first_from_raw<4800, F32IN>(XL, raw + t0, rawf + t0, a.ic, a.qc, tf);
         } else {
