@@ -178,8 +178,13 @@ __device__ __attribute__((noinline)) void fm_pass(LdsArr X, TW tw, int n_rt, int
 // have no reader and are not computed) and it is stored already scaled: X[i].x = re * (1/n), once per sample instead of
 // once per tap that reads it.  Same operands, same operations, same order for everything that IS computed.
 // TT: the two-dimensional tables of an odd half (fm_pass_t): tw[(j-1) P + k] instead of tw[k j]
-template <int NN, int PP, bool TT = false, class TW = const double2 *>
-__device__ __attribute__((noinline)) void fm_pass5_real(LdsArr X, TW tw, double norm, int tid)
+// COMPACT: the scaled real parts leave as a plain array of doubles over the (dead) image -- sample t at double slot
+// FM_RB0 + t, the previous frame's last 26 samples (hist) copied in front of them at FM_RB0 - 26 .. FM_RB0 - 1 -- so that a
+// RxDownSample window, history included, is ONE contiguous run of 27 doubles: 14 conflict-free 16-byte reads per output
+// instead of 27 eight-byte reads at a 160-byte lane stride (16 lanes on the same banks).
+constexpr int FM_RB0 = 32;
+template <int NN, int PP, bool TT = false, bool COMPACT = false, class TW = const double2 *>
+__device__ __attribute__((noinline)) void fm_pass5_real(LdsArr X, TW tw, double norm, int tid, const double *hist_ = nullptr)
 {
     constexpr int R = 5, nb = NN / R, ITERS = (nb + FM_T - 1) / FM_T;
     double o[ITERS][R];
@@ -200,6 +205,7 @@ __device__ __attribute__((noinline)) void fm_pass5_real(LdsArr X, TW tw, double 
         }
     }
     FM_PASS_SYNC();
+    lds_f64 *Rb = reinterpret_cast<lds_f64 *>(X.p);
 #pragma unroll
     for (int it = 0; it < ITERS; it++) {
         const int b = it * FM_T + tid;
@@ -207,8 +213,17 @@ __device__ __attribute__((noinline)) void fm_pass5_real(LdsArr X, TW tw, double 
             const int k = b % PP;
             const int j0 = (b - k) * R + k;
 #pragma unroll
-            for (int q = 0; q < R; q++) X[j0 + q * PP].put_x(o[it][q]);
+            for (int q = 0; q < R; q++) {
+                if (COMPACT)
+                    Rb[FM_RB0 + j0 + q * PP] = o[it][q];
+                else
+                    X[j0 + q * PP].put_x(o[it][q]);
+            }
         }
+    }
+    if (COMPACT) {
+        const lds_f64 *hist = (const lds_f64 *)(unsigned)(unsigned long long)hist_;
+        if (tid < 26) Rb[FM_RB0 - 26 + tid] = hist[tid];
     }
     FM_PASS_SYNC();
 }
@@ -566,7 +581,7 @@ constexpr int FM_LDS_TW_9600 = 596, FM_LDS_TW_4800 = 1236;
 enum { FM_FULL = 0, FM_FWD_BAND = 1, FM_INV_REAL = 2 };
 template <bool LDSTW>
 __device__ __forceinline__ void fm_forward(LdsArr X, const double2 *twL, const FftmArgs &a, int tid, bool first_done,
-                                           int mode = FM_FULL, int need_end = 0, double norm = 1.0)
+                                           int mode = FM_FULL, int need_end = 0, double norm = 1.0, const double *hist = nullptr)
 {
     const GblArr g = gbl_arr(a.f.tw);
     // the reference's two default frames: the plan is known (fftm_radices: 4,4,4,2,3,5,5 / 4,4,4,3,5,5)
@@ -597,7 +612,7 @@ __device__ __forceinline__ void fm_forward(LdsArr X, const double2 *twL, const F
         if (mode == FM_FWD_BAND)
             fm_pass5_band<9600, 1920>(X, g + 2516, need_end, tid);
         else if (mode == FM_INV_REAL)
-            fm_pass5_real<9600, 1920>(X, g + 2516, norm, tid);
+            fm_pass5_real<9600, 1920, false, LDSTW>(X, g + 2516, norm, tid, hist);  // (k_front_fftm: compact real samples)
         else
             fm_pass<5, 9600, 1920>(X, g + 2516, 9600, 1920, 0u, tid);
         return;
@@ -617,7 +632,7 @@ __device__ __forceinline__ void fm_forward(LdsArr X, const double2 *twL, const F
         if (mode == FM_FWD_BAND)
             fm_pass5_band<4800, 960>(X, g + 1236, need_end, tid);
         else if (mode == FM_INV_REAL)
-            fm_pass5_real<4800, 960>(X, g + 1236, norm, tid);
+            fm_pass5_real<4800, 960, false, LDSTW>(X, g + 1236, norm, tid, hist);
         else
             fm_pass<5, 4800, 960>(X, g + 1236, 4800, 960, 0u, tid);
         return;
@@ -839,7 +854,52 @@ __global__ __launch_bounds__(FM_T) void k_front_fftm(FftmArgs aa)
             else
                 fm_inv_blocks<4800, true>(XL, XL + (centreBin - 102), t64, 1, t64, 2, tf);
             PHASE(3)
-            fm_forward<true>(XL, twL, aa, tf, true, FM_INV_REAL, 0, norm);
+            fm_forward<true>(XL, twL, aa, tf, true, FM_INV_REAL, 0, norm, hist);
+            PHASE(4)
+            // ---- RxDownSample(re, re) (:461-463, :470-492) from the compact samples: sample t of the frame at double slot
+            // FM_RB0 + t, the previous frame's last 26 in front of them -- every window is one contiguous run
+            {
+                const double *Rb = reinterpret_cast<const double *>(smem);
+                long long jlo = (t0 - a.first_out + D - 1) / D;
+                if (t0 <= a.first_out) jlo = 0;
+                const bool even_d = (D & 1) == 0;                 // then every window of the call ends on the same parity (n is even)
+                const int par = (int)((a.first_out - t0) & 1);
+                for (long long j = jlo + tf;; j += FM_T) {
+                    const long long te = (long long)a.first_out + (long long)D * j;  // window end, call-relative
+                    if (te >= t0 + n || j >= a.nds) break;
+                    const double2 cs = a.vco_cs[j];
+                    const int e = (int)(te - t0);  // 0..n-1 within the frame
+                    double fi = 0.0;
+                    if (even_d) {
+                        // the 27 samples e-26 .. e as 14 aligned 16-byte reads: d[i] = slot ((e + 6) & ~1) + i
+                        const double2 *w2 = reinterpret_cast<const double2 *>(Rb + ((e + FM_RB0 - 26) & ~1));
+                        double d[28];
+#pragma unroll
+                        for (int i = 0; i < 14; i++) {
+                            const double2 t = w2[i];
+                            d[2 * i] = t.x;
+                            d[2 * i + 1] = t.y;
+                        }
+                        if (par) {
+#pragma unroll
+                            for (int k = 0; k < 27; k++) fi += d[27 - k] * ds_tap(k);  // newest first (:479-483)
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < 27; k++) fi += d[26 - k] * ds_tap(k);
+                        }
+                    } else {
+                        const double *w = Rb + (FM_RB0 + e);
+#pragma unroll
+                        for (int k = 0; k < 27; k++) fi += w[-k] * ds_tap(k);
+                    }
+                    const double o = fi * HOWARD;  // fi == fq: both rails get the same samples
+                    dm[64 + j] = make_double2(o * cs.x, o * cs.y);  // :515-516
+                }
+                if (tf < 26) hist[tf] = Rb[FM_RB0 + n - 26 + tf];  // (nobody reads hist[] before the next frame's last pass)
+                __syncthreads();  // every window is read before the next frame's first pass overwrites the image
+            }
+            PHASE(5)
+            continue;
         } else {
             double2 keep = make_double2(0.0, 0.0);
             if (tf < 204) keep = X[centreBin - 102 + tf];
