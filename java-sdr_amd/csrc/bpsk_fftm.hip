@@ -346,6 +346,60 @@ __device__ __attribute__((noinline)) void fm_inv_blocks(LdsArr X, LdsArr src, TW
     FM_PASS_SYNC();
 }
 
+// n = 9600: the first FOUR passes (4, 4, 4, 2) of the inverse transform straight from the gathered bins.  With C = 150 a
+// block of 64 (see fm_inv_blocks) has at most TWO live inputs -- block m holds E_m[k + 16 c] = z[m] (+, -i, -, +i) v1,
+// v1 = z[m + 150] T64[k] for m < 54, and plainly z[m] in every slot for 54 <= m < 150.  Pass 4 (radix 2, stride 64) pairs
+// block m < 75 with block m + 75 (always of the plain kind):
+//     out[128 m + kk] = E_m[kk] + w,  out[128 m + kk + 64] = E_m[kk] - w,   w = z[m + 75] T128[kk],  kk < 64
+// -- the general passes' operations on these operands, minus those whose second operand is a zero of the zeroed array (as
+// in fm_inv_blocks).  An item (m, k < 16) forms the eight outputs kk = k + 16 c, c < 4: 1200 items, one LDS round trip for
+// four passes; what follows is fm_pass2<3, 5> and the real-parts-only last pass.
+template <bool CONJ, class TW64, class TW128>
+__device__ __attribute__((noinline)) void fm_inv_blocks128_9600(LdsArr X, LdsArr src, TW64 t64, TW128 t128, int tid)
+{
+    constexpr int NITEM = 75 * 16, ITERS = (NITEM + FM_T - 1) / FM_T;
+    double2 z0[ITERS], zc[ITERS], z1[ITERS];
+#pragma unroll
+    for (int it = 0; it < ITERS; it++) {
+        const int id = it * FM_T + tid;
+        const int m = id >> 4;
+        z0[it] = zc[it] = z1[it] = make_double2(0.0, 0.0);
+        if (id < NITEM) {
+            const double2 a = src[m], c = src[m + 75];
+            z0[it] = make_double2(a.x, CONJ ? -a.y : a.y);
+            zc[it] = make_double2(c.x, CONJ ? -c.y : c.y);
+            if (m < 54) {
+                const double2 b = src[m + 150];
+                z1[it] = make_double2(b.x, CONJ ? -b.y : b.y);
+            }
+        }
+    }
+    FM_PASS_SYNC();  // every bin is in registers before the image is overwritten
+#pragma unroll
+    for (int it = 0; it < ITERS; it++) {
+        const int id = it * FM_T + tid;
+        if (id < NITEM) {
+            const int m = id >> 4, k = id & 15;
+            double2 e[4] = {z0[it], z0[it], z0[it], z0[it]};
+            if (m < 54) {
+                const double2 v1 = cdmul(z1[it], t64[k]);
+                e[0] = cdadd(z0[it], v1);
+                e[2] = cdsub(z0[it], v1);
+                e[1] = make_double2(z0[it].x + v1.y, z0[it].y - v1.x);
+                e[3] = make_double2(z0[it].x - v1.y, z0[it].y + v1.x);
+            }
+            const LdsArr o = X + (128 * m + k);
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const double2 w = cdmul(zc[it], t128[k + 16 * c]);
+                o[16 * c] = cdadd(e[c], w);
+                o[16 * c + 64] = cdsub(e[c], w);
+            }
+        }
+    }
+    FM_PASS_SYNC();
+}
+
 // TWO consecutive Stockham passes (radix R1 at stride P, then R2 at stride P*R1) in one LDS round trip.  The R1*R2
 // points of a group are closed under both passes: group g = m0*P + k1 (k1 < P) takes the R2 first-pass butterflies
 // b1 = g + j2*(n/(R1 R2)) -- their outputs q1 feed the R1 second-pass butterflies b2 = m0*P*R1 + (k1 + q1*P), which
@@ -587,6 +641,12 @@ __device__ __forceinline__ void fm_forward(LdsArr X, const double2 *twL, const F
     // the reference's two default frames: the plan is known (fftm_radices: 4,4,4,2,3,5,5 / 4,4,4,3,5,5)
     if (a.f.n == 9600) {
         if constexpr (LDSTW) {
+            if (mode == FM_INV_REAL) {
+                // k_front_fftm's inverse transform: passes 1-4 came from fm_inv_blocks128_9600
+                fm_pass2<3, 5, 9600, 128>(X, lds_arr(twL) + 212, g + 596, 9600, 128, 0u, tid);
+                fm_pass5_real<9600, 1920, false, true>(X, g + 2516, norm, tid, hist);
+                return;
+            }
             if (mode == FM_FWD_BAND && first_done) {
                 // k_front_fftm's forward transform: passes 1-2 came from fm_first2_from_raw (swizzled image); the other
                 // five go as 4,2 | 3,5 | 5 -- three LDS round trips, 1200 / 640 / 1920 work items for the 768 threads
@@ -850,7 +910,7 @@ __global__ __launch_bounds__(FM_T) void k_front_fftm(FftmArgs aa)
             // default frames: passes 1-3 straight from the bins, last pass real parts only and already scaled by 1/n
             const LdsArr t64 = lds_arr(twL) + 20;  // the 64-entry table of pass 3
             if (n == 9600)
-                fm_inv_blocks<9600, true>(XL, XL + (centreBin - 102), t64, 1, t64, 2, tf);
+                fm_inv_blocks128_9600<true>(XL, XL + (centreBin - 102), t64, lds_arr(twL) + 84, tf);
             else
                 fm_inv_blocks<4800, true>(XL, XL + (centreBin - 102), t64, 1, t64, 2, tf);
             PHASE(3)
