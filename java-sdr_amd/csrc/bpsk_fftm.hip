@@ -568,6 +568,7 @@ __device__ __attribute__((noinline)) void fm_first2_from_raw(LdsArr X, const int
             else
                 w[j2][j1] = raw[g + j2 * ng + j1 * nb1];
         }
+    const bool dc = (ic != 0) || (qc != 0);
     if (tid < ng) {
         double2 v[4][4];
 #pragma unroll
@@ -576,9 +577,8 @@ __device__ __attribute__((noinline)) void fm_first2_from_raw(LdsArr X, const int
             for (int j1 = 0; j1 < 4; j1++) {
                 if (F32IN)
                     v[j2][j1] = make_double2((double)wf[j2][j1].x, (double)wf[j2][j1].y);
-                else
-                    v[j2][j1] = make_double2((double)i16_to_float_java(java_short_add((int)(short)(w[j2][j1] & 0xffff), ic)),
-                                             (double)i16_to_float_java(java_short_add(w[j2][j1] >> 16, qc)));
+                else  // (the pair at once, the correction skipped when there is none: common.h)
+                    fm_convert(w[j2][j1], ic, qc, dc, v[j2][j1].x, v[j2][j1].y);
             }
             dft_r<4>(v[j2]);
         }
@@ -882,16 +882,27 @@ __global__ __launch_bounds__(FM_T) void k_front_fftm(FftmArgs aa)
         PHASE(7)
         // ---- centre-bin rule (:444-453), evaluated by every thread on the same values
         {
-            double maxBin = 0.0;
-            int binPos = -1;
-            for (int w = 0; w < FM_T / 64; w++) {
-                const double ov = redv[w];
-                const int oi = redi[w];
-                if (oi >= 0 && (ov > maxBin || (ov == maxBin && (binPos < 0 || oi < binPos)))) {
-                    maxBin = ov;
-                    binPos = oi;
+            // the twelve per-wave maxima meet in lanes 0..11 of every wave (the same combine as above: larger value,
+            // then smaller index; an empty candidate never wins) -- as a 12-step loop run by every thread this cost the
+            // SIMDs 3.6k cycles a frame
+            double mv = 0.0;
+            int mi = -1;
+            if (lane < FM_T / 64) {
+                mv = redv[lane];
+                mi = redi[lane];
+            }
+#pragma unroll
+            for (int off = 8; off >= 1; off >>= 1) {
+                const double ov = __shfl_xor(mv, off, 64);
+                const int oi = __shfl_xor(mi, off, 64);
+                if (oi >= 0 && (ov > mv || (ov == mv && (mi < 0 || oi < mi)))) {
+                    mv = ov;
+                    mi = oi;
                 }
             }
+            const double maxBin = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(mv)),
+                                                   __builtin_amdgcn_readfirstlane(__double2loint(mv)));
+            const int binPos = __builtin_amdgcn_readfirstlane(mi);
             if (centreBin < 0) centreBin = 0;
             if (centreBin > end - 1) centreBin = end - 1;
             // aveTemp is cleared per frame (:431) and only [beg+75, end-75) is filled
@@ -1289,16 +1300,27 @@ __global__ __launch_bounds__(FM_T) void k_front_fft2x(Fft2xArgs aa)
         __syncthreads();
         // ---- centre-bin rule (:444-453)
         {
-            double maxBin = 0.0;
-            int binPos = -1;
-            for (int w = 0; w < FM_T / 64; w++) {
-                const double ov = redv[w];
-                const int oi = redi[w];
-                if (oi >= 0 && (ov > maxBin || (ov == maxBin && (binPos < 0 || oi < binPos)))) {
-                    maxBin = ov;
-                    binPos = oi;
+            // the twelve per-wave maxima meet in lanes 0..11 of every wave (the same combine as above: larger value,
+            // then smaller index; an empty candidate never wins) -- as a 12-step loop run by every thread this cost the
+            // SIMDs 3.6k cycles a frame
+            double mv = 0.0;
+            int mi = -1;
+            if (lane < FM_T / 64) {
+                mv = redv[lane];
+                mi = redi[lane];
+            }
+#pragma unroll
+            for (int off = 8; off >= 1; off >>= 1) {
+                const double ov = __shfl_xor(mv, off, 64);
+                const int oi = __shfl_xor(mi, off, 64);
+                if (oi >= 0 && (ov > mv || (ov == mv && (mi < 0 || oi < mi)))) {
+                    mv = ov;
+                    mi = oi;
                 }
             }
+            const double maxBin = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(mv)),
+                                                   __builtin_amdgcn_readfirstlane(__double2loint(mv)));
+            const int binPos = __builtin_amdgcn_readfirstlane(mi);
             if (centreBin < 0) centreBin = 0;
             if (centreBin > end - 1) centreBin = end - 1;
             const double atc = (centreBin >= beg + 75 && centreBin < end - 75) ? A[centreBin - abase] : 0.0;
