@@ -598,6 +598,75 @@ __device__ __attribute__((noinline)) void fm_first2_from_raw(LdsArr X, const int
     __syncthreads();
 }
 
+// The same for one half of a frame of 2 NN samples (k_front_fft2x): the frame's radix-2 first pass, X_c[h] = x[h] +/- x[h + NN]
+// (dft_r<2>), feeds the half's first two passes directly -- 32 samples per thread in flight at once (as a load / convert /
+// store loop the half paid the HBM latency thirteen times).  ODD: the half of the odd bins, whose passes multiply EVERY
+// input j >= 1 by the two-dimensional tables U_p[(j-1) P' + k'] (fm_pass_t) -- tw0 = U_0 (stride 1), tw1 = U_1 (stride 4);
+// the even half has no stride-1 twiddles and tw1 = T16.
+template <int NN, bool F32IN, bool ODD>
+__device__ __attribute__((noinline)) void fm_first2x_from_raw(LdsArr X, const int *raw_, const float2 *rawf_, int ic, int qc, GblArr tw0,
+                                                               GblArr tw1, int tid)
+{
+    constexpr int ng = NN / 16, nb1 = NN / 4;
+    static_assert(ng <= FM_T, "one group per thread");
+    gbl_i32 *raw = (gbl_i32 *)(unsigned long long)raw_;
+    gbl_f2v *rawf = (gbl_f2v *)(unsigned long long)rawf_;
+    const int g = tid < ng ? tid : ng - 1;
+    const bool dc = (ic != 0) || (qc != 0);
+    double2 v[4][4];
+#pragma unroll
+    for (int j2 = 0; j2 < 4; j2++) {
+        int w0[4], w1[4];
+        f2v f0[4], f1[4];
+#pragma unroll
+        for (int j1 = 0; j1 < 4; j1++) {
+            const int h = g + j2 * ng + j1 * nb1;
+            if (F32IN) {
+                f0[j1] = rawf[h];
+                f1[j1] = rawf[h + NN];
+            } else {
+                w0[j1] = raw[h];
+                w1[j1] = raw[h + NN];
+            }
+        }
+#pragma unroll
+        for (int j1 = 0; j1 < 4; j1++) {
+            double2 a, b;
+            if (F32IN) {
+                a = make_double2((double)f0[j1].x, (double)f0[j1].y);
+                b = make_double2((double)f1[j1].x, (double)f1[j1].y);
+            } else {
+                fm_convert(w0[j1], ic, qc, dc, a.x, a.y);
+                fm_convert(w1[j1], ic, qc, dc, b.x, b.y);
+            }
+            v[j2][j1] = ODD ? cdsub(a, b) : cdadd(a, b);
+        }
+    }
+    if (tid < ng) {
+#pragma unroll
+        for (int j2 = 0; j2 < 4; j2++) {
+            if (ODD) {
+#pragma unroll
+                for (int j1 = 1; j1 < 4; j1++) v[j2][j1] = cdmul(v[j2][j1], tw0[j1 - 1]);
+            }
+            dft_r<4>(v[j2]);
+        }
+#pragma unroll
+        for (int q1 = 0; q1 < 4; q1++) {
+            double2 u[4];
+#pragma unroll
+            for (int j2 = 0; j2 < 4; j2++) {
+                u[j2] = v[j2][q1];
+                if (j2 >= 1) u[j2] = cdmul(u[j2], ODD ? tw1[(j2 - 1) * 4 + q1] : tw1[q1 * j2]);
+            }
+            dft_r<4>(u);
+#pragma unroll
+            for (int q2 = 0; q2 < 4; q2++) X[fm_swz(16 * tid + q1 + 4 * q2)] = u[q2];
+        }
+    }
+    __syncthreads();
+}
+
 template <int NN>
 __device__ __attribute__((noinline)) void fm_first_from_bins(LdsArr X, double2 in0, int tid)
 {
@@ -653,6 +722,13 @@ __device__ __forceinline__ void fm_forward(LdsArr X, const double2 *twL, const F
                 const LdsArr t = lds_arr(twL);
                 fm_pass2<4, 2, 9600, 16, true>(X, t + 20, t + 84, 9600, 16, 0u, tid);
                 fm_pass2<3, 5, 9600, 128>(X, t + 212, g + 596, 9600, 128, 0u, tid);
+                fm_pass5_band<9600, 1920>(X, g + 2516, need_end, tid);
+                return;
+            }
+        } else {
+            if (mode == FM_FWD_BAND && first_done) {  // k_front_fft2x's even half after fm_first2x_from_raw: the same, tables in L2
+                fm_pass2<4, 2, 9600, 16, true>(X, g + 20, g + 84, 9600, 16, 0u, tid);
+                fm_pass2<3, 5, 9600, 128>(X, g + 212, g + 596, 9600, 128, 0u, tid);
                 fm_pass5_band<9600, 1920>(X, g + 2516, need_end, tid);
                 return;
             }
@@ -1085,7 +1161,7 @@ __device__ __attribute__((noinline)) void fm_pass_t(LdsArr X, GblArr tw, int n, 
 }
 
 // two consecutive passes of an odd half in one LDS round trip: fm_pass2 with the two-dimensional tables
-template <int R1, int R2, int NN, int PP>
+template <int R1, int R2, int NN, int PP, bool SWZ_IN = false>
 __device__ __attribute__((noinline)) void fm_pass2_t(LdsArr X, GblArr tw1, GblArr tw2, int tid)
 {
     constexpr int RR = R1 * R2;
@@ -1102,7 +1178,7 @@ __device__ __attribute__((noinline)) void fm_pass2_t(LdsArr X, GblArr tw1, GblAr
                 const int b1 = g + j2 * ng;
 #pragma unroll
                 for (int j1 = 0; j1 < R1; j1++) {
-                    v[it][j2][j1] = X[b1 + j1 * nb1];
+                    v[it][j2][j1] = X[SWZ_IN ? fm_swz(b1 + j1 * nb1) : b1 + j1 * nb1];
                     if (j1 >= 1) v[it][j2][j1] = cdmul(v[it][j2][j1], tw1[(j1 - 1) * P + k1]);
                 }
                 dft_r<R1>(v[it][j2]);
@@ -1140,11 +1216,17 @@ __device__ __attribute__((noinline)) void fm_pass2_t(LdsArr X, GblArr tw1, GblAr
 }
 
 __device__ __forceinline__ void fm_forward_odd(LdsArr X, const Fft2xArgs &a, int tid, int mode = FM_FULL, int need_end = 0,
-                                               double norm = 1.0)
+                                               double norm = 1.0, bool first2_done = false)
 {
     const FftmArgs &m = a.sub;
     if (m.f.n == 9600) {  // the 192 kHz default: the 9600-point plan 4 | 4,4 | 2,3 | 5 | 5 with pass pairs, as fm_forward
         const GblArr t = gbl_arr(m.f.tw);
+        if (mode == FM_FWD_BAND && first2_done) {  // after fm_first2x_from_raw<.., ODD>: 4,2 | 3,5 | 5 as fm_forward
+            fm_pass2_t<4, 2, 9600, 16, true>(X, t + a.tw1_off[2], t + a.tw1_off[3], tid);
+            fm_pass2_t<3, 5, 9600, 128>(X, t + a.tw1_off[4], t + a.tw1_off[5], tid);
+            fm_pass5_band<9600, 1920, true>(X, t + a.tw1_off[6], need_end, tid);
+            return;
+        }
         if (mode != FM_INV_REAL) {
             fm_pass_t<4>(X, t + a.tw1_off[0], 9600, 1, 0u, tid);
             fm_pass2_t<4, 4, 9600, 4>(X, t + a.tw1_off[1], t + a.tw1_off[2], tid);
@@ -1242,14 +1324,26 @@ __global__ __launch_bounds__(FM_T) void k_front_fft2x(Fft2xArgs aa)
         // ---- forward, even bins
         // bins below end + 102 are read (see fm_pass5_band): even bin 2 i <=> output i of this half
         const int need_even = (end + 102 + 1) / 2, need_odd = (end + 102) / 2;
-        load_half(t0, 0, tf);
-        fm_forward<false>(XL, nullptr, aa.sub, tf, false, pruned ? FM_FWD_BAND : FM_FULL, need_even);
+        if (pruned) {
+            const GblArr tg = gbl_arr(aa.sub.f.tw);
+            fm_first2x_from_raw<9600, F32IN, false>(XL, raw + t0, rawf + t0, a.ic, a.qc, tg, tg + 4, tf);
+            fm_forward<false>(XL, nullptr, aa.sub, tf, true, FM_FWD_BAND, need_even);
+        } else {
+            load_half(t0, 0, tf);
+            fm_forward<false>(XL, nullptr, aa.sub, tf, false, FM_FULL, need_even);
+        }
         for (int i = tf; i < (pruned ? need_even : nek); i += FM_T) ek[i] = X[i];
         __threadfence_block();
         __syncthreads();
         // ---- forward, odd bins
-        load_half(t0, 1, tf);
-        fm_forward_odd(XL, aa, tf, pruned ? FM_FWD_BAND : FM_FULL, need_odd);
+        if (pruned) {
+            const GblArr tg = gbl_arr(aa.sub.f.tw);
+            fm_first2x_from_raw<9600, F32IN, true>(XL, raw + t0, rawf + t0, a.ic, a.qc, tg + aa.tw1_off[0], tg + aa.tw1_off[1], tf);
+            fm_forward_odd(XL, aa, tf, FM_FWD_BAND, need_odd, 1.0, true);
+        } else {
+            load_half(t0, 1, tf);
+            fm_forward_odd(XL, aa, tf, FM_FULL, need_odd);
+        }
         // ---- |X| over the band the boxcar reads (:425-427)
         // (pbase is even: even bins come from the scratch, odd ones from the image -- one loop each, no per-bin branch)
         for (int i = pbase + 2 * tf; i < end - 24; i += 2 * FM_T) {
