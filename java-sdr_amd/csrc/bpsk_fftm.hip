@@ -183,8 +183,10 @@ __device__ __attribute__((noinline)) void fm_pass(LdsArr X, TW tw, int n_rt, int
 // RxDownSample window, history included, is ONE contiguous run of 27 doubles: 14 conflict-free 16-byte reads per output
 // instead of 27 eight-byte reads at a 160-byte lane stride (16 lanes on the same banks).
 constexpr int FM_RB0 = 32;
-template <int NN, int PP, bool TT = false, bool COMPACT = false, class TW = const double2 *>
-__device__ __attribute__((noinline)) void fm_pass5_real(LdsArr X, TW tw, double norm, int tid, const double *hist_ = nullptr)
+// COMPACT == 2: the samples go straight to an array in global memory (the even samples of a 2 m frame, k_front_fft2x)
+template <int NN, int PP, bool TT = false, int COMPACT = 0, class TW = const double2 *>
+__device__ __attribute__((noinline)) void fm_pass5_real(LdsArr X, TW tw, double norm, int tid, const double *hist_ = nullptr,
+                                                         double *gout = nullptr)
 {
     constexpr int R = 5, nb = NN / R, ITERS = (nb + FM_T - 1) / FM_T;
     double o[ITERS][R];
@@ -214,17 +216,20 @@ __device__ __attribute__((noinline)) void fm_pass5_real(LdsArr X, TW tw, double 
             const int j0 = (b - k) * R + k;
 #pragma unroll
             for (int q = 0; q < R; q++) {
-                if (COMPACT)
+                if (COMPACT == 2)
+                    gout[j0 + q * PP] = o[it][q];
+                else if (COMPACT == 1)
                     Rb[FM_RB0 + j0 + q * PP] = o[it][q];
                 else
                     X[j0 + q * PP].put_x(o[it][q]);
             }
         }
     }
-    if (COMPACT) {
+    if (COMPACT == 1 && hist_ != nullptr) {
         const lds_f64 *hist = (const lds_f64 *)(unsigned)(unsigned long long)hist_;
         if (tid < 26) Rb[FM_RB0 - 26 + tid] = hist[tid];
     }
+    if (COMPACT == 2) __threadfence_block();
     FM_PASS_SYNC();
 }
 
@@ -704,7 +709,8 @@ constexpr int FM_LDS_TW_9600 = 596, FM_LDS_TW_4800 = 1236;
 enum { FM_FULL = 0, FM_FWD_BAND = 1, FM_INV_REAL = 2 };
 template <bool LDSTW>
 __device__ __forceinline__ void fm_forward(LdsArr X, const double2 *twL, const FftmArgs &a, int tid, bool first_done,
-                                           int mode = FM_FULL, int need_end = 0, double norm = 1.0, const double *hist = nullptr)
+                                           int mode = FM_FULL, int need_end = 0, double norm = 1.0, const double *hist = nullptr,
+                                           double *gout = nullptr)
 {
     const GblArr g = gbl_arr(a.f.tw);
     // the reference's two default frames: the plan is known (fftm_radices: 4,4,4,2,3,5,5 / 4,4,4,3,5,5)
@@ -713,7 +719,7 @@ __device__ __forceinline__ void fm_forward(LdsArr X, const double2 *twL, const F
             if (mode == FM_INV_REAL) {
                 // k_front_fftm's inverse transform: passes 1-4 came from fm_inv_blocks128_9600
                 fm_pass2<3, 5, 9600, 128>(X, lds_arr(twL) + 212, g + 596, 9600, 128, 0u, tid);
-                fm_pass5_real<9600, 1920, false, true>(X, g + 2516, norm, tid, hist);
+                fm_pass5_real<9600, 1920, false, 1>(X, g + 2516, norm, tid, hist);
                 return;
             }
             if (mode == FM_FWD_BAND && first_done) {
@@ -726,6 +732,11 @@ __device__ __forceinline__ void fm_forward(LdsArr X, const double2 *twL, const F
                 return;
             }
         } else {
+            if (mode == FM_INV_REAL && gout != nullptr) {  // k_front_fft2x's even half after fm_inv_blocks128_9600; samples to gout
+                fm_pass2<3, 5, 9600, 128>(X, g + 212, g + 596, 9600, 128, 0u, tid);
+                fm_pass5_real<9600, 1920, false, 2>(X, g + 2516, norm, tid, nullptr, gout);
+                return;
+            }
             if (mode == FM_FWD_BAND && first_done) {  // k_front_fft2x's even half after fm_first2x_from_raw: the same, tables in L2
                 fm_pass2<4, 2, 9600, 16, true>(X, g + 20, g + 84, 9600, 16, 0u, tid);
                 fm_pass2<3, 5, 9600, 128>(X, g + 212, g + 596, 9600, 128, 0u, tid);
@@ -748,7 +759,7 @@ __device__ __forceinline__ void fm_forward(LdsArr X, const double2 *twL, const F
         if (mode == FM_FWD_BAND)
             fm_pass5_band<9600, 1920>(X, g + 2516, need_end, tid);
         else if (mode == FM_INV_REAL)
-            fm_pass5_real<9600, 1920, false, LDSTW>(X, g + 2516, norm, tid, hist);  // (k_front_fftm: compact real samples)
+            fm_pass5_real<9600, 1920, false, LDSTW ? 1 : 0>(X, g + 2516, norm, tid, hist);  // (k_front_fftm: compact real samples)
         else
             fm_pass<5, 9600, 1920>(X, g + 2516, 9600, 1920, 0u, tid);
         return;
@@ -768,7 +779,7 @@ __device__ __forceinline__ void fm_forward(LdsArr X, const double2 *twL, const F
         if (mode == FM_FWD_BAND)
             fm_pass5_band<4800, 960>(X, g + 1236, need_end, tid);
         else if (mode == FM_INV_REAL)
-            fm_pass5_real<4800, 960, false, LDSTW>(X, g + 1236, norm, tid, hist);
+            fm_pass5_real<4800, 960, false, LDSTW ? 1 : 0>(X, g + 1236, norm, tid, hist);
         else
             fm_pass<5, 4800, 960>(X, g + 1236, 4800, 960, 0u, tid);
         return;
@@ -1221,6 +1232,11 @@ __device__ __forceinline__ void fm_forward_odd(LdsArr X, const Fft2xArgs &a, int
     const FftmArgs &m = a.sub;
     if (m.f.n == 9600) {  // the 192 kHz default: the 9600-point plan 4 | 4,4 | 2,3 | 5 | 5 with pass pairs, as fm_forward
         const GblArr t = gbl_arr(m.f.tw);
+        if (mode == FM_INV_REAL && first2_done) {  // after fm_inv_blocks128_9600 with the odd tables; compact real samples
+            fm_pass2_t<3, 5, 9600, 128>(X, t + a.tw1_off[4], t + a.tw1_off[5], tid);
+            fm_pass5_real<9600, 1920, true, 1>(X, t + a.tw1_off[6], norm, tid);
+            return;
+        }
         if (mode == FM_FWD_BAND && first2_done) {  // after fm_first2x_from_raw<.., ODD>: 4,2 | 3,5 | 5 as fm_forward
             fm_pass2_t<4, 2, 9600, 16, true>(X, t + a.tw1_off[2], t + a.tw1_off[3], tid);
             fm_pass2_t<3, 5, 9600, 128>(X, t + a.tw1_off[4], t + a.tw1_off[5], tid);
@@ -1439,15 +1455,13 @@ __global__ __launch_bounds__(FM_T) void k_front_fft2x(Fft2xArgs aa)
             // them (fm_inv_blocks) -- the even half with the 9600-point tables, the odd one with its own
             if (tf < 204) zb[tf] = keep;
             __syncthreads();
-            const GblArr t64 = gbl_arr(aa.sub.f.tw + aa.sub.tw_off[2]);
-            fm_inv_blocks<9600, false>(XL, lds_arr(zb), t64, 1, t64, 2, tf);
-            fm_forward<false>(XL, nullptr, aa.sub, tf, true, FM_INV_REAL, 0, norm);
-            for (int i = tf; i < m; i += FM_T) r0[i] = X[i].x;  // re = X.x / n (:462), sample 2 i
-            __threadfence_block();
-            __syncthreads();
-            const GblArr u64 = gbl_arr(aa.sub.f.tw + aa.tw1_off[2]);  // [(j-1) 16 + k]
-            fm_inv_blocks<9600, false>(XL, lds_arr(zb), u64, 1, u64 + 16, 1, tf);
-            fm_forward_odd(XL, aa, tf, FM_INV_REAL, 0, norm);
+            // (four passes, 4,4,4,2: fm_inv_blocks128_9600; the even half's samples re / n (:462) go straight to the scratch, the
+            //  odd half's stay in LDS as a compact array of doubles -- sample 2 i + 1 at slot FM_RB0 + i)
+            const GblArr tg = gbl_arr(aa.sub.f.tw);
+            fm_inv_blocks128_9600<false>(XL, lds_arr(zb), tg + 20, tg + 84, tf);
+            fm_forward<false>(XL, nullptr, aa.sub, tf, true, FM_INV_REAL, 0, norm, nullptr, r0);
+            fm_inv_blocks128_9600<false>(XL, lds_arr(zb), tg + aa.tw1_off[2], tg + aa.tw1_off[3], tf);  // U_2[k], U_3[kk]
+            fm_forward_odd(XL, aa, tf, FM_INV_REAL, 0, norm, true);
         } else {
             // even output samples: first-pass sums z[b] + z[b + m], z[b + m] being the zeroed array's
             for (int b = tf; b < m; b += FM_T) X[b] = cdadd(b < 204 ? keep : Z, Z);
@@ -1464,7 +1478,10 @@ __global__ __launch_bounds__(FM_T) void k_front_fft2x(Fft2xArgs aa)
             __syncthreads();
         }
         // ---- RxDownSample(re, re) (:461-463, :470-492): sample t of the frame = r0[t/2] (t even) or X[t/2].x / n (t odd)
-        auto sample = [&](int t) -> double { return t < 0 ? hist[26 + t] : ((t & 1) ? X[t >> 1].x : r0[t >> 1]); };
+        const double *Ro = reinterpret_cast<const double *>(smem) + FM_RB0;  // pruned: the odd samples, compact
+        auto sample = [&](int t) -> double {
+            return t < 0 ? hist[26 + t] : ((t & 1) ? (pruned ? Ro[t >> 1] : X[t >> 1].x) : r0[t >> 1]);
+        };
         {
             long long jlo = (t0 - a.first_out + D - 1) / D;
             if (t0 <= a.first_out) jlo = 0;
@@ -1478,7 +1495,46 @@ __global__ __launch_bounds__(FM_T) void k_front_fft2x(Fft2xArgs aa)
                 const double2 cs = a.vco_cs[j];
                 const int e = (int)(te - t0);
                 double fi = 0.0;
-                if (uniform_parity && e >= 26) {
+                if (pruned && (D & 3) == 0 && e >= 27) {
+                    // taps of one parity read a run of 14 even samples (scratch), the others a run of 14 odd ones (LDS), both
+                    // ending at a slot whose parity is the same for every window of the call (D/2 is even: D = 20): eight aligned
+                    // 16-byte reads each, the run picked out of them by a shift that is the same in every lane
+                    const int hi_o = epar ? (e >> 1) : (e >> 1) - 1;  // odd samples:  slots hi_o - 13 .. hi_o
+                    const int hi_e = epar ? ((e - 1) >> 1) : (e >> 1);  // even samples: slots hi_e - 13 .. hi_e
+                    const int bo = (hi_o - 13) & ~1, be = (hi_e - 13) & ~1;
+                    const bool sho = ((hi_o - 13) & 1) != 0, she = ((hi_e - 13) & 1) != 0;
+                    const double2 *po = reinterpret_cast<const double2 *>(Ro + bo);
+                    const double2 *pe = reinterpret_cast<const double2 *>(r0 + be);
+                    double dod[16], dev[16];
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        const double2 u = pe[i];
+                        dev[2 * i] = u.x;
+                        dev[2 * i + 1] = u.y;
+                    }
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        const double2 u = po[i];
+                        dod[2 * i] = u.x;
+                        dod[2 * i + 1] = u.y;
+                    }
+                    // sample q slots below the run's end: d[13 - q + shift]
+                    if (epar) {
+#pragma unroll
+                        for (int k = 0; k < 27; k++) {
+                            const int q = k >> 1;
+                            const double x = (k & 1) ? (she ? dev[14 - q] : dev[13 - q]) : (sho ? dod[14 - q] : dod[13 - q]);
+                            fi += x * ds_tap(k);  // newest first (:479-483)
+                        }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 27; k++) {
+                            const int q = (k & 1) ? ((k + 1) >> 1) - 1 : (k >> 1);
+                            const double x = (k & 1) ? (sho ? dod[14 - q] : dod[13 - q]) : (she ? dev[14 - q] : dev[13 - q]);
+                            fi += x * ds_tap(k);
+                        }
+                    }
+                } else if (!pruned && uniform_parity && e >= 26) {
                     if (epar) {  // e odd: taps 0,2,.. read odd samples (image), taps 1,3,.. even ones (scratch)
                         const double2 *xo = X + (e >> 1);
                         const double *re = r0 + ((e - 1) >> 1);
@@ -1647,7 +1703,8 @@ void fft2x_twiddles(std::vector<double2> &w, int n, int *np_out, int *rad, int *
 }
 
 size_t fft2x_scratch_ek(int n) { return (size_t)(n / 4 + 52); }
-size_t fft2x_scratch_r0(int n) { return (size_t)(n / 2); }
+// (+16: the aligned 16-byte reads of a window run may end two slots past the last sample)
+size_t fft2x_scratch_r0(int n) { return (size_t)(n / 2) + 16; }
 
 int launch_front_fft2x(const FftFrontArgs &a, int np, const int *rad, const int *tw_off, const int *tw1_off, double2 *ek,
                        double *r0, int nstreams, hipStream_t st)
