@@ -162,25 +162,83 @@ __device__ __forceinline__ void dit_pass(double2 *X, const double2 *TsL, const d
     }
 }
 
+// The LAST pass of the inverse transform, leaving the scaled real parts (all RxDownSample reads, :462) as a COMPACT array of
+// doubles over the dead image -- sample t at double slot FF_RB0 + t, the previous frame's last 26 samples (hist) in front of
+// them -- so that a RxDownSample window, history included, is one contiguous run of 27 doubles: 14 conflict-free 16-byte
+// reads instead of 27 eight-byte reads at a 160-byte lane stride.  Every butterfly of the pass is in registers before the
+// first store (the compact slots overlap other butterflies' inputs).
+constexpr int FF_RB0 = 32;
+template <int G, int HALF0, int LOGN>
+__device__ __forceinline__ void dit_pass_real_compact(double2 *X, const double2 *TsL, const double2 *__restrict__ tsg, int tid,
+                                                      double norm, const double *hist)
+{
+    constexpr int M = 1 << G;
+    constexpr int GROUPS = 1 << (LOGN - G);
+    constexpr int NIT = (GROUPS + 255) / 256;
+    constexpr int STEP = HALF0 + HALF0 / 8;
+    static_assert(GROUPS % 256 == 0, "every thread owns NIT whole groups");
+    double o[NIT][M];
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+        int q = it * 256 + tid;
+        asm volatile("" : "+v"(q));
+        const int j = q & (HALF0 - 1);
+        const int base = (q - j) << G;
+        const double2 *x0 = X + xpad(base + j);
+        double2 v[M];
+#pragma unroll
+        for (int m = 0; m < M; m++) v[m] = x0[STEP * m];
+        dit_stages<G, HALF0, true, false>(v, j, TsL, tsg);
+#pragma unroll
+        for (int m = 0; m < M; m++) o[it][m] = v[m].x * norm;
+    }
+    __syncthreads();
+    double *Rb = reinterpret_cast<double *>(X);
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+        const int q = it * 256 + tid;
+        const int j = q & (HALF0 - 1);
+        const int base = (q - j) << G;
+#pragma unroll
+        for (int m = 0; m < M; m++) Rb[FF_RB0 + base + j + HALF0 * m] = o[it][m];
+    }
+    if (tid < 26) Rb[FF_RB0 - 26 + tid] = hist[tid];
+}
+
 // the passes after the first: wings 8,64,512 (and what is left)
-template <bool INVERSE, int LOGN, bool SKIP8>
-__device__ __forceinline__ void fft_rest(double2 *X, const double2 *TsL, const double2 *__restrict__ tsg, int tid, double norm)
+// COMPACT (inverse only): the last pass is dit_pass_real_compact
+template <bool INVERSE, int LOGN, bool SKIP8, bool COMPACT = false>
+__device__ __forceinline__ void fft_rest(double2 *X, const double2 *TsL, const double2 *__restrict__ tsg, int tid, double norm,
+                                         const double *hist = nullptr)
 {
     static_assert(LOGN >= 10 && LOGN <= 13, "frame sizes 1024..8192");
     if (!SKIP8) dit_pass<3, 8, INVERSE, LOGN, false>(X, TsL, tsg, tid, norm);
-    if (LOGN == 13) {
+    if constexpr (LOGN == 13) {
         dit_pass<3, 64, INVERSE, LOGN, false>(X, TsL, tsg, tid, norm);
         dit_pass<3, 512, INVERSE, LOGN, false>(X, TsL, tsg, tid, norm);
-        dit_pass<1, 4096, INVERSE, LOGN, INVERSE>(X, TsL, tsg, tid, norm);
-    } else if (LOGN == 12) {
+        if constexpr (COMPACT)
+            dit_pass_real_compact<1, 4096, LOGN>(X, TsL, tsg, tid, norm, hist);
+        else
+            dit_pass<1, 4096, INVERSE, LOGN, INVERSE>(X, TsL, tsg, tid, norm);
+    } else if constexpr (LOGN == 12) {
         dit_pass<3, 64, INVERSE, LOGN, false>(X, TsL, tsg, tid, norm);
-        dit_pass<3, 512, INVERSE, LOGN, INVERSE>(X, TsL, tsg, tid, norm);
-    } else if (LOGN == 11) {
+        if constexpr (COMPACT)
+            dit_pass_real_compact<3, 512, LOGN>(X, TsL, tsg, tid, norm, hist);
+        else
+            dit_pass<3, 512, INVERSE, LOGN, INVERSE>(X, TsL, tsg, tid, norm);
+    } else if constexpr (LOGN == 11) {
         dit_pass<3, 64, INVERSE, LOGN, false>(X, TsL, tsg, tid, norm);
-        dit_pass<2, 512, INVERSE, LOGN, INVERSE>(X, TsL, tsg, tid, norm);
+        if constexpr (COMPACT)
+            dit_pass_real_compact<2, 512, LOGN>(X, TsL, tsg, tid, norm, hist);
+        else
+            dit_pass<2, 512, INVERSE, LOGN, INVERSE>(X, TsL, tsg, tid, norm);
     } else {
         dit_pass<3, 64, INVERSE, LOGN, false>(X, TsL, tsg, tid, norm);
-        dit_pass<1, 512, INVERSE, LOGN, INVERSE>(X, TsL, tsg, tid, norm);
+        if constexpr (COMPACT)
+            dit_pass_real_compact<1, 512, LOGN>(X, TsL, tsg, tid, norm, hist);
+        else
+            dit_pass<1, 512, INVERSE, LOGN, INVERSE>(X, TsL, tsg, tid, norm);
     }
     __syncthreads();
 }
@@ -441,7 +499,7 @@ __global__ __launch_bounds__(256, (LOGN <= 11 ? 4 : (LOGN == 12 ? 2 : 1))) void 
                 for (int m = 0; m < 8; m++) x0[9 * m] = vin[c][m];
             }
             PHASE(5)
-            fft_rest<true, LOGN, true>(X, TsL, tsg, tid, norm);  // leaves re/N in .x (:462)
+            fft_rest<true, LOGN, true, true>(X, TsL, tsg, tid, norm, hist);  // leaves re/N compact (:462)
         } else {
             // N = 1024: two inputs of a first-pass group can be non-zero; the first pass runs in full on registers
             double2 vin[G1][8];
@@ -467,38 +525,52 @@ __global__ __launch_bounds__(256, (LOGN <= 11 ? 4 : (LOGN == 12 ? 2 : 1))) void 
                 }
             }
             PHASE(5)
-            fft_rest<true, LOGN, false>(X, TsL, tsg, tid, norm);  // leaves re/N in .x (:462)
+            fft_rest<true, LOGN, false, true>(X, TsL, tsg, tid, norm, hist);  // leaves re/N compact (:462)
         }
         PHASE(6)
-        // hist[26..51] (over the unused tap slots): the frame's first 26 samples, so that a window reaching back into the
-        // previous frame is one contiguous run too
-        if (tid < 26) hist[26 + tid] = X[xpad(tid)].x;
-        __syncthreads();
-        // ---- RxDownSample(re, re) (:461-463, :470-492): outputs whose window ends inside this frame
+        // ---- RxDownSample(re, re) (:461-463, :470-492): outputs whose window ends inside this frame, from the compact samples
+        // (sample t at double slot FF_RB0 + t, the previous frame's last 26 in front: every window is one contiguous run)
+        {
+            const double *Rb = reinterpret_cast<const double *>(smem);
+            const bool even_d = (D & 1) == 0;  // then every window of the call ends on the same parity (N is even)
+            const int par = (int)((a.first_out - t0) & 1);
 #pragma unroll
-        for (int b = 0; b < JB; b++) {
-            const long long j = jlo + tid + 256 * b;
-            const long long te = (long long)a.first_out + (long long)D * j;  // window end, call-relative
-            if (te < t0 + N && j < a.nds) {
-                const int e = (int)(te - t0);  // 0..N-1 within the frame
-                double fi = 0.0;
-                if (e >= 26) {
+            for (int b = 0; b < JB; b++) {
+                const long long j = jlo + tid + 256 * b;
+                const long long te = (long long)a.first_out + (long long)D * j;  // window end, call-relative
+                if (te < t0 + N && j < a.nds) {
+                    const int e = (int)(te - t0);  // 0..N-1 within the frame
+                    double fi = 0.0;
+                    if (even_d) {
+                        // the 27 samples e-26 .. e as 14 aligned 16-byte reads: d[i] = slot ((e + 6) & ~1) + i
+                        const double2 *w2 = reinterpret_cast<const double2 *>(Rb + ((e + FF_RB0 - 26) & ~1));
+                        double d[28];
 #pragma unroll
-                    for (int k = 0; k < 27; k++) fi += X[xpad(e - k)].x * ds_tap(k);  // newest first (:479-483)
-                } else {
-                    const double *w = hist + 26 + e;  // the first three windows of a frame: history, then the frame's head
+                        for (int i = 0; i < 14; i++) {
+                            const double2 t = w2[i];
+                            d[2 * i] = t.x;
+                            d[2 * i + 1] = t.y;
+                        }
+                        if (par) {
 #pragma unroll
-                    for (int k = 0; k < 27; k++) fi += w[-k] * ds_tap(k);
+                            for (int k = 0; k < 27; k++) fi += d[27 - k] * ds_tap(k);  // newest first (:479-483)
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < 27; k++) fi += d[26 - k] * ds_tap(k);
+                        }
+                    } else {
+                        const double *w = Rb + (FF_RB0 + e);
+#pragma unroll
+                        for (int k = 0; k < 27; k++) fi += w[-k] * ds_tap(k);
+                    }
+                    const double o = fi * HOWARD;  // fi == fq: both rails get the same samples
+                    const double2 cs = (b == 0) ? cs0 : a.vco_cs[j];
+                    dm[64 + j] = make_double2(o * cs.x, o * cs.y);  // :515-516
                 }
-                const double o = fi * HOWARD;  // fi == fq: both rails get the same samples
-                const double2 cs = (b == 0) ? cs0 : a.vco_cs[j];
-                dm[64 + j] = make_double2(o * cs.x, o * cs.y);  // :515-516
             }
+            if (tid < 26) hist[tid] = Rb[FF_RB0 + N - 26 + tid];  // (nobody reads hist[] before the next frame's last pass)
+            __syncthreads();  // every window is read before the next frame's first pass overwrites the image
         }
-        double hnew = 0.0;
-        if (tid < 26) hnew = X[xpad(N - 26 + tid)].x;
-        __syncthreads();
-        if (tid < 26) hist[tid] = hnew;
         PHASE(7)
     }
 #undef PHASE

@@ -1,0 +1,17 @@
+#!/bin/bash
+# tools/ab_acq_noov.sh <frame> <lib...> -- as ab_acq.sh, but with the side stream off (JSDR_NO_OVERLAP=1): the front-end
+# kernel's own time, not stretched by the tail / sync / FEC kernels of the previous step running beside it
+mkdir -p gpurun_out; export TMPDIR=/tmp
+F=$1; shift
+for rep in 1 2; do
+for L in "$@"; do
+  JSDR_NO_OVERLAP=1 JSDR_LIB=$PWD/java-sdr_amd/$L timeout -k 10 300 python bench.py --workload bpsk --fft-acquire --bpsk-frame $F --streams 1024 --no-cpu-baseline --no-validate --steps 8 --warmup 2 > gpurun_out/ab_$L.log 2>&1
+  python3 - "$L" <<'PY'
+import json, sys
+for l in open(f"gpurun_out/ab_{sys.argv[1]}.log"):
+    if l.startswith("{"):
+        d = json.loads(l); k = d["roofline"]["kernels_ms_per_step"]
+        print(sys.argv[1], "step", d["ms_per_step"], {a: b for a, b in k.items() if a.startswith("k_front")})
+PY
+done
+done
