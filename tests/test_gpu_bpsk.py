@@ -339,6 +339,20 @@ def test_bpsk_fft_mode_default_frames_carrier_at_the_band_edges(blen, rate, do_u
     assert abs(oracles[0].counters()["centreBin"] - carrier / (rate / nsf)) <= 60
 
 
+@pytest.mark.parametrize("nsf,rate", [(9600, 48000), (9600, 192000), (19200, 96000), (19200, 48000), (4800, 96000), (4800, 192000),
+                                      (2048, 48000), (2048, 192000), (4096, 48000)])
+def test_bpsk_fft_mode_frames_at_other_decimations(nsf, rate):
+    """the front ends' RxDownSample reads the inverse's real samples as a compact array (round 3): 14 aligned 16-byte reads
+    per window at an even decimation, single reads at an odd one (48 kHz: 5), two aligned runs at n = 19200 when the
+    decimation is a multiple of 4 (192 kHz: 20) and the general loop otherwise -- every frame size at the sample rates that
+    are NOT its default, chunked so that calls begin at different frames"""
+    n = nsf * 10
+    iq = O.make_dbpsk_stream(85, 0, n, rate=rate, carrier_hz=rate / 8.0 + 333.0, noise_sigma=600.0)[0]
+    rng = np.random.default_rng(nsf + rate)
+    noise = rng.integers(-11000, 11000, 2 * n).astype(np.int16)
+    run_both([iq, noise], n, [nsf * 3, nsf, nsf * 6], rate=rate, do_fft=1, blen=4 * nsf)
+
+
 def test_bpsk_fft_mode_other_mixed_radix_frames():
     """frames of 2^a 3^b 5^c samples other than the two defaults go through the run-time (unspecialised) Stockham passes
     and pass pairs: 7680 = 4.4.4.4.2.3.5 -> [4][4,4][4,2][3,5], 1440 = 4.4.2.3.3.5 -> [4][4,2][3][3,5], 1200 = 4.4.3.5.5"""
