@@ -27,7 +27,10 @@ namespace jsdr {
 #define FM_PASS_SYNC() __syncthreads()
 #endif
 
-constexpr int FM_T = 768;
+#ifndef JSDR_FM_T
+#define JSDR_FM_T 768
+#endif
+constexpr int FM_T = JSDR_FM_T;  // (probe builds: -DJSDR_FM_T=1024)
 constexpr int FM_NMAX = 9600;
 constexpr int FM_MAXPASS = 12;
 
