@@ -279,6 +279,9 @@ def stream_text(a, psd_own_stream):
     if a.workload == "pipeline":
         return "PSD on its own HIP stream beside the demodulator; tail/sync/FEC on the handle's side stream" if psd_own_stream \
             else "PSD then demodulator on one stream; tail/sync/FEC on the handle's side stream"
+    if a.workload == "bpsk" and a.fft_acquire and (a.bpsk_frame & (a.bpsk_frame - 1)) != 0 and os.environ.get("JSDR_NO_OVERLAP", "1") != "0":
+        # a mixed-radix frame's front end fills a CU's LDS with one workgroup: the library keeps tail/sync/FEC on the caller's stream
+        return "front end, matched filter, tail/sync/FEC on one stream"
     return "tail/sync/FEC on the handle's side stream" if a.workload == "bpsk" else "one stream"
 
 
