@@ -27,11 +27,14 @@
 #include <thread>
 #include <stddef.h>
 #include <stdlib.h>
+#include <type_traits>
 #include <vector>
 
 namespace jsdr {
 
 enum { DS_N = 27, DM_N = 65, HIST_BITS = 5200, MIN_TRIG = 8, SYNC_N = 65 };
+// slack (elements) in front of and behind the (fi,fq) buffers: k_tail8 prefetches whole chunks without range checks
+enum { Y_PAD = 1024 };
 
 
 
@@ -1674,6 +1677,343 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs a)
     }
 }
 
+// ------------------------------------------------------------------------------------------- k_tail8
+// The exact-order tail (:534-593) with EIGHT STREAMS PER WAVE: lane = 8 x (stream of the wave) + bit position.  k_tail
+// (one wave per stream) keeps nine of its 64 lanes busy while the nine IIR chains run and moves every energy through
+// LDS twice to get it to a chain lane and back; here the eight dmEnergy chains of eight streams ARE the 64 lanes, and a
+// lane reads the samples of its own bit position straight from y (the eight lanes of a stream read 128 contiguous
+// bytes per period) -- no transposition on the way in.  Per chunk of CH bit periods:
+//   A  every lane: energy1 (:534), its dmEnergy link (:535) and -- speculating that its position is the peak -- a
+//      dmEnergyOut link (:538); the chain values go to an LDS image for the argmax, the (fi,fq) of the lanes that sit on
+//      the peak position to a small LDS list; the next chunk's samples are requested as this chunk's are consumed
+//   B  lane = (stream, period): first-maximum argmax of the eight energies after the period (:586-592)
+//   fast path (every stream of the wave locked: peakPos == newPeak == every measured peak): the decisions are (period,
+//      peakPos); lane = (stream, decision): differential detector, threshold, bit (:539-545), ordered compaction
+//   general path (acquisition, fades, the frame seams of the FFT-acquire mode): the peakPos / newPeak machine (:537,
+//      :577-579,:592) in closed form per period (at most two decisions fall into one period), lane-replicated per stream;
+//      the decision samples re-read from y (L2), dmEnergyOut re-run over them in time order, the detector lane-parallel
+//      over the 2 CH decision slots -- no per-stream scalar loop, the eight streams of the wave go through it together
+// energy2 = sqrt(di^2+dq^2) > 100 (:543-544) is decided as di^2+dq^2 > 10000: sqrt is correctly rounded and monotone,
+// sqrt(10000) = 100 exactly and sqrt(nextafter(10000)) = 100 + 9.1e-15 rounds to the double above 100
+// (tests/test_host_logic.py checks the neighbourhood); the square root itself is taken once, for the state the call leaves.
+#ifdef JSDR_X_T8CLK  // timing experiment: s_memtime ticks per phase, summed over every wave of every launch
+__device__ unsigned long long g_t8_clk[8];
+#define T8_CLK(i)                                                     \
+    do {                                                              \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+        t8acc_[i] += now_ - t8last_;                                  \
+        t8last_ = now_;                                               \
+    } while (0)
+#else
+#define T8_CLK(i) do {} while (0)
+#endif
+template <int CH>
+__global__ __launch_bounds__(64) void k_tail8(TailArgs a)
+{
+#ifdef JSDR_X_T8CLK
+    unsigned long long t8acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t8last_ = __builtin_amdgcn_s_memtime();
+#endif
+    static_assert(CH == 16, "two decision slots per period in one 64-bit mask, one nibble per period in another");
+    constexpr int ROW = 82;  // doubles per period of the energy image: 8 streams x 10 (8 used) + 2 -> conflict-free b128 reads
+    __shared__ __align__(16) double EoL[CH * ROW];
+    __shared__ __align__(16) double2 FQL[8][CH];
+    __shared__ __align__(16) unsigned char NPL[8][CH];
+    double *X2L = EoL;                                               // general path, once the argmax has read the image:
+    double2 *CURL = reinterpret_cast<double2 *>(EoL + 8 * 2 * CH);   // [8][2 CH] each
+    static_assert(8 * 2 * CH * 3 <= CH * ROW, "work areas fit the dead energy image");
+    const int lane = threadIdx.x, s8 = lane >> 3, c = lane & 7;
+    const int S = a.nstreams;
+    const int sraw = blockIdx.x * 8 + s8;
+    const bool live = sraw < S;
+    const int s = live ? sraw : S - 1;  // (surplus lanes of the last wave shadow its last stream and store nothing)
+    TailState *sp = &a.st[s];
+    const int nds = (int)a.nds;
+    const long long g_first = a.g_first;
+    // ---- carry the 5200-bit shift register (dmFECCorr, :503) over from the previous call's log: the whole wave per stream,
+    // dwords (the rows are 16-byte aligned, the source starts at any byte)
+    for (int t = 0; t < 8; t++) {
+        const int st = blockIdx.x * 8 + t;
+        if (st >= S) break;
+        const int nprev = __builtin_amdgcn_readfirstlane(a.st[st].nbits_prev);
+        const signed char *old = a.bitlog_old + (long long)st * a.bitlog_stride + nprev;
+        const int sh = (int)(reinterpret_cast<unsigned long long>(old) & 3ull);
+        const unsigned *ow = reinterpret_cast<const unsigned *>(old - sh);
+        unsigned *nw32 = reinterpret_cast<unsigned *>(a.bitlog_new + (long long)st * a.bitlog_stride);
+        constexpr int NW = HIST_BITS / 4, NIT = (NW + 63) / 64;
+        unsigned lo[NIT], hi[NIT];
+#pragma unroll
+        for (int q = 0; q < NIT; q++) {
+            const int i = lane + 64 * q;
+            const int ic = i < NW ? i : NW - 1;
+            lo[q] = ow[ic];
+            hi[q] = ow[ic + 1];
+        }
+#pragma unroll
+        for (int q = 0; q < NIT; q++) {
+            const int i = lane + 64 * q;
+            if (i < NW) nw32[i] = __builtin_amdgcn_alignbyte(hi[q], lo[q], (unsigned)sh);
+        }
+    }
+    const double K1 = 1.0 - 1.0 / 200.0, S1 = 1.0 / 200.0;  // BIT_SMOOTH1 (:89)
+    const double K2 = 1.0 - 1.0 / 800.0, S2 = 1.0 / 800.0;  // BIT_SMOOTH2 (:90)
+    double e = sp->dmEnergy[c];
+    double eo = sp->dmEnergyOut;
+    int pk = sp->peakPos, nw = sp->newPeak;
+    double lastI = sp->lastI, lastQ = sp->lastQ;
+    const int cntBit0 = sp->cntBit;
+    int nbits = 0;
+    int ord_last = -1;    // this lane's latest decision (ordinal within the call) and its di^2 + dq^2: the stream's last one
+    double x_last = 0.0;  // gives energy2 (:543)
+    const long long M_first = g_first >> 3, M_last = (g_first + nds - 1) >> 3;
+    const double2 *ys = a.y + (long long)s * a.y_stride;
+    signed char *blog = a.bitlog_new + (long long)s * a.bitlog_stride;
+    int rel0 = (int)(8 * M_first - g_first);  // call-relative index of the chunk's sample 0 (-7 .. 0 for the first chunk)
+    // (reads before sample 0 and past the last one stay inside the buffers' slack, Y_PAD; what they return is never used)
+    // The call's first period may start and its last may end anywhere (range masks, uniform over the streams).  One code path:
+    // with the masks under a branch -- or two sample buffers picked by a branch -- the compiler reconciles the register
+    // assignment of the requests in flight where the paths meet, with copies behind an s_waitcnt vmcnt(0): the whole memory
+    // latency per chunk (3.0 ms at 8192 streams where the reads alone take 2.2).
+    double2 F[CH];
+    if (nds > 0) {
+        const double2 *p0 = ys + (rel0 + c);
+#pragma unroll
+        for (int p = 0; p < CH; p++) F[p] = p0[8 * p];
+    }
+    T8_CLK(0);  // shift register, state, first requests
+    for (long long MB = M_first; MB <= M_last && nds > 0; MB += CH, rel0 += 8 * CH) {
+        const int v = pk;
+        const bool mine = c == v;
+        double eo_l = eo;
+        const double2 *pn = ys + (rel0 + 8 * CH + c);
+        // ---------------- A: the chains; a sample's register is asked for the next chunk's as soon as it has been read
+#pragma unroll
+        for (int p = 0; p < CH; p++) {
+            const double2 f = F[p];
+            const double en = (f.x * f.x) + (f.y * f.y);  // :534
+            if (mine) FQL[s8][p] = f;
+            // (the sample's last use lies ABOVE the request that overwrites it: scheduled the other way round -- the scheduler's
+            //  preference -- the new sample needs registers of its own and comes home through copies behind an s_waitcnt
+            //  vmcnt(0) at the loop's back edge: the whole memory latency per chunk)
+            __builtin_amdgcn_sched_barrier(0);
+#ifndef JSDR_X_T8_NOLOAD  // (timing probe: the first chunk's samples over and over -- the kernel without its HBM reads)
+            F[p] = pn[8 * p];
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+            const double ne = (e * K1) + (en * S1);       // :535
+            const double no = (eo_l * K2) + (en * S2);    // :538, were this lane's position the peak
+            const bool inr = (unsigned)(rel0 + 8 * p + c) < (unsigned)nds;
+            e = inr ? ne : e;
+            eo_l = inr ? no : eo_l;
+            EoL[p * ROW + s8 * 10 + c] = e;
+        }
+        JSDR_WAVE_SYNC();
+        T8_CLK(1);  // A
+#ifdef JSDR_X_T8_LOADONLY  // (timing probe: the reads and the chains only)
+        if (nds > 0) continue;
+#endif
+        // ---------------- B: new peak after every period whose last sample is in range (:582-593); lane = (stream, period)
+        bool fail = pk != nw;
+#pragma unroll
+        for (int i = 0; i < CH / 8; i++) {
+            const int p = 8 * i + c;
+            const double2 *row = reinterpret_cast<const double2 *>(&EoL[p * ROW + s8 * 10]);
+            const double2 q0 = row[0], q1 = row[1], q2 = row[2], q3 = row[3];
+            double bv = q0.x;
+            int np = 0;
+            if (q0.y > bv) { bv = q0.y; np = 1; }  // strict: the first maximum wins
+            if (q1.x > bv) { bv = q1.x; np = 2; }
+            if (q1.y > bv) { bv = q1.y; np = 3; }
+            if (q2.x > bv) { bv = q2.x; np = 4; }
+            if (q2.y > bv) { bv = q2.y; np = 5; }
+            if (q3.x > bv) { bv = q3.x; np = 6; }
+            if (q3.y > bv) { bv = q3.y; np = 7; }
+            const bool meas = rel0 + 8 * p + 7 < nds;
+            np = meas ? np : 8;
+            NPL[s8][p] = (unsigned char)np;
+            fail = fail || (meas && np != v);
+        }
+        const bool general = __ballot(fail) != 0ull;
+        JSDR_WAVE_SYNC();
+        T8_CLK(2);  // B
+        const int ord0 = 2 * (int)(MB - M_first) * 1;  // ordinal of the chunk's slot 0 (two slots per period)
+        if (!general) {
+            // ---------------- locked: one decision per period, at bit position v
+            eo = __shfl(eo_l, 8 * s8 + v, 64);
+#pragma unroll
+            for (int i = 0; i < CH / 8; i++) {
+                const int p = 8 * i + c;
+                const int drel = rel0 + 8 * p + v;
+                const bool inr = drel >= 0 && drel < nds;
+                const double2 cur = FQL[s8][p];
+                const double2 pv = FQL[s8][p > 0 ? p - 1 : 0];
+                const bool from_state = p == 0 || drel < 8;  // the decision before this one fell into an earlier chunk or call
+                const double pI = from_state ? lastI : pv.x, pQ = from_state ? lastQ : pv.y;
+                const double di = -((pI * cur.x) + (pQ * cur.y));  // :539
+                const double dq = (pI * cur.y) - (pQ * cur.x);     // :540
+                const double x = (di * di) + (dq * dq);
+                const bool valid = inr && x > 10000.0;             // energy2 > 100 (:544)
+                const unsigned vm = (unsigned)(__ballot(valid) >> (8 * s8)) & 0xffu;
+                if (valid && live) {
+                    const int pos = nbits + __popc(vm & ((1u << c) - 1u));
+                    if (pos < a.max_bits) blog[HIST_BITS + pos] = (di < 0.0) ? (signed char)1 : (signed char)-1;  // :545
+                }
+                nbits += __popc(vm);
+                if (inr) {
+                    ord_last = ord0 + 2 * p;
+                    x_last = x;
+                }
+            }
+            {   // dmLastIQ (:541-542) = the chunk's last decision sample
+                int plast = (nds - 1 - rel0 - v) >> 3;  // (arithmetic shift: floor)
+                plast = plast < CH - 1 ? plast : CH - 1;
+                const int pfirst = rel0 + v >= 0 ? 0 : 1;
+                const double2 l = FQL[s8][plast > 0 ? plast : 0];
+                if (plast >= pfirst) {
+                    lastI = l.x;
+                    lastQ = l.y;
+                }
+            }
+            T8_CLK(3);  // locked
+        } else {
+            // ---------------- general: the peakPos / newPeak machine per period, in closed form.  Walking the bit positions
+            // cf..cl of a period (:537,:577-579): a decision where c == peakPos; at c == (peakPos+4)&7 peakPos = newPeak, after
+            // which a second decision can fall at the NEW peakPos if that position is still to come.
+            unsigned long long smask = 0ull;  // bit 2p+k: decision slot k of period p is taken
+            unsigned long long pos1 = 0ull, pos2 = 0ull;  // nibble p: the bit position of slot 0 / slot 1
+            {
+                const uint4 n4 = *reinterpret_cast<const uint4 *>(&NPL[s8][0]);
+#pragma unroll
+                for (int p = 0; p < CH; p++) {
+                    const unsigned w = p < 4 ? n4.x : (p < 8 ? n4.y : (p < 12 ? n4.z : n4.w));
+                    const int np = (int)((w >> (8 * (p & 3))) & 0xffu);
+                    int cf = -(rel0 + 8 * p), cl = nds - 1 - (rel0 + 8 * p);
+                    cf = cf < 0 ? 0 : cf;    // first / last bit position of the period that belongs to the call
+                    cl = cl > 7 ? 7 : cl;    // (cl < cf: none of it does)
+                    const int h = (pk + 4) & 7;
+                    const bool pin = pk >= cf && pk <= cl;
+                    const bool hin = h >= cf && h <= cl && pk != nw;
+                    // the old peakPos decides unless the switch came first (h < peakPos and h inside the period)
+                    const bool d1 = pin && !(hin && h < pk);
+                    const bool d2 = hin && nw > h && nw <= cl;
+                    if (d1) {
+                        smask |= 1ull << (2 * p);
+                        pos1 |= (unsigned long long)pk << (4 * p);
+                    }
+                    if (d2) {
+                        smask |= 1ull << (2 * p + 1);
+                        pos2 |= (unsigned long long)nw << (4 * p);
+                    }
+                    pk = hin ? nw : pk;
+                    nw = np < 8 ? np : nw;  // :592
+                }
+            }
+            // the decision samples, lane = (stream, slot); dmEnergyOut's inputs and the samples themselves go to LDS
+            double2 cur[2 * CH / 8];
+            bool has[2 * CH / 8];
+#pragma unroll
+            for (int r = 0; r < 2 * CH / 8; r++) {
+                const int slot = 8 * r + c, p = slot >> 1;
+                has[r] = ((smask >> slot) & 1ull) != 0ull;
+                const int cpos = (int)((((slot & 1) ? pos2 : pos1) >> (4 * p)) & 15ull);
+                const int rel = has[r] ? rel0 + 8 * p + cpos : 0;
+                cur[r] = ys[rel];
+            }
+#pragma unroll
+            for (int r = 0; r < 2 * CH / 8; r++) {
+                const int slot = 8 * r + c;
+                const double en = (cur[r].x * cur[r].x) + (cur[r].y * cur[r].y);
+                X2L[s8 * 2 * CH + slot] = en * S2;
+                CURL[s8 * 2 * CH + slot] = cur[r];
+            }
+            JSDR_WAVE_SYNC();
+            // dmEnergyOut (:538) over the decisions in time order (lane-replicated per stream)
+            {
+                const double2 *x2 = reinterpret_cast<const double2 *>(&X2L[s8 * 2 * CH]);
+#pragma unroll
+                for (int q = 0; q < CH; q++) {
+                    const double2 xx = x2[q];
+                    const double n0 = (eo * K2) + xx.x;
+                    eo = ((smask >> (2 * q)) & 1ull) ? n0 : eo;
+                    const double n1 = (eo * K2) + xx.y;
+                    eo = ((smask >> (2 * q + 1)) & 1ull) ? n1 : eo;
+                }
+            }
+            // detector per slot; the previous decision is the nearest taken slot below (or the state)
+#pragma unroll
+            for (int r = 0; r < 2 * CH / 8; r++) {
+                const int slot = 8 * r + c;
+                const unsigned long long below = smask & ((1ull << slot) - 1ull);
+                const int prev = below ? 63 - __clzll((long long)below) : 0;
+                const double2 pv = CURL[s8 * 2 * CH + prev];
+                const double pI = below ? pv.x : lastI, pQ = below ? pv.y : lastQ;
+                const double di = -((pI * cur[r].x) + (pQ * cur[r].y));
+                const double dq = (pI * cur[r].y) - (pQ * cur[r].x);
+                const double x = (di * di) + (dq * dq);
+                const bool valid = has[r] && x > 10000.0;
+                const unsigned vm = (unsigned)(__ballot(valid) >> (8 * s8)) & 0xffu;
+                if (valid && live) {
+                    const int pos = nbits + __popc(vm & ((1u << c) - 1u));
+                    if (pos < a.max_bits) blog[HIST_BITS + pos] = (di < 0.0) ? (signed char)1 : (signed char)-1;
+                }
+                nbits += __popc(vm);
+                if (has[r]) {
+                    ord_last = ord0 + slot;
+                    x_last = x;
+                }
+            }
+            if (smask) {
+                const double2 l = CURL[s8 * 2 * CH + (63 - __clzll((long long)smask))];
+                lastI = l.x;
+                lastQ = l.y;
+            }
+            T8_CLK(4);  // general
+        }
+        JSDR_WAVE_SYNC();
+    }
+    // ---------------- what the call leaves
+    double energy1 = sp->energy1, energy2 = sp->energy2;
+    if (nds > 0) {
+        const double2 q = ys[nds - 1];
+        energy1 = (q.x * q.x) + (q.y * q.y);  // that of the last sample processed (:534)
+    }
+    {   // energy2 (:543) of the stream's last decision: the lane of the stream that holds the highest ordinal
+        int o = ord_last;
+        double x = x_last;
+#pragma unroll
+        for (int off = 1; off < 8; off <<= 1) {
+            const int oo = __shfl_xor(o, off, 64);
+            const double xo = __shfl_xor(x, off, 64);
+            if (oo > o) {
+                o = oo;
+                x = xo;
+            }
+        }
+        if (o >= 0) energy2 = sqrt(x);
+    }
+    if (live) {
+        sp->dmEnergy[c] = e;
+        if (c == 0) {
+            sp->dmEnergyOut = eo;
+            sp->lastI = lastI;
+            sp->lastQ = lastQ;
+            sp->energy1 = energy1;
+            sp->energy2 = energy2;
+            sp->peakPos = pk;
+            sp->newPeak = nw;
+            const int nb = nbits < a.max_bits ? nbits : a.max_bits;
+            sp->cntBit = cntBit0 + nb;
+            sp->nbits_prev = nb;
+            if (nbits > a.max_bits) sp->overflow = 1;
+            a.nbits[s] = nb;
+        }
+    }
+#ifdef JSDR_X_T8CLK
+    T8_CLK(5);  // write-back
+    if (lane == 0)
+        for (int i = 0; i < 6; i++) atomicAdd(&g_t8_clk[i], t8acc_[i]);
+#endif
+}
+
 // ------------------------------------------------------------------------------------------- k_sync
 // sync-vector correlation for every new bit (:556-559): window = the 5200 most recent bits, 65 taps at
 // stride 80.  corr[b] kept (int8) for the dmMaxCorr bookkeeping; hits (>=45, :560) go to a per-stream list.
@@ -2551,7 +2891,7 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
         ma.sincos = h->sincos.p;
         ma.dmh_old = h->dmh[h->dmh_cur].p;
         ma.dmh_new = h->dmh[h->dmh_cur ^ 1].p;
-        ma.y = h->y[h->y_cur].p;
+        ma.y = h->y[h->y_cur].p + Y_PAD;
         ma.y_stride = h->y_stride;
         ma.nds = (int)nds;
         ma.g_first = g_first;
@@ -2643,7 +2983,7 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
         MatchedArgs ma;
         ma.dm = h->dm.p;
         ma.dm_stride = h->dm_stride;
-        ma.y = h->y[yb].p;
+        ma.y = h->y[yb].p + Y_PAD;
         ma.y_stride = h->y_stride;
         ma.nds = nds;
         ma.g_first = g_first;
@@ -2679,7 +3019,7 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
     }
     {
         TailArgs ta;
-        ta.y = h->y[yb].p;
+        ta.y = h->y[yb].p + Y_PAD;
         ta.y_stride = h->y_stride;
         ta.nds = nds;
         ta.g_first = g_first;
@@ -2706,8 +3046,14 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
         ta.kvco = kvco_p;
         ta.sincos = h->sincos.p;
         ProfScope ps(h, PK_TAIL, ts);
+        static const bool use_tail8 = [] {
+            const char *e = getenv("JSDR_TAIL8");  // JSDR_TAIL8=0: the one-wave-per-stream tail (A/B timing)
+            return !e || atoi(e) != 0;
+        }();
         if (h->variant != 0 && !h->do_fft && fa.raw)
             hipLaunchKernelGGL(k_tail<true>, dim3((unsigned)S), dim3(64), 0, ts, ta);
+        else if (use_tail8)
+            hipLaunchKernelGGL(k_tail8<16>, dim3((unsigned)((S + 7) / 8)), dim3(64), 0, ts, ta);
         else
             hipLaunchKernelGGL(k_tail<false>, dim3((unsigned)S), dim3(64), 0, ts, ta);
         JSDR_LAUNCH_CHECK();
@@ -2877,11 +3223,11 @@ int jsdr_bpsk_create(jsdr_bpsk **out, int rate, int nsamples_per_frame, int tuni
     const size_t S = (size_t)nstreams;
     h->dm_stride = 64 + h->max_ds + 64;
     h->y_stride = h->max_ds;
-    h->bitlog_stride = HIST_BITS + h->max_bits + 64;
+    h->bitlog_stride = (HIST_BITS + h->max_bits + 64 + 15) & ~15LL;  // (rows 16-byte aligned: k_tail8 carries the register over in dwords)
     bool ok = h->sincos.alloc(512) == JSDR_OK && h->ktu.alloc((size_t)h->max_batch + 8192) == JSDR_OK &&
               h->kvco.alloc(2 * (size_t)h->max_ds) == JSDR_OK && h->hist_in[0].alloc(S * 32) == JSDR_OK &&
               h->hist_in[1].alloc(S * 32) == JSDR_OK && h->dm.alloc(S * (size_t)h->dm_stride) == JSDR_OK &&
-              h->y[0].alloc(S * (size_t)h->y_stride) == JSDR_OK && h->y[1].alloc(S * (size_t)h->y_stride) == JSDR_OK && h->tail.alloc(S) == JSDR_OK &&
+              h->y[0].alloc(S * (size_t)h->y_stride + 2 * Y_PAD) == JSDR_OK && h->y[1].alloc(S * (size_t)h->y_stride + 2 * Y_PAD) == JSDR_OK && h->tail.alloc(S) == JSDR_OK &&
               h->bitlog[0].alloc(S * (size_t)h->bitlog_stride) == JSDR_OK &&
               h->bitlog[1].alloc(S * (size_t)h->bitlog_stride) == JSDR_OK && h->nbits.alloc(S) == JSDR_OK &&
               h->trig_count.alloc(S) == JSDR_OK && h->trig_bits.alloc(S * h->trig_cap) == JSDR_OK &&
@@ -3064,6 +3410,19 @@ int jsdr_bpsk_destroy(jsdr_bpsk *h)
     h->fft2x_ek.release();
     h->fft2x_r0.release();
     h->vco_cs.release();
+#ifdef JSDR_X_T8CLK
+    {
+        unsigned long long cc[8] = {0};
+        if (hipMemcpyFromSymbol(cc, HIP_SYMBOL(g_t8_clk), sizeof(cc)) == hipSuccess) {
+            static const char *nm[6] = {"prologue", "A chains", "B argmax", "locked", "general", "write-back"};
+            unsigned long long tot = 0;
+            for (int i = 0; i < 6; i++) tot += cc[i];
+            for (int i = 0; i < 6; i++) fprintf(stderr, "k_tail8 clk %-12s %14llu ticks %5.1f%%\n", nm[i], cc[i], 100.0 * cc[i] / (tot ? tot : 1));
+            memset(cc, 0, sizeof(cc));
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_t8_clk), cc, sizeof(cc));
+        }
+    }
+#endif
 #ifdef JSDR_X_CLK
     {
         static unsigned long long cc[256][64];
@@ -3399,7 +3758,7 @@ int jsdr_bpsk_get_trace(jsdr_bpsk *h, int stream, double *out_host, int64_t cap_
     *npairs = h->last_nds;
     long long n = h->last_nds < cap_pairs ? h->last_nds : cap_pairs;
     if (n > 0 && out_host)
-        JSDR_HIP_TRY(hipMemcpy(out_host, h->y[h->last_y].p + (size_t)stream * h->y_stride, sizeof(double2) * (size_t)n,
+        JSDR_HIP_TRY(hipMemcpy(out_host, h->y[h->last_y].p + Y_PAD + (size_t)stream * h->y_stride, sizeof(double2) * (size_t)n,
                                hipMemcpyDeviceToHost));
     return JSDR_OK;
 }
