@@ -2066,17 +2066,37 @@ __global__ __launch_bounds__(256) void k_sync_t(SyncArgs a, int row_stride, Sync
         if (f.fuse && threadIdx.x == 0) f.trig_count[s] = 0;
         return;
     }
-    const signed char *W = a.bitlog + (long long)s * a.bitlog_stride + 1;
-    const int np = HIST_BITS - 1 + nb;  // W[0 .. np): the last window ends at W[nb-1 + 80*64]
+    const int np = HIST_BITS - 1 + nb;  // W[0 .. np), W = the stream's log from byte 1: the last window ends at W[nb-1 + 80*64]
     {
-        int p = threadIdx.x, r = p % 80, q = p / 80;
-        for (; p < np; p += 256) {
-            T[r * row_stride + q] = W[p];
-            r += 256 % 80;
-            q += 256 / 80;
-            if (r >= 80) {
-                r -= 80;
-                q += 1;
+        // the log comes in as 16-byte loads, eight per thread in flight (the rows are 16-byte aligned; W[p] is byte p + 1 of
+        // the row): as a byte-at-a-time loop every one of its 120 iterations waited for its own load
+        const uint4 *row16 = reinterpret_cast<const uint4 *>(a.bitlog + (long long)s * a.bitlog_stride);
+        const int n16 = (np + 1 + 15) / 16;
+        for (int i0 = 0; i0 < n16; i0 += 256 * 8) {
+            uint4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int i = i0 + 256 * u + (int)threadIdx.x;
+                v[u] = row16[i < n16 ? i : n16 - 1];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int i = i0 + 256 * u + (int)threadIdx.x;
+                if (i < n16) {
+                    const int p0 = 16 * i - 1;  // W index of the quad's first byte
+                    int r = (p0 + 80) % 80, q = (p0 + 80) / 80 - 1;
+                    const unsigned w4[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+                    for (int b = 0; b < 16; b++) {
+                        const int p = p0 + b;
+                        if (p >= 0 && p < np) T[r * row_stride + q] = (signed char)((w4[b >> 2] >> (8 * (b & 3))) & 0xffu);
+                        r += 1;
+                        if (r >= 80) {
+                            r = 0;
+                            q += 1;
+                        }
+                    }
+                }
             }
         }
     }
@@ -2204,6 +2224,7 @@ struct SnapPack {
     signed char bits[512];
 };
 
+struct SideJob;
 struct jsdr_bpsk {
     int rate = 0, nsf = 0, tuning = 0, do_fft = 0, do_up = 0, nstreams = 0, decim = 0;
     long long max_batch = 0, max_ds = 0;
@@ -2257,6 +2278,9 @@ struct jsdr_bpsk {
     bool prefetch_on = true;       // JSDR_SCHED_PREFETCH=0: always on the calling thread
     long long sched_sync = 0, sched_prefetched = 0;  // schedules computed on the calling thread / taken from the worker
     hipStream_t tail_stream = nullptr;   // non-blocking side stream for the latency-bound 9600 Hz tail + FEC
+    struct SideJob *side_job = nullptr;  // deferred mode: the side section of the last call, not enqueued yet
+    bool defer_side = false;             // JSDR_SIDE_DEFER=1
+    hipEvent_t ev_gate = nullptr;        // caller stream -> tail stream: where the deferred side section may start
     hipEvent_t ev_matched = nullptr;     // caller stream -> tail stream: (fi,fq) of this call are complete
     hipEvent_t ev_tail_done[2] = {nullptr, nullptr};  // tail stream -> caller stream: y[i] may be overwritten
     bool tail_pending[2] = {false, false};
@@ -2278,6 +2302,8 @@ struct jsdr_bpsk {
     DevBuf<signed char> corr;
     DevBuf<unsigned char> fec_data, decoded;
     DevBuf<unsigned long long> fec_scratch;  // Viterbi decision words of every (stream, hit) block
+    DevBuf<unsigned char> fec_vit;           // batch form (k_vitq): the Viterbi output bytes of every (stream, hit) block
+    DevBuf<int> fec_work;                    // ... its work list, [0] = count
     DevBuf<int> fec_done;                    // [S] k_fec_bpsk's per-stream count of finished blocks (zero between launches)
     // receive_*() of a 1-stream handle: every host<->device copy of the call goes through ONE pinned arena (the frame in,
     // the schedule's tables when they change, the packed results out).  A copy from / to pageable memory is staged by the
@@ -2692,6 +2718,190 @@ static int h2d_call(jsdr_bpsk *h, void *dst_dev, const void *src_host, size_t by
     return JSDR_OK;
 }
 
+// The side section of a call: the 9600 Hz tail, the sync correlation and the FEC of every hit, on the handle's side stream
+// (the caller's when there is none), after the front end of THAT call.  Everything it needs from the call is in the job.
+struct SideJob {
+    bool valid = false;
+    int yb = 0;
+    long long nds = 0, g_first = 0;
+    int first_out = 0, ic = 0, qc = 0;
+    const int *raw = nullptr;
+    long long stride_pairs = 0;
+    unsigned char *kvco_p = nullptr;
+    double2 *tcs_p = nullptr;
+    hipStream_t st = nullptr;
+};
+
+static int run_side(jsdr_bpsk *h, const SideJob &j)
+{
+    const int S = h->nstreams;
+    const int yb = j.yb;
+    hipStream_t ts = h->overlap ? h->tail_stream : j.st;
+    if (h->overlap) JSDR_HIP_TRY(hipStreamWaitEvent(ts, h->ev_matched, 0));
+    if (h->pack_pending) {  // a pack of the previous call's results may still be reading what the tail section rewrites
+        JSDR_HIP_TRY(hipStreamWaitEvent(ts, h->ev_pack_done, 0));
+        h->pack_pending = false;
+    }
+    {
+        TailArgs ta;
+        ta.y = h->y[yb].p + Y_PAD;
+        ta.y_stride = h->y_stride;
+        ta.nds = j.nds;
+        ta.g_first = j.g_first;
+        ta.st = h->tail.p;
+        ta.bitlog_new = h->bitlog[h->bitlog_cur ^ 1].p;
+        ta.bitlog_old = h->bitlog[h->bitlog_cur].p;
+        ta.bitlog_stride = h->bitlog_stride;
+        ta.nbits = h->nbits.p;
+        ta.max_bits = h->max_bits;
+        ta.nstreams = S;
+        ta.ey = h->fast_ey;
+        ta.amax = h->amax.p;
+        ta.margin_scale = h->margin_scale;
+        ta.argmax_scale = h->argmax_scale;
+        ta.raw = j.raw;
+        ta.stride_pairs = j.stride_pairs;
+        ta.ic = j.ic;
+        ta.qc = j.qc;
+        ta.decim = h->decim;
+        ta.first_out = j.first_out;
+        ta.mix = h->mix;
+        ta.tper = (h->mix == 1) ? h->c_tper : 0;
+        ta.tcs = j.tcs_p;
+        ta.kvco = j.kvco_p;
+        ta.sincos = h->sincos.p;
+        ProfScope ps(h, PK_TAIL, ts);
+        static const bool use_tail8 = [] {
+            const char *e = getenv("JSDR_TAIL8");  // JSDR_TAIL8=0: the one-wave-per-stream tail (A/B timing)
+            return !e || atoi(e) != 0;
+        }();
+        if (h->variant != 0 && !h->do_fft && j.raw)
+            hipLaunchKernelGGL(k_tail<true>, dim3((unsigned)S), dim3(64), 0, ts, ta);
+        else if (use_tail8)
+            hipLaunchKernelGGL(k_tail8<16>, dim3((unsigned)((S + 7) / 8)), dim3(64), 0, ts, ta);
+        else
+            hipLaunchKernelGGL(k_tail<false>, dim3((unsigned)S), dim3(64), 0, ts, ta);
+        JSDR_LAUNCH_CHECK();
+        h->bitlog_cur ^= 1;
+    }
+    {
+        SyncArgs sa;
+        sa.bitlog = h->bitlog[h->bitlog_cur].p;
+        sa.bitlog_stride = h->bitlog_stride;
+        sa.nbits = h->nbits.p;
+        sa.corr = h->corr.p;
+        sa.max_bits = h->max_bits;
+        int gx = (h->max_bits + 255) / 256;
+        long long maxnew = j.nds / 4 + 8;
+        if ((long long)gx * 256 > maxnew + 255) gx = (int)((maxnew + 255) / 256);
+        if (gx < 1) gx = 1;
+        {
+            // transposed-image kernel when the stream's log fits a workgroup's LDS (always, up to ~8M samples a call)
+            int cols = (HIST_BITS + h->max_bits + 79) / 80 + 72;  // + the 18 dwords an output reads past its first column
+            int rs = (cols + 3) & ~3;
+            if (((rs / 4) & 1) == 0) rs += 4;  // 4 * odd
+            const size_t lds = (size_t)80 * rs + 16;
+            static const bool use_t = [] {
+                const char *e = getenv("JSDR_SYNC_T");  // JSDR_SYNC_T=0: the strided kernel
+                return !e || atoi(e) != 0;
+            }();
+            ProfScope ps(h, (use_t && lds <= 150 * 1024) ? PK_SYNCT : PK_SYNC, ts);  // timed under the name rocprof shows
+            if (use_t && lds <= 150 * 1024) {
+                static size_t attr_for = 0;
+                if (attr_for < lds) {
+                    JSDR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sync_t), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    attr_for = lds;
+                }
+                SyncFinArgs sf;
+                sf.trig_count = h->trig_count.p;
+                sf.trig_bits = h->trig_bits.p;
+                sf.trig_cap = h->trig_cap;
+                sf.st = h->tail.p;
+                // (the hand-over inside the workgroup is a device-scope release / acquire pair: an L2 write-back per
+                //  workgroup on this multi-XCD part -- nothing for one stream, a tax beside the PSD kernel for thousands)
+                sf.fuse = (S == 1 && j.nds <= 16384) ? 1 : 0;  // at most ~2000 new bits: the scan is a few dozen iterations
+                hipLaunchKernelGGL(k_sync_t, dim3((unsigned)S), dim3(256), lds, ts, sa, rs, sf);
+                JSDR_LAUNCH_CHECK();
+                if (!sf.fuse) {
+                    ProfScope ps2(h, PK_SYNCFIN, ts);
+                    hipLaunchKernelGGL(k_sync_fin, dim3((unsigned)S), dim3(64), 0, ts, h->nbits.p, h->corr.p, h->max_bits,
+                                       h->trig_count.p, h->trig_bits.p, h->trig_cap, h->tail.p, S);
+                    JSDR_LAUNCH_CHECK();
+                }
+            } else {
+                hipLaunchKernelGGL(k_sync, dim3((unsigned)gx, (unsigned)S), dim3(256), 0, ts, sa);
+                JSDR_LAUNCH_CHECK();
+                ProfScope ps2(h, PK_SYNCFIN, ts);
+                hipLaunchKernelGGL(k_sync_fin, dim3((unsigned)S), dim3(64), 0, ts, h->nbits.p, h->corr.p, h->max_bits,
+                                   h->trig_count.p, h->trig_bits.p, h->trig_cap, h->tail.p, S);
+                JSDR_LAUNCH_CHECK();
+            }
+        }
+        BpskFecArgs fa2;
+        fa2.bitlog = h->bitlog[h->bitlog_cur].p;
+        fa2.bitlog_stride = h->bitlog_stride;
+        fa2.trig_count = h->trig_count.p;
+        fa2.trig_bits = h->trig_bits.p;
+        fa2.max_trig = h->trig_cap;
+        fa2.decoded = h->decoded.p;
+        fa2.fec_rc = h->fec_rc.p;
+        fa2.fec_data = h->fec_data.p;
+        fa2.last = h->fec_last.p;
+        fa2.cnt_dec = h->cnt_dec.p;
+        fa2.nstreams = S;
+        fa2.dec_scratch = h->fec_scratch.p;
+        fa2.done = h->fec_done.p;
+        fa2.fuse = (S == 1) ? 1 : 0;
+        fa2.ncopy = 0;
+        fa2.vit = h->fec_vit.p;  // (null below VIT64_MIN_STREAMS: one wave per block)
+        fa2.work_count = h->fec_work.p;
+        fa2.work_list = h->fec_work.p ? h->fec_work.p + 1 : nullptr;
+        h->snap_fused = false;
+        if (S == 1 && h->pin_call) {  // receive(): the snapshot is packed by the block that completes the FEC work
+            SnapPack *sp = h->snap_dev.p;
+            auto add = [&](const void *src, void *dst, size_t bytes) {
+                fa2.csrc[fa2.ncopy] = static_cast<const unsigned char *>(src);
+                fa2.cdst[fa2.ncopy] = static_cast<unsigned char *>(dst);
+                fa2.cbytes[fa2.ncopy] = (int)bytes;
+                fa2.ncopy++;
+            };
+            add(h->tail.p, &sp->t, sizeof(TailState));
+            add(h->fec_last.p, sp->last, 2 * sizeof(int));
+            add(h->cnt_dec.p, &sp->cdec, sizeof(int));
+            add(h->nbits.p, &sp->nbits, sizeof(int));
+            if (h->do_fft) {
+                add(&h->fft_state.p->centreBin, &sp->centreBin, sizeof(int));
+                add(&h->fft_state.p->avePeakPower, &sp->avePeakPower, 2 * sizeof(double));  // avePeakPower, aveCentreBin
+            }
+            add(h->decoded.p, sp->decoded, 256);
+            // the call's bits: what the log holds behind the history (the host clears the snapshot's bytes beyond nbits)
+            const long long have = h->bitlog_stride - HIST_BITS;
+            add(h->bitlog[h->bitlog_cur].p + HIST_BITS, sp->bits, (size_t)(have < 512 ? have : 512));
+            h->snap_fused = true;
+        }
+        ProfScope ps(h, PK_FEC, ts);
+        if (launch_fec_bpsk(fa2, ts) != JSDR_OK) return JSDR_ERR;
+    }
+    if (h->overlap) {
+        JSDR_HIP_TRY(hipEventRecord(h->ev_tail_done[yb], ts));
+        h->tail_pending[yb] = true;
+        h->y_cur ^= 1;
+    }
+    return JSDR_OK;
+}
+
+// launch a deferred side section now; gate: the stream whose work enqueued so far it has to wait for as well
+static int flush_side(jsdr_bpsk *h, hipStream_t gate, bool use_gate)
+{
+    if (!h->side_job || !h->side_job->valid) return JSDR_OK;
+    h->side_job->valid = false;
+    if (use_gate && h->overlap) {
+        JSDR_HIP_TRY(hipEventRecord(h->ev_gate, gate));
+        JSDR_HIP_TRY(hipStreamWaitEvent(h->tail_stream, h->ev_gate, 0));
+    }
+    return run_side(h, *h->side_job);
+}
+
 static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev, long long stride_i16, long long L,
                     int ic, int qc, hipStream_t st)
 {
@@ -2702,6 +2912,7 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
                  "bpsk: stream stride %lld too small for %lld samples", stride_i16, L);
     JSDR_REQUIRE(!h->do_fft || (L % h->nsf) == 0, "bpsk: FFT-acquire mode needs whole frames (%lld %% %d != 0)", L, h->nsf);
     JSDR_REQUIRE(h->variant == 0 || raw_dev, "bpsk: the fast variant takes int16 input (its certification pass re-reads the raw samples)");
+    if (flush_side(h, st, true) != JSDR_OK) return JSDR_ERR;  // the previous call's side section (deferred mode)
     const int first_out = h->decim - 1 - h->dsCnt;
     const long long g_first = h->n_ds;
     const long long nds = build_schedule(h, L);
@@ -3009,155 +3220,30 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
         hipLaunchKernelGGL(k_dm_history, dim3((unsigned)S), dim3(64), 0, st, h->dm.p, h->dm_stride, nds, S);
         JSDR_LAUNCH_CHECK();
     }
-    if (h->overlap) {
-        JSDR_HIP_TRY(hipEventRecord(h->ev_matched, st));
-        JSDR_HIP_TRY(hipStreamWaitEvent(ts, h->ev_matched, 0));
-    }
-    if (h->pack_pending) {  // a pack of the previous call's results may still be reading what the tail section rewrites
-        JSDR_HIP_TRY(hipStreamWaitEvent(ts, h->ev_pack_done, 0));
-        h->pack_pending = false;
-    }
     {
-        TailArgs ta;
-        ta.y = h->y[yb].p + Y_PAD;
-        ta.y_stride = h->y_stride;
-        ta.nds = nds;
-        ta.g_first = g_first;
-        ta.st = h->tail.p;
-        ta.bitlog_new = h->bitlog[h->bitlog_cur ^ 1].p;
-        ta.bitlog_old = h->bitlog[h->bitlog_cur].p;
-        ta.bitlog_stride = h->bitlog_stride;
-        ta.nbits = h->nbits.p;
-        ta.max_bits = h->max_bits;
-        ta.nstreams = S;
-        ta.ey = h->fast_ey;
-        ta.amax = h->amax.p;
-        ta.margin_scale = h->margin_scale;
-        ta.argmax_scale = h->argmax_scale;
-        ta.raw = fa.raw;
-        ta.stride_pairs = fa.stride_pairs;
-        ta.ic = ic;
-        ta.qc = qc;
-        ta.decim = h->decim;
-        ta.first_out = first_out;
-        ta.mix = h->mix;
-        ta.tper = (h->mix == 1) ? h->c_tper : 0;
-        ta.tcs = tcs_p;
-        ta.kvco = kvco_p;
-        ta.sincos = h->sincos.p;
-        ProfScope ps(h, PK_TAIL, ts);
-        static const bool use_tail8 = [] {
-            const char *e = getenv("JSDR_TAIL8");  // JSDR_TAIL8=0: the one-wave-per-stream tail (A/B timing)
-            return !e || atoi(e) != 0;
-        }();
-        if (h->variant != 0 && !h->do_fft && fa.raw)
-            hipLaunchKernelGGL(k_tail<true>, dim3((unsigned)S), dim3(64), 0, ts, ta);
-        else if (use_tail8)
-            hipLaunchKernelGGL(k_tail8<16>, dim3((unsigned)((S + 7) / 8)), dim3(64), 0, ts, ta);
-        else
-            hipLaunchKernelGGL(k_tail<false>, dim3((unsigned)S), dim3(64), 0, ts, ta);
-        JSDR_LAUNCH_CHECK();
-        h->bitlog_cur ^= 1;
-    }
-    {
-        SyncArgs sa;
-        sa.bitlog = h->bitlog[h->bitlog_cur].p;
-        sa.bitlog_stride = h->bitlog_stride;
-        sa.nbits = h->nbits.p;
-        sa.corr = h->corr.p;
-        sa.max_bits = h->max_bits;
-        int gx = (h->max_bits + 255) / 256;
-        long long maxnew = nds / 4 + 8;
-        if ((long long)gx * 256 > maxnew + 255) gx = (int)((maxnew + 255) / 256);
-        if (gx < 1) gx = 1;
-        {
-            // transposed-image kernel when the stream's log fits a workgroup's LDS (always, up to ~8M samples a call)
-            int cols = (HIST_BITS + h->max_bits + 79) / 80 + 72;  // + the 18 dwords an output reads past its first column
-            int rs = (cols + 3) & ~3;
-            if (((rs / 4) & 1) == 0) rs += 4;  // 4 * odd
-            const size_t lds = (size_t)80 * rs + 16;
-            static const bool use_t = [] {
-                const char *e = getenv("JSDR_SYNC_T");  // JSDR_SYNC_T=0: the strided kernel
-                return !e || atoi(e) != 0;
-            }();
-            ProfScope ps(h, (use_t && lds <= 150 * 1024) ? PK_SYNCT : PK_SYNC, ts);  // timed under the name rocprof shows
-            if (use_t && lds <= 150 * 1024) {
-                static size_t attr_for = 0;
-                if (attr_for < lds) {
-                    JSDR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sync_t), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                    attr_for = lds;
-                }
-                SyncFinArgs sf;
-                sf.trig_count = h->trig_count.p;
-                sf.trig_bits = h->trig_bits.p;
-                sf.trig_cap = h->trig_cap;
-                sf.st = h->tail.p;
-                // (the hand-over inside the workgroup is a device-scope release / acquire pair: an L2 write-back per
-                //  workgroup on this multi-XCD part -- nothing for one stream, a tax beside the PSD kernel for thousands)
-                sf.fuse = (S == 1 && nds <= 16384) ? 1 : 0;  // at most ~2000 new bits: the scan is a few dozen iterations
-                hipLaunchKernelGGL(k_sync_t, dim3((unsigned)S), dim3(256), lds, ts, sa, rs, sf);
-                JSDR_LAUNCH_CHECK();
-                if (!sf.fuse) {
-                    ProfScope ps2(h, PK_SYNCFIN, ts);
-                    hipLaunchKernelGGL(k_sync_fin, dim3((unsigned)S), dim3(64), 0, ts, h->nbits.p, h->corr.p, h->max_bits,
-                                       h->trig_count.p, h->trig_bits.p, h->trig_cap, h->tail.p, S);
-                    JSDR_LAUNCH_CHECK();
-                }
-            } else {
-                hipLaunchKernelGGL(k_sync, dim3((unsigned)gx, (unsigned)S), dim3(256), 0, ts, sa);
-                JSDR_LAUNCH_CHECK();
-                ProfScope ps2(h, PK_SYNCFIN, ts);
-                hipLaunchKernelGGL(k_sync_fin, dim3((unsigned)S), dim3(64), 0, ts, h->nbits.p, h->corr.p, h->max_bits,
-                                   h->trig_count.p, h->trig_bits.p, h->trig_cap, h->tail.p, S);
-                JSDR_LAUNCH_CHECK();
-            }
+        SideJob job;
+        job.valid = true;
+        job.yb = yb;
+        job.nds = nds;
+        job.g_first = g_first;
+        job.first_out = first_out;
+        job.ic = ic;
+        job.qc = qc;
+        job.raw = fa.raw;
+        job.stride_pairs = fa.stride_pairs;
+        job.kvco_p = kvco_p;
+        job.tcs_p = tcs_p;
+        job.st = st;
+        if (h->overlap) JSDR_HIP_TRY(hipEventRecord(h->ev_matched, st));
+        // Deferred (batch handles, exact variant): the side section of this call is enqueued at the START of the next one,
+        // behind whatever the caller has put on its stream by then -- in the pipeline that is the PSD kernel, which is HBM
+        // bound like the tail: side by side they only share the bandwidth.  This way the tail runs beside the NEXT call's
+        // FP64-bound front end, which leaves the memory system idle.  Getters, sync and pack_slots flush it.
+        if (h->defer_side && h->overlap && h->variant == 0 && S > 1) {
+            *h->side_job = job;
+        } else if (run_side(h, job) != JSDR_OK) {
+            return JSDR_ERR;
         }
-        BpskFecArgs fa2;
-        fa2.bitlog = h->bitlog[h->bitlog_cur].p;
-        fa2.bitlog_stride = h->bitlog_stride;
-        fa2.trig_count = h->trig_count.p;
-        fa2.trig_bits = h->trig_bits.p;
-        fa2.max_trig = h->trig_cap;
-        fa2.decoded = h->decoded.p;
-        fa2.fec_rc = h->fec_rc.p;
-        fa2.fec_data = h->fec_data.p;
-        fa2.last = h->fec_last.p;
-        fa2.cnt_dec = h->cnt_dec.p;
-        fa2.nstreams = S;
-        fa2.dec_scratch = h->fec_scratch.p;
-        fa2.done = h->fec_done.p;
-        fa2.fuse = (S == 1) ? 1 : 0;
-        fa2.ncopy = 0;
-        h->snap_fused = false;
-        if (S == 1 && h->pin_call) {  // receive(): the snapshot is packed by the block that completes the FEC work
-            SnapPack *sp = h->snap_dev.p;
-            auto add = [&](const void *src, void *dst, size_t bytes) {
-                fa2.csrc[fa2.ncopy] = static_cast<const unsigned char *>(src);
-                fa2.cdst[fa2.ncopy] = static_cast<unsigned char *>(dst);
-                fa2.cbytes[fa2.ncopy] = (int)bytes;
-                fa2.ncopy++;
-            };
-            add(h->tail.p, &sp->t, sizeof(TailState));
-            add(h->fec_last.p, sp->last, 2 * sizeof(int));
-            add(h->cnt_dec.p, &sp->cdec, sizeof(int));
-            add(h->nbits.p, &sp->nbits, sizeof(int));
-            if (h->do_fft) {
-                add(&h->fft_state.p->centreBin, &sp->centreBin, sizeof(int));
-                add(&h->fft_state.p->avePeakPower, &sp->avePeakPower, 2 * sizeof(double));  // avePeakPower, aveCentreBin
-            }
-            add(h->decoded.p, sp->decoded, 256);
-            // the call's bits: what the log holds behind the history (the host clears the snapshot's bytes beyond nbits)
-            const long long have = h->bitlog_stride - HIST_BITS;
-            add(h->bitlog[h->bitlog_cur].p + HIST_BITS, sp->bits, (size_t)(have < 512 ? have : 512));
-            h->snap_fused = true;
-        }
-        ProfScope ps(h, PK_FEC, ts);
-        if (launch_fec_bpsk(fa2, ts) != JSDR_OK) return JSDR_ERR;
-    }
-    if (h->overlap) {
-        JSDR_HIP_TRY(hipEventRecord(h->ev_tail_done[yb], ts));
-        h->tail_pending[yb] = true;
-        h->y_cur ^= 1;
     }
     h->last_y = yb;
     h->n_in += L;
@@ -3218,9 +3304,15 @@ int jsdr_bpsk_create(jsdr_bpsk **out, int rate, int nsamples_per_frame, int tuni
     // a step at n = 9600, 17.5 vs 18.1 at 4800, no difference at 19200)
     if (do_fft && !fft_pow2) h->overlap = false;
     if (const char *e = getenv("JSDR_NO_OVERLAP")) h->overlap = atoi(e) == 0;
+    if (const char *e = getenv("JSDR_SIDE_DEFER")) h->defer_side = atoi(e) != 0;
+    h->side_job = new SideJob();
     if (const char *e = getenv("JSDR_FM")) h->use_fm = atoi(e) != 0;
     if (const char *e = getenv("JSDR_SCHED_PREFETCH")) h->prefetch_on = atoi(e) != 0;
     const size_t S = (size_t)nstreams;
+    // FEC of a batch handle: the lane-per-block Viterbi (fec.hip, k_vitq) once there are enough blocks to fill waves of 64;
+    // below that (and for the 1-stream receive() form, whose latency counts) one wave per block
+    bool vitq = nstreams >= 256;
+    if (const char *e = getenv("JSDR_VITQ")) vitq = atoi(e) != 0 && nstreams > 1;
     h->dm_stride = 64 + h->max_ds + 64;
     h->y_stride = h->max_ds;
     h->bitlog_stride = (HIST_BITS + h->max_bits + 64 + 15) & ~15LL;  // (rows 16-byte aligned: k_tail8 carries the register over in dwords)
@@ -3231,7 +3323,8 @@ int jsdr_bpsk_create(jsdr_bpsk **out, int rate, int nsamples_per_frame, int tuni
               h->bitlog[0].alloc(S * (size_t)h->bitlog_stride) == JSDR_OK &&
               h->bitlog[1].alloc(S * (size_t)h->bitlog_stride) == JSDR_OK && h->nbits.alloc(S) == JSDR_OK &&
               h->trig_count.alloc(S) == JSDR_OK && h->trig_bits.alloc(S * h->trig_cap) == JSDR_OK &&
-              h->fec_scratch.alloc(S * h->trig_cap * (size_t)fec_dec_scratch_words()) == JSDR_OK && h->fec_done.alloc(S) == JSDR_OK &&
+              h->fec_scratch.alloc(vitq ? (size_t)fec_vitq_scratch_words(nstreams, h->trig_cap) : S * h->trig_cap * (size_t)fec_dec_scratch_words()) == JSDR_OK && h->fec_done.alloc(S) == JSDR_OK &&
+              (!vitq || (h->fec_vit.alloc(S * h->trig_cap * 320) == JSDR_OK && h->fec_work.alloc(S * h->trig_cap + 1) == JSDR_OK)) &&
               h->fec_rc.alloc(S * h->trig_cap) == JSDR_OK && h->fec_last.alloc(S * 2) == JSDR_OK &&
               h->cnt_dec.alloc(S) == JSDR_OK && h->corr.alloc(S * (size_t)h->max_bits) == JSDR_OK &&
               h->fec_data.alloc(S * h->trig_cap * 256) == JSDR_OK && h->decoded.alloc(S * 256) == JSDR_OK &&
@@ -3349,6 +3442,7 @@ int jsdr_bpsk_create(jsdr_bpsk **out, int rate, int nsamples_per_frame, int tuni
               h->cnt_dec.zero() == JSDR_OK && h->y[0].zero() == JSDR_OK && h->y[1].zero() == JSDR_OK &&
               hipStreamCreateWithFlags(&h->tail_stream, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreateWithFlags(&h->ev_matched, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&h->ev_gate, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&h->ev_tail_done[0], hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&h->ev_tail_done[1], hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&h->ev_pack_done, hipEventDisableTiming) == hipSuccess;
@@ -3385,6 +3479,9 @@ int jsdr_bpsk_destroy(jsdr_bpsk *h)
         (void)hipStreamDestroy(h->tail_stream);
     }
     if (h->ev_matched) (void)hipEventDestroy(h->ev_matched);
+    if (h->ev_gate) (void)hipEventDestroy(h->ev_gate);
+    delete h->side_job;
+    h->side_job = nullptr;
     if (h->ev_pack_done) (void)hipEventDestroy(h->ev_pack_done);
     for (int i = 0; i < 2; i++)
         if (h->ev_tail_done[i]) (void)hipEventDestroy(h->ev_tail_done[i]);
@@ -3400,6 +3497,8 @@ int jsdr_bpsk_destroy(jsdr_bpsk *h)
     h->corr.release();
     h->fec_data.release();
     h->fec_scratch.release();
+    h->fec_vit.release();
+    h->fec_work.release();
     h->fec_done.release();
     if (h->pin) (void)hipHostFree(h->pin);
     h->pin = nullptr;
@@ -3658,6 +3757,7 @@ static int publish_snapshot(jsdr_bpsk *h)
 
 static int sync_last(jsdr_bpsk *h)
 {
+    if (flush_side(h, nullptr, false) != JSDR_OK) return JSDR_ERR;
     JSDR_HIP_TRY(hipStreamSynchronize(h->last_stream));
     if (h->tail_stream) JSDR_HIP_TRY(hipStreamSynchronize(h->tail_stream));
     return JSDR_OK;
@@ -3993,6 +4093,7 @@ extern "C" int jsdr_bpsk_pack_slots(jsdr_bpsk *h, uint8_t *slots_dev, void *stre
     int64_t slot_bytes = 0;
     int slot_bits = 0;
     jsdr_bpsk_slot_info(h, &slot_bytes, nullptr, nullptr, &slot_bits, nullptr);
+    if (flush_side(h, nullptr, false) != JSDR_OK) return JSDR_ERR;
     if (h->overlap && h->tail_pending[h->last_y]) {  // results of the last call come from the side stream
         JSDR_HIP_TRY(hipStreamWaitEvent(as_stream(stream), h->ev_tail_done[h->last_y], 0));
     } else if (!h->overlap && as_stream(stream) != h->last_stream && h->ev_matched) {

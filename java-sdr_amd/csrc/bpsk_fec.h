@@ -31,10 +31,16 @@ struct BpskFecArgs {
     const unsigned char *csrc[8];
     unsigned char *cdst[8];
     int cbytes[8];
+    // the batch form (k_vitq, lane-per-block Viterbi): set vit to select it; dec_scratch then holds
+    // fec_vitq_scratch_words(nstreams, max_trig) words
+    unsigned char *vit;         // [nstreams][max_trig][320] Viterbi output bytes, or null
+    int *work_list;             // [nstreams * max_trig]
+    int *work_count;            // [1]
 };
 
 int launch_fec_bpsk(const BpskFecArgs &a, hipStream_t st);
 int fec_prepare();
 int fec_dec_scratch_words();
+long long fec_vitq_scratch_words(int nstreams, int max_trig);
 
 }  // namespace jsdr

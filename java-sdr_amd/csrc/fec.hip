@@ -384,13 +384,14 @@ __device__ __forceinline__ int dec_gpos(int k)
 
 // FECDecode (:703-852) on L.raw; payload to L.data only on success (as the reference leaves
 // RSdecdata untouched on failure).  Returns -1 or the channel error count (wave-uniform).
-template <int DECW>
+template <int DECW, bool VIT_DONE = false>
 __device__ __forceinline__ int fec_decode_wave(FecLdsT<DECW> &L, int lane, unsigned long long *decg = nullptr)
 {
     constexpr bool DEC_GLOBAL = DECW != DECW_LDS;  // decision words in the global scratch decg[DEC_SCRATCH_WORDS]
+    // (VIT_DONE: k_vit64 has run the Viterbi decoder; L.vit holds its output bytes)
     // ---- steps 1+2: de-interleave (:715-722) fused with the branch metrics (:220-225), 512 trellis steps at
     // a time, then add-compare-select with lane = state (:229-253).  Metrics fit int32 (|m| < 3e6).
-    {
+    if constexpr (!VIT_DONE) {
         // Syms[i] = (Partab[i&0x4f]<<1) | (1-Partab[i&0x6d])   (:105-114)
         const int ia = (parity7(lane & 0x4f) << 1) | (1 - parity7(lane & 0x6d));
         const int ib = (parity7((lane ^ 1) & 0x4f) << 1) | (1 - parity7((lane ^ 1) & 0x6d));
@@ -437,7 +438,7 @@ __device__ __forceinline__ int fec_decode_wave(FecLdsT<DECW> &L, int lane, unsig
         }
     }
     // ---- step 2c: chain back from state 0 (:264-276); decision words fetched 64 steps at a time
-    {
+    if constexpr (!VIT_DONE) {
         for (int i = lane; i < 320; i += 64) L.vit[i] = 0;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -711,6 +712,308 @@ __global__ __launch_bounds__(64) void k_fec_bpsk(BpskFecArgs a)
     }
 }
 
+// ---------------------------------------------------------------------------------------------- k_vitq
+// The batch form of the demodulator's hook: FOUR LANES PER BLOCK for the Viterbi decoder, sixteen blocks per wave.
+// With lane = state (above) a trellis step costs ~20 wave instructions for ONE block -- two cross-lane reads through the
+// LDS crossbar, the ballot, the bookkeeping of the decision word -- and a lone wave waits out every one of their latencies.
+// Here lane d of a quad keeps the 16 path metrics of the states n = 4m + d (m = register index) of ITS block.  The
+// predecessors of state 4m + d are 2m + (d >> 1) and that + 32: registers m >> 1 and (m >> 1) + 8 of quad lane
+// 2 (m & 1) + (d >> 1) -- a FIXED quad permutation per register ([0,0,1,1] for even m, [2,2,3,3] for odd m), which the
+// DPP operand of the add performs on the way: no instruction is spent on moving data.  The branch symbols
+// Syms[n] (:105-114) are linear in the bits of n, Syms[4m + d] = Syms[4m] ^ G(d), so a lane keeps its own permutation of
+// the step's four branch metrics and indexes it with the compile-time Syms[4m].  A step = 4 selects + 4 adds for the
+// branch metrics and, per register, 2 adds, 1 compare whose result an add-with-carry shifts into the lane's decision
+// word, 1 maximum: ~100 wave instructions for 16 blocks = 6 per block instead of 20, and sixteen times fewer waves
+// than blocks.  Same integer metrics (mettab sums, :220-225), same strict comparison m1 > m0 (:240-251), same decisions;
+// the chain-back (:264-276) runs in the same wave, the four lanes of a quad following the same path.
+// (Tried first: ONE lane per block, all 64 metrics in its registers, 64 blocks per wave -- no cross-lane traffic at all, 6
+// instructions per block and step as well, but 261 waves for the 16 700 blocks of an 8192-stream call: 3.5 ms of latency
+// on a quarter of the SIMDs against 1.97 ms for the lane = state kernel, and beside the main stream's kernels its 159
+// VGPRs + 41 KB of LDS cost every CU it sat on one of their workgroups.)
+//   k_fec_list : the (stream, hit) pairs of the call, compacted into one work list
+//   k_vitq     : symbols -> hard bits in trellis order (whole wave per block, ballots; LDS), ACS, chain-back -> the 320
+//                output bytes per block; decision words through a global scratch [4 steps][lane] (coalesced both ways)
+//   k_fec_rs   : one wave per block, as k_fec_bpsk from its step 3: RS syndromes / correction, re-encode, error count
+struct VitArgs {
+    const signed char *bitlog;
+    long long bitlog_stride;
+    const int *trig_count, *trig_bits;
+    int max_trig, nstreams;
+    int *work_list;            // [nstreams * max_trig] item = stream * max_trig + hit
+    int *work_count;           // [1]
+    unsigned long long *dec;   // [waves][VQ_GROUPS][64]
+    unsigned char *vit;        // [nstreams * max_trig][320]
+    int quad_cap;              // blocks one round of quad waves takes: 16 x the device's SIMDs
+    unsigned long long *rem_dec;  // [VQ_REM_MAX][DEC_SCRATCH_WORDS] decision words of the remainder's blocks
+};
+// How many of the nwork blocks take the quad kernel.  A quad wave issues ~100 instructions per trellis step whatever the
+// number of its blocks, and it fills its SIMD's issue slots: 1044 of them on 1024 SIMDs take as long as 2048.  So the blocks
+// beyond a whole number of rounds -- when they are few -- go through the lane = state decoder (one wave per block: latency
+// bound, its waves fit between the quad waves' instructions) in the SAME launch.
+enum { VQ_REM_MAX = 4096 };
+__host__ __device__ inline int vq_quad_blocks(int nwork, int quad_cap)
+{
+    const int rem = nwork % quad_cap;
+    return rem < VQ_REM_MAX && nwork >= quad_cap ? nwork - rem : nwork;
+}
+enum { VQ_BLOCKS = 16, VQ_GROUPS = (NBITS + 3) / 4 };
+
+// A block's 5200 symbols as hard bits (FUNcubeBPSKDemod.java:562-564: bit == 1 -> 0xc0, else 0x40), one wave per block:
+//   words 0 .. 80   : in the order the trellis takes them (de-interleaver, :715-722: symbols 2k, 2k+1 of step k sit at
+//                     (j % 65) * 80 + j / 65 + 1), for k_vitq
+//   words 81 .. 162 : in their own order, for k_fec_rs (what k_fec_bpsk keeps in L.raw)
+// The window comes in with all its loads in flight (dwords around the byte-aligned start) and is looked up in LDS: as 163
+// dependent global byte gathers per wave this took longer than the trellis.
+enum { VQ_SW = 81, VQ_NW = (SYMPBLOCK + 63) / 64, VQ_BITS = VQ_SW + VQ_NW };
+__global__ __launch_bounds__(64) void k_fec_bits(VitArgs a, unsigned long long *bits)
+{
+    __shared__ unsigned winL[SYMPBLOCK / 4 + 4];
+    const int lane = threadIdx.x;
+    const int nwork = __builtin_amdgcn_readfirstlane(*a.work_count);
+    const int idx = blockIdx.x;
+    if (idx >= nwork) return;
+    const int item = __builtin_amdgcn_readfirstlane(a.work_list[idx]);
+    const int s = item / a.max_trig;
+    const signed char *win = a.bitlog + (long long)s * a.bitlog_stride + (a.trig_bits[item] + 1);
+    const int sh = (int)(reinterpret_cast<unsigned long long>(win) & 3ull);
+    const unsigned *w32 = reinterpret_cast<const unsigned *>(win - sh);
+    constexpr int NDW = SYMPBLOCK / 4 + 1, NIT = (NDW + 63) / 64;  // (+1: the start may sit inside a dword)
+    unsigned v[NIT];
+#pragma unroll
+    for (int q = 0; q < NIT; q++) {
+        const int i = lane + 64 * q;
+        v[q] = w32[i < NDW ? i : NDW - 1];
+    }
+#pragma unroll
+    for (int q = 0; q < NIT; q++) {
+        const int i = lane + 64 * q;
+        if (i < NDW) winL[i] = v[q];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const signed char *wl = reinterpret_cast<const signed char *>(winL) + sh;  // wl[i] == win[i]
+    unsigned long long *dst = bits + (long long)item * VQ_BITS;
+    unsigned long long m0 = 0ull, m1 = 0ull, m2 = 0ull;  // lane q keeps word q, q + 64, q + 128
+#pragma unroll 9
+    for (int q = 0; q < VQ_SW; q++) {
+        const int j = 64 * q + lane;
+        const int jc = j < 2 * NBITS ? j : 2 * NBITS - 1;
+        const int src = (jc % COLUMNS) * ROWS + (jc / COLUMNS + 1);
+        const unsigned long long m = __ballot(j < 2 * NBITS && wl[src] == 1);
+        if (q < 64) m0 = (lane == q) ? m : m0; else m1 = (lane == q - 64) ? m : m1;
+    }
+#pragma unroll 2
+    for (int q = 0; q < VQ_NW; q++) {
+        const int i = 64 * q + lane;
+        const unsigned long long m = __ballot(i < SYMPBLOCK && wl[i < SYMPBLOCK ? i : SYMPBLOCK - 1] == 1);
+        const int w = VQ_SW + q;
+        if (w < 128) m1 = (lane == w - 64) ? m : m1; else m2 = (lane == w - 128) ? m : m2;
+    }
+    dst[lane] = m0;
+    dst[64 + lane] = m1;
+    if (128 + lane < VQ_BITS) dst[128 + lane] = m2;
+}
+
+__global__ void k_fec_list(VitArgs a)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= a.nstreams) return;
+    int nt = a.trig_count[s];
+    if (nt > a.max_trig) nt = a.max_trig;
+    if (nt <= 0) return;
+    const int base = atomicAdd(a.work_count, nt);
+    for (int t = 0; t < nt; t++) a.work_list[base + t] = s * a.max_trig + t;
+}
+
+__host__ __device__ constexpr int vit_par7(int v)
+{
+    int p = 0;
+    for (int b = 0; b < 7; b++) p ^= (v >> b) & 1;
+    return p;
+}
+// Syms[n] = (Partab[n&0x4f]<<1) | (1-Partab[n&0x6d])   (:105-114): the symbol pair on the branch INTO state n from n>>1
+__host__ __device__ constexpr int vit_ia(int n) { return (vit_par7(n & 0x4f) << 1) | (1 - vit_par7(n & 0x6d)); }
+static_assert((vit_ia(4 * 5 + 1) == (vit_ia(4 * 5) ^ 3)) && (vit_ia(4 * 9 + 2) == (vit_ia(4 * 9) ^ 2)) && (vit_ia(4 * 14 + 3) == (vit_ia(4 * 14) ^ 1)),
+              "Syms[4m + d] = Syms[4m] ^ G(d), G = 0, 3, 2, 1");
+
+template <int CTRL>
+__device__ __forceinline__ int vq_dpp(int v)
+{
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
+}
+
+// one trellis step of the quad's block: O -> N; returns the lane's 16 decisions (bit m: state 4m + d)
+__device__ __forceinline__ unsigned vitq_step(const int (&O)[16], int (&N)[16], const int (&pb)[4])
+{
+    unsigned dw = 0u;
+#pragma unroll
+    for (int m = 15; m >= 0; m--) {  // shifted in from the top register down: bit m ends at position m
+        constexpr int EVEN = 0x50, ODD = 0xfa;  // quad_perm [0,0,1,1] / [2,2,3,3]
+        const int x0 = (m & 1) ? vq_dpp<ODD>(O[m >> 1]) : vq_dpp<EVEN>(O[m >> 1]);
+        const int x1 = (m & 1) ? vq_dpp<ODD>(O[(m >> 1) + 8]) : vq_dpp<EVEN>(O[(m >> 1) + 8]);
+        const int m0 = x0 + pb[vit_ia(4 * m)];
+        const int m1 = x1 + pb[vit_ia(4 * m) ^ 3];
+        // dw = 2 dw + (m1 > m0): the compare's result goes in as the carry of dw + dw (the compiler's own form is a select
+        // and a shift-or per bit, with wait states behind every compare: 135 instead of 100 instructions a step)
+        asm("v_cmp_gt_i32_e32 vcc, %2, %3\n\tv_addc_co_u32_e32 %0, vcc, %1, %1, vcc" : "=v"(dw) : "v"(dw), "v"(m1), "v"(m0) : "vcc");
+        N[m] = m1 > m0 ? m1 : m0;
+    }
+    return dw;
+}
+
+__global__ __launch_bounds__(64) void k_vitq(VitArgs a, const unsigned long long *bits, BpskFecArgs fa)
+{
+    const int lane = threadIdx.x, quad = lane >> 2, d = lane & 3;
+    const int nwork_all = __builtin_amdgcn_readfirstlane(*a.work_count);
+    const int nwork = vq_quad_blocks(nwork_all, a.quad_cap);  // the list's first nwork blocks are the quad waves'
+    const int base = blockIdx.x * VQ_BLOCKS;
+    if (base >= nwork) {
+        // ---- the remainder: one wave per block, the whole of FECDecode (what k_fec_bpsk does)
+        const int ridx = (int)blockIdx.x - (nwork + VQ_BLOCKS - 1) / VQ_BLOCKS;
+        if (nwork + ridx >= nwork_all) return;
+        __shared__ FecLdsT<DECW_WORK> L;
+        const int item = __builtin_amdgcn_readfirstlane(a.work_list[nwork + ridx]);
+        const int s = item / a.max_trig, t = item % a.max_trig;
+        fec_lds_init(L, lane);
+        {
+            const unsigned long long *nat = bits + (long long)item * VQ_BITS + VQ_SW;
+            unsigned long long *raw = reinterpret_cast<unsigned long long *>(L.raw);
+            raw[lane] = nat[lane];
+            if (64 + lane < VQ_NW) raw[64 + lane] = nat[64 + lane];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int r = fec_decode_wave(L, lane, a.rem_dec + (long long)ridx * DEC_SCRATCH_WORDS);
+        unsigned char *logd = fa.fec_data + ((long long)s * a.max_trig + t) * 256;
+        if (r >= 0)
+            for (int i = lane; i < 256; i += 64) logd[i] = L.data[i];
+        if (lane == 0) fa.fec_rc[s * a.max_trig + t] = r;
+        return;
+    }
+    const int nit = nwork - base < VQ_BLOCKS ? nwork - base : VQ_BLOCKS;
+    const int my = quad < nit ? quad : nit - 1;  // (surplus quads shadow the last block and store nothing)
+    const bool live = quad < nit;
+    // ---- add-compare-select (:229-253).  The lane's permutation of the branch metrics: pb[k] = bm[k ^ G(d)],
+    // bm[i] = mettab[i >> 1][y0] + mettab[i & 1][y1] (:220-225)
+    const int A0 = c_fec.mettab[0][0x40], A1 = c_fec.mettab[0][0xc0];  // a received 0 / 1 against a sent 0
+    const int B0 = c_fec.mettab[1][0x40], B1 = c_fec.mettab[1][0xc0];  // ... against a sent 1
+    const bool g1 = d == 1 || d == 2, g0 = d == 1 || d == 3;           // G(d) = 0, 3, 2, 1
+    const int T00 = g1 ? B0 : A0, T01 = g1 ? B1 : A1, T10 = g1 ? A0 : B0, T11 = g1 ? A1 : B1;
+    const int U00 = g0 ? B0 : A0, U01 = g0 ? B1 : A1, U10 = g0 ? A0 : B0, U11 = g0 ? A1 : B1;
+    int M[16], N[16];
+#pragma unroll
+    for (int m = 0; m < 16; m++) M[m] = (m == 0 && d == 0) ? 0 : -999999;
+    const int item = a.work_list[base + my];
+    const unsigned *symw = reinterpret_cast<const unsigned *>(bits + (long long)item * VQ_BITS);  // (k_fec_bits)
+    unsigned long long *decw = a.dec + (long long)blockIdx.x * (VQ_GROUPS * 64) + lane;
+    auto two_steps = [&](unsigned w, unsigned &d0, unsigned &d1) {  // M -> N -> M, symbol bits 0..3 of w
+        int pb[4];
+        {
+            const int t0 = (w & 1u) ? T01 : T00, t1 = (w & 1u) ? T11 : T10;
+            const int u0 = (w & 2u) ? U01 : U00, u1 = (w & 2u) ? U11 : U10;
+            pb[0] = t0 + u0;
+            pb[1] = t0 + u1;
+            pb[2] = t1 + u0;
+            pb[3] = t1 + u1;
+        }
+        d0 = vitq_step(M, N, pb);
+        {
+            const int t0 = (w & 4u) ? T01 : T00, t1 = (w & 4u) ? T11 : T10;
+            const int u0 = (w & 8u) ? U01 : U00, u1 = (w & 8u) ? U11 : U10;
+            pb[0] = t0 + u0;
+            pb[1] = t0 + u1;
+            pb[2] = t1 + u0;
+            pb[3] = t1 + u1;
+        }
+        d1 = vitq_step(N, M, pb);
+    };
+    constexpr int NQ = (2 * NBITS + 31) / 32;  // 161 dwords of symbol bits: 160 x 16 steps + 6
+    static_assert(NBITS - 16 * (NQ - 1) == 6 && VQ_GROUPS == 4 * (NQ - 1) + 2, "the last dword holds six steps: a group of four, a group of two");
+    unsigned wn = symw[0];
+#pragma unroll 1
+    for (int q = 0; q < NQ; q++) {
+        unsigned w = wn;
+        wn = symw[q + 1 < NQ ? q + 1 : q];  // (one dword = sixteen steps ahead)
+        const int ng = q < NQ - 1 ? 4 : 2;
+#pragma unroll 1
+        for (int g = 0; g < ng; g++) {
+            unsigned d0, d1, d2 = 0u, d3 = 0u;
+            two_steps(w, d0, d1);
+            if (q < NQ - 1 || g == 0) two_steps(w >> 4, d2, d3);  // (the call's last group holds two steps)
+            if (live) decw[(long long)(4 * q + g) * 64] = ((unsigned long long)(d2 | (d3 << 16)) << 32) | (d0 | (d1 << 16));
+            w >>= 8;
+        }
+    }
+    // ---- chain back from state 0 (:264-276).  Bit i of the output is decided at trellis step k = i + 6: group k >> 2,
+    // field k & 3 of the word of quad lane (state & 3), bit state >> 2.  The four lanes follow the same path: each looks the
+    // bit up in ITS word, the quad ORs the four candidates together (two DPP steps) and picks lane state & 3's.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // the words were written by this wave; read back past the L1
+    __builtin_amdgcn_wave_barrier();
+    unsigned char *vitp = a.vit + (long long)item * 320;
+    int st = 0;
+    unsigned cur = 0;
+#pragma unroll 1
+    for (int gb = VQ_GROUPS - 1; gb >= 0; gb -= 8) {
+        unsigned long long W[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int g = gb - u;
+            W[u] = __hip_atomic_load(&decw[(long long)(g < 0 ? 0 : g) * 64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+#pragma unroll
+            for (int t = 3; t >= 0; t--) {
+                const int k = 4 * (gb - u) + t, i = k - 6;  // (uniform)
+                if (i >= 0 && i <= NBITS - 7) {
+                    const unsigned f = (unsigned)(W[u] >> (16 * t)) & 0xffffu;
+                    unsigned c4 = ((f >> (st >> 2)) & 1u) << d;
+                    c4 |= (unsigned)vq_dpp<0xb1>((int)c4);  // quad_perm [1,0,3,2]
+                    c4 |= (unsigned)vq_dpp<0x4e>((int)c4);  // quad_perm [2,3,0,1]
+                    const unsigned bit = (c4 >> (st & 3)) & 1u;
+                    st = (int)(((unsigned)st | (bit << 6)) >> 1);
+                    cur |= bit << (7 - (i & 7));  // bit i sits at 0x80 >> (i & 7)  (:270-273)
+                    if ((i & 7) == 0) {
+                        if (live && d == 0) vitp[i >> 3] = (unsigned char)cur;
+                        cur = 0;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// stage 1b of the batch form: everything of FECDecode behind the Viterbi decoder, one wave per (stream, hit)
+__global__ __launch_bounds__(64) void k_fec_rs(BpskFecArgs a, const unsigned char *vit, const unsigned long long *bits, int quad_cap)
+{
+    __shared__ FecLdsT<DECW_WORK> L;
+    const int lane = threadIdx.x;
+    const int nwork = vq_quad_blocks(__builtin_amdgcn_readfirstlane(*a.work_count), quad_cap);  // (the others are done)
+    const int idx = blockIdx.x;
+    if (idx >= nwork) return;
+    const int item = __builtin_amdgcn_readfirstlane(a.work_list[idx]);
+    const int s = item / a.max_trig, t = item % a.max_trig;
+    fec_lds_init(L, lane);
+    {
+        const unsigned long long *nat = bits + (long long)item * VQ_BITS + VQ_SW;  // the symbols' hard bits in their own order
+        unsigned long long *raw = reinterpret_cast<unsigned long long *>(L.raw);
+        raw[lane] = nat[lane];
+        if (64 + lane < VQ_NW) raw[64 + lane] = nat[64 + lane];
+    }
+    const unsigned char *v = vit + ((long long)s * a.max_trig + t) * 320;
+    for (int i = lane; i < 320; i += 64) L.vit[i] = v[i];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int r = fec_decode_wave<DECW_WORK, true>(L, lane, nullptr);
+    unsigned char *logd = a.fec_data + ((long long)s * a.max_trig + t) * 256;
+    if (r >= 0)
+        for (int i = lane; i < 256; i += 64) logd[i] = L.data[i];
+    if (lane == 0) a.fec_rc[s * a.max_trig + t] = r;
+}
+
 __global__ __launch_bounds__(256) void k_fec_fin(BpskFecArgs a)
 {
     const int s = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -723,9 +1026,64 @@ __global__ __launch_bounds__(256) void k_fec_fin(BpskFecArgs a)
 
 int fec_dec_scratch_words() { return DEC_SCRATCH_WORDS; }
 
+static long long fec_vitq_dec_words(int nstreams, int max_trig)
+{
+    const long long waves = ((long long)nstreams * max_trig + VQ_BLOCKS - 1) / VQ_BLOCKS;
+    return waves * 64 * VQ_GROUPS;
+}
+// decision words of every quad wave + the hard bits of every block + the decision words of the remainder's blocks
+long long fec_vitq_scratch_words(int nstreams, int max_trig)
+{
+    return fec_vitq_dec_words(nstreams, max_trig) + (long long)nstreams * max_trig * VQ_BITS + (long long)VQ_REM_MAX * DEC_SCRATCH_WORDS;
+}
+
+static int simd_count()
+{
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) {
+            (void)hipGetLastError();
+            cus = 256;
+        }
+        n = 4 * cus;
+    }
+    return n;
+}
+
 int launch_fec_bpsk(const BpskFecArgs &a, hipStream_t st)
 {
     if (upload_tables() != JSDR_OK) return JSDR_ERR;
+    if (a.vit && !a.fuse) {  // the batch form: four lanes per block
+        VitArgs v;
+        v.bitlog = a.bitlog;
+        v.bitlog_stride = a.bitlog_stride;
+        v.trig_count = a.trig_count;
+        v.trig_bits = a.trig_bits;
+        v.max_trig = a.max_trig;
+        v.nstreams = a.nstreams;
+        v.work_list = a.work_list;
+        v.work_count = a.work_count;
+        v.dec = a.dec_scratch;
+        v.vit = a.vit;
+        JSDR_HIP_TRY(hipMemsetAsync(a.work_count, 0, sizeof(int), st));
+        hipLaunchKernelGGL(k_fec_list, dim3((unsigned)((a.nstreams + 255) / 256)), dim3(256), 0, st, v);
+        JSDR_LAUNCH_CHECK();
+        const long long waves = ((long long)a.nstreams * a.max_trig + VQ_BLOCKS - 1) / VQ_BLOCKS;
+        unsigned long long *bits = a.dec_scratch + fec_vitq_dec_words(a.nstreams, a.max_trig);  // behind the decision words
+        const unsigned nmax = (unsigned)((long long)a.nstreams * a.max_trig);  // (one workgroup per POSSIBLE block; those behind the list's end leave at once)
+        hipLaunchKernelGGL(k_fec_bits, dim3(nmax), dim3(64), 0, st, v, bits);
+        JSDR_LAUNCH_CHECK();
+        v.quad_cap = VQ_BLOCKS * simd_count();
+        v.rem_dec = bits + (long long)a.nstreams * a.max_trig * VQ_BITS;
+        hipLaunchKernelGGL(k_vitq, dim3((unsigned)(waves + VQ_REM_MAX)), dim3(64), 0, st, v, (const unsigned long long *)bits, a);
+        JSDR_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_fec_rs, dim3(nmax), dim3(64), 0, st, a, (const unsigned char *)a.vit, (const unsigned long long *)bits, v.quad_cap);
+        JSDR_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_fec_fin, dim3((unsigned)((a.nstreams + 3) / 4)), dim3(256), 0, st, a);
+        JSDR_LAUNCH_CHECK();
+        return JSDR_OK;
+    }
     hipLaunchKernelGGL(k_fec_bpsk, dim3((unsigned)a.nstreams, (unsigned)a.max_trig), dim3(64), 0, st, a);
     JSDR_LAUNCH_CHECK();
     if (!a.fuse) {
