@@ -1773,6 +1773,9 @@ __global__ __launch_bounds__(64) void k_tail8(TailArgs a)
     // with the masks under a branch -- or two sample buffers picked by a branch -- the compiler reconciles the register
     // assignment of the requests in flight where the paths meet, with copies behind an s_waitcnt vmcnt(0): the whole memory
     // latency per chunk (3.0 ms at 8192 streams where the reads alone take 2.2).
+    // (the state is due HERE, before the first requests go out: a loop-carried value that is still on its way at the loop's
+    //  entry makes the compiler wait for it -- and for everything requested before it -- in EVERY iteration)
+    asm volatile("" : "+v"(e), "+v"(eo), "+v"(lastI), "+v"(lastQ), "+v"(pk), "+v"(nw));
     double2 F[CH];
     if (nds > 0) {
         const double2 *p0 = ys + (rel0 + c);
@@ -1791,6 +1794,8 @@ __global__ __launch_bounds__(64) void k_tail8(TailArgs a)
             const double2 f = F[p];
             const double en = (f.x * f.x) + (f.y * f.y);  // :534
             if (mine) FQL[s8][p] = f;
+            double x1 = en * S1, x2 = en * S2;
+            asm volatile("" : "+v"(x1), "+v"(x2));  // (due HERE: nothing of the sample may be needed below the request)
             // (the sample's last use lies ABOVE the request that overwrites it: scheduled the other way round -- the scheduler's
             //  preference -- the new sample needs registers of its own and comes home through copies behind an s_waitcnt
             //  vmcnt(0) at the loop's back edge: the whole memory latency per chunk)
@@ -1799,8 +1804,8 @@ __global__ __launch_bounds__(64) void k_tail8(TailArgs a)
             F[p] = pn[8 * p];
 #endif
             __builtin_amdgcn_sched_barrier(0);
-            const double ne = (e * K1) + (en * S1);       // :535
-            const double no = (eo_l * K2) + (en * S2);    // :538, were this lane's position the peak
+            const double ne = (e * K1) + x1;       // :535
+            const double no = (eo_l * K2) + x2;    // :538, were this lane's position the peak
             const bool inr = (unsigned)(rel0 + 8 * p + c) < (unsigned)nds;
             e = inr ? ne : e;
             eo_l = inr ? no : eo_l;
