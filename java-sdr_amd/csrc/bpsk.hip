@@ -2998,7 +2998,9 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
         }
         else if (h->do_fft && fresh && nds > 0) {
             // FFT-acquire mode: the VCO factors of the call's outputs (the only table its front end reads) behind the frame
-            const size_t ov = (total + 63) & ~(size_t)63, vb = sizeof(double2) * (size_t)nds;
+            // (at a FIXED offset behind the largest frame form -- a float frame: parked behind the int16 frame, the factors of
+            //  a cached schedule were overwritten by the next float frame that failed the short-grid check, and read as they were)
+            const size_t ov = (sizeof(float) * 2 * (size_t)h->nsf + 63) & ~(size_t)63, vb = sizeof(double2) * (size_t)nds;
             if (ov + vb <= h->pin_bytes && ov + vb <= h->stage_raw.n * sizeof(int)) {
                 double2 *dst = reinterpret_cast<double2 *>(h->pin + ov);
                 for (long long j = 0; j < nds; j++)
@@ -3603,7 +3605,7 @@ int jsdr_bpsk_receive_i16(jsdr_bpsk *h, const int16_t *raw_host, int ic, int qc)
         rc = bpsk_run(h, reinterpret_cast<const int16_t *>(h->stage_raw.p), nullptr, 2LL * h->nsf, h->nsf, ic, qc, 0);
     h->rx_frame_bytes = 0;
     if (rc == JSDR_OK) rc = publish_snapshot(h);  // synchronises: the arena is free again
-    else (void)hipDeviceSynchronize();            // (a failed call: nothing may still be reading the arena)
+    if (rc != JSDR_OK) (void)hipDeviceSynchronize();  // (a failed call, wherever it failed: nothing may still be reading the arena)
     h->pin_call = false;
     return rc;
 }
@@ -3632,7 +3634,11 @@ int jsdr_bpsk_receive_f32(jsdr_bpsk *h, const float *iq_host)
         for (size_t i = 0; i < nfl; i++) {
             const float f = iq_host[i];
             float v = f * 32767.0f;
-            v = v > 32767.0f ? 32767.0f : (v < -32768.0f ? -32768.0f : v);  // (also sends NaN to a value that fails the check)
+            if (!(v == v)) {  // NaN: not the conversion of any short (and the casts below are undefined for it)
+                bad = 1;
+                v = 0.0f;
+            }
+            v = v > 32767.0f ? 32767.0f : (v < -32768.0f ? -32768.0f : v);
             const int sv = (int)__builtin_rintf(v);
             const float back = (float)sv / 32767.0f;
             unsigned bf, bb;  // compared as bit patterns: -0.0f is NOT the conversion of any short, and stays a float
@@ -3654,7 +3660,7 @@ int jsdr_bpsk_receive_f32(jsdr_bpsk *h, const float *iq_host)
         if (rc == JSDR_OK) rc = bpsk_run(h, nullptr, reinterpret_cast<const float *>(h->stage_raw.p), 2LL * h->nsf, h->nsf, 0, 0, 0);
     }
     if (rc == JSDR_OK) rc = publish_snapshot(h);
-    else (void)hipDeviceSynchronize();
+    if (rc != JSDR_OK) (void)hipDeviceSynchronize();
     h->pin_call = false;
     return rc;
 }

@@ -87,6 +87,16 @@ struct PinnedStage {
     }
 };
 
+// Once a receive() has queued an asynchronous copy from / to its pinned stage, EVERY way out waits for the device: the next
+// call memcpy's into the same stage.  Disarmed on the path that has synchronised itself.
+struct SyncOnExit {
+    bool armed = true;
+    ~SyncOnExit()
+    {
+        if (armed) (void)hipDeviceSynchronize();
+    }
+};
+
 // ---- int16 -> float, JavaAudio.java:281-288:  (float)s / (float)Short.MAX_VALUE -----------------
 // IEEE-correct float division costs ~10 VALU ops (v_div_scale/fmas/fixup).  For the 65536 possible
 // dividends and the constant divisor 32767 the quotient is q = fma(a, rh, a*rl) with rh = RN(1/d) and

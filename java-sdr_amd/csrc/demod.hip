@@ -886,14 +886,14 @@ int jsdr_demod_receive_f32(jsdr_demod *h, const float *buf_host, int16_t *audio_
     }
     if (h->pin.p) {
         memcpy(h->pin.p, buf_host, in_bytes);
+        SyncOnExit guard;  // (an error exit below must not leave the device reading or writing the stage)
         JSDR_HIP_TRY(hipMemcpyAsync(h->stage_in.p, h->pin.p, in_bytes, hipMemcpyHostToDevice, 0));
         if (demod_run<true>(h, nullptr, h->stage_in.p, 2 * (int64_t)h->n, h->n, 0, 0, reinterpret_cast<int16_t *>(h->stage_out.p),
-                            2 * (int64_t)h->n, 0) != JSDR_OK) {
-            (void)hipDeviceSynchronize();
+                            2 * (int64_t)h->n, 0) != JSDR_OK)
             return JSDR_ERR;
-        }
         JSDR_HIP_TRY(hipMemcpyAsync(h->pin.p + in_bytes, h->stage_out.p, out_bytes, hipMemcpyDeviceToHost, 0));
         JSDR_HIP_TRY(hipStreamSynchronize(0));
+        guard.armed = false;
         memcpy(audio_host, h->pin.p + in_bytes, out_bytes);
         return JSDR_OK;
     }

@@ -541,13 +541,12 @@ static int fft_receive(jsdr_fft *h, const void *in_host, size_t in_bytes, int in
     const size_t out_bytes = sizeof(float) * ((size_t)h->n + 2), in_room = (size_t)h->n * 8;
     if (h->pin.p && h->pin.bytes >= in_room + out_bytes) {
         memcpy(h->pin.p, in_host, in_bytes);
+        SyncOnExit guard;  // (an error exit below must not leave the device reading or writing the stage)
         JSDR_HIP_TRY(hipMemcpyAsync(h->in_stage.p, h->pin.p, in_bytes, hipMemcpyHostToDevice, 0));
-        if (fft_run(h, h->in_stage.p, in_kind, OUT_PSD, 1, ic, qc, h->out_stage.p, 0) != JSDR_OK) {
-            (void)hipDeviceSynchronize();
-            return JSDR_ERR;
-        }
+        if (fft_run(h, h->in_stage.p, in_kind, OUT_PSD, 1, ic, qc, h->out_stage.p, 0) != JSDR_OK) return JSDR_ERR;
         JSDR_HIP_TRY(hipMemcpyAsync(h->pin.p + in_room, h->out_stage.p, out_bytes, hipMemcpyDeviceToHost, 0));
         JSDR_HIP_TRY(hipStreamSynchronize(0));
+        guard.armed = false;
         memcpy(psd_host, h->pin.p + in_room, out_bytes);
         return JSDR_OK;
     }

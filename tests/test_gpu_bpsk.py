@@ -559,3 +559,34 @@ def test_bpsk_switching_to_int16_after_arbitrary_floats_is_refused():
     d.receive(np.full(4096, 0.123456789, np.float32))  # not a (float)s/32767f value
     with pytest.raises(J.JsdrError):
         d.batch_i16(J.DeviceBuffer.from_host(np.zeros(4096, np.int16)), 4096, 2048)
+
+
+def test_bpsk_fft_mode_one_stream_fed_int16_and_arbitrary_float_frames_in_turn():
+    """in FFT-acquire mode a 1-stream handle parks the schedule's VCO factors behind the frame in its staging
+    buffer and re-uses them while the schedule cache hits.  A float frame that is NOT a (float)s/32767f image takes the float
+    path and is twice as long as the int16 frame the factors were parked behind: they must survive it.  Frames of both
+    forms in turn (either order), against one oracle fed the same floats."""
+    nsf, nfr = 9600, 8  # the application's default frame: 960 outputs a frame, so EVERY frame hits the schedule cache
+    rng = np.random.default_rng(20260104)
+    iq = O.make_dbpsk_stream(77, 0, nsf * nfr, noise_sigma=700.0)[0]
+    exact = O.convert_i16(iq)  # what JavaAudio delivers
+    for first_form in ("i", "f"):
+        d = J.Bpsk(nstreams=1, do_fft=1, blen=4 * nsf)
+        o = O.Bpsk(do_fft=1, blen=4 * nsf, trace=nsf * nfr // 10 + 8)
+        bits, tr = [], []
+        for k in range(nfr):
+            fr = exact[2 * nsf * k:2 * nsf * (k + 1)].copy()
+            as_float = ((k // 2) % 2 == 0) == (first_form == "f")
+            if as_float:  # off the short grid (and a silent frame now and then: all zeros pass the grid check)
+                fr = (fr * np.float32(0.999) + rng.normal(0, 1e-6, fr.size).astype(np.float32)).astype(np.float32) if k % 5 else np.zeros_like(fr)
+                d.receive(fr)
+            else:
+                d.receive_raw(iq[2 * nsf * k:2 * nsf * (k + 1)])
+            o.receive(fr)
+            bits.append(d.bits().copy())
+            tr.append(d.trace().copy())
+        assert np.array_equal(np.concatenate(tr), o.trace()), first_form
+        assert np.array_equal(np.concatenate(bits), o.bits()), first_form
+        same_counters(d.counters(), o.counters())
+        same_state(d.state(), o.state())
+        assert d.counters()["centreBin"] == o.counters()["centreBin"]
