@@ -41,7 +41,7 @@ BYTES_PER_SAMPLE = {"fft": 4.0 + 4.0 * 2050.0 / 2048.0, "bpsk": 4.0125, "pipelin
                     "demod": 8.0, "fir": 4.0 + 1.6}  # fir (config 3): one double2 per 10 input samples  # demod.java: 4 B read, one (L,R) int16 pair written per sample
 DEMOD_MODES = {"raw": 1, "am": 2, "nfm": 3, "wfm": 4}
 N_FFT = 2048
-RATE = 96000
+RATE = 96000  # --rate overrides it (192000 = the FUNcube Dongle Pro+ default, JavaAudio.java:59, with frames of 19200)
 SEED = 20020109
 SEED_TONES = 20020107
 # measured FP64 issue rate of the box, separately rounded v_mul_f64 + v_add_f64 (tools/microbench_fp64.hip,
@@ -87,6 +87,9 @@ def parse():
                     help="--workload fir: 27 = dsFilter (FUNcubeBPSKDemod.java:27-55), 65 = dmFilter (:58-77), 21 = fir.java weights(500,1500)")
     ap.add_argument("--fir-decim", type=int, default=10, choices=[1, 10, 20], help="--workload fir: decimation")
     ap.add_argument("--fft-acquire", action="store_true", help="demodulator in FFT-acquire mode (bpsk-dofft=1) instead of tune mode")
+    ap.add_argument("--rate", type=int, default=96000, choices=[44100, 48000, 96000, 192000],
+                    help="--workload bpsk: sample rate of the synthetic streams and of the demodulator (audio-rate); 192000 with "
+                         "--bpsk-frame 19200 --fft-acquire is the FUNcube Dongle Pro+ default configuration")
     return ap.parse_args()
 
 
@@ -145,6 +148,46 @@ def validate_fft(J, d_iq, d_psd, nframes, rate):
         if kr != k and abs(float(ref[kr]) - float(ref[k])) > 1e-3:
             return False, {"frames_checked": len(idx), "first_bad_frame": f, "why": "maximum bin differs from the oracle's"}
     return worst <= 1e-5, {"frames_checked": len(idx), "worst_amplitude_error_over_frame_peak": worst}
+
+
+def validate_acquire(J, dem, d_iq, S, L, ncalls, frame, rate, prefer=()):
+    """FFT-acquire mode (FUNcubeBPSKDemod.java:406-464) cannot be checked by payload at every frame size -- the block-wise FFT
+    filter puts a seam into the signal every frame and the reference itself loses frames.  So sampled streams of the
+    measured handle are compared with the oracle replaying the SAME calls (ncalls x the step's input): every counter incl.
+    centreBin, every state double, the last call's bits, the last call's FECDecode results.  `prefer`: streams to include
+    (those the payload check found without a decoded frame: the oracle must lose them too).  Outside the timed region."""
+    import threading
+    import oracle_lib as O
+    idx = sorted(set(list(prefer)[:3]) | set(int(v) for v in np.linspace(0, S - 1, 6)))
+    res = {}
+
+    def one(st):
+        raw = d_iq.to_host(np.int16, 2 * L, offset_bytes=st * L * 4)
+        o = O.Bpsk(rate=rate, blen=4 * frame, tuning=12000, do_fft=1)
+        nb0 = nf0 = 0
+        for k in range(ncalls):
+            if k == ncalls - 1:
+                nb0, nf0 = len(o.bits()), len(o.fec_results())
+            o.receive_i16(raw)
+        res[st] = (o.counters(), o.state(), o.bits()[nb0:], o.fec_results()[nf0:])
+
+    th = [threading.Thread(target=one, args=(st,)) for st in idx]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    bad = []
+    lost = 0
+    for st in idx:
+        oc, os_, obits, ofec = res[st]
+        gc, gs, gbits, gfec = dem.counters(st), dem.state(st), dem.bits(st), dem.fec_results(st)
+        same = all(gc[k] == oc[k] for k in oc) and gs.tobytes() == os_.tobytes() and np.array_equal(gbits, obits) and \
+            len(gfec) == len(ofec) and all(x[0] == y[0] and np.array_equal(x[2], y[2]) for x, y in zip(gfec, ofec))
+        if not same:
+            bad.append(st)
+        lost += 1 if oc["cntDec"] == 0 else 0
+    return not bad, {"streams_compared_with_the_oracle": len(idx), "calls_replayed": ncalls, "streams_that_differ": bad,
+                     "of_them_without_a_decoded_frame_in_the_oracle_too": lost}
 
 
 def validate_fir(J, d_iq, d_fir, S, L, taps, decim, scale):
@@ -275,14 +318,14 @@ def variant_text(a):
     return f"exact-order FP64 (bit-exact bits/bytes and doubles), {front}"
 
 
-def stream_text(a, psd_own_stream):
+def stream_text(a, psd_own_stream, dem):
+    """what ran where; the side-stream part is the handle's own answer (jsdr_bpsk_side_stream), not a copy of its rule"""
+    side = "tail/sync/FEC on the handle's side stream" if (dem is not None and dem.side_stream()) else "tail/sync/FEC on the same stream"
     if a.workload == "pipeline":
-        return "PSD on its own HIP stream beside the demodulator; tail/sync/FEC on the handle's side stream" if psd_own_stream \
-            else "PSD then demodulator on one stream; tail/sync/FEC on the handle's side stream"
-    if a.workload == "bpsk" and a.fft_acquire and (a.bpsk_frame & (a.bpsk_frame - 1)) != 0 and os.environ.get("JSDR_NO_OVERLAP", "1") != "0":
-        # a mixed-radix frame's front end fills a CU's LDS with one workgroup: the library keeps tail/sync/FEC on the caller's stream
-        return "front end, matched filter, tail/sync/FEC on one stream"
-    return "tail/sync/FEC on the handle's side stream" if a.workload == "bpsk" else "one stream"
+        return ("PSD on its own HIP stream beside the demodulator; " if psd_own_stream else "PSD then demodulator on one stream; ") + side
+    if a.workload == "bpsk":
+        return ("front end, matched filter on the caller's stream; " if a.fft_acquire else "") + side
+    return "one stream"
 
 
 def backend_text():
@@ -296,22 +339,29 @@ def launch_ranks(N):
     WORLD_SIZE / MASTER_* as torch.distributed.run would set them), BEFORE anything in this process has touched the GPU
     (no exec from a process that has).  Rank 0's stdout (the JSON line) is relayed; every other rank's goes to stderr.
     Returns the exit code: 0 only when every rank ended with 0."""
-    import socket
     import subprocess
+    import tempfile
 
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
+    # rendezvous through a file store (JSDR_BENCH_RDZV_FILE -> init_method=file://...): no port to pick, so none that
+    # another process can take between picking and binding (ADVICE r3)
+    fd, rdzv = tempfile.mkstemp(prefix="jsdr_bench_rdzv_")
+    os.close(fd)
+    os.unlink(rdzv)  # the FileStore creates it
     procs = []
     for r in range(N):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(N), LOCAL_WORLD_SIZE=str(N),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL needs it on this driver
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT="0", JSDR_BENCH_RDZV_FILE=rdzv)
+        # dmabuf IPC: this image's host driver supports no other kind, and without the setting RCCL's buffer exchange between
+        # the ranks' processes fails with `hipIpcGetMemHandle: invalid argument` (the environment's note on multi-process
+        # GPU work; the image exports it already -- setdefault only covers a caller that cleaned the environment)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else sys.stderr))
     rc = 0
     pending = dict(enumerate(procs))
+    limit = float(os.environ.get("JSDR_BENCH_LAUNCH_TIMEOUT", "1500"))  # a rank stuck in a collective must not hang the driver
+    t_start = time.monotonic()
+    t_term = None  # when the survivors were told to end
     while pending:
         for r, p in list(pending.items()):
             code = p.poll()
@@ -321,14 +371,36 @@ def launch_ranks(N):
             if code != 0:
                 print(f"[bench] rank {r} exited with {code}", file=sys.stderr)
                 rc = rc or (code if code > 0 else 1)
-                for q in pending.values():  # a rank is gone: the others would wait in a collective for ever
-                    q.terminate()
+                if t_term is None:
+                    for q in pending.values():  # a rank is gone: the others would wait in a collective for ever
+                        q.terminate()
+                    t_term = time.monotonic()
+        now = time.monotonic()
+        if pending and t_term is None and now - t_start > limit:
+            print(f"[bench] ranks {sorted(pending)} still running after {limit:.0f} s: ending the run", file=sys.stderr)
+            rc = rc or 124
+            for q in pending.values():
+                q.terminate()
+            t_term = now
+        if pending and t_term is not None and now - t_term > 10.0:  # a rank that ignores SIGTERM
+            for q in pending.values():
+                q.kill()
+            t_term = now + 1e9
         time.sleep(0.05)
+    try:
+        os.unlink(rdzv)
+    except OSError:
+        pass
     return rc
 
 
 def main():
+    global RATE
     a = parse()
+    if a.rate != RATE:
+        if a.workload != "bpsk":
+            raise SystemExit("--rate needs --workload bpsk (the pipeline line is BASELINE's 96 kHz configuration)")
+        RATE = a.rate
     knobs = sorted(k for k in os.environ if k.startswith("JSDR_EXPERIMENT_"))
     if knobs:
         raise SystemExit(f"bench.py: {', '.join(knobs)} set -- experiment knobs make the product skip work; refusing to measure")
@@ -353,10 +425,12 @@ def main():
         backend = os.environ.get("JSDR_BENCH_BACKEND", "nccl")
         dev_index = 0 if same_dev else local_rank
         torch.cuda.set_device(dev_index)
+        rdzv = os.environ.get("JSDR_BENCH_RDZV_FILE")  # set by launch_ranks(); under torch.distributed.run: env://
+        kw = dict(init_method="file://" + rdzv, rank=rank, world_size=world) if rdzv else {}
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index), **kw)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, **kw)
     import java_sdr_amd as J
     from java_sdr_amd import sharding as SH
 
@@ -479,7 +553,11 @@ def main():
     dt = time.perf_counter() - t0
     if dem is not None:
         dem.profile_enable(False)
+    per_rank_ms = None
     if N > 1:
+        per_rank = [None] * N
+        dist.all_gather_object(per_rank, dt)
+        per_rank_ms = [round(v / a.steps * 1e3, 4) for v in per_rank]
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -563,7 +641,8 @@ def main():
     #  tests/test_gpu_bpsk.py -- rarely brings a 5200-bit FEC block through; parity for that mode is the tests')
     cert = None
     vstats = None
-    if dem is not None and not a.no_validate and not (a.fft_acquire and a.bpsk_frame != 9600):
+    none_streams = []
+    if dem is not None and not a.no_validate and not (a.fft_acquire and (a.bpsk_frame != 9600 or RATE != 96000)):
         payloads = pay.to_host(np.uint8).reshape(S, nfr, 256)
         info = dem.slot_info()
         vslots = J.DeviceBuffer(S * info["slot_bytes"])
@@ -578,6 +657,8 @@ def main():
             n_good += len(good)
             n_failed += len(fr) - len(good)
             n_none += 0 if good else 1
+            if not good and len(none_streams) < 8:
+                none_streams.append(s)
             n_wrong += sum(0 if any(np.array_equal(r[2], payloads[s, f]) for f in range(nfr)) else 1 for r in good)
         # tune mode: every stream must bring a frame through.  FFT-acquire mode puts a seam into the signal every frame
         # (FUNcubeBPSKDemod.java:458-463) and loses some frames by design -- the oracle does, bit for bit (tests); there only a
@@ -592,9 +673,18 @@ def main():
         if a.fft_acquire and n_good < S // 2:
             # FFT-acquire mode may lose frames by design, but a run in which (almost) nothing decodes has checked nothing
             validated = None if n_good == 0 else False
-    elif fft is not None and dem is None and not a.no_validate:
-        validated, vstats = validate_fft(J, d_iq, d_psd, nframes, RATE)
-    elif fir_taps is not None and not a.no_validate:
+    if dem is not None and a.fft_acquire and not a.no_validate:
+        # any frame size: sampled streams against the oracle replaying the same calls (the payload check above only exists
+        # for the 9600-sample frame, and passes over streams without a decoded frame: here the oracle must lose those too)
+        ok_o, st_o = validate_acquire(J, dem, d_iq, S, L, a.warmup + a.steps, a.bpsk_frame, RATE, prefer=none_streams)
+        vstats = dict(vstats or {}, **st_o)
+        validated = bool(ok_o) if validated is None else bool(validated and ok_o)
+    if fft is not None and not a.no_validate:
+        # the PSD the step wrote (also on the pipeline line: it used to go unread there)
+        ok_f, st_f = validate_fft(J, d_iq, d_psd, nframes, RATE)
+        vstats = dict(vstats or {}, psd=st_f)
+        validated = bool(ok_f) if dem is None else bool(validated and ok_f)
+    if fir_taps is not None and not a.no_validate:
         validated, vstats = validate_fir(J, d_iq, d_fir, S, L, fir_taps, a.fir_decim, 0.9 * 32768.0)
     if dem is not None and a.variant == "fast":
         cert = dem.cert_stats()
@@ -633,10 +723,16 @@ def main():
                 x[0] == y[0] and x[1] == y[1] and np.array_equal(x[2], y[2]) for x, y in zip(u["fec"], fr))
         flags = [None] * N
         dist.all_gather_object(flags, bool(all(seg_ok) and get_ok))
+        # ... and every rank's own verdict on ITS streams (payloads / oracle): rank 0's line vouches for all of them
+        rank_valid = [None] * N
+        dist.all_gather_object(rank_valid, validated)
         gather_check = {"every_rank_segment_equals_that_ranks_slots": bool(all(seg_ok)),
-                        "sampled_slots_equal_getters": bool(get_ok), "all_ranks_ok": bool(all(flags))}
-        if not all(flags):
+                        "sampled_slots_equal_getters": bool(get_ok), "all_ranks_ok": bool(all(flags)),
+                        "validated_per_rank": rank_valid}
+        if not all(flags) or any(v is False for v in rank_valid):
             validated = False
+        elif validated is not None and any(v is None for v in rank_valid):
+            validated = None
 
     if rank == 0:
         total = float(N) * S * L * a.steps
@@ -655,7 +751,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": workload_text(a), "streams_per_gpu": S, "total_streams": N * S, "samples_per_stream": L,
                        "rate_hz": RATE, "frame": a.bpsk_frame if a.workload == "bpsk" else N_FFT, "input_bytes_per_gpu": S * L * 4,
-                       "variant": variant_text(a), "streams": stream_text(a, psd_stream is not None),
+                       "variant": variant_text(a), "streams": stream_text(a, psd_stream is not None, dem),
                        "parallelism": f"{N * S} streams sharded contiguously over {N} GPU(s)" +
                                       (f", one all-gather of result slots per step ({backend_text()})" if N > 1 else "")},
             "roofline": roofline,
@@ -666,6 +762,8 @@ def main():
             out["validation"] = vstats
         if gather_check is not None:
             out["gather_check"] = gather_check
+        if per_rank_ms is not None:
+            out["ms_per_step_per_rank"] = per_rank_ms
         if cert is not None:
             out["certification"] = cert
         if N == 1 and not a.no_cpu_baseline:

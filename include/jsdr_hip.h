@@ -205,6 +205,10 @@ int jsdr_bpsk_snapshot_read(jsdr_bpsk *h, jsdr_bpsk_snapshot *out);
 int jsdr_bpsk_profile_enable(jsdr_bpsk *h, int on);
 int jsdr_bpsk_profile_count(void);                 /* number of kernels in the pipeline */
 const char *jsdr_bpsk_front_kernel(jsdr_bpsk *h);  /* name of the front-end kernel the last call launched */
+/* 1 when the handle runs its tail / sync / FEC on a side stream of its own (batch handles), 0 when on the caller's stream
+ * (1-stream handles; FFT-acquire with a mixed-radix frame; JSDR_NO_OVERLAP): *on receives it.  What a benchmark reports
+ * instead of re-deriving the library's rule.                                                                        */
+int jsdr_bpsk_side_stream(jsdr_bpsk *h, int *on);
 /* the input-independent tuner / VCO schedules built so far: on the calling thread / taken from the look-ahead worker
  * (periodic configurations reuse one schedule and build none after the first calls) */
 int jsdr_bpsk_schedule_stats(jsdr_bpsk *h, int64_t *computed_inline, int64_t *prefetched);

@@ -448,6 +448,11 @@ class Bpsk:
     def front_kernel_name(self):
         return lib().jsdr_bpsk_front_kernel(self.h).decode()
 
+    def side_stream(self):
+        on = C.c_int()
+        _check(lib().jsdr_bpsk_side_stream(self.h, C.byref(on)), "jsdr_bpsk_side_stream")
+        return bool(on.value)
+
     def receive(self, buf):
         buf = np.ascontiguousarray(buf, np.float32)
         assert buf.size == 2 * self.samples

@@ -3951,6 +3951,13 @@ int jsdr_bpsk_profile_count(void) { return PK_COUNT; }
 
 const char *jsdr_bpsk_front_kernel(jsdr_bpsk *h) { return h ? h->front_name : ""; }
 
+int jsdr_bpsk_side_stream(jsdr_bpsk *h, int *on)
+{
+    JSDR_REQUIRE(h && on, "jsdr_bpsk_side_stream: null argument");
+    *on = h->overlap ? 1 : 0;
+    return JSDR_OK;
+}
+
 // fast variant: decisions redone in exact order (all streams, since creation), streams that ended up uncertified, the
 // error bound of (fi,fq) the margins are built on
 int jsdr_bpsk_cert_stats(jsdr_bpsk *h, int64_t *redone, int64_t *uncertified_streams, double *ey)
