@@ -2,11 +2,15 @@
 // jsdr.java:477 passes, same configuration keys (:27-32), same filterMove rule (:300-312) and publications; the
 // demodulated frame lands in a little-endian byte array of (L,R) int16 pairs exactly as `bbf` holds it (:469-481) and is
 // written to the SourceDataLine the caller opened (demod.java's own output thread and device dialog stay in demod.java).
+// It is a tab like the class it replaces (jsdr.java:477: tabs.add("Demod", new demod(...)) takes a Swing component): it
+// extends IUIComponent as demod.java does; paintComponent shows mode, band edges and the frame's max / avg (:465-467).
 package com.ashbysoft.java_sdr;
 
+import java.awt.Color;
+import java.awt.Graphics;
 import javax.sound.sampled.SourceDataLine;
 
-public class HipDemod implements IAudioHandler, IPublishListener {
+public class HipDemod extends IUIComponent implements IAudioHandler, IPublishListener {
     private static final String CFG_DEMOD_FLOW = "demod-filter-low";
     private static final String CFG_DEMOD_FHGH = "demod-filter-high";
     private static final String CFG_DEMOD_MODE = "demod-mode";
@@ -19,10 +23,11 @@ public class HipDemod implements IAudioHandler, IPublishListener {
     private final ILogger logger;
     private IAudio audio;
     private long handle;
-    private int mode, flo, fhi;
-    private boolean dofir, dodwn, doagc;
+    private volatile int mode, flo, fhi;          // (volatile: the painter reads them without the receive() monitor)
+    private volatile boolean dofir, dodwn, doagc;
     private byte[] bbf;
     private final float[] stats = new float[2];
+    private final float[] shownStats = new float[2];  // max, avg of the last frame, for the painter (its own lock)
     private volatile SourceDataLine sdl;
 
     public HipDemod(IConfig cfg, IPublish pub, ILogger log, IUIHost hst, IAudio aud) {
@@ -96,9 +101,35 @@ public class HipDemod implements IAudioHandler, IPublishListener {
         if (MODE_OFF == mode)
             return;
         HipNative.demodReceive(handle, buf, bbf);
+        HipNative.demodFrameStats(handle, stats);
+        synchronized (shownStats) {
+            shownStats[0] = stats[0];
+            shownStats[1] = stats[1];
+        }
         SourceDataLine line = sdl;
         if (line != null)
             line.write(bbf, 0, bbf.length);
+        repaint();
+    }
+
+    public void hotKey(char c) {
+    }
+
+    /** mode, band edges, and max / avg of the last frame (demod.java:465-467); never takes the receive() monitor */
+    public void paintComponent(Graphics g) {
+        if (!isVisible())
+            return;
+        float mx, av;
+        synchronized (shownStats) {
+            mx = shownStats[0];
+            av = shownStats[1];
+        }
+        g.setColor(Color.BLACK);
+        g.fillRect(0, 0, getWidth(), getHeight());
+        g.setColor(Color.GREEN);
+        String[] names = {"off", "raw", "am", "nfm", "wfm"};
+        g.drawString("mode=" + names[mode < 0 || mode > 4 ? 0 : mode] + " fir=" + dofir + " agc=" + doagc + " band=" + flo + ".." + fhi + " Hz", 10, 20);
+        g.drawString("max=" + mx + " avg=" + av, 10, 36);
     }
 
     /** the frame's audio as demod.java's bbf holds it */

@@ -1,9 +1,15 @@
 // HipFUNcubeBPSKDemod.java -- FUNcubeBPSKDemod's receive chain (FUNcubeBPSKDemod.java:357-595) and FECDecoder on the
 // MI355X.  Constructor as jsdr.java:479-483 builds the reference class; the same three configuration keys
 // (:102-104,195-200); the same publications (:377-378,455-456); the painted fields (:220-228,331-337) through getters.
+// It is a tab like the class it replaces (jsdr.java:479-483: tabs.add(nm, new FUNcubeBPSKDemod(...)) takes a Swing
+// component): it extends IUIComponent as FUNcubeBPSKDemod.java:24 does, with hotKey and a paintComponent that draws the
+// text statistics of :220-228 and the decoded frame of :331-337 from the lock-free snapshot.
 package com.ashbysoft.java_sdr;
 
-public class HipFUNcubeBPSKDemod implements IAudioHandler, IRawHandler, IPublishListener {
+import java.awt.Color;
+import java.awt.Graphics;
+
+public class HipFUNcubeBPSKDemod extends IUIComponent implements IAudioHandler, IRawHandler, IPublishListener {
     private static final String CFG_TUNING = "bpsk-tuning";
     private static final String CFG_DOFFT = "bpsk-dofft";
     private static final String CFG_UPPER = "bpsk-upper";
@@ -96,6 +102,38 @@ public class HipFUNcubeBPSKDemod implements IAudioHandler, IRawHandler, IPublish
         } else {      // :377-378
             publish.setPublish(name + "-bpsk-centre", -1);
             publish.setPublish(name + "-bpsk-tune", tuning);
+        }
+        repaint();
+    }
+
+    public void hotKey(char c) {
+    }
+
+    /** the statistics of FUNcubeBPSKDemod.java:220-228 and, after a successful decode, the frame's bytes as :331-337
+     *  prints them.  From the getters: takes resultLock only, never the receive() monitor. */
+    public void paintComponent(Graphics g) {
+        if (!isVisible())
+            return;
+        int[] c = getCounters();
+        double[] st = getState();
+        byte[] dec = getDecoded();
+        g.setColor(Color.BLACK);
+        g.fillRect(0, 0, getWidth(), getHeight());
+        g.setColor(Color.GREEN);
+        g.drawString("decodeOK=" + (c[8] != 0) + " dmErrBits=" + c[5] + " raw=" + c[0] + " ds=" + c[1] + " bit=" + c[2]
+                     + " fec=" + c[3] + " dec=" + c[4], 10, 20);
+        if (doFFT)
+            g.drawString("centreBin=" + c[9], getWidth() - 250, 20);
+        else
+            g.drawString("tuning=" + tuning, getWidth() - 250, 20);
+        g.drawString("e1=" + st[4], getWidth() - 250, 36);
+        g.drawString("e2=" + st[5], getWidth() - 250, 52);
+        g.drawString("eO=" + st[3], getWidth() - 250, 68);
+        g.drawString("com=" + c[7] + " co=" + c[6], getWidth() - 250, 84);
+        if (c[8] != 0) {
+            for (int n = 0; n < dec.length; n += 16)
+                for (int l = 0; l < 16 && n + l < dec.length; l++)
+                    g.drawString(String.format("%02x ", dec[n + l] & 0xff), 10 + (20 * l), 40 + n);
         }
     }
 

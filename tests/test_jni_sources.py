@@ -5,8 +5,9 @@ against a JDK here (none in the image).  What can be checked without one:
   * every native method the Hip* plugin classes call exists;
   * every jsdr_* function the shim calls is declared in include/jsdr_hip.h and exported by libjsdr_hip.so;
   * the shim type-checks (gcc -fsyntax-only -Wall -Werror) against prototype-only JNI declarations;
-  * the plugin classes implement the reference's handler interfaces and keep its constructor shapes
-    (IAudioHandler.java:3-6, IRawHandler.java:3-6, jsdr.java:475-483)."""
+  * the plugin classes implement the reference's handler interfaces, keep its constructor shapes and ARE what jsdr hosts:
+    IUIComponent subclasses with hotKey and paintComponent (IAudioHandler.java:3-6, IRawHandler.java:3-6,
+    IUIComponent.java:5-7, jsdr.java:475-483)."""
 import os
 import re
 import subprocess
@@ -86,6 +87,12 @@ def test_plugin_classes_keep_the_reference_surface():
     pha = strip_comments(open(os.path.join(JDIR, "HipPhase.java")).read())
     for src in (fft, bpsk, dem, pha):
         assert "package com.ashbysoft.java_sdr;" in src
+        # jsdr.java:475-483 hosts its plugins with tabs.add(name, new X(...)): a Swing component, i.e. the reference's
+        # IUIComponent (IUIComponent.java:5-7: abstract class extends JPanel, abstract hotKey(char))
+        assert re.search(r"public class Hip\w+ extends IUIComponent implements\s+IAudioHandler", src)
+        assert "public void hotKey(char c)" in src
+        assert "public void paintComponent(Graphics g)" in src and "import java.awt.Graphics;" in src
+        assert "repaint();" in src
         assert re.search(r"implements\s+IAudioHandler", src)
         assert "public synchronized void receive(float[] buf)" in src
         assert '"audio-change".equals(key)' in src
@@ -125,6 +132,18 @@ def test_java_handles_are_zeroed_before_a_create_that_may_throw():
         setup = setup[:setup.index("\n    }\n")]
         assert setup.index("handle = 0;") < setup.index("HipNative.%sDestroy(old)" % kind) < setup.index("HipNative.%sCreate(" % kind), fn
         assert "HipNative.%sDestroy(handle)" % kind not in src, fn
+
+
+def test_painting_never_takes_the_receive_monitor_except_where_the_reference_does():
+    """paintComponent runs on the Swing EDT while the audio thread holds the plugin's monitor for the whole of receive()
+    (SURVEY 8b): fft / FUNcube / demod paint from copies under their own small locks; phase.java's own paintComponent is
+    synchronized (phase.java:42), so HipPhase's may wait for a frame as well"""
+    for fn in ("HipFft.java", "HipFUNcubeBPSKDemod.java", "HipDemod.java"):
+        src = strip_comments(open(os.path.join(JDIR, fn)).read())
+        body = src[src.index("public void paintComponent(Graphics g)"):]
+        body = body[:body.index("\n    }\n")]
+        assert "HipNative." not in body, fn            # no device call from the painter
+        assert not re.search(r"synchronized\s*\(\s*this\s*\)", body), fn
 
 
 def test_painter_getters_use_the_lock_free_snapshot():
