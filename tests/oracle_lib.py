@@ -14,6 +14,8 @@ SO = os.path.join(ODIR, "libjsdr_oracle.so")
 
 
 def build(force=False):
+    if os.environ.get("JSDR_ORACLE_SO"):  # another build of the same sources (the sanitizer build: `make -C oracle asan`)
+        return os.environ["JSDR_ORACLE_SO"]
     srcs = [os.path.join(ODIR, f) for f in os.listdir(ODIR) if f.endswith((".c", ".h"))]
     stale = force or not os.path.exists(SO) or any(os.path.getmtime(s) > os.path.getmtime(SO) for s in srcs)
     if stale:
@@ -27,8 +29,7 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        build()
-        _lib = C.CDLL(SO)
+        _lib = C.CDLL(build())
         _proto(_lib)
     return _lib
 
