@@ -115,6 +115,13 @@ int  jo_bpsk_fec_get(const jo_bpsk_t *d, int idx, int32_t *rc, int64_t *bitidx, 
 void jo_bpsk_decoded(const jo_bpsk_t *d, uint8_t out[256]);
 /* optional trace of matched-filter outputs (fi,fq) at 9600 Hz: enable before receive */
 void jo_bpsk_trace_enable(jo_bpsk_t *d, int64_t cap_pairs);
+/* instruments of doBufferFFT's two data-dependent decisions (FUNcubeBPSKDemod.java:433-447), for the robustness test:
+ * per frame {binPos, maxBin, runner-up sum, threshold avePeakPower/4*5, rule taken, centreBin after, ||x||_2, n}; and a
+ * perturbation of the forward spectrum by scale x u x log2(n) x ||x||_2 per component (an FFT's own forward error) */
+#define JO_BPSK_PROBE_N 8
+void jo_bpsk_fft_probe_enable(jo_bpsk_t *d, int64_t cap_frames);
+int64_t jo_bpsk_fft_probe(const jo_bpsk_t *d, double *out, int64_t cap_frames);
+void jo_bpsk_fft_perturb(jo_bpsk_t *d, double scale, uint64_t seed);
 int64_t jo_bpsk_trace(const jo_bpsk_t *d, double *out, int64_t cap_pairs);
 /* optional trace of down-sampler outputs (after x HOWARD_FUDGE_FACTOR)           */
 int64_t jo_bpsk_trace_ds(const jo_bpsk_t *d, double *out, int64_t cap_pairs);

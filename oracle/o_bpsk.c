@@ -150,6 +150,13 @@ struct jo_bpsk {
     int nfec, capfec;
     double *trace, *trace_ds;
     int64_t ntrace, ntrace_ds, captrace;
+    /* test instruments of doBufferFFT (never part of the arithmetic unless switched on): a per-frame record of the two
+     * data-dependent decisions and their margins, and a perturbation of the forward spectrum of the size of an FFT's own
+     * rounding error -- "how often would another correct double FFT have decided differently?" */
+    double *probe;          /* JO_BPSK_PROBE_N doubles per frame */
+    int64_t nprobe, capprobe;
+    double perturb_scale;   /* 0: off; else every bin's re, im += scale * u * log2(n) * ||x||_2 * U(-1,1) */
+    uint64_t perturb_state;
 };
 
 jo_bpsk_t *jo_bpsk_new(int rate, int blen, int size, int tuning, int do_fft, int do_up)
@@ -178,6 +185,7 @@ void jo_bpsk_free(jo_bpsk_t *d)
     free(d->fec);
     free(d->trace);
     free(d->trace_ds);
+    free(d->probe);
     free(d);
 }
 
@@ -340,7 +348,24 @@ static void doBufferFFT(jo_bpsk_t *d, const float *buf)
         fftFwd[2 * n] = (double)buf[n * 2];
         fftFwd[2 * n + 1] = (double)buf[n * 2 + 1];
     }
+    double xnorm = 0.0;  /* (instruments only) ||x||_2 of the frame */
+    if (d->probe || d->perturb_scale != 0.0) {
+        for (int n = 0; n < 2 * samples; n++) xnorm += fftFwd[n] * fftFwd[n];
+        xnorm = sqrt(xnorm);
+    }
     jo_fft_f64(fftFwd, samples, 0, 0);
+    if (d->perturb_scale != 0.0) {
+        /* a forward-error bound of a floating-point FFT: |X'_k - X_k| <= c u log2(n) ||x||_2 (Higham, ASNA 24.2); here
+         * every component moves by up to scale x that, uniformly distributed (splitmix64) */
+        const double bound = d->perturb_scale * 1.1102230246251565e-16 * log2((double)samples) * xnorm;
+        for (int n = 0; n < 2 * samples; n++) {
+            uint64_t z = (d->perturb_state += 0x9e3779b97f4a7c15ull);
+            z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+            z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+            z ^= z >> 31;
+            fftFwd[n] += bound * (((double)(z >> 11) * (1.0 / 9007199254740992.0)) * 2.0 - 1.0);
+        }
+    }
     for (int i = 0; i < samples / 2; i++)
         psd[i] = sqrt(fftFwd[2 * i] * fftFwd[2 * i] + fftFwd[2 * i + 1] * fftFwd[2 * i + 1]);
     double maxBin = 0.0;
@@ -359,11 +384,27 @@ static void doBufferFFT(jo_bpsk_t *d, const float *buf)
     if (d->centreBin < 0) d->centreBin = 0;
     if (d->centreBin > end - 1) d->centreBin = end - 1;
     d->avePeakPower = (PSD_AVERAGE_FACTOR * avePsd[d->centreBin]) + (PSD_INV_AVERAGE_FACTOR * d->avePeakPower);
-    if (maxBin > (d->avePeakPower / 4) * 5 && binPos > 0) {
+    const int took = maxBin > (d->avePeakPower / 4) * 5 && binPos > 0;
+    if (took) {
         d->aveCentreBin = (CFREQ_AVERAGE_FACTOR * (float)binPos) + (CFREQ_INV_AVERAGE_FACTOR * d->aveCentreBin);
         d->centreBin = (int)(d->aveCentreBin + 1.0F);
     }
     if (d->centreBin < 102) d->centreBin = 102;
+    if (d->probe && d->nprobe < d->capprobe) {
+        /* the runner-up of the first-maximum search: the largest sum at any OTHER position */
+        double second = -1.0;
+        for (int i = beg + 75; i < end - 75; i++)
+            if (i != binPos && avePsd[i] > second) second = avePsd[i];
+        double *r = d->probe + JO_BPSK_PROBE_N * d->nprobe++;
+        r[0] = (double)binPos;
+        r[1] = maxBin;
+        r[2] = second;
+        r[3] = (d->avePeakPower / 4) * 5;  /* the threshold maxBin was compared with (:447) */
+        r[4] = (double)took;
+        r[5] = (double)d->centreBin;
+        r[6] = xnorm;
+        r[7] = (double)samples;
+    }
     memcpy(fftRev, fftFwd + 2 * (d->centreBin - 102), sizeof(double) * 2 * 204);
     jo_fft_f64(fftRev, samples, 1, 1);
     for (int i = 0; i < samples; i++) RxDownSample(d, fftRev[2 * i], fftRev[2 * i]); /* Q dropped (:462) */
@@ -427,6 +468,28 @@ void jo_bpsk_trace_enable(jo_bpsk_t *d, int64_t cap_pairs)
     d->trace_ds = (double *)malloc(sizeof(double) * 2 * (size_t)cap_pairs);
     d->captrace = cap_pairs;
     d->ntrace = d->ntrace_ds = 0;
+}
+
+/* test instruments of doBufferFFT (see struct jo_bpsk) */
+void jo_bpsk_fft_probe_enable(jo_bpsk_t *d, int64_t cap_frames)
+{
+    free(d->probe);
+    d->probe = (double *)calloc((size_t)cap_frames * JO_BPSK_PROBE_N, sizeof(double));
+    d->capprobe = cap_frames;
+    d->nprobe = 0;
+}
+
+int64_t jo_bpsk_fft_probe(const jo_bpsk_t *d, double *out, int64_t cap_frames)
+{
+    int64_t n = d->nprobe < cap_frames ? d->nprobe : cap_frames;
+    if (out && n > 0) memcpy(out, d->probe, sizeof(double) * JO_BPSK_PROBE_N * (size_t)n);
+    return d->nprobe;
+}
+
+void jo_bpsk_fft_perturb(jo_bpsk_t *d, double scale, uint64_t seed)
+{
+    d->perturb_scale = scale;
+    d->perturb_state = seed;
 }
 
 int64_t jo_bpsk_trace(const jo_bpsk_t *d, double *out, int64_t cap_pairs)

@@ -374,6 +374,24 @@ class Bpsk:
         lib().jo_bpsk_trace(self.h, ptr(out), n)
         return out[:n]
 
+    def fft_probe_enable(self, cap_frames):
+        lib().jo_bpsk_fft_probe_enable.argtypes = [C.c_void_p, C.c_int64]
+        lib().jo_bpsk_fft_probe_enable(self.h, cap_frames)
+
+    def fft_probe(self):
+        """per frame: binPos, maxBin, runner-up, threshold, rule taken, centreBin after, ||x||_2, n"""
+        f = lib().jo_bpsk_fft_probe
+        f.restype = C.c_int64
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+        n = f(self.h, None, 0)
+        out = np.empty((max(n, 1), 8), np.float64)
+        f(self.h, out.ctypes.data, n)
+        return out[:n]
+
+    def fft_perturb(self, scale, seed):
+        lib().jo_bpsk_fft_perturb.argtypes = [C.c_void_p, C.c_double, C.c_uint64]
+        lib().jo_bpsk_fft_perturb(self.h, float(scale), int(seed))
+
     def trace_ds(self):
         n = lib().jo_bpsk_trace_ds(self.h, None, 0)
         out = np.empty((max(n, 1), 2), np.float64)

@@ -43,3 +43,23 @@ def test_strong_scaling_shards_are_contiguous_and_cover_every_stream():
             s0, cnt = SH.shard_streams(total, n, rank)
             seen.extend(range(s0, s0 + cnt))
         assert seen == list(range(total)), (total, n)
+
+
+def test_energy2_threshold_is_the_same_decision_on_the_squared_value():
+    """k_tail8 decides `energy2 = Math.sqrt(di*di + dq*dq) > 100.0` (FUNcubeBPSKDemod.java:543-544) as
+    `di*di + dq*dq > 10000.0`: sqrt is correctly rounded and monotone, sqrt(10000) is exactly 100, and the square root of
+    the double above 10000 (100 + 9.1e-15) rounds to the double above 100 (100 + 1.42e-14).  Checked on every double within
+    4096 ulps of 10000 and on random arguments."""
+    import math
+    import numpy as np
+    x = np.float64(10000.0)
+    lo = x
+    for _ in range(4096):
+        lo = np.nextafter(lo, -np.inf)
+    v = lo
+    for _ in range(8193):
+        assert (math.sqrt(float(v)) > 100.0) == (float(v) > 10000.0), float(v).hex()
+        v = np.nextafter(v, np.inf)
+    rng = np.random.default_rng(7)
+    for a in np.concatenate([rng.uniform(0.0, 2.0e4, 200000), 10.0 ** rng.uniform(-300, 300, 20000)]):
+        assert (math.sqrt(float(a)) > 100.0) == (float(a) > 10000.0)
