@@ -417,6 +417,8 @@ def main():
             raise SystemExit(launch_ranks(N))
         if world != N:
             raise SystemExit(f"--gpus {N} under a launcher needs WORLD_SIZE={N}; got {world}")
+        if os.environ.get("JSDR_BENCH_TEST_HANG_RANK") == str(rank):  # tests/test_gpu_bench_launcher.py: a stuck rank
+            time.sleep(3600)
         import torch  # noqa: F811  (first, so libjsdr_hip.so binds to the same HIP runtime)
         import torch.distributed as dist  # noqa: F811
         # rehearsal knobs for a 1-GPU box (never set by the driver): JSDR_BENCH_SAME_DEVICE=1 maps every rank to

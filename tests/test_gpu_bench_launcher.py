@@ -36,6 +36,32 @@ def test_bare_command_two_ranks_gather_is_checked():
     assert g["every_rank_segment_equals_that_ranks_slots"] and g["sampled_slots_equal_getters"] and g["all_ranks_ok"], g
     assert out["roofline"]["per_kernel"]["k_fm"]["bound"] == "fp64-issue"
     assert 0.0 < out["roofline"]["per_kernel"]["k_fm"]["fp64_issue_frac"] < 1.0
+    assert g["validated_per_rank"] == [True, True] and len(out["ms_per_step_per_rank"]) == 2
+
+
+def test_bare_command_four_ranks_strong_scaling_shape():
+    """the shape of the driver's N > 2 lines: --total-streams fixed, S/N per rank, contiguous shards, one gather a step.
+    Four ranks, not eight: the GPU box allows six processes on the card at once (this test process is one of them)."""
+    r, lines = run_bench(["--gpus", "4", "--steps", "2", "--warmup", "1", "--total-streams", "32", "--samples", "524288",
+                          "--no-cpu-baseline"], {"JSDR_BENCH_SAME_DEVICE": "1", "JSDR_BENCH_BACKEND": "gloo"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert len(lines) == 1, (r.stdout[-2000:], r.stderr[-2000:])
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 4 and out["config"]["total_streams"] == 32 and out["config"]["streams_per_gpu"] == 8
+    assert out["scaling"] == "strong" and out["validated"] is True, out
+    g = out["gather_check"]
+    assert g["all_ranks_ok"] and g["validated_per_rank"] == [True] * 4 and len(out["ms_per_step_per_rank"]) == 4, g
+
+
+def test_bare_command_ends_a_run_whose_rank_hangs():
+    """a rank that never finishes (here: asked to sleep) must not hang the launcher: after JSDR_BENCH_LAUNCH_TIMEOUT the
+    survivors are terminated, then killed, and the command exits non-zero"""
+    import time
+    t0 = time.time()
+    r, lines = run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0", "--streams", "8", "--samples", "262144", "--no-cpu-baseline"],
+                         {"JSDR_BENCH_SAME_DEVICE": "1", "JSDR_BENCH_BACKEND": "gloo", "JSDR_BENCH_LAUNCH_TIMEOUT": "20",
+                          "JSDR_BENCH_TEST_HANG_RANK": "1"})
+    assert r.returncode != 0 and time.time() - t0 < 120, (r.returncode, time.time() - t0)
 
 
 def test_bare_command_fails_when_a_rank_fails():
