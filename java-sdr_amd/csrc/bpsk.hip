@@ -311,6 +311,67 @@ __global__ __launch_bounds__(128, 4) void k_front(FrontArgs a)
     }
 }
 
+// ------------------------------------------------------------------------------------------- k_front_any
+// The front end for ANY decimation rate / 9600 (the reference's audio-rate is a free integer, JavaAudio.java:49,59: 32 kHz
+// gives 3, 22.05 kHz 2, 64 kHz 6 ...): one thread per output, its 27-sample window walked newest -> oldest (:479-483) with the
+// decimation a run-time value.  Same conversions, same operand order as k_front; no staging, no register blocking -- the
+// rates java-sdr ships defaults for (44.1 / 48 / 96 / 192 kHz: decimation 4, 5, 10, 20) have the specialised kernels.
+template <bool F32IN>
+__global__ __launch_bounds__(256) void k_front_any(FrontArgs a, int D)
+{
+    __shared__ double sc[512];
+    for (int i = threadIdx.x; i < 512; i += blockDim.x) sc[i] = a.sincos[i];
+    __syncthreads();
+    const int s = blockIdx.y;
+    const double HOWARD = 0.9 * 32768.0;  // :469
+    const int *raw = a.raw + (long long)s * a.stride_pairs;
+    const float2 *rawf = a.rawf + (long long)s * a.stride_pairs;
+    const int2 *hist = a.hist + (long long)s * 32;
+    for (long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x; j < a.nds; j += (long long)gridDim.x * blockDim.x) {
+        const long long n_new = (long long)a.first_out + (long long)D * j;  // the input whose arrival completes output j
+        double fi = 0.0, fq = 0.0;
+        for (int age = 0; age < DS_N; age++) {
+            const long long n = n_new - age;  // >= -26: before the call, the history k_hist_in kept (zeros at the stream's start)
+            double di, dq;
+            if constexpr (F32IN) {
+                float2 f;
+                if (n >= 0) {
+                    f = rawf[n];
+                } else {
+                    const int2 h = hist[26 + n];
+                    f = make_float2(__int_as_float(h.x), __int_as_float(h.y));
+                }
+                di = (double)f.x;  // (double)buf[n*2]  :372
+                dq = (double)f.y;
+            } else {
+                int w;
+                if (n >= 0) {
+                    w = raw[n];
+                    const int si = java_short_add((int)(short)(w & 0xffff), a.ic);
+                    const int sq = java_short_add(w >> 16, a.qc);
+                    w = (si & 0xffff) | (sq << 16);
+                } else {
+                    w = hist[26 + n].x;  // kept DC-corrected
+                }
+                di = (double)i16_to_float_java((int)(short)(w & 0xffff));
+                dq = (double)i16_to_float_java(w >> 16);
+            }
+            if (a.mix) {  // :388-390 component-wise, not a complex multiply
+                const int k = a.ktu[26 + n];
+                di = di * sc[k];
+                dq = dq * sc[256 + k];
+            }
+            const double tp = c_bpsk.ds_taps[age];
+            fi += di * tp;
+            fq += dq * tp;
+        }
+        const double oi = fi * HOWARD, oq = fq * HOWARD;  // :486
+        if (a.ds_dbg) a.ds_dbg[(long long)s * a.nds + j] = make_double2(oi, oq);
+        const int kv = a.kvco[j];
+        a.dm[(long long)s * a.dm_stride + 64 + j] = make_double2(oi * sc[kv], oq * sc[256 + kv]);  // :515-516
+    }
+}
+
 // lane-span geometry of the register-staged front end: a lane owns RD samples = R outputs, its window NS samples
 template <int D, int RD>
 struct FrontDmaGeom {
@@ -2942,9 +3003,10 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
     }
     // fused path (k_fm): int16 input, a tuner schedule that is periodic with a period dividing the lane span (or
     // no tuner at all), 32-bit sample indices
+    const bool std_decim = h->decim == 4 || h->decim == 5 || h->decim == 10 || h->decim == 20;  // the specialised front ends
     const int fm_rd = h->decim == 4 ? 20 : h->decim * 4;  // D * R of the k_fm instantiation
     const bool per_ok = !h->do_fft && h->mix == 1 && h->c_tper > 0 && fm_rd % h->c_tper == 0;
-    const bool fm_ok = h->use_fm && !h->do_fft && raw_dev && !rawf_dev && nds > 0 && L <= 0x3fffffffLL &&
+    const bool fm_ok = h->use_fm && std_decim && !h->do_fft && raw_dev && !rawf_dev && nds > 0 && L <= 0x3fffffffLL &&
                        (h->mix == 0 || per_ok);
     const int kshift = 0;
     const bool fresh = !h->cache_valid;
@@ -2962,8 +3024,7 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
     unsigned char *kvco_p = h->kvco.p + (size_t)h->tab_cur * (size_t)h->max_ds;
     double2 *tcs_p = h->tcs.p + (size_t)h->tab_cur * (256 + FM_TABLE_SLACK);
     // the 1 B/sample index table is only read by the kernels without the periodic table (k_front, k_front_reg<PER = false>)
-    const bool reg_will_run = front_reg_enabled() && raw_dev && !rawf_dev && L <= 0x3fffffffLL && L >= 64 &&
-                              true;
+    const bool reg_will_run = front_reg_enabled() && std_decim && raw_dev && !rawf_dev && L <= 0x3fffffffLL && L >= 64;
     const bool need_ktu = !h->do_fft && !fm_ok && !(per_ok && reg_will_run) && h->mix != 0;
     if (need_ktu && (!h->ktu_uploaded || kshift != h->c_kshift)) {
         h->c_kshift = kshift;
@@ -3169,7 +3230,15 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
                 if (launch_front_reg<20, 80>(fa, S, nds, fast, st)) h->front_name = "k_front_reg";
                 else launch_front<20, 80>(fa, S, nds, st);
                 break;
-            default: JSDR_REQUIRE(false, "bpsk: unsupported decimation %d", h->decim);
+            default: {  // any other rate
+                h->front_name = "k_front_any";
+                long long gx = (nds + 255) / 256;
+                if (gx > 4096) gx = 4096;
+                if (fa.rawf)
+                    hipLaunchKernelGGL(k_front_any<true>, dim3((unsigned)gx, (unsigned)S), dim3(256), 0, st, fa, h->decim);
+                else
+                    hipLaunchKernelGGL(k_front_any<false>, dim3((unsigned)gx, (unsigned)S), dim3(256), 0, st, fa, h->decim);
+            }
         }
         JSDR_LAUNCH_CHECK();
     }
@@ -3269,9 +3338,10 @@ int jsdr_bpsk_create(jsdr_bpsk **out, int rate, int nsamples_per_frame, int tuni
     *out = nullptr;
     JSDR_REQUIRE(rate >= 9600, "jsdr_bpsk_create: rate %d below the 9600 Hz demodulator rate", rate);
     const int decim = rate / 9600;  // adsc.rate/DOWN_SAMPLE_RATE (:476), int division
-    JSDR_REQUIRE(decim == 4 || decim == 5 || decim == 10 || decim == 20,
-                 "jsdr_bpsk_create: rate %d gives decimation %d; built for 4, 5, 10, 20 (44.1k, 48k, 96k, 192k)", rate,
-                 decim);
+    // any rate the reference would take (:476: adsc.rate / DOWN_SAMPLE_RATE, whatever it is); 4, 5, 10, 20 -- the rates
+    // java-sdr has defaults for -- take the specialised front ends, everything else the one-thread-per-output kernel.
+    // FFT-acquire mode sizes its per-thread output lists for a decimation of at least 4.
+    JSDR_REQUIRE(!do_fft || decim >= 4, "jsdr_bpsk_create: FFT-acquire mode needs a rate of at least 38400 Hz (decimation %d < 4)", decim);
     JSDR_REQUIRE(nsamples_per_frame > 0 && nstreams > 0 && nstreams <= 65535, "jsdr_bpsk_create: bad geometry");
     if (max_batch_samples < nsamples_per_frame) max_batch_samples = nsamples_per_frame;
     const bool fft_pow2 = nsamples_per_frame >= 1024 && nsamples_per_frame <= 8192 &&

@@ -404,7 +404,7 @@ def test_bpsk_api_errors():
     with pytest.raises(J.JsdrError):
         J.Bpsk(rate=8000)
     with pytest.raises(J.JsdrError):
-        J.Bpsk(rate=32000)  # decimation 3 has no kernel
+        J.Bpsk(rate=32000, do_fft=1)  # FFT-acquire mode needs a decimation of at least 4
     d = J.Bpsk(nstreams=2)
     with pytest.raises(J.JsdrError):
         d.receive(np.zeros(4096, np.float32))  # receive() is the 1-stream form
@@ -590,3 +590,32 @@ def test_bpsk_fft_mode_one_stream_fed_int16_and_arbitrary_float_frames_in_turn()
         same_counters(d.counters(), o.counters())
         same_state(d.state(), o.state())
         assert d.counters()["centreBin"] == o.counters()["centreBin"]
+
+
+@pytest.mark.parametrize("rate,tuning", [(32000, 4000), (22050, 3000), (11025, 1500), (64000, 12000), (9600, 1200), (250000, 30000),
+                                         (32000, -4000)])
+def test_bpsk_any_audio_rate_takes_the_generic_front_end(rate, tuning):
+    """the reference's audio-rate is a free integer (JavaAudio.java:49,59) and RxDownSample takes whatever rate / 9600 is
+    (FUNcubeBPSKDemod.java:476): decimations other than 4 / 5 / 10 / 20 go through k_front_any (one thread per output).
+    Same bar as everywhere: (fi,fq), bits, counters, state bit for bit; ragged calls; int16 batches and float frames."""
+    D = rate // 9600
+    n = 2048 * 24
+    streams = [O.make_dbpsk_stream(90 + s, s, n, rate=rate, carrier_hz=abs(tuning) + 1200.0, noise_sigma=500.0 + 300 * s)[0]
+               for s in range(3)]
+    d, _ = run_both(streams, n, [2048 * 5 + 7, 13, 2048 * 11 - 20, n - (2048 * 16)], rate=rate, tuning=tuning)
+    assert d.front_kernel_name() == "k_front_any", D
+    # one stream through receive(float[]) with floats off the short grid (the float form of the same kernel)
+    buf = (O.convert_i16(streams[0]) * np.float32(0.93)).astype(np.float32)
+    d1 = J.Bpsk(rate=rate, tuning=tuning, nstreams=1)
+    o1 = O.Bpsk(rate=rate, tuning=tuning, trace=n // D + 8)
+    tr, bits = [], []
+    for k in range(6):
+        d1.receive(buf[4096 * k:4096 * (k + 1)])
+        o1.receive(buf[4096 * k:4096 * (k + 1)])
+        tr.append(d1.trace().copy())
+        bits.append(d1.bits().copy())
+    assert d1.front_kernel_name() == "k_front_any"
+    assert np.array_equal(np.concatenate(tr), o1.trace())
+    assert np.array_equal(np.concatenate(bits), o1.bits())
+    same_counters(d1.counters(), o1.counters())
+    same_state(d1.state(), o1.state())
