@@ -22,6 +22,7 @@ SOURCES = {
     "runtime.hip": [],
     "fft_psd.hip": [],
     "fft_mixed.hip": [],
+    "fft_any.hip": ["-ffp-contract=off"],
     "fir_phase.hip": ["-ffp-contract=off"],
     "fir_batch.hip": ["-ffp-contract=off"],
     "fec.hip": [],

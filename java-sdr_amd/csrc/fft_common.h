@@ -159,4 +159,8 @@ int mixed_launch(const MixedPlan &p, const FftArgs &a, int in_kind, int out_kind
 // split2 plans: half-size spectra of `nframes` frames into tmp [2*nframes][n/2], then the combine pass
 int mixed_launch_split2(const MixedPlan &p, const FftArgs &a, int in_kind, int out_kind, int num_cu, hipStream_t st);
 
+// any other frame size (fft_any.hip): the DFT itself, double accumulation
+bool dft_any_supported(int n);
+int dft_any_launch(const FftArgs &a, int n, int in_kind, int out_kind, int num_cu, hipStream_t st);
+
 }  // namespace jsdr

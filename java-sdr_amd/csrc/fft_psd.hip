@@ -374,6 +374,7 @@ struct jsdr_fft {
     int num_cu = 256;
     bool mixed = false;  // non power-of-two frame: fft_mixed.hip
     MixedPlan mplan;
+    bool direct = false;  // any other frame size: fft_any.hip
 };
 
 static int fft_run(jsdr_fft *h, const void *in_dev, int in_kind, int out_kind, long long nframes, int ic, int qc,
@@ -384,6 +385,16 @@ static int fft_run(jsdr_fft *h, const void *in_dev, int in_kind, int out_kind, l
     JSDR_REQUIRE(nframes >= 0, "fft: negative frame count");
     if (nframes == 0) return JSDR_OK;
     FftArgs a;
+    if (h->direct) {
+        a.in = in_dev;
+        a.out = out_dev;
+        a.tw = nullptr;
+        a.nframes = nframes;
+        a.rate = h->rate;
+        a.ic = ic;
+        a.qc = qc;
+        return dft_any_launch(a, h->n, in_kind, out_kind, h->num_cu, s);
+    }
     if (h->mixed) {
         a.in = in_dev;
         a.out = out_dev;
@@ -438,9 +449,9 @@ int jsdr_fft_create(jsdr_fft **out, int n, int rate)
     MixedPlan mp;
     const bool pow2 = n >= 64 && n <= 8192 && (n & (n - 1)) == 0;
     const bool mixed = !pow2 && mixed_plan(n, mp);
-    JSDR_REQUIRE(pow2 || mixed,
-                 "jsdr_fft_create: n=%d unsupported (powers of two 64..8192, and 4800 / 9600 / 19200 = the reference's "
-                 "default 48 / 96 / 192 kHz frames)", n);
+    const bool direct = !pow2 && !mixed && dft_any_supported(n);
+    JSDR_REQUIRE(pow2 || mixed || direct,
+                 "jsdr_fft_create: n=%d unsupported (2 .. 20000 samples)", n);
     JSDR_REQUIRE(rate > 0, "jsdr_fft_create: rate must be positive");
     int dev = 0;
     JSDR_HIP_TRY(hipGetDevice(&dev));
@@ -450,6 +461,15 @@ int jsdr_fft_create(jsdr_fft **out, int n, int rate)
     h->n = n;
     h->rate = rate;
     h->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (direct) {  // no tables: the twiddles are computed where they are used
+        h->direct = true;
+        if (h->in_stage.alloc((size_t)n * 8) != JSDR_OK || h->out_stage.alloc((size_t)n + 2) != JSDR_OK) {
+            jsdr_fft_destroy(h);
+            return JSDR_ERR;
+        }
+        *out = h;
+        return JSDR_OK;
+    }
     if (mixed) {
         h->mixed = true;
         h->mplan = mp;

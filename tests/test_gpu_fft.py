@@ -171,9 +171,59 @@ def test_fft_default_non_power_of_two_frames(n, rate):
 
 
 def test_fft_rejects_unsupported_sizes():
-    for n in (38400, 100, 32, 16384, 9601):
+    for n in (38400, 20001, 1, 0, -5):
         with pytest.raises(J.JsdrError):
             J.Fft(n, 96000)
+
+
+@pytest.mark.parametrize("n,rate", [(4410, 44100), (2205, 22050), (3200, 32000), (1102, 11025), (8820, 88200), (17640, 176400),
+                                    (9601, 96010), (16384, 96000), (100, 1000), (37, 370)])
+def test_fft_any_frame_size(n, rate):
+    """the reference's audio-rate is a free integer and its frame rate / 10 (JavaAudio.java:49,59; JTransforms takes any n,
+    fft.java:67,194): 44.1 kHz -> 4410 = 2.3^2.5.7^2 (the reference's own sine4410.wav), 11.025 kHz -> 1102 = 2.19.29,
+    primes ...  Frames without a Stockham kernel take the DFT itself (fft_any.hip).  Same bar as the other sizes: spectrum
+    within 1e-5 of the peak of the exact DFT, PSD / first maximum / Hz rule against the oracle, int16 form with DC
+    correction, ragged batch, the all-zero frame."""
+    rng = np.random.default_rng(n)
+    t = np.arange(n)
+    bufs = np.zeros((3, 2 * n), np.float32)
+    x = 0.3 * np.exp(2j * np.pi * (n // 7) * t / n) + 0.05 * np.exp(-2j * np.pi * (n / 9.0 + 0.5) * t / n)
+    bufs[0, 0::2], bufs[0, 1::2] = x.real, x.imag
+    bufs[1] = (rng.standard_normal(2 * n) * 0.2).astype(np.float32)
+    bufs[2, 0::2] = 0.4 * np.cos(2 * np.pi * (n / 5.0 + 0.25) * t / n)
+    f = J.Fft(n, rate)
+    spec = f.spectrum(bufs).astype(np.float64)
+    for k in range(3):
+        want = np.fft.fft(bufs[k, 0::2].astype(np.float64) + 1j * bufs[k, 1::2].astype(np.float64))
+        got = spec[k, 0::2] + 1j * spec[k, 1::2]
+        assert np.abs(got - want).max() <= FFT_RTOL * np.abs(want).max()
+    nchk = 3 if n <= 4410 else 1  # (the oracle's exact DFT is O(n^2) in long double)
+    for k in range(nchk):
+        check_psd(f.receive(bufs[k]), O.fft_receive(bufs[k], rate), n)
+    raw = rng.integers(-20000, 20000, (5, 2 * n)).astype(np.int16)
+    psd = f.batch_host_i16(raw, ic=11, qc=-7)
+    check_psd(psd[4], O.fft_receive(O.convert_i16(raw[4], ic=11, qc=-7), rate), n)
+    for k in range(5):
+        xx = O.convert_i16(raw[k], ic=11, qc=-7).astype(np.float64)
+        pw = np.abs(np.fft.fft(xx[0::2] + 1j * xx[1::2])) ** 2 * (2.0 / n) ** 2
+        assert np.abs(lin(psd[k][:n]) - np.sqrt(pw)).max() <= FFT_RTOL * np.sqrt(pw).max()
+        assert np.array_equal(f.receive_raw(raw[k], ic=11, qc=-7), psd[k])  # one frame spread over the chip == the batch form
+    z = f.receive(np.zeros(2 * n, np.float32))
+    assert np.all(np.isneginf(z[:n])) and z[n] == float(int(-1 * rate / (2 * n))) and z[n + 1] == -np.finfo(np.float32).max
+
+
+def test_fft_sine4410_wav_at_its_own_rate(golden_dir):
+    """the reference's sine4410.wav is a 44.1 kHz recording: its own frame is 4410 samples (audio-buflen = rate*size/10)"""
+    import wave
+    with wave.open(os.path.join(golden_dir, "sine4410.wav")) as w:
+        assert (w.getnchannels(), w.getsampwidth(), w.getframerate()) == (2, 2, 44100)
+        raw = np.frombuffer(w.readframes(2 * 4410), dtype="<i2")
+    n = 4410
+    f = J.Fft(n, 44100)
+    for k in range(2):
+        psd = f.receive_raw(raw[2 * n * k:2 * n * (k + 1)])
+        check_psd(psd, O.fft_receive(O.convert_i16(raw[2 * n * k:2 * n * (k + 1)]), 44100), n)
+        assert abs(abs(psd[n]) - 4410.0) <= 44100 / n + 1  # the tone the file is named after
 
 
 def test_fft_linearity_property_at_full_batch_size():

@@ -58,10 +58,10 @@ def test_harness_at_the_reference_default_frame(tmp_path):
 
 
 def test_harness_reports_handler_failure_like_the_audio_loop(golden_dir):
-    # blen 40000 -> n=10000: no kernel for that frame size -> the fft plugin's setup fails, the loop ends with a
-    # status message and a non-zero exit instead of wrong data
+    # blen 100000 -> n=25000: no kernel for that frame size (above 20000 samples) -> the fft plugin's setup fails, the
+    # loop ends with a status message and a non-zero exit instead of wrong data
     fx = os.path.join(golden_dir, "sine4410.raw")
-    r = subprocess.run([HARNESS, fx, "96000", "40000"], capture_output=True, text=True, timeout=120)
+    r = subprocess.run([HARNESS, fx, "96000", "100000"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 1 and "Audio oops" in r.stderr
 
 
