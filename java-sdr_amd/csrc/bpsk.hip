@@ -2841,9 +2841,15 @@ static int run_side(jsdr_bpsk *h, const SideJob &j)
             const char *e = getenv("JSDR_TAIL8");  // JSDR_TAIL8=0: the one-wave-per-stream tail (A/B timing)
             return !e || atoi(e) != 0;
         }();
+        static const bool force_tail8 = [] {
+            const char *e = getenv("JSDR_TAIL8");  // JSDR_TAIL8=2: k_tail8 whatever the number of streams (the tests' small handles)
+            return e && atoi(e) == 2;
+        }();
         if (h->variant != 0 && !h->do_fft && j.raw)
             hipLaunchKernelGGL(k_tail<true>, dim3((unsigned)S), dim3(64), 0, ts, ta);
-        else if (use_tail8)
+        else if (use_tail8 && (S >= 2048 || force_tail8))
+            // (below ~2000 streams there are too few waves of eight streams to fill the chip and a wave's own latency per chunk
+            //  decides: 1024 streams, FFT-acquire lines of round 4: locked 0.64 ms (k_tail) against 1.6, unlocked 5.6 against 3.5)
             hipLaunchKernelGGL(k_tail8<16>, dim3((unsigned)((S + 7) / 8)), dim3(64), 0, ts, ta);
         else
             hipLaunchKernelGGL(k_tail<false>, dim3((unsigned)S), dim3(64), 0, ts, ta);
