@@ -619,3 +619,20 @@ def test_bpsk_any_audio_rate_takes_the_generic_front_end(rate, tuning):
     assert np.array_equal(np.concatenate(bits), o1.bits())
     same_counters(d1.counters(), o1.counters())
     same_state(d1.state(), o1.state())
+
+
+def test_bpsk_suite_with_the_eight_streams_per_wave_tail():
+    """k_tail8 (eight streams per wave) serves handles of 2048 streams and more; the parity tests use a few streams.  The same
+    tests once more in a child process with JSDR_TAIL8=2, which makes every handle take k_tail8 (ragged calls, surplus lane
+    groups shadowing the last stream, acquisition and fades through the general path, FFT-acquire frame seams)."""
+    if os.environ.get("JSDR_TAIL8") == "2":
+        return
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, JSDR_TAIL8="2")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-p", "no:cacheprovider", "-m", "gpu",
+                        os.path.join(here, "test_gpu_bpsk.py"), os.path.join(here, "test_gpu_fixtures.py"),
+                        "-k", "not eight_streams_per_wave and not alternately"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
