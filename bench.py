@@ -53,7 +53,8 @@ FP64_OPS_PER_DS_SAMPLE = {"k_fm": 368.0, "k_front_reg": 108.0, "k_front": 108.0,
 # what binds each kernel, from the measurements cited in DESIGN.md 3 (not from the roofline arithmetic)
 KERNEL_BOUND = {"k_fft": "hbm", "k_fir_batch": "hbm", "k_waterfall": "hbm", "k_fm": "fp64-issue", "k_front_reg": "fp64-issue",
                 "k_front": "fp64-issue", "k_matched": "fp64-issue", "k_front_fft": "valu-issue", "k_front_fftm": "valu-issue",
-                "k_front_fft2x": "valu-issue", "k_acq_fwd": "valu-issue", "k_acq_inv": "valu-issue", "k_tail": "lds-issue/latency",
+                "k_front_fft2x": "valu-issue", "k_acq_fwd": "valu-issue", "k_acq_inv": "valu-issue", "k_tail": "lds-issue/latency", "k_tail8": "hbm (16 B per 9600 Hz sample; a wave's latency below ~2000 streams)",
+                "k_fec_bits+k_vitq+k_fec_rs": "valu-issue",
                 "k_sync_t": "latency", "k_sync": "latency", "k_sync_fin": "latency", "k_fec_bpsk": "latency",
                 "k_demod_front": "valu-issue", "k_demod_fused": "valu-issue", "k_demod_out": "hbm", "k_demod_mean": "latency"}
 
@@ -581,13 +582,15 @@ def main():
             if cnt:
                 kern[name] = (ms, cnt, BYTES_PER_SAMPLE["demod"])
     if dem is not None:
-        front_name = dem.front_kernel_name()  # which front-end kernel ran: k_front_reg / k_front_fft / k_front_fftm / ...
+        # which kernels ran under the library's timing scopes: the front end (k_front_reg / k_front_fft / k_front_fftm / ...),
+        # the tail (k_tail / k_tail8), the FEC form (k_fec_bpsk, or the batch form's three kernels under one scope)
+        rename = {"k_front": dem.front_kernel_name(), "k_tail": dem.tail_kernel_name(), "k_fec_bpsk": dem.fec_kernel_name()}
         for name, (ms, cnt) in dem.profile_read().items():
             if cnt:
-                kern[front_name if name == "k_front" else name] = (ms, cnt, BYTES_PER_SAMPLE["bpsk"])
+                kern[rename.get(name, name)] = (ms, cnt, BYTES_PER_SAMPLE["bpsk"])
     # the dominant kernel is taken on the critical path: the tail / sync / FEC kernels run on the handle's side
     # stream under the next step's throughput kernels (their times are listed, they do not bound the step)
-    SIDE = ("k_tail", "k_sync", "k_sync_t", "k_sync_fin", "k_fec_bpsk", "k_fec_fin")
+    SIDE = ("k_tail", "k_tail8", "k_sync", "k_sync_t", "k_sync_fin", "k_fec_bpsk", "k_fec_fin", "k_fec_bits+k_vitq+k_fec_rs")
     main = {k: v for k, v in kern.items() if k not in SIDE or a.fft_acquire}
     dom = max(main, key=lambda k: main[k][0])
     dom_ms = kern[dom][0] / kern[dom][1]

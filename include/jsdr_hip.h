@@ -205,6 +205,8 @@ int jsdr_bpsk_snapshot_read(jsdr_bpsk *h, jsdr_bpsk_snapshot *out);
 int jsdr_bpsk_profile_enable(jsdr_bpsk *h, int on);
 int jsdr_bpsk_profile_count(void);                 /* number of kernels in the pipeline */
 const char *jsdr_bpsk_front_kernel(jsdr_bpsk *h);  /* name of the front-end kernel the last call launched */
+const char *jsdr_bpsk_tail_kernel(jsdr_bpsk *h);   /* ... of its tail kernel: k_tail (one wave per stream) or k_tail8 (eight streams per wave) */
+const char *jsdr_bpsk_fec_kernel(jsdr_bpsk *h);    /* ... of its FEC form: k_fec_bpsk, or the batch form's k_fec_bits+k_vitq+k_fec_rs */
 /* 1 when the handle runs its tail / sync / FEC on a side stream of its own (batch handles), 0 when on the caller's stream
  * (1-stream handles; FFT-acquire with a mixed-radix frame; JSDR_NO_OVERLAP): *on receives it.  What a benchmark reports
  * instead of re-deriving the library's rule.                                                                        */

@@ -45,10 +45,12 @@ def lib():
         _lib.jsdr_last_error.restype = C.c_char_p
         _lib.jsdr_bpsk_profile_name.restype = C.c_char_p
         _lib.jsdr_demod_profile_name.restype = C.c_char_p
-        _lib.jsdr_bpsk_front_kernel.restype = C.c_char_p
-        _lib.jsdr_bpsk_front_kernel.argtypes = [C.c_void_p]
+        for fn in ("jsdr_bpsk_front_kernel", "jsdr_bpsk_tail_kernel", "jsdr_bpsk_fec_kernel"):
+            getattr(_lib, fn).restype = C.c_char_p
+            getattr(_lib, fn).argtypes = [C.c_void_p]
         for name in EXPORTED_SYMBOLS:
-            if name not in ("jsdr_last_error", "jsdr_bpsk_profile_name", "jsdr_demod_profile_name", "jsdr_bpsk_front_kernel"):
+            if name not in ("jsdr_last_error", "jsdr_bpsk_profile_name", "jsdr_demod_profile_name", "jsdr_bpsk_front_kernel",
+                            "jsdr_bpsk_tail_kernel", "jsdr_bpsk_fec_kernel"):
                 getattr(_lib, name).restype = C.c_int
     return _lib
 
@@ -447,6 +449,12 @@ class Bpsk:
 
     def front_kernel_name(self):
         return lib().jsdr_bpsk_front_kernel(self.h).decode()
+
+    def tail_kernel_name(self):
+        return lib().jsdr_bpsk_tail_kernel(self.h).decode()
+
+    def fec_kernel_name(self):
+        return lib().jsdr_bpsk_fec_kernel(self.h).decode()
 
     def side_stream(self):
         on = C.c_int()

@@ -1352,6 +1352,17 @@ __device__ __forceinline__ double2 tail_exact_sample(const TailArgs &a, int s, l
     return make_double2(yi, yq);
 }
 
+#ifdef JSDR_X_T8CLK  // timing experiment: s_memtime ticks per phase, summed over every wave of every launch
+__device__ unsigned long long g_t8_clk[8];
+#define T8_CLK(i)                                                     \
+    do {                                                              \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+        t8acc_[i] += now_ - t8last_;                                  \
+        t8last_ = now_;                                               \
+    } while (0)
+#else
+#define T8_CLK(i) do {} while (0)
+#endif
 // CERT = the fast variant's tail: the same arithmetic on (fi,fq) that carry a bounded error |d| <= ey, plus, for every
 // data-dependent decision, a margin that covers the worst case of that error (DESIGN.md "fast variant"):
 //   argmax of the eight smoothed energies (:586-592): certified when the winner leads by more than twice the bound on
@@ -1366,6 +1377,13 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs a)
     // peak) reads its sample from y.  The whole chunk (8 KB) used to sit here: with 10 KB instead of 17 KB a CU holds
     // sixteen of these one-wave workgroups instead of nine, and the kernel is occupancy x latency bound.
     __shared__ double2 ydL[64];        // [period]
+    // The exact kernel serves handles of fewer than 2048 streams since round 4 (k_tail8 takes the others): a wave per SIMD at
+    // most, so LDS no longer decides how many of these workgroups a CU holds -- the whole chunk's (fi,fq) stay here for the
+    // decisions that fall on another bit position (acquisition, fades, the FFT-acquire mode's frame seams) instead of being
+    // read again from y (two dependent L2 round trips per chunk: with the serial state machine below, 27 us a chunk unlocked
+    // against 3 us locked).  The fast variant's tail (CERT) runs at 8192 streams and keeps the small footprint.
+    constexpr bool ALLY = !CERT;
+    __shared__ double2 yAll[ALLY ? 512 : 1];
     // The chains' work area, in place and ROW PER CHAIN: before the chain, row c < 8 holds the inputs of dmEnergy[c] --
     // energy1 x 1/200 of the sample at bit position c of every period (the products are taken lane-parallel when the chunk
     // is staged, not by the nine chain lanes one at a time) -- and row 8 energy1 x 1/800 of the sample at position v, for
@@ -1380,6 +1398,9 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs a)
     const int lane = threadIdx.x;
     const int s = blockIdx.x;
     if (s >= a.nstreams) return;
+#ifdef JSDR_X_T8CLK
+    unsigned long long t8acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t8last_ = __builtin_amdgcn_s_memtime();
+#endif
     TailState *sp = &a.st[s];
     double emax = CERT ? sp->emax : 0.0;
     long long last_g = CERT ? sp->last_g : -1;
@@ -1438,6 +1459,7 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs a)
 #pragma unroll
         for (int k = 0; k < 8; k++) {  // sample k*64 + lane = period k*8 + lane/8, position lane%8
             const double en = pre[k].x * pre[k].x + pre[k].y * pre[k].y;  // :534
+            if constexpr (ALLY) yAll[k * 64 + lane] = pre[k];
             eT[lane & 7][k * 8 + (lane >> 3)] = en * S1;
             if ((lane & 7) == v) {
                 ydL[k * 8 + (lane >> 3)] = pre[k];
@@ -1446,7 +1468,10 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs a)
         }
         JSDR_WAVE_SYNC();
         const double2 *ychunk = y + (8 * MB - g_first);  // sample i of the chunk (only in-range samples are ever decisions)
-        auto ysample = [&](int pos) { return (pos & 7) == v ? ydL[pos >> 3] : ychunk[pos]; };
+        auto ysample = [&](int pos) {
+            if constexpr (ALLY) return yAll[pos];
+            else return (pos & 7) == v ? ydL[pos >> 3] : ychunk[pos];
+        };
         double m_en = 0.0, m_d = 0.0, m_e2 = 0.0;  // this chunk's margins
         if constexpr (CERT) {
             double em = 0.0;
@@ -1473,6 +1498,7 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs a)
         if (MB + 64 <= M_last) fetch(MB + 64);
         const int nper = (int)((M_last - MB + 1) < 64 ? (M_last - MB + 1) : 64);
         const bool interior = (8 * MB >= g_first) && (8 * (MB + 64) <= g_end);  // every sample of all 64 periods is in range (uniform)
+        T8_CLK(0);  // staging
         // ---------------- serial IIRs, speculating that the peak position stays at v
         const bool spec = (newPeak == peakPos);
         const double e_in = e;
@@ -1530,6 +1556,7 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs a)
             }
         }
         JSDR_WAVE_SYNC();
+        T8_CLK(1);  // chains
         // ---------------- new peak after every period whose last sample (bitPos 7) is in range (:582-593)
         int np = -1;
         if (lane < nper) {
@@ -1554,6 +1581,7 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs a)
                 }
             }
         }
+        T8_CLK(2);  // argmax
         bool replay = false;
         const bool bad = (np >= 0) && (np != v);
         const bool held = spec && (__ballot(bad) == 0ull);
@@ -1573,20 +1601,39 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs a)
                 // machine of :537,:577-579,:592 is integer only -- its inputs are the per-period argmax values np,
                 // which do not depend on dmEnergyOut -- so it runs as scalar code over the periods, one mask per
                 // period; dmEnergyOut is then redone from its saved value along the decision list further down.
+                // Walking the bit positions cfirst..clast of a period: a decision where c == peakPos (:537); at c ==
+                // (peakPos+4)&7 peakPos = newPeak (dmHalfTable, :500,:577-578), after which a second decision can fall at the NEW
+                // peakPos if that position is still to come.  In closed form (k_tail8's; branch-free, scalar).
+                // Away from the call's edges every period is whole and measured, and then the machine is not serial at all:
+                // whenever peakPos != newPeak the switch position (peakPos+4)&7 lies inside the period, so peakPos leaves every
+                // period equal to the newPeak it entered with, which is the peak measured one period earlier --
+                //     newPeak(p) = np[p-1],  peakPos(p) = np[p-2]   (the chunk's first two periods take the carried state)
+                // and each lane writes down its own period's decisions (the scalar walk over 64 periods was most of the 27 us an
+                // unlocked chunk took, against 3 us for a locked one).
                 int mymask_r = 0;
+                if (interior) {
+                    const int up1 = __shfl_up(np, 1, 64), up2 = __shfl_up(np, 2, 64);
+                    const int nwv = lane == 0 ? newPeak : up1;
+                    const int pkv = lane == 0 ? peakPos : (lane == 1 ? newPeak : up2);
+                    const int h = (pkv + 4) & 7;
+                    const bool diff = pkv != nwv;
+                    const bool d1 = !(diff && h < pkv);
+                    const bool d2 = diff && nwv > h;
+                    mymask_r = (d1 ? 1 << pkv : 0) | (d2 ? 1 << nwv : 0);
+                    peakPos = __builtin_amdgcn_readlane(np, 62);
+                    newPeak = __builtin_amdgcn_readlane(np, 63);
+                } else
                 for (int p = 0; p < nper; p++) {
                     const long long gbase = 8 * (MB + p);
                     const int cfirst = (gbase < g_first) ? (int)(g_first - gbase) : 0;
                     const int clast = (gbase + 7 >= g_end) ? (int)(g_end - 1 - gbase) : 7;
-                    int mask = 0;
-                    if (peakPos == newPeak) {  // nothing can change inside the period
-                        if (peakPos >= cfirst && peakPos <= clast) mask = 1 << peakPos;
-                    } else {
-                        for (int c = cfirst; c <= clast; c++) {
-                            if (c == peakPos) mask |= 1 << c;                          // decision point (:537)
-                            if (c == ((peakPos + 4) & 7)) peakPos = newPeak;           // dmHalfTable (:500,:577-578)
-                        }
-                    }
+                    const int h = (peakPos + 4) & 7;
+                    const bool pin = peakPos >= cfirst && peakPos <= clast;
+                    const bool hin = h >= cfirst && h <= clast && peakPos != newPeak;
+                    const bool d1 = pin && !(hin && h < peakPos);  // the old peakPos decides unless the switch came first
+                    const bool d2 = hin && newPeak > h && newPeak <= clast;
+                    const int mask = (d1 ? 1 << peakPos : 0) | (d2 ? 1 << newPeak : 0);
+                    peakPos = hin ? newPeak : peakPos;
                     if (lane == p) mymask_r = mask;
                     if (clast == 7) newPeak = __builtin_amdgcn_readlane(np, p);
                 }
@@ -1597,13 +1644,12 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs a)
             // ---------------- decision list of the chunk, in time order
             const int mymask = (lane < nper) ? (int)maskL[lane] : 0;
             const int mycnt = __popc(mymask);
-            int pre_sum = mycnt;  // inclusive prefix sum over lanes
-    #pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                int o = __shfl_up(pre_sum, off, 64);
-                if (lane >= off) pre_sum += o;
-            }
-            nd = __shfl(pre_sum, 63, 64);
+            // inclusive prefix sum over lanes: a period holds at most two decisions, so two ballots count them (six dependent
+            // cross-lane adds before)
+            const unsigned long long b1 = __ballot(mycnt >= 1), b2 = __ballot(mycnt >= 2);
+            const unsigned long long upto = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
+            const int pre_sum = __popcll(b1 & upto) + __popcll(b2 & upto);
+            nd = __popcll(b1) + __popcll(b2);
             {
                 int pos = pre_sum - mycnt;
                 int m = mymask;
@@ -1625,15 +1671,29 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs a)
                 if (lane < nd) xa = en_of(declist[lane]) * S2;
                 if (lane + 64 < nd) xb = en_of(declist[lane + 64]) * S2;
                 double eo = __shfl(e_in, 8, 64);
-                for (int d = 0; d < nd; d++) {  // d is uniform: v_readlane, no LDS round trip on the chain
-                    const double xs = (d < 64) ? xa : xb;
-                    const int lo = __builtin_amdgcn_readlane(__double2loint(xs), d & 63);
-                    const int hi = __builtin_amdgcn_readlane(__double2hiint(xs), d & 63);
-                    eo = (eo * K2) + __hiloint2double(hi, lo);
-                }
+                // (lane indices as constants, sixteen links per uniform test: as a counted loop every link paid the hazards
+                //  of a lane select in an SGPR and a branch)
+                auto chain = [&](double xs, int cnt) {
+#pragma unroll 1
+                    for (int d0 = 0; d0 < 64; d0 += 16) {
+                        if (d0 >= cnt) break;
+#pragma unroll
+                        for (int u = 0; u < 16; u++) {
+                            const int lo = __builtin_amdgcn_readlane(__double2loint(xs), u);
+                            const int hi = __builtin_amdgcn_readlane(__double2hiint(xs), u);
+                            const double ne = (eo * K2) + __hiloint2double(hi, lo);
+                            eo = (d0 + u < cnt) ? ne : eo;
+                        }
+                        // the next sixteen inputs move down to lanes 0..15
+                        xs = __hiloint2double(__shfl_down(__double2hiint(xs), 16, 64), __shfl_down(__double2loint(xs), 16, 64));
+                    }
+                };
+                chain(xa, nd < 64 ? nd : 64);
+                if (nd > 64) chain(xb, nd - 64);
                 if (lane == 8) e = eo;
             }
         }
+        T8_CLK(3);  // machine, list, replay
         // ---------------- parallel: differential detector per decision (:539-545)
         for (int d0 = 0; d0 < nd; d0 += 64) {
             const int d = d0 + lane;
@@ -1707,6 +1767,11 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs a)
         }
         JSDR_WAVE_SYNC();
     }
+#ifdef JSDR_X_T8CLK
+    T8_CLK(4);  // detector (of the last chunk; the others' land on "staging")
+    if (lane == 0)
+        for (int i = 0; i < 6; i++) atomicAdd(&g_t8_clk[i], t8acc_[i]);
+#endif
     // energy1 = that of the last sample processed (:534)
     if (a.nds > 0) {
         const double2 q = y[a.nds - 1];
@@ -1757,17 +1822,6 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs a)
 // energy2 = sqrt(di^2+dq^2) > 100 (:543-544) is decided as di^2+dq^2 > 10000: sqrt is correctly rounded and monotone,
 // sqrt(10000) = 100 exactly and sqrt(nextafter(10000)) = 100 + 9.1e-15 rounds to the double above 100
 // (tests/test_host_logic.py checks the neighbourhood); the square root itself is taken once, for the state the call leaves.
-#ifdef JSDR_X_T8CLK  // timing experiment: s_memtime ticks per phase, summed over every wave of every launch
-__device__ unsigned long long g_t8_clk[8];
-#define T8_CLK(i)                                                     \
-    do {                                                              \
-        const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
-        t8acc_[i] += now_ - t8last_;                                  \
-        t8last_ = now_;                                               \
-    } while (0)
-#else
-#define T8_CLK(i) do {} while (0)
-#endif
 template <int CH>
 __global__ __launch_bounds__(64) void k_tail8(TailArgs a)
 {
@@ -2336,6 +2390,8 @@ struct jsdr_bpsk {
     double margin_scale = 1.0;     // JSDR_FAST_MARGIN_SCALE: widens the detector margins (tests force the exact redo path with it)
     double argmax_scale = 1.0;     // JSDR_FAST_ARGMAX_SCALE: widens the argmax margin (tests provoke an uncertifiable stream)
     const char *front_name = "k_front";  // the front-end kernel the last call launched
+    const char *tail_name = "k_tail";    // ... the tail kernel (k_tail / k_tail8) ...
+    const char *fec_name = "k_fec_bpsk"; // ... and the FEC form (one wave per block, or the batch form's kernels)
     int c_tper = 0;                // period of the cached tuner schedule (0: not periodic with a period <= 256)
     bool ktu_uploaded = false;     // the device copy of the per-sample tuner index table matches the cached schedule
     std::vector<double2> h_tcs;
@@ -2845,6 +2901,7 @@ static int run_side(jsdr_bpsk *h, const SideJob &j)
             const char *e = getenv("JSDR_TAIL8");  // JSDR_TAIL8=2: k_tail8 whatever the number of streams (the tests' small handles)
             return e && atoi(e) == 2;
         }();
+        h->tail_name = (h->variant == 0 || h->do_fft || !j.raw) && use_tail8 && (S >= 2048 || force_tail8) ? "k_tail8" : "k_tail";
         if (h->variant != 0 && !h->do_fft && j.raw)
             hipLaunchKernelGGL(k_tail<true>, dim3((unsigned)S), dim3(64), 0, ts, ta);
         else if (use_tail8 && (S >= 2048 || force_tail8))
@@ -2952,6 +3009,7 @@ static int run_side(jsdr_bpsk *h, const SideJob &j)
             h->snap_fused = true;
         }
         ProfScope ps(h, PK_FEC, ts);
+        h->fec_name = (fa2.vit && !fa2.fuse) ? "k_fec_bits+k_vitq+k_fec_rs" : "k_fec_bpsk";
         if (launch_fec_bpsk(fa2, ts) != JSDR_OK) return JSDR_ERR;
     }
     if (h->overlap) {
@@ -4026,6 +4084,9 @@ int jsdr_bpsk_table(int which, double *out, int cap)
 int jsdr_bpsk_profile_count(void) { return PK_COUNT; }
 
 const char *jsdr_bpsk_front_kernel(jsdr_bpsk *h) { return h ? h->front_name : ""; }
+
+const char *jsdr_bpsk_tail_kernel(jsdr_bpsk *h) { return h ? h->tail_name : ""; }
+const char *jsdr_bpsk_fec_kernel(jsdr_bpsk *h) { return h ? h->fec_name : ""; }
 
 int jsdr_bpsk_side_stream(jsdr_bpsk *h, int *on)
 {
