@@ -1822,23 +1822,29 @@ __global__ __launch_bounds__(64) void k_tail(TailArgs a)
 // energy2 = sqrt(di^2+dq^2) > 100 (:543-544) is decided as di^2+dq^2 > 10000: sqrt is correctly rounded and monotone,
 // sqrt(10000) = 100 exactly and sqrt(nextafter(10000)) = 100 + 9.1e-15 rounds to the double above 100
 // (tests/test_host_logic.py checks the neighbourhood); the square root itself is taken once, for the state the call leaves.
-template <int CH>
-__global__ __launch_bounds__(64) void k_tail8(TailArgs a)
+template <int CH, int WPB>
+__global__ __launch_bounds__(64 * WPB) void k_tail8(TailArgs a)
 {
 #ifdef JSDR_X_T8CLK
     unsigned long long t8acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t8last_ = __builtin_amdgcn_s_memtime();
 #endif
     static_assert(CH == 16, "two decision slots per period in one 64-bit mask, one nibble per period in another");
     constexpr int ROW = 82;  // doubles per period of the energy image: 8 streams x 10 (8 used) + 2 -> conflict-free b128 reads
-    __shared__ __align__(16) double EoL[CH * ROW];
-    __shared__ __align__(16) double2 FQL[8][CH];
-    __shared__ __align__(16) unsigned char NPL[8][CH];
+    __shared__ __align__(16) double EoL_[WPB][CH * ROW];
+    __shared__ __align__(16) double2 FQL_[WPB][8][CH];
+    __shared__ __align__(16) unsigned char NPL_[WPB][8][CH];
+    // (WPB waves per workgroup, each on its own: a workgroup of four puts one wave on every SIMD of a CU, so that the four
+    //  take the registers ONE workgroup of the kernel they run beside leaves free -- four one-wave workgroups land on four CUs)
+    const int wv = WPB > 1 ? (int)(threadIdx.x >> 6) : 0, wblk = (int)blockIdx.x * WPB + wv;
+    double *EoL = EoL_[wv];
+    double2 (*FQL)[CH] = FQL_[wv];
+    unsigned char (*NPL)[CH] = NPL_[wv];
     double *X2L = EoL;                                               // general path, once the argmax has read the image:
     double2 *CURL = reinterpret_cast<double2 *>(EoL + 8 * 2 * CH);   // [8][2 CH] each
     static_assert(8 * 2 * CH * 3 <= CH * ROW, "work areas fit the dead energy image");
-    const int lane = threadIdx.x, s8 = lane >> 3, c = lane & 7;
+    const int lane = threadIdx.x & 63, s8 = lane >> 3, c = lane & 7;
     const int S = a.nstreams;
-    const int sraw = blockIdx.x * 8 + s8;
+    const int sraw = wblk * 8 + s8;
     const bool live = sraw < S;
     const int s = live ? sraw : S - 1;  // (surplus lanes of the last wave shadow its last stream and store nothing)
     TailState *sp = &a.st[s];
@@ -1847,7 +1853,7 @@ __global__ __launch_bounds__(64) void k_tail8(TailArgs a)
     // ---- carry the 5200-bit shift register (dmFECCorr, :503) over from the previous call's log: the whole wave per stream,
     // dwords (the rows are 16-byte aligned, the source starts at any byte)
     for (int t = 0; t < 8; t++) {
-        const int st = blockIdx.x * 8 + t;
+        const int st = wblk * 8 + t;
         if (st >= S) break;
         const int nprev = __builtin_amdgcn_readfirstlane(a.st[st].nbits_prev);
         const signed char *old = a.bitlog_old + (long long)st * a.bitlog_stride + nprev;
@@ -2400,9 +2406,6 @@ struct jsdr_bpsk {
     bool prefetch_on = true;       // JSDR_SCHED_PREFETCH=0: always on the calling thread
     long long sched_sync = 0, sched_prefetched = 0;  // schedules computed on the calling thread / taken from the worker
     hipStream_t tail_stream = nullptr;   // non-blocking side stream for the latency-bound 9600 Hz tail + FEC
-    struct SideJob *side_job = nullptr;  // deferred mode: the side section of the last call, not enqueued yet
-    bool defer_side = false;             // JSDR_SIDE_DEFER=1
-    hipEvent_t ev_gate = nullptr;        // caller stream -> tail stream: where the deferred side section may start
     hipEvent_t ev_matched = nullptr;     // caller stream -> tail stream: (fi,fq) of this call are complete
     hipEvent_t ev_tail_done[2] = {nullptr, nullptr};  // tail stream -> caller stream: y[i] may be overwritten
     bool tail_pending[2] = {false, false};
@@ -2907,7 +2910,17 @@ static int run_side(jsdr_bpsk *h, const SideJob &j)
         else if (use_tail8 && (S >= 2048 || force_tail8))
             // (below ~2000 streams there are too few waves of eight streams to fill the chip and a wave's own latency per chunk
             //  decides: 1024 streams, FFT-acquire lines of round 4: locked 0.64 ms (k_tail) against 1.6, unlocked 5.6 against 3.5)
-            hipLaunchKernelGGL(k_tail8<16>, dim3((unsigned)((S + 7) / 8)), dim3(64), 0, ts, ta);
+        {
+            static const int wpb = [] {
+                const char *e = getenv("JSDR_TAIL8_WPB");  // JSDR_TAIL8_WPB=1: one-wave workgroups (A/B timing)
+                return e ? atoi(e) : 4;
+            }();
+            const unsigned waves = (unsigned)((S + 7) / 8);
+            if (wpb == 1)
+                hipLaunchKernelGGL((k_tail8<16, 1>), dim3(waves), dim3(64), 0, ts, ta);
+            else
+                hipLaunchKernelGGL((k_tail8<16, 4>), dim3((waves + 3) / 4), dim3(256), 0, ts, ta);
+        }
         else
             hipLaunchKernelGGL(k_tail<false>, dim3((unsigned)S), dim3(64), 0, ts, ta);
         JSDR_LAUNCH_CHECK();
@@ -3020,18 +3033,6 @@ static int run_side(jsdr_bpsk *h, const SideJob &j)
     return JSDR_OK;
 }
 
-// launch a deferred side section now; gate: the stream whose work enqueued so far it has to wait for as well
-static int flush_side(jsdr_bpsk *h, hipStream_t gate, bool use_gate)
-{
-    if (!h->side_job || !h->side_job->valid) return JSDR_OK;
-    h->side_job->valid = false;
-    if (use_gate && h->overlap) {
-        JSDR_HIP_TRY(hipEventRecord(h->ev_gate, gate));
-        JSDR_HIP_TRY(hipStreamWaitEvent(h->tail_stream, h->ev_gate, 0));
-    }
-    return run_side(h, *h->side_job);
-}
-
 static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev, long long stride_i16, long long L,
                     int ic, int qc, hipStream_t st)
 {
@@ -3042,7 +3043,6 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
                  "bpsk: stream stride %lld too small for %lld samples", stride_i16, L);
     JSDR_REQUIRE(!h->do_fft || (L % h->nsf) == 0, "bpsk: FFT-acquire mode needs whole frames (%lld %% %d != 0)", L, h->nsf);
     JSDR_REQUIRE(h->variant == 0 || raw_dev, "bpsk: the fast variant takes int16 input (its certification pass re-reads the raw samples)");
-    if (flush_side(h, st, true) != JSDR_OK) return JSDR_ERR;  // the previous call's side section (deferred mode)
     const int first_out = h->decim - 1 - h->dsCnt;
     const long long g_first = h->n_ds;
     const long long nds = build_schedule(h, L);
@@ -3375,15 +3375,10 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
         job.tcs_p = tcs_p;
         job.st = st;
         if (h->overlap) JSDR_HIP_TRY(hipEventRecord(h->ev_matched, st));
-        // Deferred (batch handles, exact variant): the side section of this call is enqueued at the START of the next one,
-        // behind whatever the caller has put on its stream by then -- in the pipeline that is the PSD kernel, which is HBM
-        // bound like the tail: side by side they only share the bandwidth.  This way the tail runs beside the NEXT call's
-        // FP64-bound front end, which leaves the memory system idle.  Getters, sync and pack_slots flush it.
-        if (h->defer_side && h->overlap && h->variant == 0 && S > 1) {
-            *h->side_job = job;
-        } else if (run_side(h, job) != JSDR_OK) {
-            return JSDR_ERR;
-        }
+        // (the side section goes out now.  In the pipeline it then waits behind the NEXT call's PSD kernel anyway -- k_fft holds
+        //  every register of every SIMD, a tail wave finds no room until it ends -- and runs beside the first 5 ms of that call's
+        //  k_fm: profiles/r04_b_timeline.txt.  Holding it back on the host until the next call's start measured slower.)
+        if (run_side(h, job) != JSDR_OK) return JSDR_ERR;
     }
     h->last_y = yb;
     h->n_in += L;
@@ -3445,8 +3440,6 @@ int jsdr_bpsk_create(jsdr_bpsk **out, int rate, int nsamples_per_frame, int tuni
     // a step at n = 9600, 17.5 vs 18.1 at 4800, no difference at 19200)
     if (do_fft && !fft_pow2) h->overlap = false;
     if (const char *e = getenv("JSDR_NO_OVERLAP")) h->overlap = atoi(e) == 0;
-    if (const char *e = getenv("JSDR_SIDE_DEFER")) h->defer_side = atoi(e) != 0;
-    h->side_job = new SideJob();
     if (const char *e = getenv("JSDR_FM")) h->use_fm = atoi(e) != 0;
     if (const char *e = getenv("JSDR_SCHED_PREFETCH")) h->prefetch_on = atoi(e) != 0;
     const size_t S = (size_t)nstreams;
@@ -3583,7 +3576,6 @@ int jsdr_bpsk_create(jsdr_bpsk **out, int rate, int nsamples_per_frame, int tuni
               h->cnt_dec.zero() == JSDR_OK && h->y[0].zero() == JSDR_OK && h->y[1].zero() == JSDR_OK &&
               hipStreamCreateWithFlags(&h->tail_stream, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreateWithFlags(&h->ev_matched, hipEventDisableTiming) == hipSuccess &&
-              hipEventCreateWithFlags(&h->ev_gate, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&h->ev_tail_done[0], hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&h->ev_tail_done[1], hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&h->ev_pack_done, hipEventDisableTiming) == hipSuccess;
@@ -3620,9 +3612,6 @@ int jsdr_bpsk_destroy(jsdr_bpsk *h)
         (void)hipStreamDestroy(h->tail_stream);
     }
     if (h->ev_matched) (void)hipEventDestroy(h->ev_matched);
-    if (h->ev_gate) (void)hipEventDestroy(h->ev_gate);
-    delete h->side_job;
-    h->side_job = nullptr;
     if (h->ev_pack_done) (void)hipEventDestroy(h->ev_pack_done);
     for (int i = 0; i < 2; i++)
         if (h->ev_tail_done[i]) (void)hipEventDestroy(h->ev_tail_done[i]);
@@ -3902,7 +3891,6 @@ static int publish_snapshot(jsdr_bpsk *h)
 
 static int sync_last(jsdr_bpsk *h)
 {
-    if (flush_side(h, nullptr, false) != JSDR_OK) return JSDR_ERR;
     JSDR_HIP_TRY(hipStreamSynchronize(h->last_stream));
     if (h->tail_stream) JSDR_HIP_TRY(hipStreamSynchronize(h->tail_stream));
     return JSDR_OK;
@@ -4248,7 +4236,6 @@ extern "C" int jsdr_bpsk_pack_slots(jsdr_bpsk *h, uint8_t *slots_dev, void *stre
     int64_t slot_bytes = 0;
     int slot_bits = 0;
     jsdr_bpsk_slot_info(h, &slot_bytes, nullptr, nullptr, &slot_bits, nullptr);
-    if (flush_side(h, nullptr, false) != JSDR_OK) return JSDR_ERR;
     if (h->overlap && h->tail_pending[h->last_y]) {  // results of the last call come from the side stream
         JSDR_HIP_TRY(hipStreamWaitEvent(as_stream(stream), h->ev_tail_done[h->last_y], 0));
     } else if (!h->overlap && as_stream(stream) != h->last_stream && h->ev_matched) {

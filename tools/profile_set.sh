@@ -51,6 +51,9 @@ step b_1k 300 python bench.py --streams 1024 $B;                         line $O
 step b_acq 300 python bench.py --workload bpsk --fft-acquire --streams 1024 $B;                    line $O/${T}_b_acq.log > $O/${T}_b_acq.json
 step b_acq9600 300 python bench.py --workload bpsk --fft-acquire --bpsk-frame 9600 --streams 1024 $B;  line $O/${T}_b_acq9600.log > $O/${T}_b_acq9600.json
 step b_acq19200 300 python bench.py --workload bpsk --fft-acquire --bpsk-frame 19200 --streams 1024 $B;  line $O/${T}_b_acq19200.log > $O/${T}_b_acq19200.json
+step b_acq4800 300 python bench.py --workload bpsk --fft-acquire --bpsk-frame 4800 --streams 1024 $B;  line $O/${T}_b_acq4800.log > $O/${T}_b_acq4800.json
+# the FUNcube Dongle Pro+ default: 192 kHz, frames of 19200 (JavaAudio.java:59)
+step b_acq19200_192k 300 python bench.py --workload bpsk --fft-acquire --bpsk-frame 19200 --rate 192000 --streams 1024 $B;  line $O/${T}_b_acq19200_192k.log > $O/${T}_b_acq19200_192k.json
 # FFT-acquire at the reference's default frame, all 8192 streams, every stream validated by payload
 step b_acq9600_8k 500 python bench.py --workload bpsk --fft-acquire --bpsk-frame 9600 $B;  line $O/${T}_b_acq9600_8k.log > $O/${T}_b_acq9600_8k.json
 step b_fir65 300 python bench.py --workload fir --fir-taps 65 --streams 1024 $B;  line $O/${T}_b_fir65.log > $O/${T}_b_fir65.json
