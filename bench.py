@@ -59,6 +59,11 @@ KERNEL_BOUND = {"k_fft": "hbm", "k_fir_batch": "hbm", "k_waterfall": "hbm", "k_f
                 "k_demod_front": "valu-issue", "k_demod_fused": "valu-issue", "k_demod_out": "hbm", "k_demod_mean": "latency"}
 
 
+# what the counters say limits a kernel where that is not the roofline it is priced against ("bound" stays the roofline)
+KERNEL_LIMIT = {"k_fft": "latency at 4 waves/SIMD: VALU issues 61 % of the cycles, HBM at 4.35 of the ~5 TB/s a copy of this shape "
+                         "reaches, 46 % of the wave-cycles in s_waitcnt (profiles/r04_sq_counters_k_fft_*.txt)"}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -618,6 +623,8 @@ def main():
                     "note": "side stream, measured while sharing the CUs with the main stream's kernels"}
         e = {"avg_launch_ms": round(ms, 4), "algorithmic_bytes_per_launch": int(v[2] * S * L),
              "frac": round(v[2] * S * L / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "bound": KERNEL_BOUND.get(k, "hbm")}
+        if k in KERNEL_LIMIT:
+            e["binding_limit"] = KERNEL_LIMIT[k]
         if k in FP64_OPS_PER_DS_SAMPLE and a.variant == "exact":
             # the exact-order FIRs cannot be contracted: their separately rounded FP64 operations against the box's
             # measured issue rate (tools/microbench_fp64.hip, profiles/r01_fp64_microbench.txt)
@@ -628,7 +635,7 @@ def main():
     # the dominant kernel is "binding_limit" (and per kernel in per_kernel[...]["bound"])
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "binding_limit": KERNEL_BOUND.get(dom, "hbm"),
+                "binding_limit": KERNEL_LIMIT.get(dom, KERNEL_BOUND.get(dom, "hbm")),
                 "avg_launch_ms": round(dom_ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes),
                 "kernels_ms_per_step": {k: round(v[0] / v[1], 4) for k, v in sorted(kern.items())},
                 # every critical-path kernel against the same roofline (the dominant one is the slowest AS MEASURED, i.e.
