@@ -130,12 +130,26 @@ __device__ __forceinline__ void dit_first3_i16(double2 (&v)[8], const double2 *_
 
 // one LDS round trip: G stages starting at wing HALF0 over the whole frame.  REAL_OUT: scale and store only
 // the real part (last pass of the inverse transform; :462 reads nothing else).
+// A pass whose groups span at most 512 elements (HALF0 << G <= 512) is WAVE-LOCAL when the pass before it was one too (or
+// was the first pass): thread q's group lies in elements [512 (q >> 6), 512 (q >> 6) + 512), the block its own wave wrote
+// -- no other wave's stores are read, so the wave's own LDS order is all the synchronisation there is to do.
 template <int G, int HALF0, bool INVERSE, int LOGN, bool REAL_OUT>
 __device__ __forceinline__ void dit_pass(double2 *X, const double2 *TsL, const double2 *__restrict__ tsg, int tid, double norm)
 {
     constexpr int M = 1 << G;
     constexpr int GROUPS = 1 << (LOGN - G);
+    constexpr bool WAVE_LOCAL = (HALF0 << G) <= 512 && GROUPS >= 256;
+#ifdef JSDR_X_FFT_WGBAR  // (probe: workgroup barriers in front of every pass, as before round 4)
     __syncthreads();
+#else
+    if constexpr (WAVE_LOCAL) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+        __syncthreads();
+    }
+#endif
 #pragma unroll
     for (int q0 = 0; q0 < GROUPS; q0 += 256) {
         int q = q0 + tid;
@@ -158,6 +172,49 @@ __device__ __forceinline__ void dit_pass(double2 *X, const double2 *TsL, const d
                 x0[STEP * m].x = v[m].x * norm;
             else
                 x0[STEP * m] = v[m];
+        }
+    }
+}
+
+// The LAST pass of the FORWARD transform at LOGN = 11 (wings H = 512 and 2H = 1024; group j holds x[j + H m], m = 0..3, and
+// ends as bins j, j + H, j + 2H, j + 3H) restricted to the bins below need_end that anybody reads (|X| over the searched
+// quarter band, the 204 bins around the centre: need_end = end + 102 = 614 / 1126).  A bin nobody reads is neither computed
+// nor stored; the ones that are come from the same operations in the same order as dit_stages<2, H> performs them.  Lower
+// half band: 24 instead of 40 operations and one store instead of four for 410 of the 512 groups.
+template <int LOGN>
+__device__ __forceinline__ void dit_last2_band(double2 *X, const double2 *__restrict__ tsg, int tid, int need_end)
+{
+    constexpr int H = 1 << (LOGN - 2);
+    constexpr int STEP = H + H / 8;
+    static_assert(H > kLdsTwiddleWing && H % 256 == 0, "wide stages: twiddles from the global table");
+    auto bf = [](const double2 aq, const double2 bq, const double2 wv, bool want_b, double2 &ao, double2 &bo) {
+        const double wr = wv.x, wi = wv.y;
+        const double p1 = wr * bq.x, p2 = wi * bq.y, p3 = wr * bq.y, p4 = wi * bq.x;
+        const double tr = p1 - p2;
+        const double ti = p3 + p4;
+        ao = make_double2(aq.x + tr, aq.y + ti);
+        if (want_b) bo = make_double2(aq.x - tr, aq.y - ti);
+    };
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < H / 256; it++) {
+        int j = it * 256 + tid;
+        asm volatile("" : "+v"(j));
+        const bool n1 = j + H < need_end, n2 = j + 2 * H < need_end, n3 = j + 3 * H < need_end;
+        double2 *x0 = X + xpad(j);
+        const double2 v0 = x0[0], v1 = x0[STEP], v2 = x0[2 * STEP], v3 = x0[3 * STEP];
+        const double2 w1 = tsg[(unsigned)(H - 1 + j)];
+        double2 a01, b01 = v0, a23, b23 = v2;
+        bf(v0, v1, w1, n1 || n3, a01, b01);  // wing H
+        bf(v2, v3, w1, n1 || n3, a23, b23);
+        double2 o0, o2 = a01, o1 = b01, o3 = b01;
+        bf(a01, a23, tsg[(unsigned)(2 * H - 1 + j)], n2, o0, o2);  // wing 2H
+        x0[0] = o0;
+        if (n2) x0[2 * STEP] = o2;
+        if (n1 || n3) {
+            bf(b01, b23, tsg[(unsigned)(2 * H - 1 + j + H)], n3, o1, o3);
+            x0[STEP] = o1;
+            if (n3) x0[3 * STEP] = o3;
         }
     }
 }
@@ -208,9 +265,10 @@ __device__ __forceinline__ void dit_pass_real_compact(double2 *X, const double2 
 
 // the passes after the first: wings 8,64,512 (and what is left)
 // COMPACT (inverse only): the last pass is dit_pass_real_compact
+// need_end > 0 (forward transform, LOGN = 11): only the bins below need_end are read afterwards
 template <bool INVERSE, int LOGN, bool SKIP8, bool COMPACT = false>
 __device__ __forceinline__ void fft_rest(double2 *X, const double2 *TsL, const double2 *__restrict__ tsg, int tid, double norm,
-                                         const double *hist = nullptr)
+                                         const double *hist = nullptr, int need_end = 0)
 {
     static_assert(LOGN >= 10 && LOGN <= 13, "frame sizes 1024..8192");
     if (!SKIP8) dit_pass<3, 8, INVERSE, LOGN, false>(X, TsL, tsg, tid, norm);
@@ -231,7 +289,12 @@ __device__ __forceinline__ void fft_rest(double2 *X, const double2 *TsL, const d
         dit_pass<3, 64, INVERSE, LOGN, false>(X, TsL, tsg, tid, norm);
         if constexpr (COMPACT)
             dit_pass_real_compact<2, 512, LOGN>(X, TsL, tsg, tid, norm, hist);
-        else
+        else if constexpr (!INVERSE) {
+            if (need_end > 0)
+                dit_last2_band<LOGN>(X, tsg, tid, need_end);
+            else
+                dit_pass<2, 512, false, LOGN, false>(X, TsL, tsg, tid, norm);
+        } else
             dit_pass<2, 512, INVERSE, LOGN, INVERSE>(X, TsL, tsg, tid, norm);
     } else {
         dit_pass<3, 64, INVERSE, LOGN, false>(X, TsL, tsg, tid, norm);
@@ -364,7 +427,11 @@ __global__ __launch_bounds__(256, (LOGN <= 11 ? 4 : (LOGN == 12 ? 2 : 1))) void 
             }
         }
         PHASE(0)
+#ifdef JSDR_X_FFT_NOBAND  // (probe: the forward transform's last pass in full)
         fft_rest<false, LOGN, false>(X, TsL, tsg, tid, norm);
+#else
+        fft_rest<false, LOGN, false>(X, TsL, tsg, tid, norm, nullptr, LOGN == 11 ? end + 102 : 0);  // bins < end + 102 are read
+#endif
         PHASE(1)
         // ---- |X| (:425-427), for the bins the boxcar reads: [beg+24, end-24) -- a quarter band, not the N/2 bins the
         // reference fills (the double-precision root is ~28 instructions a bin)
