@@ -3399,15 +3399,19 @@ int jsdr_bpsk_create(jsdr_bpsk **out, int rate, int nsamples_per_frame, int tuni
     const int decim = rate / 9600;  // adsc.rate/DOWN_SAMPLE_RATE (:476), int division
     // any rate the reference would take (:476: adsc.rate / DOWN_SAMPLE_RATE, whatever it is); 4, 5, 10, 20 -- the rates
     // java-sdr has defaults for -- take the specialised front ends, everything else the one-thread-per-output kernel.
-    // FFT-acquire mode sizes its per-thread output lists for a decimation of at least 4.
-    JSDR_REQUIRE(!do_fft || decim >= 4, "jsdr_bpsk_create: FFT-acquire mode needs a rate of at least 38400 Hz (decimation %d < 4)", decim);
+    // FFT-acquire mode: the power-of-two and the 2 m front ends size their per-thread output lists for a decimation of at
+    // least 4; the mixed-radix one (any other frame up to 9600 samples) loops and takes any.
+    JSDR_REQUIRE(!do_fft || decim >= 4 || fftm_supported(nsamples_per_frame),
+                 "jsdr_bpsk_create: FFT-acquire mode with a power-of-two frame or a frame above 9600 samples needs a rate of at "
+                 "least 38400 Hz (decimation %d < 4)", decim);
     JSDR_REQUIRE(nsamples_per_frame > 0 && nstreams > 0 && nstreams <= 65535, "jsdr_bpsk_create: bad geometry");
     if (max_batch_samples < nsamples_per_frame) max_batch_samples = nsamples_per_frame;
     const bool fft_pow2 = nsamples_per_frame >= 1024 && nsamples_per_frame <= 8192 &&
                           (nsamples_per_frame & (nsamples_per_frame - 1)) == 0;
     JSDR_REQUIRE(!do_fft || fft_pow2 || fftm_supported(nsamples_per_frame) || fft2x_supported(nsamples_per_frame),
-                 "jsdr_bpsk_create: FFT-acquire mode needs a frame of 1024 / 2048 / 4096 / 8192 samples, or n = 2^a 3^b 5^c with "
-                 "n %% 16 == 0 and 1024 < n <= 9600 such as the default 9600 / 4800, or twice such a frame (19200) (got %d)",
+                 "jsdr_bpsk_create: FFT-acquire mode needs a frame of 1024 / 2048 / 4096 / 8192 samples, or n = 2^a 3^b 5^c 7^d with "
+                 "1024 < n <= 9600 such as the default 9600 / 4800 or a 44.1 kHz card's 4410, or twice a 2^a 3^b 5^c frame that is a "
+                 "multiple of 16 (19200) (got %d)",
                  nsamples_per_frame);
     JSDR_REQUIRE(bit_clock_is_regular(), "jsdr_bpsk_create: bit clock schedule is not the regular 8-cycle");
     if (fec_prepare() != JSDR_OK) return JSDR_ERR;

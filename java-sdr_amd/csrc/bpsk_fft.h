@@ -90,7 +90,7 @@ __device__ __forceinline__ void boxcar_pair(const double2 *w, double &a0, double
 }
 
 int launch_front_fft(const FftFrontArgs &a, int nstreams, hipStream_t st);
-// frames that are not a power of two (bpsk_fftm.hip): n = 2^a 3^b 5^c, 1024 < n <= 9600, n % 16 == 0
+// frames that are not a power of two (bpsk_fftm.hip): n = 2^a 3^b 5^c 7^d, 1024 < n <= 9600
 bool fftm_supported(int n);
 void fftm_twiddles(std::vector<double2> &w, int n, int *np_out, int *rad, int *tw_off);
 int launch_front_fftm(const FftFrontArgs &a, int np, const int *rad, const int *tw_off, int nstreams, hipStream_t st);

@@ -119,8 +119,28 @@ __device__ __forceinline__ void dft_r(double2 *v)
         v[0] = cdadd(v[0], t1);
         v[1] = make_double2(t2.x + t3.y, t2.y - t3.x);
         v[2] = make_double2(t2.x - t3.y, t2.y + t3.x);
+    } else if constexpr (R == 7) {
+        // (round 4: n = 4410 = 2 3^2 5 7^2, the frame of a 44.1 kHz sound card)
+        const double C1 = 0.62348980185873353053, C2 = -0.22252093395631440429, C3 = -0.90096886790241912624;  // cos(2 pi k/7)
+        const double S1 = 0.78183148246802980871, S2 = 0.97492791218182360702, S3 = 0.43388373911755812048;   // sin(2 pi k/7)
+        const double2 a1 = cdadd(v[1], v[6]), a2 = cdadd(v[2], v[5]), a3 = cdadd(v[3], v[4]);
+        const double2 b1 = cdsub(v[1], v[6]), b2 = cdsub(v[2], v[5]), b3 = cdsub(v[3], v[4]);
+        const double2 x0 = v[0];
+        const double2 m1 = make_double2(((x0.x + C1 * a1.x) + C2 * a2.x) + C3 * a3.x, ((x0.y + C1 * a1.y) + C2 * a2.y) + C3 * a3.y);
+        const double2 m2 = make_double2(((x0.x + C2 * a1.x) + C3 * a2.x) + C1 * a3.x, ((x0.y + C2 * a1.y) + C3 * a2.y) + C1 * a3.y);
+        const double2 m3 = make_double2(((x0.x + C3 * a1.x) + C1 * a2.x) + C2 * a3.x, ((x0.y + C3 * a1.y) + C1 * a2.y) + C2 * a3.y);
+        const double2 n1 = make_double2((S1 * b1.x + S2 * b2.x) + S3 * b3.x, (S1 * b1.y + S2 * b2.y) + S3 * b3.y);
+        const double2 n2 = make_double2((S2 * b1.x - S3 * b2.x) - S1 * b3.x, (S2 * b1.y - S3 * b2.y) - S1 * b3.y);
+        const double2 n3 = make_double2((S3 * b1.x - S1 * b2.x) + S2 * b3.x, (S3 * b1.y - S1 * b2.y) + S2 * b3.y);
+        v[0] = make_double2(((x0.x + a1.x) + a2.x) + a3.x, ((x0.y + a1.y) + a2.y) + a3.y);
+        v[1] = make_double2(m1.x + n1.y, m1.y - n1.x);
+        v[6] = make_double2(m1.x - n1.y, m1.y + n1.x);
+        v[2] = make_double2(m2.x + n2.y, m2.y - n2.x);
+        v[5] = make_double2(m2.x - n2.y, m2.y + n2.x);
+        v[3] = make_double2(m3.x + n3.y, m3.y - n3.x);
+        v[4] = make_double2(m3.x - n3.y, m3.y + n3.x);
     } else {
-        static_assert(R == 5, "radices 2, 3, 4, 5");
+        static_assert(R == 5, "radices 2, 3, 4, 5, 7");
         const double C1 = 0.30901699437494742410, C2 = -0.80901699437494742410;  // cos(2 pi/5), cos(4 pi/5)
         const double S1 = 0.95105651629515357212, S2 = 0.58778525229247312917;   // sin(2 pi/5), sin(4 pi/5)
         const double2 a1 = cdadd(v[1], v[4]), a2 = cdadd(v[2], v[3]), b1 = cdsub(v[1], v[4]), b2 = cdsub(v[2], v[3]);
@@ -815,6 +835,8 @@ __device__ __forceinline__ void fm_forward(LdsArr X, const double2 *twL, const F
             fm_pass<2>(X, tw, a.f.n, P, a.pmagic[p], tid);
         else if (r == 3)
             fm_pass<3>(X, tw, a.f.n, P, a.pmagic[p], tid);
+        else if (r == 7)
+            fm_pass<7>(X, tw, a.f.n, P, a.pmagic[p], tid);
         else
             fm_pass<5>(X, tw, a.f.n, P, a.pmagic[p], tid);
         P *= r;
@@ -1592,14 +1614,21 @@ int fftm_radices(int n, int *rad)
         rad[c++] = 5;
         n /= 5;
     }
+    while (n % 7 == 0 && c < FM_MAXPASS) {
+        rad[c++] = 7;
+        n /= 7;
+    }
     return n == 1 ? c : 0;
 }
 
 bool fftm_supported(int n)
 {
     int rad[FM_MAXPASS];
-    // the band arithmetic needs n/4 > 150 and beg = n/4 a multiple of 4; the image must fit the LDS
-    return n >= 1024 && n <= FM_NMAX && (n % 16) == 0 && (n & (n - 1)) != 0 && fftm_radices(n, rad) > 0;
+    // the band arithmetic (:429-443: beg = n/4 or 0, end = n/2 or n/4 in Java's integer division, a 100-wide window and 75
+    // bins of margin either side) needs n/4 > 150; the image must fit the LDS.  Round 4: any such n = 2^a 3^b 5^c 7^d -- n need
+    // not be a multiple of 16 (the 16-byte boxcar reads are aligned relative to the band's own start), so the 4410-sample
+    // frame of a 44.1 kHz sound card is in
+    return n >= 1024 && n <= FM_NMAX && (n & (n - 1)) != 0 && fftm_radices(n, rad) > 0;
 }
 
 // per-pass tables T[m] = exp(-2 pi i m/(P r)), m < P r: long double + one rounding, exact on the axes -- the same
@@ -1675,7 +1704,12 @@ int launch_front_fftm(const FftFrontArgs &a, int np, const int *rad, const int *
 }
 
 // frames of n = 2 m samples with m an LDS-sized mixed-radix frame (n = 19200: m = 9600)
-bool fft2x_supported(int n) { return n > FM_NMAX && (n % 2) == 0 && fftm_supported(n / 2); }
+// (the halves' passes are the blocked ones of the 2^a 3^b 5^c frames: m a multiple of 16 without a factor 7)
+bool fft2x_supported(int n)
+{
+    const int m = n / 2;
+    return n > FM_NMAX && (n % 2) == 0 && (m % 16) == 0 && (m % 7) != 0 && fftm_supported(m);
+}
 
 // the m-point tables (fftm_twiddles) followed by the c = 1 tables U_p[(j-1) P' + k'] = T_{2 P' r}[(2 k' + 1) j]
 void fft2x_twiddles(std::vector<double2> &w, int n, int *np_out, int *rad, int *tw_off, int *tw1_off)

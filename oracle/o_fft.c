@@ -73,7 +73,7 @@ void jo_fft_twiddles_f64(double *w, int n)
  * The HIP double FFT (csrc/bpsk_fft.hip) performs the same butterflies on the same
  * twiddle table, so both are bit-identical.  PARITY UNPINNED vs JTransforms.          */
 /* ---- non power-of-two frames (n = 2^a 3^b 5^c, e.g. the reference's default 9600 = blen/size):
- * Stockham autosort passes, radices 4,4,..,(2),3..,5.. in this order (frames above 9600 samples: one radix-2 pass
+ * Stockham autosort passes, radices 4,4,..,(2),3..,5..,7.. in this order (frames above 9600 samples: one radix-2 pass
  * first, see jo_fft_mixed_radices); pass with radix r and P = product of the
  * earlier radices takes butterfly b (k = b mod P) from in[b + j*n/r], j < r, multiplies input j >= 1 by the
  * table entry T[k*j] = exp(-2 pi i k j/(P r)) (cosl/sinl rounded once; exact on the axes), applies the fixed-order
@@ -107,6 +107,29 @@ static void dft_r(cd_t *v, int r)
         v[0] = cadd(v[0], t1);
         v[1] = cd(t2.x + t3.y, t2.y - t3.x);
         v[2] = cd(t2.x - t3.y, t2.y + t3.x);
+    } else if (r == 7) {
+        /* 7 (round 4: 44.1 kHz sound cards give n = rate/10 = 4410 = 2 3^2 5 7^2, the reference's own sine4410.wav):
+         * the radix-5 scheme one size up.  a_k = v[k] + v[7-k], b_k = v[k] - v[7-k];
+         *   out[j], out[7-j] = m_j -/+ i n_j,  m_j = ((x0 + C(j) a1) + C(2j) a2) + C(3j) a3,  n_j = (S(j) b1 + S(2j) b2) + S(3j) b3
+         * with C(k) = cos(2 pi k/7), S(k) = sin(2 pi k/7), indices mod 7 (C(7-k) = C(k), S(7-k) = -S(k)); sums left to right */
+        const double C1 = 0.62348980185873353053, C2 = -0.22252093395631440429, C3 = -0.90096886790241912624;
+        const double S1 = 0.78183148246802980871, S2 = 0.97492791218182360702, S3 = 0.43388373911755812048;
+        cd_t a1 = cadd(v[1], v[6]), a2 = cadd(v[2], v[5]), a3 = cadd(v[3], v[4]);
+        cd_t b1 = csub(v[1], v[6]), b2 = csub(v[2], v[5]), b3 = csub(v[3], v[4]);
+        cd_t x0 = v[0];
+        cd_t m1 = cd(((x0.x + C1 * a1.x) + C2 * a2.x) + C3 * a3.x, ((x0.y + C1 * a1.y) + C2 * a2.y) + C3 * a3.y);
+        cd_t m2 = cd(((x0.x + C2 * a1.x) + C3 * a2.x) + C1 * a3.x, ((x0.y + C2 * a1.y) + C3 * a2.y) + C1 * a3.y);
+        cd_t m3 = cd(((x0.x + C3 * a1.x) + C1 * a2.x) + C2 * a3.x, ((x0.y + C3 * a1.y) + C1 * a2.y) + C2 * a3.y);
+        cd_t n1 = cd((S1 * b1.x + S2 * b2.x) + S3 * b3.x, (S1 * b1.y + S2 * b2.y) + S3 * b3.y);
+        cd_t n2 = cd((S2 * b1.x - S3 * b2.x) - S1 * b3.x, (S2 * b1.y - S3 * b2.y) - S1 * b3.y);
+        cd_t n3 = cd((S3 * b1.x - S1 * b2.x) + S2 * b3.x, (S3 * b1.y - S1 * b2.y) + S2 * b3.y);
+        v[0] = cd(((x0.x + a1.x) + a2.x) + a3.x, ((x0.y + a1.y) + a2.y) + a3.y);
+        v[1] = cd(m1.x + n1.y, m1.y - n1.x);
+        v[6] = cd(m1.x - n1.y, m1.y + n1.x);
+        v[2] = cd(m2.x + n2.y, m2.y - n2.x);
+        v[5] = cd(m2.x - n2.y, m2.y + n2.x);
+        v[3] = cd(m3.x + n3.y, m3.y - n3.x);
+        v[4] = cd(m3.x - n3.y, m3.y + n3.x);
     } else { /* 5 */
         const double C1 = 0.30901699437494742410, C2 = -0.80901699437494742410; /* cos(2 pi/5), cos(4 pi/5) */
         const double S1 = 0.95105651629515357212, S2 = 0.58778525229247312917; /* sin(2 pi/5), sin(4 pi/5) */
@@ -124,7 +147,7 @@ static void dft_r(cd_t *v, int r)
     }
 }
 
-/* radix list for n = 2^a 3^b 5^c; returns the count (0: unsupported) */
+/* radix list for n = 2^a 3^b 5^c 7^d; returns the count (0: unsupported) */
 int jo_fft_mixed_radices(int n, int *rad)
 {
     int c = 0;
@@ -137,6 +160,7 @@ int jo_fft_mixed_radices(int n, int *rad)
     if (n % 2 == 0) { rad[c++] = 2; n /= 2; }
     while (n % 3 == 0) { rad[c++] = 3; n /= 3; }
     while (n % 5 == 0) { rad[c++] = 5; n /= 5; }
+    while (n % 7 == 0) { rad[c++] = 7; n /= 7; }
     return n == 1 ? c : 0;
 }
 
@@ -175,7 +199,7 @@ static void fft_f64_mixed_forward(cd_t *a, int n)
         jo_fft_mixed_table(t, len);
         for (int bf = 0; bf < nb; bf++) {
             const int k = bf % P;
-            cd_t v[5];
+            cd_t v[7];
             for (int j = 0; j < r; j++) {
                 v[j] = in[bf + j * nb];
                 if (j >= 1 && P > 1) v[j] = cmul(v[j], cd(t[2 * (k * j)], t[2 * (k * j) + 1]));

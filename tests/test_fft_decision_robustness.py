@@ -35,6 +35,8 @@ def corpus():
     out.append(("2048 noise only", 96000, 2048, 0, rng.integers(-12000, 12000, 2 * n).astype(np.int16)))
     out.append(("9600 default frame", 96000, 9600, 0, O.make_dbpsk_stream(43, 2, 9600 * 60, noise_sigma=900.0)[0]))
     out.append(("19200 FCD Pro+ frame", 192000, 19200, 0, O.make_dbpsk_stream(44, 3, 19200 * 30, rate=192000, noise_sigma=900.0)[0]))
+    out.append(("4410 (44.1 kHz sound card)", 44100, 4410, 0,
+                O.make_dbpsk_stream(45, 4, 4410 * 60, rate=44100, carrier_hz=6000.0, noise_sigma=900.0)[0]))
     raw = np.fromfile(os.path.join(GOLD, "sine4410.raw"), dtype="<i2")
     out.append(("sine4410.raw", 96000, 2048, 0, raw[:(raw.size // 4096) * 4096]))
     return out

@@ -340,7 +340,13 @@ def test_bpsk_fft_mode_default_frames_carrier_at_the_band_edges(blen, rate, do_u
 
 
 @pytest.mark.parametrize("nsf,rate", [(9600, 48000), (9600, 192000), (19200, 96000), (19200, 48000), (4800, 96000), (4800, 192000),
-                                      (2048, 48000), (2048, 192000), (4096, 48000)])
+                                      (2048, 48000), (2048, 192000), (4096, 48000),
+                                      # round 4: frames with factors of 7 and frames that are not multiples of 16 -- 4410 is what a
+                                      # 44.1 kHz sound card delivers (JavaAudio.java:59; the reference's own sine4410.wav), 8820 the
+                                      # same at 88.2 kHz (decimation 9), 3430 = 2.5.7^3, 7000 = 2^3.5^3.7, 2646 = 2.3^3.7^2
+                                      (4410, 44100), (8820, 88200), (3430, 48000), (7000, 96000), (2646, 44100),
+                                      # ... and rates below 38.4 kHz (decimation 3, 2, 1), which only the mixed-radix front end takes
+                                      (3200, 32000), (2205, 22050), (1200, 9600)])
 def test_bpsk_fft_mode_frames_at_other_decimations(nsf, rate):
     """the front ends' RxDownSample reads the inverse's real samples as a compact array (round 3): 14 aligned 16-byte reads
     per window at an even decimation, single reads at an odd one (48 kHz: 5), two aligned runs at n = 19200 when the
@@ -397,14 +403,14 @@ def test_bpsk_fft_mode_rejects_partial_frames_and_odd_sizes():
     with pytest.raises(J.JsdrError):
         J.Bpsk(nstreams=1, do_fft=1, blen=4 * 38400, rate=192000)  # n = 38400: neither an LDS-sized frame nor twice one
     with pytest.raises(J.JsdrError):
-        J.Bpsk(nstreams=1, do_fft=1, blen=4 * 7000)  # 7000 = 2^3 5^3 7: no radix-7
+        J.Bpsk(nstreams=1, do_fft=1, blen=4 * 1100)  # 1100 = 2^2 5^2 11: no radix-11 pass (factors 2, 3, 5, 7 only)
 
 
 def test_bpsk_api_errors():
     with pytest.raises(J.JsdrError):
         J.Bpsk(rate=8000)
     with pytest.raises(J.JsdrError):
-        J.Bpsk(rate=32000, do_fft=1)  # FFT-acquire mode needs a decimation of at least 4
+        J.Bpsk(rate=32000, do_fft=1)  # FFT-acquire mode with a power-of-two frame (2048 here) needs a decimation of at least 4
     d = J.Bpsk(nstreams=2)
     with pytest.raises(J.JsdrError):
         d.receive(np.zeros(4096, np.float32))  # receive() is the 1-stream form

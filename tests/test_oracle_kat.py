@@ -396,9 +396,11 @@ def test_oracle_mixed_radix_f64_transform_against_numpy():
     rad = np.zeros(32, np.int32)
     assert L.jo_fft_mixed_radices(9600, rad.ctypes.data) == 7 and list(rad[:7]) == [4, 4, 4, 2, 3, 5, 5]
     assert L.jo_fft_mixed_radices(4800, rad.ctypes.data) == 6 and list(rad[:6]) == [4, 4, 4, 3, 5, 5]
-    assert L.jo_fft_mixed_radices(7000, rad.ctypes.data) == 0  # a factor 7
+    assert L.jo_fft_mixed_radices(7000, rad.ctypes.data) == 6 and list(rad[:6]) == [4, 2, 5, 5, 5, 7]  # round 4: radix 7
+    assert L.jo_fft_mixed_radices(4410, rad.ctypes.data) == 6 and list(rad[:6]) == [2, 3, 3, 5, 7, 7]  # a 44.1 kHz sound card's frame
+    assert L.jo_fft_mixed_radices(1100, rad.ctypes.data) == 0  # a factor 11
     rng = np.random.default_rng(12)
-    for n in (9600, 4800, 2400, 60, 15, 6):
+    for n in (9600, 4800, 2400, 60, 15, 6, 4410, 7000, 49, 7, 2646):
         x = rng.standard_normal(2 * n)
         a = x.copy()
         L.jo_fft_f64(a.ctypes.data, n, 0, 0)
