@@ -1,0 +1,12 @@
+#!/bin/bash
+# tools/ab_args.sh "<common bench args>" "<args A>" "<args B>" ... -- one bench line under several argument sets in ONE session, each twice, interleaved
+mkdir -p gpurun_out; export TMPDIR=/tmp
+C=$1; shift
+for rep in 1 2; do
+i=0
+for A in "$@"; do
+  i=$((i+1))
+  timeout -k 10 300 python bench.py $C $A --no-cpu-baseline > "gpurun_out/abargs_$i.log" 2>&1
+  echo -n "[$A] "; python3 tools/kms.py "gpurun_out/abargs_$i.log"
+done
+done
