@@ -3439,10 +3439,11 @@ int jsdr_bpsk_create(jsdr_bpsk **out, int rate, int nsamples_per_frame, int tuni
     // one stream (the receive() drop-in): nothing of another stream to run beside the tail, and the hop to the side
     // stream costs a cross-stream event per call
     if (nstreams == 1) h->overlap = false;
-    // FFT-acquire with a mixed-radix frame (4800 / 9600 / 19200): the front end holds a CU's whole LDS with ONE workgroup, so
-    // the side stream's kernels cannot run beside it -- they only delay it (measured, tools/ab_overlap_acq.sh: 14.0 vs 14.9 ms
-    // a step at n = 9600, 17.5 vs 18.1 at 4800, no difference at 19200)
-    if (do_fft && !fft_pow2) h->overlap = false;
+    // FFT-acquire mode: the front ends hold a CU's whole LDS (one workgroup of a mixed-radix frame, four of a power-of-two
+    // frame), so the side stream's kernels cannot run beside them -- they starve and delay it (measured, one session each,
+    // tools/ab_overlap_acq.sh / ab_env.sh: a step 14.0 vs 14.9 ms at n = 9600, 17.5 vs 18.1 at 4800, no difference at 19200;
+    // round 4: 11.4 vs 12.15 at n = 2048 -- k_sync_t takes 5.1 ms beside k_front_fft against 0.11 alone -- 11.6 vs 12.5 at 4096)
+    if (do_fft) h->overlap = false;
     if (const char *e = getenv("JSDR_NO_OVERLAP")) h->overlap = atoi(e) == 0;
     if (const char *e = getenv("JSDR_FM")) h->use_fm = atoi(e) != 0;
     if (const char *e = getenv("JSDR_SCHED_PREFETCH")) h->prefetch_on = atoi(e) != 0;
