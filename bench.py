@@ -75,6 +75,9 @@ def parse():
     ap.add_argument("--streams", type=int, default=0, help="streams PER GPU (weak scaling) instead of --total-streams")
     ap.add_argument("--variant", default="exact", choices=["exact", "fast"],
                     help="demodulator arithmetic: exact-order FP64 (default) or FMA-contracted FP64 with margin-certified decisions")
+    ap.add_argument("--serial", action="store_true",
+                    help="pipeline workload: PSD then demodulator on ONE stream, each kernel with the whole chip (the default until round 4). "
+                         "Default now: side by side on two streams with the CU shares set (jsdr_fft_set_cu_share 2, jsdr_bpsk_set_cu_share 1)")
     ap.add_argument("--psd-stream", action="store_true",
                     help="PSD kernel on a HIP stream of its own beside the demodulator (measured: within 2 %% of the default, "
                          "one after the other on one stream, whose per-kernel times are not inflated by the overlap)")
@@ -328,6 +331,9 @@ def stream_text(a, psd_own_stream, dem):
     """what ran where; the side-stream part is the handle's own answer (jsdr_bpsk_side_stream), not a copy of its rule"""
     side = "tail/sync/FEC on the handle's side stream" if (dem is not None and dem.side_stream()) else "tail/sync/FEC on the same stream"
     if a.workload == "pipeline":
+        if psd_own_stream and not a.psd_stream:
+            return ("PSD kernel (2 persistent workgroups per CU) and the demodulator's front-end kernel (1 per CU) side by side on two "
+                    "streams; ") + side
         return ("PSD on its own HIP stream beside the demodulator; " if psd_own_stream else "PSD then demodulator on one stream; ") + side
     if a.workload == "bpsk":
         return ("front end, matched filter on the caller's stream; " if a.fft_acquire else "") + side
@@ -476,7 +482,15 @@ def main():
     # every kernel of the timed loop goes to an explicit stream (the NULL stream would serialise with blocking streams)
     main_stream = J.Stream()
     ms_ = main_stream.ptr
-    psd_stream = J.Stream() if (fft is not None and dem is not None and a.psd_stream) else None
+    # pipeline default: the PSD kernel (memory-latency bound) and the demodulator's front-end kernel (FP64-issue bound) side by
+    # side, each held to its share of every CU (2 + 1 persistent workgroups: what one CU's registers and LDS take) -- left
+    # alone each fills the chip and the two streams just run one after the other
+    side_by_side = (a.workload == "pipeline" and fft is not None and dem is not None and not a.serial and not a.psd_stream
+                    and not a.fft_acquire and RATE == 96000)
+    if side_by_side:
+        fft.set_cu_share(2)
+        dem.set_cu_share(1)
+    psd_stream = J.Stream() if (fft is not None and dem is not None and (a.psd_stream or side_by_side)) else None
     ps = psd_stream.ptr if psd_stream else ms_
     fir_taps = d_fir = None
     if a.workload == "fir":
@@ -642,6 +656,12 @@ def main():
                 # with whatever the side stream's kernels took from it)
                 "per_kernel": {k: kernel_entry(k, v) for k, v in sorted(kern.items())
                                if v[0] / v[1] > 0.02 * dom_ms}}  # (not the helper kernels)
+    if side_by_side:
+        # k_fft and k_fm run CONCURRENTLY: each one's launch duration is the time it shared the chip with the other, not a time
+        # it had the HBM to itself -- the step is what counts: its algorithmic bytes against its duration
+        roofline["concurrent_kernels"] = ["k_fft", dem.front_kernel_name()]
+        roofline["step_algorithmic_bytes"] = int(BYTES_PER_SAMPLE["pipeline"] * S * L)
+        roofline["step_frac"] = round(BYTES_PER_SAMPLE["pipeline"] * S * L / (dt / a.steps) / 1e9 / HBM_PEAK_GBS, 4)
     if a.workload in ("pipeline", "bpsk") and not a.fft_acquire:
         roofline["note"] = ("the exact-order demodulator is FP64-issue bound, not HBM bound: see per_kernel[k_fm].fp64_issue_frac "
                             f"(368 separately rounded operations per 9600 Hz sample against {FP64_ISSUE_TOPS} T lane-ops/s measured)")

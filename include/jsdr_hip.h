@@ -73,6 +73,15 @@ int jsdr_fft_receive_f32(jsdr_fft *h, const float *iq_host, float *psd_host);   
 int jsdr_fft_receive_i16(jsdr_fft *h, const int16_t *raw_host, int ic, int qc,
                          float *psd_host);                                          /* IRawHandler.receive(byte[]) + a0 */
 int jsdr_fft_batch_f32(jsdr_fft *h, const float *iq_dev, int64_t nframes, float *psd_dev, void *stream);
+/* Running fft.receive and FUNcubeBPSKDemod.receive over the same batch SIDE BY SIDE (jsdr.java:476,482 feeds both from
+ * one audio buffer): the PSD kernel is bound by memory latency, the demodulator's front-end kernel by FP64 issue, and
+ * each, left alone, fills every CU -- launched on two streams they simply run one after the other.  With a share set on
+ * both handles the batch kernels are launched as that many PERSISTENT workgroups per CU (0 = the default: all a CU takes):
+ * jsdr_fft_set_cu_share(f, 2) + jsdr_bpsk_set_cu_share(h, 1) is the split that fits one CU's registers and LDS (2 x 128 +
+ * 2 x 120 VGPRs per SIMD, 2 x 40 + 69.5 KB), both kernels resident from the start whichever stream gets there first.
+ * Results are unchanged (bit for bit); measured on 8192 streams x 2^20 samples: 33.8 ms a step against 35.0 one after the
+ * other (DESIGN.md "the step").  A handle used on its own should keep the default. */
+int jsdr_fft_set_cu_share(jsdr_fft *h, int wgs_per_cu);
 int jsdr_fft_batch_i16(jsdr_fft *h, const int16_t *raw_dev, int64_t nframes, int ic, int qc,
                        float *psd_dev, void *stream);
 /* complex spectrum only (float2[n] per frame), for the 1e-5 FFT parity tests */
@@ -171,6 +180,7 @@ int jsdr_bpsk_receive_i16(jsdr_bpsk *h, const int16_t *raw_host, int ic, int qc)
  * multiple of nsamples_per_frame in FFT mode; asynchronous on `stream`.                        */
 int jsdr_bpsk_batch_i16(jsdr_bpsk *h, const int16_t *raw_dev, int64_t stream_stride_i16,
                         int64_t nsamples, int ic, int qc, void *stream);
+int jsdr_bpsk_set_cu_share(jsdr_bpsk *h, int wgs_per_cu); /* see jsdr_fft_set_cu_share; applies to the tune-mode front-end kernel */
 /* wait until every kernel of the calls made so far has finished (the 9600 Hz tail and the FEC decoder run on
  * an internal side stream so that they overlap the next call's front end; the getters below call this). */
 int jsdr_bpsk_sync(jsdr_bpsk *h);

@@ -203,6 +203,9 @@ class Fft:
         _check(lib().jsdr_fft_receive_i16(self.h, _addr(raw), ic, qc, _addr(psd)), "jsdr_fft_receive_i16")
         return psd
 
+    def set_cu_share(self, wgs_per_cu):
+        _check(lib().jsdr_fft_set_cu_share(self.h, int(wgs_per_cu)), "jsdr_fft_set_cu_share")
+
     def batch_i16(self, raw_dev, nframes, psd_dev, ic=0, qc=0, stream=None):
         _check(lib().jsdr_fft_batch_i16(self.h, _addr(raw_dev), C.c_int64(nframes), ic, qc, _addr(psd_dev),
                                         C.c_void_p(stream)), "jsdr_fft_batch_i16")
@@ -474,6 +477,9 @@ class Bpsk:
     def batch_i16(self, raw_dev, stride_i16, nsamples, ic=0, qc=0, stream=None):
         _check(lib().jsdr_bpsk_batch_i16(self.h, _addr(raw_dev), C.c_int64(stride_i16), C.c_int64(nsamples), ic, qc,
                                          C.c_void_p(stream)), "jsdr_bpsk_batch_i16")
+
+    def set_cu_share(self, wgs_per_cu):
+        _check(lib().jsdr_bpsk_set_cu_share(self.h, int(wgs_per_cu)), "jsdr_bpsk_set_cu_share")
 
     def sync(self):
         _check(lib().jsdr_bpsk_sync(self.h), "jsdr_bpsk_sync")

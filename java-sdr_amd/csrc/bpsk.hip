@@ -868,6 +868,7 @@ struct FmArgs {
     int first_out;              // input index whose arrival completes output 0
     int *amax;                  // FAST: [S] running maximum of |int16 sample| per stream, float bits (never reset)
     int ntiles, nstreams;       // work items = ntiles x nstreams, stream-major; the grid strides over them
+    int grid_limit;             // > 0: at most that many workgroups, striding over the work items (jsdr_bpsk_set_cu_share)
 };
 
 // The stream's edge images for k_fm: E[0 .. 2*FM_EDGE) = samples -FM_EDGE .. FM_EDGE-1, E[2*FM_EDGE .. 4*FM_EDGE) = samples
@@ -2391,6 +2392,8 @@ struct jsdr_bpsk {
     int tab_cur = 0;               // which half of kvco / tcs holds the current schedule's tables
     bool halo_in_dmh = false;      // where the last call left the 64 VCO-mixed history samples (dm[s][0..63] or dmh)
     bool use_fm = true;            // JSDR_FM=0: always the three-kernel path
+    int share_wgs_per_cu = 0;      // jsdr_bpsk_set_cu_share: workgroups per CU k_fm is held to (0: one per tile, all the chip takes)
+    int num_cu = 256;
     int variant = 0;               // 0 exact-order FP64, 1 fast (FMA-contracted FP64, margin-certified decisions)
     double fast_ey = 0.0;          // bound on the error of (fi,fq) in the fast variant (set at create from the taps)
     double margin_scale = 1.0;     // JSDR_FAST_MARGIN_SCALE: widens the detector margins (tests force the exact redo path with it)
@@ -2775,6 +2778,7 @@ static int launch_fm_t(const FmArgs &a_in, bool mix, bool dc, bool fast, int nst
     }();
     long long gx = ntiles * nstreams;
     if (grid_cap > 0 && gx > grid_cap) gx = grid_cap;
+    if (a.grid_limit > 0 && gx > a.grid_limit) gx = a.grid_limit;
     const dim3 grid((unsigned)gx), block(FM_THREADS);
 #define JSDR_FM_LAUNCH(MIX, DC, FAST)                                                                           \
     do {                                                                                                        \
@@ -3241,6 +3245,7 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
         ma.tile0 = g_first - (((g_first - 64) % 65 + 65) % 65);
         ma.first_out = first_out;
         ma.amax = h->amax.p;
+        ma.grid_limit = h->share_wgs_per_cu > 0 ? h->share_wgs_per_cu * h->num_cu : 0;
         {
             EdgeArgs ea;
             ea.raw = fa.raw;
@@ -3711,6 +3716,19 @@ int jsdr_bpsk_batch_i16(jsdr_bpsk *h, const int16_t *raw_dev, int64_t stream_str
                         int qc, void *stream)
 {
     return bpsk_run(h, raw_dev, nullptr, stream_stride_i16, nsamples, ic, qc, as_stream(stream));
+}
+
+int jsdr_bpsk_set_cu_share(jsdr_bpsk *h, int wgs_per_cu)
+{
+    JSDR_REQUIRE(h && wgs_per_cu >= 0 && wgs_per_cu <= 16, "jsdr_bpsk_set_cu_share: bad argument");
+    if (wgs_per_cu > 0) {
+        int dev = 0, cus = 0;
+        JSDR_HIP_TRY(hipGetDevice(&dev));
+        JSDR_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        h->num_cu = cus > 0 ? cus : 256;
+    }
+    h->share_wgs_per_cu = wgs_per_cu;
+    return JSDR_OK;
 }
 
 int jsdr_bpsk_receive_i16(jsdr_bpsk *h, const int16_t *raw_host, int ic, int qc)

@@ -375,6 +375,7 @@ struct jsdr_fft {
     bool mixed = false;  // non power-of-two frame: fft_mixed.hip
     MixedPlan mplan;
     bool direct = false;  // any other frame size: fft_any.hip
+    int share_wgs_per_cu = 0;  // jsdr_fft_set_cu_share: workgroups per CU the batch kernel is held to (0: all it can use)
 };
 
 static int fft_run(jsdr_fft *h, const void *in_dev, int in_kind, int out_kind, long long nframes, int ic, int qc,
@@ -434,6 +435,9 @@ static int fft_run(jsdr_fft *h, const void *in_dev, int in_kind, int out_kind, l
         return e ? atoi(e) : 0;
     }();
     if (abs_grid > 0) cap = abs_grid;
+    // a caller that runs the demodulator BESIDE this kernel (jsdr_fft_set_cu_share): exactly that many persistent workgroups
+    // per CU, so that both kernels' workgroups are resident from the start whichever is launched first
+    if (h->share_wgs_per_cu > 0) cap = (long long)h->num_cu * h->share_wgs_per_cu;
     int grid = (int)(groups < cap ? groups : cap);
     l.launch(a, grid, s);
     JSDR_LAUNCH_CHECK();
@@ -542,6 +546,13 @@ int jsdr_fft_destroy(jsdr_fft *h)
 int jsdr_fft_batch_f32(jsdr_fft *h, const float *iq_dev, int64_t nframes, float *psd_dev, void *stream)
 {
     return fft_run(h, iq_dev, IN_F32, OUT_PSD, nframes, 0, 0, psd_dev, as_stream(stream));
+}
+
+int jsdr_fft_set_cu_share(jsdr_fft *h, int wgs_per_cu)
+{
+    JSDR_REQUIRE(h && wgs_per_cu >= 0 && wgs_per_cu <= 16, "jsdr_fft_set_cu_share: bad argument");
+    h->share_wgs_per_cu = wgs_per_cu;
+    return JSDR_OK;
 }
 
 int jsdr_fft_batch_i16(jsdr_fft *h, const int16_t *raw_dev, int64_t nframes, int ic, int qc, float *psd_dev,
