@@ -75,9 +75,10 @@ def parse():
     ap.add_argument("--streams", type=int, default=0, help="streams PER GPU (weak scaling) instead of --total-streams")
     ap.add_argument("--variant", default="exact", choices=["exact", "fast"],
                     help="demodulator arithmetic: exact-order FP64 (default) or FMA-contracted FP64 with margin-certified decisions")
+    ap.add_argument("--side-by-side", action="store_true", help="pipeline workload: the CU split below 8192 streams per GPU as well")
     ap.add_argument("--serial", action="store_true",
                     help="pipeline workload: PSD then demodulator on ONE stream, each kernel with the whole chip (the default until round 4). "
-                         "Default now: side by side on two streams with the CU shares set (jsdr_fft_set_cu_share 2, jsdr_bpsk_set_cu_share 1)")
+                         "Default now, from 8192 streams per GPU: side by side on two streams with the CU shares set (jsdr_fft_set_cu_share 2, jsdr_bpsk_set_cu_share 1)")
     ap.add_argument("--psd-stream", action="store_true",
                     help="PSD kernel on a HIP stream of its own beside the demodulator (measured: within 2 %% of the default, "
                          "one after the other on one stream, whose per-kernel times are not inflated by the overlap)")
@@ -485,8 +486,11 @@ def main():
     # pipeline default: the PSD kernel (memory-latency bound) and the demodulator's front-end kernel (FP64-issue bound) side by
     # side, each held to its share of every CU (2 + 1 persistent workgroups: what one CU's registers and LDS take) -- left
     # alone each fills the chip and the two streams just run one after the other
+    # (measured, one session each: 34.1 against 35.2 ms at 8192 streams -- but 19.8 against 17.9 at 4096, 10.2 / 9.5 at 2048,
+    #  5.9 / 5.1 at 1024, and 35.7 against 33.1 with the fast variant's kernels: the split pays only for the full single-GPU
+    #  batch of the exact variant, which is where it is used)
     side_by_side = (a.workload == "pipeline" and fft is not None and dem is not None and not a.serial and not a.psd_stream
-                    and not a.fft_acquire and RATE == 96000)
+                    and not a.fft_acquire and RATE == 96000 and a.variant == "exact" and (S >= 8192 or a.side_by_side))
     if side_by_side:
         fft.set_cu_share(2)
         dem.set_cu_share(1)

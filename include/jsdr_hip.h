@@ -80,7 +80,8 @@ int jsdr_fft_batch_f32(jsdr_fft *h, const float *iq_dev, int64_t nframes, float 
  * jsdr_fft_set_cu_share(f, 2) + jsdr_bpsk_set_cu_share(h, 1) is the split that fits one CU's registers and LDS (2 x 128 +
  * 2 x 120 VGPRs per SIMD, 2 x 40 + 69.5 KB), both kernels resident from the start whichever stream gets there first.
  * Results are unchanged (bit for bit); measured on 8192 streams x 2^20 samples: 33.8 ms a step against 35.0 one after the
- * other (DESIGN.md "the step").  A handle used on its own should keep the default. */
+ * other (DESIGN.md "the step") -- and SLOWER than one after the other on batches of 4096 streams and below, and with the
+ * fast variant: it is for the full-size batch of the exact variant.  A handle used on its own keeps the default. */
 int jsdr_fft_set_cu_share(jsdr_fft *h, int wgs_per_cu);
 int jsdr_fft_batch_i16(jsdr_fft *h, const int16_t *raw_dev, int64_t nframes, int ic, int qc,
                        float *psd_dev, void *stream);

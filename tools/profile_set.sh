@@ -42,6 +42,8 @@ for tag, ctr in (("rd", "FETCH_SIZE"), ("wr", "WRITE_SIZE")):
             o.write(f'"{k}",{ctr},{len(acc[k])},{sum(acc[k]) / len(acc[k]):.1f}\n')
 PY
 B="--no-cpu-baseline"
+# the pipeline the old way: PSD then demodulator on one stream, each kernel with the whole chip (per-kernel times not stretched by the other)
+step b_serial 300 python bench.py --serial --steps 20 --warmup 5 $B;     line $O/${T}_b_serial.log > $O/${T}_b_serial.json
 step b_bpsk 300 python bench.py --workload bpsk $B;                      line $O/${T}_b_bpsk.log > $O/${T}_b_bpsk.json
 step b_bpsk_fast 300 python bench.py --workload bpsk --variant fast $B;  line $O/${T}_b_bpsk_fast.log > $O/${T}_b_bpsk_fast.json
 step b_pipe_fast 300 python bench.py --variant fast $B;                  line $O/${T}_b_pipe_fast.log > $O/${T}_b_pipe_fast.json
