@@ -642,3 +642,30 @@ def test_bpsk_suite_with_the_eight_streams_per_wave_tail():
                         "-k", "not eight_streams_per_wave and not alternately"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("nsf,rate", [(4410, 44100), (3200, 32000), (2205, 22050)])
+def test_bpsk_fft_mode_receive_at_consumer_sound_card_rates(nsf, rate):
+    """the IAudioHandler form (one stream, one frame per receive()) in FFT-acquire mode at the frames a 44.1 / 32 / 22.05 kHz
+    card delivers (JavaAudio.java:59): radix-7 passes, frames that are not multiples of 16, decimations 4 / 3 / 2 -- int16
+    and float frames in turn, against the oracle"""
+    nfr = 10
+    iq = O.make_dbpsk_stream(91, 0, nsf * nfr, rate=rate, carrier_hz=rate / 8.0 + 150.0, noise_sigma=600.0)[0]
+    exact = O.convert_i16(iq)
+    d = J.Bpsk(nstreams=1, do_fft=1, rate=rate, blen=4 * nsf)
+    o = O.Bpsk(do_fft=1, rate=rate, blen=4 * nsf, trace=nsf * nfr // (rate // 9600) + 8)
+    bits, tr = [], []
+    for k in range(nfr):
+        fr = exact[2 * nsf * k:2 * nsf * (k + 1)].copy()
+        if k % 3 == 1:
+            d.receive(fr)
+        else:
+            d.receive_raw(iq[2 * nsf * k:2 * nsf * (k + 1)])
+        o.receive(fr)
+        bits.append(d.bits().copy())
+        tr.append(d.trace().copy())
+    assert np.array_equal(np.concatenate(tr), o.trace())
+    assert np.array_equal(np.concatenate(bits), o.bits())
+    same_counters(d.counters(), o.counters())
+    same_state(d.state(), o.state())
+    assert d.counters()["centreBin"] == o.counters()["centreBin"]
