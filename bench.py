@@ -670,6 +670,27 @@ def main():
         roofline["note"] = ("the exact-order demodulator is FP64-issue bound, not HBM bound: see per_kernel[k_fm].fp64_issue_frac "
                             f"(368 separately rounded operations per 9600 Hz sample against {FP64_ISSUE_TOPS} T lane-ops/s measured)")
 
+    # ---- the same pipeline one after the other, on this box, right after the timed region (boxes differ by more than the two
+    # forms do): a short leg outside the timed region, reported beside the line's own number
+    if side_by_side and N == 1:
+        fft.set_cu_share(0)
+        dem.set_cu_share(0)
+
+        def serial_step():
+            fft.batch_i16(d_iq, nframes, d_psd, stream=ms_)
+            dem.batch_i16(d_iq, 2 * L, L, stream=ms_)
+
+        for _ in range(2):
+            serial_step()
+        sync()
+        ts = time.perf_counter()
+        for _ in range(5):
+            serial_step()
+        sync()
+        roofline["one_after_the_other_ms_per_step"] = round((time.perf_counter() - ts) / 5 * 1e3, 4)
+        fft.set_cu_share(2)
+        dem.set_cu_share(1)
+
     # ---- validation outside the timed region: every sampled stream decodes what it was sent
     validated = None
     # (FFT-acquire mode is not validated by payload: the reference's block-wise FFT filter puts a seam into the
