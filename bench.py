@@ -76,6 +76,10 @@ def parse():
     ap.add_argument("--variant", default="exact", choices=["exact", "fast"],
                     help="demodulator arithmetic: exact-order FP64 (default) or FMA-contracted FP64 with margin-certified decisions")
     ap.add_argument("--side-by-side", action="store_true", help="pipeline workload: the CU split below 8192 streams per GPU as well")
+    ap.add_argument("--compare-serial", action="store_true",
+                    help="pipeline workload, side by side: time five steps of the one-after-the-other form on the same box right after the "
+                         "timed region as well (roofline.one_after_the_other_ms_per_step); off by default so that a profiler's per-kernel "
+                         "averages of the default command are those of ONE form")
     ap.add_argument("--serial", action="store_true",
                     help="pipeline workload: PSD then demodulator on ONE stream, each kernel with the whole chip (the default until round 4). "
                          "Default now, from 8192 streams per GPU: side by side on two streams with the CU shares set (jsdr_fft_set_cu_share 2, jsdr_bpsk_set_cu_share 1)")
@@ -670,9 +674,9 @@ def main():
         roofline["note"] = ("the exact-order demodulator is FP64-issue bound, not HBM bound: see per_kernel[k_fm].fp64_issue_frac "
                             f"(368 separately rounded operations per 9600 Hz sample against {FP64_ISSUE_TOPS} T lane-ops/s measured)")
 
-    # ---- the same pipeline one after the other, on this box, right after the timed region (boxes differ by more than the two
-    # forms do): a short leg outside the timed region, reported beside the line's own number
-    if side_by_side and N == 1:
+    # ---- --compare-serial: the same pipeline one after the other, on this box, right after the timed region (boxes differ by
+    # more than the two forms do): a short leg outside the timed region, reported beside the line's own number
+    if side_by_side and N == 1 and a.compare_serial:
         fft.set_cu_share(0)
         dem.set_cu_share(0)
 
