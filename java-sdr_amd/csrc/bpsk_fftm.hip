@@ -653,8 +653,16 @@ __device__ __attribute__((noinline)) void fm_first2x_from_raw(LdsArr X, const in
                 f0[j1] = rawf[h];
                 f1[j1] = rawf[h + NN];
             } else {
-                w0[j1] = raw[h];
-                w1[j1] = raw[h + NN];
+                // (the frame's SECOND read -- the odd half's -- is its last use: marked so, like the dm stores, to leave the L2 to the
+                //  per-stream scratch of the even halves.  Counter traffic 27.7 -> 26.8 GB a step, the kernel 15.58 -> 15.4 ms: the 32
+                //  workgroups of an XCD still cycle 7 MB of frame + scratch through a 4 MB L2)
+                if (ODD) {
+                    w0[j1] = __builtin_nontemporal_load(&raw[h]);
+                    w1[j1] = __builtin_nontemporal_load(&raw[h + NN]);
+                } else {
+                    w0[j1] = raw[h];
+                    w1[j1] = raw[h + NN];
+                }
             }
         }
 #pragma unroll
@@ -1576,7 +1584,8 @@ __global__ __launch_bounds__(FM_T) void k_front_fft2x(Fft2xArgs aa)
                     for (int k = 0; k < 27; k++) fi += sample(e - k) * ds_tap(k);  // newest first (:479-483)
                 }
                 const double o = fi * HOWARD;
-                dm[64 + j] = make_double2(o * cs.x, o * cs.y);  // :515-516
+                __builtin_nontemporal_store(o * cs.x, &dm[64 + j].x);  // :515-516 (written once, read by the next kernel)
+                __builtin_nontemporal_store(o * cs.y, &dm[64 + j].y);
             }
         }
         double hnew = 0.0;
