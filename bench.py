@@ -76,10 +76,11 @@ def parse():
     ap.add_argument("--variant", default="exact", choices=["exact", "fast"],
                     help="demodulator arithmetic: exact-order FP64 (default) or FMA-contracted FP64 with margin-certified decisions")
     ap.add_argument("--side-by-side", action="store_true", help="pipeline workload: the CU split below 8192 streams per GPU as well")
-    ap.add_argument("--compare-serial", action="store_true",
-                    help="pipeline workload, side by side: time five steps of the one-after-the-other form on the same box right after the "
-                         "timed region as well (roofline.one_after_the_other_ms_per_step); off by default so that a profiler's per-kernel "
-                         "averages of the default command are those of ONE form")
+    ap.add_argument("--no-compare-serial", dest="compare_serial", action="store_false",
+                    help="pipeline workload, side by side: skip the five steps of the one-after-the-other form that are otherwise timed on "
+                         "the same box right after the timed region (roofline.one_after_the_other_ms_per_step: boxes differ by more "
+                         "than the two forms do, so the pair belongs in one record); profile runs pass it so that per-kernel averages "
+                         "are those of ONE form")
     ap.add_argument("--serial", action="store_true",
                     help="pipeline workload: PSD then demodulator on ONE stream, each kernel with the whole chip (the default until round 4). "
                          "Default now, from 8192 streams per GPU: side by side on two streams with the CU shares set (jsdr_fft_set_cu_share 2, jsdr_bpsk_set_cu_share 1)")
@@ -164,20 +165,23 @@ def validate_fft(J, d_iq, d_psd, nframes, rate):
     return worst <= 1e-5, {"frames_checked": len(idx), "worst_amplitude_error_over_frame_peak": worst}
 
 
-def validate_acquire(J, dem, d_iq, S, L, ncalls, frame, rate, prefer=()):
-    """FFT-acquire mode (FUNcubeBPSKDemod.java:406-464) cannot be checked by payload at every frame size -- the block-wise FFT
+def validate_acquire(J, dem, d_iq, S, L, ncalls, frame, rate, prefer=(), do_fft=1, nsample=6):
+    """Sampled streams of the measured handle against the oracle replaying the SAME calls (both modes; the tune-mode pipeline
+    line uses it with do_fft=0: FUNcubeBPSKDemod.java:366-397,466-595 -- the headline's persistent-stride k_fm, k_tail8 and
+    the batch FEC at full width, compared bit for bit with the reference's restatement).
+    FFT-acquire mode (FUNcubeBPSKDemod.java:406-464) cannot be checked by payload at every frame size -- the block-wise FFT
     filter puts a seam into the signal every frame and the reference itself loses frames.  So sampled streams of the
     measured handle are compared with the oracle replaying the SAME calls (ncalls x the step's input): every counter incl.
     centreBin, every state double, the last call's bits, the last call's FECDecode results.  `prefer`: streams to include
     (those the payload check found without a decoded frame: the oracle must lose them too).  Outside the timed region."""
     import threading
     import oracle_lib as O
-    idx = sorted(set(list(prefer)[:3]) | set(int(v) for v in np.linspace(0, S - 1, 6)))
+    idx = sorted(set(list(prefer)[:3]) | set(int(v) for v in np.linspace(0, S - 1, nsample)))
     res = {}
 
     def one(st):
         raw = d_iq.to_host(np.int16, 2 * L, offset_bytes=st * L * 4)
-        o = O.Bpsk(rate=rate, blen=4 * frame, tuning=12000, do_fft=1)
+        o = O.Bpsk(rate=rate, blen=4 * frame, tuning=12000, do_fft=do_fft)
         nb0 = nf0 = 0
         for k in range(ncalls):
             if k == ncalls - 1:
@@ -195,7 +199,9 @@ def validate_acquire(J, dem, d_iq, S, L, ncalls, frame, rate, prefer=()):
     for st in idx:
         oc, os_, obits, ofec = res[st]
         gc, gs, gbits, gfec = dem.counters(st), dem.state(st), dem.bits(st), dem.fec_results(st)
-        same = all(gc[k] == oc[k] for k in oc) and gs.tobytes() == os_.tobytes() and np.array_equal(gbits, obits) and \
+        sidx = list(range(18)) if do_fft else [0, 1, 2, 3, 4, 5] + list(range(8, 18))  # 6, 7: the FFT-acquire mode's own state
+        ckeys = [k for k in oc if do_fft or k != "centreBin"]
+        same = all(gc[k] == oc[k] for k in ckeys) and gs[sidx].tobytes() == os_[sidx].tobytes() and np.array_equal(gbits, obits) and \
             len(gfec) == len(ofec) and all(x[0] == y[0] and np.array_equal(x[2], y[2]) for x, y in zip(gfec, ofec))
         if not same:
             bad.append(st)
@@ -418,9 +424,10 @@ def main():
         if a.workload != "bpsk":
             raise SystemExit("--rate needs --workload bpsk (the pipeline line is BASELINE's 96 kHz configuration)")
         RATE = a.rate
-    knobs = sorted(k for k in os.environ if k.startswith("JSDR_EXPERIMENT_"))
+    knobs = sorted(k for k in os.environ if k.startswith("JSDR_EXPERIMENT_") or k.startswith("JSDR_FAST_"))
     if knobs:
-        raise SystemExit(f"bench.py: {', '.join(knobs)} set -- experiment knobs make the product skip work; refusing to measure")
+        raise SystemExit(f"bench.py: {', '.join(knobs)} set -- experiment knobs make the product skip work / change what the fast "
+                         "variant certifies; refusing to measure")
     N = a.gpus
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -657,6 +664,9 @@ def main():
     # the dominant kernel is "binding_limit" (and per kernel in per_kernel[...]["bound"])
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "traffic_source": (os.path.relpath(pmc, ROOT) + ": separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                   "workload (gfx950 correction 2 x FETCH + WRITE), scaled by streams x samples; not counted in this run")
+                if traffic is not None else None,
                 "binding_limit": KERNEL_LIMIT.get(dom, KERNEL_BOUND.get(dom, "hbm")),
                 "avg_launch_ms": round(dom_ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes),
                 "kernels_ms_per_step": {k: round(v[0] / v[1], 4) for k, v in sorted(kern.items())},
@@ -666,17 +676,48 @@ def main():
                                if v[0] / v[1] > 0.02 * dom_ms}}  # (not the helper kernels)
     if side_by_side:
         # k_fft and k_fm run CONCURRENTLY: each one's launch duration is the time it shared the chip with the other, not a time
-        # it had the HBM to itself -- the step is what counts: its algorithmic bytes against its duration
-        roofline["concurrent_kernels"] = ["k_fft", dem.front_kernel_name()]
-        roofline["step_algorithmic_bytes"] = int(BYTES_PER_SAMPLE["pipeline"] * S * L)
-        roofline["step_frac"] = round(BYTES_PER_SAMPLE["pipeline"] * S * L / (dt / a.steps) / 1e9 / HBM_PEAK_GBS, 4)
+        # it had the HBM to itself -- so the PAIR is the unit that is priced: the step's algorithmic bytes
+        # (PSD in + out, demodulator in + bits) against the step's duration; the two kernels' own launch times are listed as
+        # concurrent, without a fraction
+        step_ms = dt / a.steps * 1e3
+        step_bytes = BYTES_PER_SAMPLE["pipeline"] * S * L
+        fm = dem.front_kernel_name()
+        roofline["kernel"] = f"k_fft + {fm} (concurrent, two streams)"
+        roofline["concurrent_kernels"] = ["k_fft", fm]
+        roofline["achieved"] = round(step_bytes / (step_ms * 1e-3) / 1e9, 2)
+        roofline["frac"] = round(step_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        roofline["avg_launch_ms"] = round(step_ms, 4)
+        roofline["algorithmic_bytes_per_launch"] = int(step_bytes)
+        roofline["step_algorithmic_bytes"] = int(step_bytes)
+        roofline["step_frac"] = roofline["frac"]
+        roofline["binding_limit"] = ("VALU issue of the pair: k_fm's separately rounded FP64 operations and k_fft's packed FP32 butterflies "
+                                     "share every SIMD (profiles/r05_*: k_fm alone issues VALU for 90 % of its cycles)")
+        tab = None
+        try:
+            tab = json.load(open(pmc))
+        except Exception:
+            pass
+        if tab:
+            # every kernel of a step (not the input generator's: k_synth_*, k_fec_encode run once, before the timed region)
+            per = sum(v.get("hbm_bytes_per_launch", 0) for k, v in tab.items()
+                      if isinstance(v, dict) and not k.startswith("k_synth") and k != "k_fec_encode")
+            roofline["traffic"] = int(per * (S * L) / tab.get("_samples_per_launch", 1024 * 1048576)) if per else None
+        for k in ("k_fft", fm):
+            if k in roofline["per_kernel"]:
+                e = roofline["per_kernel"][k]
+                e["frac"] = None
+                e.pop("fp64_issue_frac", None)
+                e.pop("binding_limit", None)
+                e["note"] = "concurrent with the other kernel of the pair: its launch time is time it SHARED the chip"
     if a.workload in ("pipeline", "bpsk") and not a.fft_acquire:
         roofline["note"] = ("the exact-order demodulator is FP64-issue bound, not HBM bound: see per_kernel[k_fm].fp64_issue_frac "
                             f"(368 separately rounded operations per 9600 Hz sample against {FP64_ISSUE_TOPS} T lane-ops/s measured)")
 
     # ---- --compare-serial: the same pipeline one after the other, on this box, right after the timed region (boxes differ by
     # more than the two forms do): a short leg outside the timed region, reported beside the line's own number
+    calls_made = a.warmup + a.steps
     if side_by_side and N == 1 and a.compare_serial:
+        calls_made += 7
         fft.set_cu_share(0)
         dem.set_cu_share(0)
 
@@ -734,10 +775,13 @@ def main():
         if a.fft_acquire and n_good < S // 2:
             # FFT-acquire mode may lose frames by design, but a run in which (almost) nothing decodes has checked nothing
             validated = None if n_good == 0 else False
-    if dem is not None and a.fft_acquire and not a.no_validate:
+    if dem is not None and not a.no_validate and (a.fft_acquire or a.variant == "exact"):
         # any frame size: sampled streams against the oracle replaying the same calls (the payload check above only exists
-        # for the 9600-sample frame, and passes over streams without a decoded frame: here the oracle must lose those too)
-        ok_o, st_o = validate_acquire(J, dem, d_iq, S, L, a.warmup + a.steps, a.bpsk_frame, RATE, prefer=none_streams)
+        # for the 9600-sample frame, and passes over streams without a decoded frame: here the oracle must lose those too).
+        # Tune mode (the default line): 8 sampled streams, every call of the run, bit for bit -- counters, state doubles,
+        # the last call's bits and FECDecode bytes (the fast variant's doubles differ by design: its bar is the payload check)
+        ok_o, st_o = validate_acquire(J, dem, d_iq, S, L, calls_made, a.bpsk_frame, RATE, prefer=none_streams,
+                                      do_fft=int(a.fft_acquire), nsample=6 if a.fft_acquire else 8)
         vstats = dict(vstats or {}, **st_o)
         validated = bool(ok_o) if validated is None else bool(validated and ok_o)
     if fft is not None and not a.no_validate:

@@ -83,6 +83,9 @@ int jsdr_fft_batch_f32(jsdr_fft *h, const float *iq_dev, int64_t nframes, float 
  * other (DESIGN.md "the step") -- and SLOWER than one after the other on batches of 4096 streams and below, and with the
  * fast variant: it is for the full-size batch of the exact variant.  A handle used on its own keeps the default. */
 int jsdr_fft_set_cu_share(jsdr_fft *h, int wgs_per_cu);
+/* diagnostics: what the handle's last power-of-two batch launch covered -- work items (groups of frames) and the
+ * workgroups that strode over them.  workgroups < work_items means the persistent-stride path ran (the tests assert it). */
+int jsdr_fft_last_launch(jsdr_fft *h, int64_t *work_items, int64_t *workgroups);
 int jsdr_fft_batch_i16(jsdr_fft *h, const int16_t *raw_dev, int64_t nframes, int ic, int qc,
                        float *psd_dev, void *stream);
 /* complex spectrum only (float2[n] per frame), for the 1e-5 FFT parity tests */
@@ -182,6 +185,8 @@ int jsdr_bpsk_receive_i16(jsdr_bpsk *h, const int16_t *raw_host, int ic, int qc)
 int jsdr_bpsk_batch_i16(jsdr_bpsk *h, const int16_t *raw_dev, int64_t stream_stride_i16,
                         int64_t nsamples, int ic, int qc, void *stream);
 int jsdr_bpsk_set_cu_share(jsdr_bpsk *h, int wgs_per_cu); /* see jsdr_fft_set_cu_share; applies to the tune-mode front-end kernel */
+/* diagnostics: tiles x streams of the last tune-mode front-end launch (k_fm) and the workgroups that strode over them */
+int jsdr_bpsk_last_launch(jsdr_bpsk *h, int64_t *work_items, int64_t *workgroups);
 /* wait until every kernel of the calls made so far has finished (the 9600 Hz tail and the FEC decoder run on
  * an internal side stream so that they overlap the next call's front end; the getters below call this). */
 int jsdr_bpsk_sync(jsdr_bpsk *h);

@@ -206,6 +206,11 @@ class Fft:
     def set_cu_share(self, wgs_per_cu):
         _check(lib().jsdr_fft_set_cu_share(self.h, int(wgs_per_cu)), "jsdr_fft_set_cu_share")
 
+    def last_launch(self):
+        a, b = C.c_int64(), C.c_int64()
+        _check(lib().jsdr_fft_last_launch(self.h, C.byref(a), C.byref(b)), "jsdr_fft_last_launch")
+        return a.value, b.value
+
     def batch_i16(self, raw_dev, nframes, psd_dev, ic=0, qc=0, stream=None):
         _check(lib().jsdr_fft_batch_i16(self.h, _addr(raw_dev), C.c_int64(nframes), ic, qc, _addr(psd_dev),
                                         C.c_void_p(stream)), "jsdr_fft_batch_i16")
@@ -480,6 +485,11 @@ class Bpsk:
 
     def set_cu_share(self, wgs_per_cu):
         _check(lib().jsdr_bpsk_set_cu_share(self.h, int(wgs_per_cu)), "jsdr_bpsk_set_cu_share")
+
+    def last_launch(self):
+        a, b = C.c_int64(), C.c_int64()
+        _check(lib().jsdr_bpsk_last_launch(self.h, C.byref(a), C.byref(b)), "jsdr_bpsk_last_launch")
+        return a.value, b.value
 
     def sync(self):
         _check(lib().jsdr_bpsk_sync(self.h), "jsdr_bpsk_sync")

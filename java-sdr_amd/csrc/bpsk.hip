@@ -2392,6 +2392,7 @@ struct jsdr_bpsk {
     int tab_cur = 0;               // which half of kvco / tcs holds the current schedule's tables
     bool halo_in_dmh = false;      // where the last call left the 64 VCO-mixed history samples (dm[s][0..63] or dmh)
     bool use_fm = true;            // JSDR_FM=0: always the three-kernel path
+    long long last_fm_items = 0, last_fm_grid = 0;  // jsdr_bpsk_last_launch
     int share_wgs_per_cu = 0;      // jsdr_bpsk_set_cu_share: workgroups per CU k_fm is held to (0: one per tile, all the chip takes)
     int num_cu = 256;
     int variant = 0;               // 0 exact-order FP64, 1 fast (FMA-contracted FP64, margin-certified decisions)
@@ -2763,6 +2764,8 @@ static void launch_front(const FrontArgs &fa, int nstreams, long long nds, hipSt
 }
 
 
+static thread_local long long g_fm_last_items = 0, g_fm_last_grid = 0;  // what the last k_fm launch of this thread covered (jsdr_bpsk_last_launch)
+
 template <int D, int R>
 static int launch_fm_t(const FmArgs &a_in, bool mix, bool dc, bool fast, int nstreams, hipStream_t st)
 {
@@ -2779,6 +2782,8 @@ static int launch_fm_t(const FmArgs &a_in, bool mix, bool dc, bool fast, int nst
     long long gx = ntiles * nstreams;
     if (grid_cap > 0 && gx > grid_cap) gx = grid_cap;
     if (a.grid_limit > 0 && gx > a.grid_limit) gx = a.grid_limit;
+    g_fm_last_items = ntiles * nstreams;
+    g_fm_last_grid = gx;
     const dim3 grid((unsigned)gx), block(FM_THREADS);
 #define JSDR_FM_LAUNCH(MIX, DC, FAST)                                                                           \
     do {                                                                                                        \
@@ -3276,6 +3281,8 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
         ProfScope ps(h, PK_FM, st);
         h->front_name = "k_fm";
         if (launch_fm(ma, h->decim, h->mix != 0, (ic != 0) || (qc != 0), h->variant != 0, S, st) != JSDR_OK) return JSDR_ERR;
+        h->last_fm_items = g_fm_last_items;
+        h->last_fm_grid = g_fm_last_grid;
         h->dmh_cur ^= 1;
     } else if (nds > 0) {
         ProfScope ps(h, PK_FRONT, st);
@@ -3728,6 +3735,14 @@ int jsdr_bpsk_set_cu_share(jsdr_bpsk *h, int wgs_per_cu)
         h->num_cu = cus > 0 ? cus : 256;
     }
     h->share_wgs_per_cu = wgs_per_cu;
+    return JSDR_OK;
+}
+
+int jsdr_bpsk_last_launch(jsdr_bpsk *h, int64_t *work_items, int64_t *workgroups)
+{
+    JSDR_REQUIRE(h && work_items && workgroups, "jsdr_bpsk_last_launch: null argument");
+    *work_items = h->last_fm_items;
+    *workgroups = h->last_fm_grid;
     return JSDR_OK;
 }
 

@@ -375,6 +375,7 @@ struct jsdr_fft {
     bool mixed = false;  // non power-of-two frame: fft_mixed.hip
     MixedPlan mplan;
     bool direct = false;  // any other frame size: fft_any.hip
+    long long last_items = 0, last_grid = 0;  // jsdr_fft_last_launch
     int share_wgs_per_cu = 0;  // jsdr_fft_set_cu_share: workgroups per CU the batch kernel is held to (0: all it can use)
 };
 
@@ -439,6 +440,8 @@ static int fft_run(jsdr_fft *h, const void *in_dev, int in_kind, int out_kind, l
     // per CU, so that both kernels' workgroups are resident from the start whichever is launched first
     if (h->share_wgs_per_cu > 0) cap = (long long)h->num_cu * h->share_wgs_per_cu;
     int grid = (int)(groups < cap ? groups : cap);
+    h->last_items = groups;
+    h->last_grid = grid;
     l.launch(a, grid, s);
     JSDR_LAUNCH_CHECK();
     return JSDR_OK;
@@ -552,6 +555,14 @@ int jsdr_fft_set_cu_share(jsdr_fft *h, int wgs_per_cu)
 {
     JSDR_REQUIRE(h && wgs_per_cu >= 0 && wgs_per_cu <= 16, "jsdr_fft_set_cu_share: bad argument");
     h->share_wgs_per_cu = wgs_per_cu;
+    return JSDR_OK;
+}
+
+int jsdr_fft_last_launch(jsdr_fft *h, int64_t *work_items, int64_t *workgroups)
+{
+    JSDR_REQUIRE(h && work_items && workgroups, "jsdr_fft_last_launch: null argument");
+    *work_items = h->last_items;
+    *workgroups = h->last_grid;
     return JSDR_OK;
 }
 

@@ -101,10 +101,14 @@ public class HipDemod extends IUIComponent implements IAudioHandler, IPublishLis
         if (MODE_OFF == mode)
             return;
         HipNative.demodReceive(handle, buf, bbf);
-        HipNative.demodFrameStats(handle, stats);
-        synchronized (shownStats) {
-            shownStats[0] = stats[0];
-            shownStats[1] = stats[1];
+        if (isVisible()) {
+            // max / avg feed the painter only (demod.java:465-467): a second device round trip per frame on the live audio
+            // thread is paid only while the tab is showing
+            HipNative.demodFrameStats(handle, stats);
+            synchronized (shownStats) {
+                shownStats[0] = stats[0];
+                shownStats[1] = stats[1];
+            }
         }
         SourceDataLine line = sdl;
         if (line != null)
