@@ -321,6 +321,36 @@ int jsdr_recordings_load(const char *const *paths, int nstreams, int channels, i
                          int64_t nframes, int16_t *raw_dev, int64_t stream_stride_i16, int64_t *frames_loaded,
                          void *stream);
 
+/* ------------------------------------------------------------------ one process, several GPUs
+ * The reference hosts all its demodulators in one JVM (jsdr.java:479-483: `new FUNcubeBPSKDemod(i, ...)` in a loop) and one
+ * audio thread feeds them (JavaAudio.java:298-304).  A group is that across `ndev` GPUs: `total_streams` lock-step
+ * demodulators split into contiguous equal shards (device index g owns streams [g S, (g+1) S), S = total_streams / ndev),
+ * ONE host thread per device that owns the device's jsdr_bpsk (and, with JSDR_GROUP_WITH_PSD, jsdr_fft) handle and its
+ * HIP streams, and after every batch call ONE ncclAllGather per device (RCCL over xGMI, librccl.so loaded at the first
+ * create) of the fixed-size per-stream result slots (jsdr_bpsk_pack_slots' layout), on a gather stream of its own beside
+ * the next call's kernels.  There is no other exchange: streams are independent.
+ *   devices: ndev device ordinals, or NULL for 0 .. ndev-1.
+ *   JSDR_GROUP_GATHER_COPY: gather with device-to-device copies instead of RCCL (a host without librccl; or several
+ *     group members on ONE device, which RCCL refuses -- the rehearsal a one-GPU box can run).
+ * jsdr_group_batch_i16: raw_dev[g] = device g's [S][stream_stride] int16 IQ (on THAT device); psd_dev[g] (optional,
+ * WITH_PSD) = float[S * nsamples / n][n + 2] on that device.  Returns when every device thread has enqueued its work;
+ * a failure on any device abandons the step's gather on ALL of them (nobody waits in a collective for a rank that is
+ * gone) and is reported here.  jsdr_group_sync waits for kernels, tails and gathers of every device.
+ * jsdr_group_gathered: device g's copy of ALL total_streams slots, ordered by global stream id.                  */
+typedef struct jsdr_group jsdr_group;
+#define JSDR_GROUP_GATHER_COPY 1
+#define JSDR_GROUP_WITH_PSD 2
+int jsdr_group_create(jsdr_group **g, int ndev, const int *devices, int rate, int nsamples_per_frame, int tuning_hz,
+                      int do_fft, int do_up, int total_streams, int64_t max_batch_samples, int flags);
+int jsdr_group_destroy(jsdr_group *g);
+int jsdr_group_info(jsdr_group *g, int *ndev, int *streams_per_device, int64_t *slot_bytes, int *rccl_version);
+int jsdr_group_device(jsdr_group *g, int index, int *device, jsdr_bpsk **dem, jsdr_fft **fft);
+int jsdr_group_batch_i16(jsdr_group *g, const int16_t *const *raw_dev, int64_t stream_stride_i16, int64_t nsamples,
+                         int ic, int qc, float *const *psd_dev);
+int jsdr_group_sync(jsdr_group *g);
+int jsdr_group_gathered(jsdr_group *g, int index, const uint8_t **slots_dev, int64_t *bytes);
+int jsdr_group_read_slot(jsdr_group *g, int index, int stream, uint8_t *slot_host);
+
 #ifdef __cplusplus
 }
 #endif

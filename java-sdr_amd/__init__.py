@@ -10,7 +10,7 @@ shim module of that name at the repo root.
 """
 from . import sharding  # noqa: F401
 from .binding import (  # noqa: F401
-    JsdrError, lib, library_path, have_gpu, DeviceBuffer, Fft, Fir, Bpsk, Timer, Stream, Phase,
+    JsdrError, lib, library_path, have_gpu, DeviceBuffer, Fft, Fir, Bpsk, Group, Timer, Stream, Phase,
     convert_i16, fir_batch_decimate_i16, bpsk_table, phase_maxabs, phase_columns, fec_decode, fec_encode, fec_decode_batch, fec_encode_batch, fec_encode_dev, fec_decode_dev,
     synth_payloads, synth_diffsign, synth_dbpsk, synth_tones, EXPORTED_SYMBOLS,
     Demod, waterfall_lines, waterfall_lines_dev, recording_probe, recordings_load, RecordingInfo,

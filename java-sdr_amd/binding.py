@@ -560,7 +560,66 @@ class Bpsk:
 
     def __del__(self):
         try:
+            if getattr(self, "borrowed", False):
+                return
             lib().jsdr_bpsk_destroy(self.h)
+        except Exception:
+            pass
+
+
+class Group:
+    """jsdr_group_*: `total_streams` demodulators of ONE process over `ndev` devices, one host thread per device, the result
+    slots gathered to every device after each call (RCCL, or device-to-device copies with gather_copy=True)."""
+
+    def __init__(self, ndev, total_streams, max_batch_samples, devices=None, rate=96000, frame=2048, tuning=12000, do_fft=0,
+                 do_up=0, gather_copy=False, with_psd=False):
+        self.h = C.c_void_p()
+        self.ndev = ndev
+        devs = (C.c_int * ndev)(*devices) if devices is not None else None
+        flags = (1 if gather_copy else 0) | (2 if with_psd else 0)
+        _check(lib().jsdr_group_create(C.byref(self.h), ndev, devs, rate, frame, tuning, do_fft, do_up, total_streams,
+                                       C.c_int64(max_batch_samples), flags), "jsdr_group_create")
+        n, s, sb, v = C.c_int(), C.c_int(), C.c_int64(), C.c_int()
+        _check(lib().jsdr_group_info(self.h, C.byref(n), C.byref(s), C.byref(sb), C.byref(v)), "jsdr_group_info")
+        self.streams_per_device, self.slot_bytes, self.rccl_version = s.value, sb.value, v.value
+        self.total_streams = total_streams
+
+    def device(self, index):
+        """(device ordinal, a borrowed Bpsk view of that device's handle)"""
+        d, dem, fft = C.c_int(), C.c_void_p(), C.c_void_p()
+        _check(lib().jsdr_group_device(self.h, index, C.byref(d), C.byref(dem), C.byref(fft)), "jsdr_group_device")
+        view = Bpsk.__new__(Bpsk)
+        view.h, view.nstreams, view.borrowed = dem, self.streams_per_device, True
+        return d.value, view
+
+    def batch_i16(self, raw_devs, stride_i16, nsamples, ic=0, qc=0, psd_devs=None):
+        raws = (C.c_void_p * self.ndev)(*[_addr(r) for r in raw_devs])
+        psds = (C.c_void_p * self.ndev)(*[_addr(p) for p in psd_devs]) if psd_devs is not None else None
+        _check(lib().jsdr_group_batch_i16(self.h, raws, C.c_int64(stride_i16), C.c_int64(nsamples), ic, qc, psds),
+               "jsdr_group_batch_i16")
+
+    def sync(self):
+        _check(lib().jsdr_group_sync(self.h), "jsdr_group_sync")
+
+    def read_slot(self, index, stream):
+        out = np.empty(self.slot_bytes, np.uint8)
+        _check(lib().jsdr_group_read_slot(self.h, index, stream, _addr(out)), "jsdr_group_read_slot")
+        return out
+
+    def gathered(self, index):
+        """device `index`'s gathered buffer as a host array [total_streams][slot_bytes] (the device must be current-able)"""
+        p, nb = C.c_void_p(), C.c_int64()
+        self.sync()
+        _check(lib().jsdr_group_gathered(self.h, index, C.byref(p), C.byref(nb)), "jsdr_group_gathered")
+        dev, _ = self.device(index)
+        out = np.empty(nb.value, np.uint8)
+        _check(lib().jsdr_set_device(dev), "jsdr_set_device")
+        _check(lib().jsdr_memcpy_d2h(_addr(out), p, C.c_size_t(nb.value)), "jsdr_memcpy_d2h")
+        return out.reshape(self.total_streams, self.slot_bytes)
+
+    def __del__(self):
+        try:
+            lib().jsdr_group_destroy(self.h)
         except Exception:
             pass
 

@@ -32,6 +32,7 @@ SOURCES = {
     "bpsk.hip": ["-ffp-contract=off"],
     "bpsk_fft.hip": ["-ffp-contract=off"],
     "bpsk_fftm.hip": ["-ffp-contract=off"],
+    "group.hip": [],
 }
 
 
@@ -78,7 +79,7 @@ def build(force=False, verbose=False):
             if verbose and warn.strip():
                 print(warn)
     if force or jobs or newer(OUT, objs):
-        run([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + ["-Wl,-rpath,/opt/rocm/lib"])
+        run([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + ["-Wl,-rpath,/opt/rocm/lib", "-ldl", "-lpthread"])
     return OUT
 
 

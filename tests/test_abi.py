@@ -34,3 +34,15 @@ def test_compute_fails_loudly_without_a_device():
         J.fec_decode(np.zeros(5200, np.uint8))
     with pytest.raises(J.JsdrError):
         J.Bpsk()
+    with pytest.raises(J.JsdrError):
+        J.Group(1, 4, 4096)
+    with pytest.raises(J.JsdrError):
+        J.Group(2, 4, 4096, devices=[0, 0], gather_copy=True)
+
+
+def test_group_arguments_are_checked_before_any_device_work():
+    import pytest
+    with pytest.raises(J.JsdrError, match="split evenly"):
+        J.Group(3, 8, 4096, gather_copy=True)
+    with pytest.raises(J.JsdrError):
+        J.Group(0, 8, 4096)

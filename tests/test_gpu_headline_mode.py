@@ -109,7 +109,7 @@ def test_persistent_stride_under_cu_shares_against_the_oracle():
     fft0 = J.Fft(N, 96000)
     d_ref = J.DeviceBuffer(S * (L // N) * (N + 2) * 4)
     fft0.batch_i16(d_iq, S * (L // N), d_ref)
-    J.stream_sync()
+    J.binding.stream_sync()
     wi0, wg0 = fft0.last_launch()
     assert wg0 > wg
     assert np.array_equal(allpsd.view(np.int32).ravel(), d_ref.to_host(np.float32).view(np.int32))
