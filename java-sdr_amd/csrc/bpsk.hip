@@ -3222,7 +3222,7 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
         ProfScope ps(h, PK_FRONT, st);
         h->front_name = h->fft_2x ? "k_front_fft2x" : (h->fft_mixed ? "k_front_fftm" : "k_front_fft");
         const int frc = h->fft_2x ? launch_front_fft2x(xa, h->fm_np, h->fm_rad, h->fm_off, h->fm_off1, h->fft2x_ek.p, h->fft2x_r0.p, S, st)
-                                  : (h->fft_mixed ? launch_front_fftm(xa, h->fm_np, h->fm_rad, h->fm_off, S, st) : launch_front_fft(xa, S, st));
+                                  : (h->fft_mixed ? launch_front_fftm(xa, h->fm_np, h->fm_rad, h->fm_off, h->fm_off1, h->fft2x_ek.p, S, st) : launch_front_fft(xa, S, st));
         if (frc != JSDR_OK) return JSDR_ERR;
     } else if (nds > 0 && fm_ok) {
         // wait for the tail that last read y[y_cur] (two calls ago) before the fused kernel overwrites it
@@ -3407,8 +3407,10 @@ int jsdr_bpsk_create(jsdr_bpsk **out, int rate, int nsamples_per_frame, int tuni
 {
     JSDR_REQUIRE(out, "jsdr_bpsk_create: null handle pointer");
     *out = nullptr;
-    JSDR_REQUIRE(rate >= 9600, "jsdr_bpsk_create: rate %d below the 9600 Hz demodulator rate", rate);
-    const int decim = rate / 9600;  // adsc.rate/DOWN_SAMPLE_RATE (:476), int division
+    JSDR_REQUIRE(rate >= 1, "jsdr_bpsk_create: rate %d", rate);
+    // adsc.rate/DOWN_SAMPLE_RATE (:476), int division.  Below 9600 Hz (an 8 kHz card) the quotient is 0 and `++dsCnt >= 0`
+    // holds for every sample: RxDownSample filters at every input, which is what a decimation of 1 does
+    const int decim = rate / 9600 > 0 ? rate / 9600 : 1;
     // any rate the reference would take (:476: adsc.rate / DOWN_SAMPLE_RATE, whatever it is); 4, 5, 10, 20 -- the rates
     // java-sdr has defaults for -- take the specialised front ends, everything else the one-thread-per-output kernel.
     // FFT-acquire mode: the power-of-two and the 2 m front ends size their per-thread output lists for a decimation of at
@@ -3421,9 +3423,9 @@ int jsdr_bpsk_create(jsdr_bpsk **out, int rate, int nsamples_per_frame, int tuni
     const bool fft_pow2 = nsamples_per_frame >= 1024 && nsamples_per_frame <= 8192 &&
                           (nsamples_per_frame & (nsamples_per_frame - 1)) == 0;
     JSDR_REQUIRE(!do_fft || fft_pow2 || fftm_supported(nsamples_per_frame) || fft2x_supported(nsamples_per_frame),
-                 "jsdr_bpsk_create: FFT-acquire mode needs a frame of 1024 / 2048 / 4096 / 8192 samples, or n = 2^a 3^b 5^c 7^d with "
-                 "1024 < n <= 9600 such as the default 9600 / 4800 or a 44.1 kHz card's 4410, or twice a 2^a 3^b 5^c frame that is a "
-                 "multiple of 16 (19200) (got %d)",
+                 "jsdr_bpsk_create: FFT-acquire mode needs a frame of 1024 / 2048 / 4096 / 8192 samples, or any other frame of 416 .. 9600 "
+                 "samples (the default 9600 / 4800, a 44.1 kHz card's 4410, an 11.025 kHz card's 1102), or twice a 2^a 3^b 5^c frame "
+                 "that is a multiple of 16 (19200) (got %d)",
                  nsamples_per_frame);
     JSDR_REQUIRE(bit_clock_is_regular(), "jsdr_bpsk_create: bit clock schedule is not the regular 8-cycle");
     if (fec_prepare() != JSDR_OK) return JSDR_ERR;
@@ -3487,7 +3489,10 @@ int jsdr_bpsk_create(jsdr_bpsk **out, int rate, int nsamples_per_frame, int tuni
                             h->vco_cs.alloc((size_t)h->max_ds) == JSDR_OK)) &&
               (!(do_fft && fft2x_supported(nsamples_per_frame)) ||
                (h->fft2x_ek.alloc(S * fft2x_scratch_ek(nsamples_per_frame)) == JSDR_OK &&
-                h->fft2x_r0.alloc(S * fft2x_scratch_r0(nsamples_per_frame)) == JSDR_OK));
+                h->fft2x_r0.alloc(S * fft2x_scratch_r0(nsamples_per_frame)) == JSDR_OK)) &&
+              // (a mixed-radix frame with a prime factor above 7: the out-of-place pass's scratch, in the 2 m front end's slot)
+              (!(do_fft && !fft_pow2 && fftm_supported(nsamples_per_frame) && fftm_scratch(nsamples_per_frame) > 0) ||
+               h->fft2x_ek.alloc(S * fftm_scratch(nsamples_per_frame)) == JSDR_OK);
     if (ok && nstreams == 1) {
         // [frame | ktu | kvco | vco_cs | tcs] + alignment slack, then the SnapPack slot (not handed out by h2d_call)
         const size_t need = sizeof(float) * 2 * (size_t)nsamples_per_frame + ((size_t)h->max_batch + 26) + (size_t)h->max_ds +
@@ -3540,7 +3545,7 @@ int jsdr_bpsk_create(jsdr_bpsk **out, int rate, int nsamples_per_frame, int tuni
         else if (h->fft_2x)
             fft2x_twiddles(tw, nsamples_per_frame, &h->fm_np, h->fm_rad, h->fm_off, h->fm_off1);
         else
-            fftm_twiddles(tw, nsamples_per_frame, &h->fm_np, h->fm_rad, h->fm_off);
+            fftm_twiddles(tw, nsamples_per_frame, &h->fm_np, h->fm_rad, h->fm_off, h->fm_off1);  // (fm_off1: the prime radices' r-point tables)
         if (tw.size() > h->fft_tw.n || hipMemcpy(h->fft_tw.p, tw.data(), sizeof(double2) * tw.size(), hipMemcpyHostToDevice) != hipSuccess ||
             h->fft_state.zero() != JSDR_OK) {
             set_error("jsdr_bpsk_create: FFT-mode initialisation failed");

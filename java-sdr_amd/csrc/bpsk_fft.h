@@ -90,10 +90,13 @@ __device__ __forceinline__ void boxcar_pair(const double2 *w, double &a0, double
 }
 
 int launch_front_fft(const FftFrontArgs &a, int nstreams, hipStream_t st);
-// frames that are not a power of two (bpsk_fftm.hip): n = 2^a 3^b 5^c 7^d, 1024 < n <= 9600
+// frames that are not a power of two (bpsk_fftm.hip): any n with 416 <= n <= 9600 (2^a 3^b 5^c 7^d through the radix passes, any
+// other prime factor through a pass that is the DFT's definition and needs fftm_scratch(n) elements of scratch per stream)
 bool fftm_supported(int n);
-void fftm_twiddles(std::vector<double2> &w, int n, int *np_out, int *rad, int *tw_off);
-int launch_front_fftm(const FftFrontArgs &a, int np, const int *rad, const int *tw_off, int nstreams, hipStream_t st);
+size_t fftm_scratch(int n);
+void fftm_twiddles(std::vector<double2> &w, int n, int *np_out, int *rad, int *tw_off, int *wr_off);
+int launch_front_fftm(const FftFrontArgs &a, int np, const int *rad, const int *tw_off, const int *wr_off, double2 *gscratch,
+                      int nstreams, hipStream_t st);
 void fft_twiddles_f64(std::vector<double2> &w, int n);
 // frames of 2 m samples, m an LDS-sized mixed-radix frame (n = 19200 at 192 kHz): two m-point halves per transform
 bool fft2x_supported(int n);

@@ -41,6 +41,11 @@ struct FftmArgs {
     int tw_off[FM_MAXPASS];  // offset of pass p's table T[m] = exp(-2 pi i m/(P r)), m < P r
     unsigned pmagic[FM_MAXPASS];  // b / P == (b * pmagic) >> 32 for b < 2^16 (P = product of the earlier radices)
     int lds_tw;              // the tables of the first passes, lds_tw entries in all, are copied to LDS
+    // round 5: a prime radix above 7 (fm_pass_generic): wr_off[p] = offset of W[m] = exp(-2 pi i m/r), m < r; the pass is
+    // out of place through a per-stream scratch of n elements in global memory
+    int wr_off[FM_MAXPASS];
+    double2 *gscratch;
+    long long gscratch_stride;
 };
 
 // Typed views of the LDS image and of the twiddle tables.  The passes are separate (noinline) functions: through a plain
@@ -721,6 +726,34 @@ __device__ __attribute__((noinline)) void fm_first_from_bins(LdsArr X, double2 i
     __syncthreads();
 }
 
+// A pass whose radix is a prime above 7 (round 5; the oracle's generic branch in fft_f64_mixed_forward): one thread per OUTPUT,
+//   out[(b - k) r + k + q P] = v_0 + v_1 W[q mod r] + ... + v_{r-1} W[(r-1) q mod r],   v_j = X[b + j nb] (x T[k j] for j >= 1, P > 1)
+// every product a full complex multiply, summed left to right -- the same operations in the same order as the oracle, the
+// twiddled inputs re-formed for every output (identical values).  Out of place: outputs go to the stream's scratch in
+// global memory, then back into the image.  O(n r) multiplications a pass: a correctness path (11.025 kHz: n = 1102 = 2 19 29).
+__device__ __attribute__((noinline)) void fm_pass_generic(LdsArr X, const double2 *tw, const double2 *wr, double2 *G, int n, int P, int r,
+                                                          int tid)
+{
+    const int nb = n / r;
+    for (int o = tid; o < n; o += FM_T) {
+        const int q = o / nb, b = o - q * nb;  // outputs of one q are contiguous over b: neighbouring threads read neighbouring inputs
+        const int k = b % P;
+        double2 acc = X[b];
+        int m = 0;  // (j q) mod r
+        for (int j = 1; j < r; j++) {
+            m += q;
+            if (m >= r) m -= r;
+            double2 v = X[b + j * nb];
+            if (P > 1) v = cdmul(v, tw[k * j]);
+            acc = cdadd(acc, cdmul(v, wr[m]));
+        }
+        G[(b - k) * r + k + q * P] = acc;
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += FM_T) X[i] = G[i];
+    __syncthreads();
+}
+
 __device__ __forceinline__ const double2 *fm_table(const double2 *twL, const FftmArgs &a, int p, int P)
 {
     // the narrow tables sit in LDS: a pass that starts with a round trip to L2 for its twiddles costs ~2 us,
@@ -837,7 +870,9 @@ __device__ __forceinline__ void fm_forward(LdsArr X, const double2 *twL, const F
             p += 2;
             continue;
         }
-        if (r == 4)
+        if (r > 7)
+            fm_pass_generic(X, tw, a.f.tw + a.wr_off[p], a.gscratch + (long long)blockIdx.x * a.gscratch_stride, a.f.n, P, r, tid);
+        else if (r == 4)
             fm_pass<4>(X, tw, a.f.n, P, a.pmagic[p], tid);
         else if (r == 2)
             fm_pass<2>(X, tw, a.f.n, P, a.pmagic[p], tid);
@@ -1627,7 +1662,25 @@ int fftm_radices(int n, int *rad)
         rad[c++] = 7;
         n /= 7;
     }
+    // any other prime factor, ascending (the oracle's jo_fft_mixed_radices)
+    for (int p = 11; n > 1 && c < FM_MAXPASS; p += 2) {
+        if (p * p > n) p = n;
+        while (n % p == 0 && c < FM_MAXPASS) {
+            rad[c++] = p;
+            n /= p;
+        }
+    }
     return n == 1 ? c : 0;
+}
+
+// frames whose plan holds a prime radix above 7 need a per-stream scratch of n elements (0: none)
+size_t fftm_scratch(int n)
+{
+    int rad[FM_MAXPASS];
+    const int np = fftm_radices(n, rad);
+    for (int p = 0; p < np; p++)
+        if (rad[p] > 7) return (size_t)n;
+    return 0;
 }
 
 bool fftm_supported(int n)
@@ -1637,16 +1690,34 @@ bool fftm_supported(int n)
     // bins of margin either side) needs n/4 > 150; the image must fit the LDS.  Round 4: any such n = 2^a 3^b 5^c 7^d -- n need
     // not be a multiple of 16 (the 16-byte boxcar reads are aligned relative to the band's own start), so the 4410-sample
     // frame of a 44.1 kHz sound card is in
-    return n >= 1024 && n <= FM_NMAX && (n & (n - 1)) != 0 && fftm_radices(n, rad) > 0;
+    // Round 5: any prime factor (a pass of that radix as the DFT's definition: 11.025 kHz gives n = 1102 = 2 19 29), and frames
+    // down to 416 samples (8 kHz gives 800): below n = 604 the boxcar range [beg+75, end-75) is empty -- as in the reference,
+    // whose loop (:433) then never runs -- and the 204 gathered bins (centreBin <= n/2 - 1) still end inside the frame.
+    return n >= 416 && n <= FM_NMAX && (n & (n - 1)) != 0 && fftm_radices(n, rad) > 0;
 }
 
 // per-pass tables T[m] = exp(-2 pi i m/(P r)), m < P r: long double + one rounding, exact on the axes -- the same
 // values as the oracle's jo_fft_mixed_table
-void fftm_twiddles(std::vector<double2> &w, int n, int *np_out, int *rad, int *tw_off)
+void fftm_twiddles(std::vector<double2> &w, int n, int *np_out, int *rad, int *tw_off, int *wr_off)
 {
     const int np = fftm_radices(n, rad);
     *np_out = np;
     w.clear();
+    struct Fill {
+        static void table(std::vector<double2> &w, size_t o, int len)
+        {
+            for (int m = 0; m < len; m++) {
+                const long double ang = 2.0L * 3.14159265358979323846264338327950288L * (long double)m / (long double)len;
+                w[o + m] = make_double2((double)cosl(ang), (double)(-sinl(ang)));
+            }
+            w[o] = make_double2(1.0, -0.0);
+            if (len % 4 == 0) {
+                w[o + len / 4] = make_double2(0.0, -1.0);
+                w[o + 3 * len / 4] = make_double2(-0.0, 1.0);
+            }
+            if (len % 2 == 0) w[o + len / 2] = make_double2(-1.0, -0.0);
+        }
+    };
     int P = 1;
     for (int p = 0; p < np; p++) {
         const int len = P * rad[p];
@@ -1665,13 +1736,33 @@ void fftm_twiddles(std::vector<double2> &w, int n, int *np_out, int *rad, int *t
         if (len % 2 == 0) w[o + len / 2] = make_double2(-1.0, -0.0);
         P *= rad[p];
     }
+    // the r-point tables of the prime radices above 7, behind every pass table (so the default frames' offsets stay put)
+    for (int p = 0; p < np; p++) {
+        if (wr_off) wr_off[p] = 0;
+        if (rad[p] > 7 && wr_off) {
+            wr_off[p] = (int)w.size();
+            const size_t o = w.size();
+            w.resize(o + (size_t)rad[p]);
+            Fill::table(w, o, rad[p]);
+        }
+    }
 }
 
-int launch_front_fftm(const FftFrontArgs &a, int np, const int *rad, const int *tw_off, int nstreams, hipStream_t st)
+int launch_front_fftm(const FftFrontArgs &a, int np, const int *rad, const int *tw_off, const int *wr_off, double2 *gscratch,
+                      int nstreams, hipStream_t st)
 {
     FftmArgs aa;
     aa.f = a;
     aa.np = np;
+    aa.gscratch = gscratch;
+    aa.gscratch_stride = a.n;
+    for (int p = 0; p < FM_MAXPASS; p++) {
+        aa.wr_off[p] = (p < np && wr_off) ? wr_off[p] : 0;
+        if (p < np && rad[p] > 7 && (!gscratch || !wr_off || wr_off[p] <= 0)) {
+            set_error("launch_front_fftm: a radix-%d pass without its table or scratch", rad[p]);
+            return JSDR_ERR;
+        }
+    }
     const size_t fixed = sizeof(double2) * (size_t)a.n + sizeof(double) * (32 + 16) + sizeof(int) * 16 + 64;
     const size_t room = (size_t)160 * 1024 - fixed;  // LDS left for twiddle tables (at n = 9600: 596 entries, the first five passes')
     aa.lds_tw = 0;
@@ -1724,7 +1815,7 @@ bool fft2x_supported(int n)
 void fft2x_twiddles(std::vector<double2> &w, int n, int *np_out, int *rad, int *tw_off, int *tw1_off)
 {
     const int m = n / 2;
-    fftm_twiddles(w, m, np_out, rad, tw_off);
+    fftm_twiddles(w, m, np_out, rad, tw_off, nullptr);
     int P = 1;
     for (int p = 0; p < *np_out; p++) {
         const int r = rad[p], len = 2 * P * r;

@@ -39,7 +39,7 @@ void jo_convert_i16(const int16_t *raw, int nframes, int chns, int ic, int qc, f
  * (inverse optionally scaled by 1/n, as complexInverse(a,true)).                   */
 void jo_fft_f32(float *a, int n);
 void jo_fft_f64(double *a, int n, int inverse, int scale);
-int  jo_fft_mixed_radices(int n, int *rad);      /* n = 2^a 3^b 5^c 7^d: Stockham radix list, 0 if unsupported */
+int  jo_fft_mixed_radices(int n, int *rad);      /* Stockham radix list of any n >= 2 (4,..,(2),3..,5..,7.., then every other prime factor ascending) */
 void jo_fft_mixed_table(double *t, int len);
 /* twiddle table used by jo_fft_f64 (and uploaded verbatim to the GPU by tests that
  * want bit-identical double FFTs): w[2k]=cos(2 pi k/n), w[2k+1]=-sin(2 pi k/n), k<n/2 */

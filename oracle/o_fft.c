@@ -161,6 +161,12 @@ int jo_fft_mixed_radices(int n, int *rad)
     while (n % 3 == 0) { rad[c++] = 3; n /= 3; }
     while (n % 5 == 0) { rad[c++] = 5; n /= 5; }
     while (n % 7 == 0) { rad[c++] = 7; n /= 7; }
+    /* round 5: any other prime factor, ascending (11.025 kHz cards give n = 1102 = 2 19 29; audio-rate is a free integer,
+     * JavaAudio.java:49,58-59) -- a pass of that radix with the r-point DFT written out as its definition (below) */
+    for (int p = 11; n > 1 && c < 30; p += 2) {
+        if (p * p > n) p = n;
+        while (n % p == 0 && c < 30) { rad[c++] = p; n /= p; }
+    }
     return n == 1 ? c : 0;
 }
 
@@ -197,6 +203,32 @@ static void fft_f64_mixed_forward(cd_t *a, int n)
         const int r = rad[p], nb = n / r, len = P * r;
         double *t = (double *)malloc(sizeof(double) * 2 * (size_t)len);
         jo_fft_mixed_table(t, len);
+        if (r > 7) {
+            /* a prime radix above 7: the r-point DFT as its definition.  Inputs twiddled as in every pass, then
+             *   out_q = v_0 + v_1 W[q mod r] + v_2 W[2q mod r] + ... + v_{r-1} W[(r-1)q mod r],  W[m] = exp(-2 pi i m/r)
+             * (jo_fft_mixed_table(r): long double, one rounding), every product a full complex multiply (even by W[0]),
+             * summed left to right.  O(r) per output: a correctness path for the sizes consumer cards produce. */
+            double *wr = (double *)malloc(sizeof(double) * 2 * (size_t)r);
+            cd_t *v = (cd_t *)malloc(sizeof(cd_t) * (size_t)r);
+            jo_fft_mixed_table(wr, r);
+            for (int bf = 0; bf < nb; bf++) {
+                const int k = bf % P;
+                for (int j = 0; j < r; j++) {
+                    v[j] = in[bf + j * nb];
+                    if (j >= 1 && P > 1) v[j] = cmul(v[j], cd(t[2 * (k * j)], t[2 * (k * j) + 1]));
+                }
+                for (int q = 0; q < r; q++) {
+                    cd_t acc = v[0];
+                    for (int j = 1; j < r; j++) {
+                        const int m = (int)(((long long)j * q) % r);
+                        acc = cadd(acc, cmul(v[j], cd(wr[2 * m], wr[2 * m + 1])));
+                    }
+                    out[(bf - k) * r + k + q * P] = acc;
+                }
+            }
+            free(v);
+            free(wr);
+        } else
         for (int bf = 0; bf < nb; bf++) {
             const int k = bf % P;
             cd_t v[7];

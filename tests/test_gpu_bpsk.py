@@ -60,7 +60,7 @@ def run_both(iq_streams, nsamples, chunks, rate=96000, tuning=12000, ic=0, qc=0,
     stride = 2 * nsamples
     d_iq = J.DeviceBuffer.from_host(np.concatenate(iq_streams))
     oracles = [O.Bpsk(rate=rate, blen=(blen if do_fft else 4), tuning=tuning, do_fft=do_fft, do_up=do_up,
-                      trace=nsamples // (rate // 9600) + 8) for _ in range(S)]
+                      trace=nsamples // max(1, rate // 9600) + 8) for _ in range(S)]
     gbits = [[] for _ in range(S)]
     gtrace = [[] for _ in range(S)]
     gfec = [[] for _ in range(S)]
@@ -346,7 +346,12 @@ def test_bpsk_fft_mode_default_frames_carrier_at_the_band_edges(blen, rate, do_u
                                       # same at 88.2 kHz (decimation 9), 3430 = 2.5.7^3, 7000 = 2^3.5^3.7, 2646 = 2.3^3.7^2
                                       (4410, 44100), (8820, 88200), (3430, 48000), (7000, 96000), (2646, 44100),
                                       # ... and rates below 38.4 kHz (decimation 3, 2, 1), which only the mixed-radix front end takes
-                                      (3200, 32000), (2205, 22050), (1200, 9600)])
+                                      (3200, 32000), (2205, 22050), (1200, 9600),
+                                      # round 5: ANY frame of 416 .. 9600 samples -- prime factors above 7 through the pass that is
+                                      # the DFT's definition (11.025 kHz: 1102 = 2.19.29; 1100 = 4.5.5.11; 1103 is prime; 3146 =
+                                      # 2.11.11.13 at a decimation of 3), and frames below 1024 samples (8 kHz: 800; 6 kHz: 600, where
+                                      # the boxcar range is empty, as in the reference's loop :433; 418 = 2.11.19)
+                                      (1102, 11025), (1100, 11000), (1103, 11030), (3146, 31460), (800, 8000), (600, 9600), (418, 9600)])
 def test_bpsk_fft_mode_frames_at_other_decimations(nsf, rate):
     """the front ends' RxDownSample reads the inverse's real samples as a compact array (round 3): 14 aligned 16-byte reads
     per window at an even decimation, single reads at an odd one (48 kHz: 5), two aligned runs at n = 19200 when the
@@ -399,16 +404,18 @@ def test_bpsk_fft_mode_rejects_partial_frames_and_odd_sizes():
     with pytest.raises(J.JsdrError):
         d.batch_i16(buf, 2 * 8192, 3000)
     with pytest.raises(J.JsdrError):
-        J.Bpsk(nstreams=1, do_fft=1, blen=2000)
+        J.Bpsk(nstreams=1, do_fft=1, blen=4 * 512)  # a power of two below 1024: the oracle defines those through the radix-2 network, no kernel does
     with pytest.raises(J.JsdrError):
         J.Bpsk(nstreams=1, do_fft=1, blen=4 * 38400, rate=192000)  # n = 38400: neither an LDS-sized frame nor twice one
     with pytest.raises(J.JsdrError):
-        J.Bpsk(nstreams=1, do_fft=1, blen=4 * 1100)  # 1100 = 2^2 5^2 11: no radix-11 pass (factors 2, 3, 5, 7 only)
+        J.Bpsk(nstreams=1, do_fft=1, blen=4 * 400)  # below 416 samples the 204 gathered bins would not fit the frame
+    with pytest.raises(J.JsdrError):
+        J.Bpsk(nstreams=1, do_fft=1, blen=4 * 9602)  # above 9600 samples only twice an LDS-sized 2^a 3^b 5^c frame
 
 
 def test_bpsk_api_errors():
     with pytest.raises(J.JsdrError):
-        J.Bpsk(rate=8000)
+        J.Bpsk(rate=0)
     with pytest.raises(J.JsdrError):
         J.Bpsk(rate=32000, do_fft=1)  # FFT-acquire mode with a power-of-two frame (2048 here) needs a decimation of at least 4
     d = J.Bpsk(nstreams=2)
@@ -599,12 +606,12 @@ def test_bpsk_fft_mode_one_stream_fed_int16_and_arbitrary_float_frames_in_turn()
 
 
 @pytest.mark.parametrize("rate,tuning", [(32000, 4000), (22050, 3000), (11025, 1500), (64000, 12000), (9600, 1200), (250000, 30000),
-                                         (32000, -4000)])
+                                         (32000, -4000), (8000, 1000)])
 def test_bpsk_any_audio_rate_takes_the_generic_front_end(rate, tuning):
     """the reference's audio-rate is a free integer (JavaAudio.java:49,59) and RxDownSample takes whatever rate / 9600 is
     (FUNcubeBPSKDemod.java:476): decimations other than 4 / 5 / 10 / 20 go through k_front_any (one thread per output).
     Same bar as everywhere: (fi,fq), bits, counters, state bit for bit; ragged calls; int16 batches and float frames."""
-    D = rate // 9600
+    D = max(1, rate // 9600)  # (below 9600 Hz the reference's `++dsCnt >= 0` fires at every sample: decimation 1)
     n = 2048 * 24
     streams = [O.make_dbpsk_stream(90 + s, s, n, rate=rate, carrier_hz=abs(tuning) + 1200.0, noise_sigma=500.0 + 300 * s)[0]
                for s in range(3)]
@@ -644,7 +651,7 @@ def test_bpsk_suite_with_the_eight_streams_per_wave_tail():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
-@pytest.mark.parametrize("nsf,rate", [(4410, 44100), (3200, 32000), (2205, 22050)])
+@pytest.mark.parametrize("nsf,rate", [(4410, 44100), (3200, 32000), (2205, 22050), (1102, 11025), (800, 8000)])
 def test_bpsk_fft_mode_receive_at_consumer_sound_card_rates(nsf, rate):
     """the IAudioHandler form (one stream, one frame per receive()) in FFT-acquire mode at the frames a 44.1 / 32 / 22.05 kHz
     card delivers (JavaAudio.java:59): radix-7 passes, frames that are not multiples of 16, decimations 4 / 3 / 2 -- int16
@@ -653,7 +660,7 @@ def test_bpsk_fft_mode_receive_at_consumer_sound_card_rates(nsf, rate):
     iq = O.make_dbpsk_stream(91, 0, nsf * nfr, rate=rate, carrier_hz=rate / 8.0 + 150.0, noise_sigma=600.0)[0]
     exact = O.convert_i16(iq)
     d = J.Bpsk(nstreams=1, do_fft=1, rate=rate, blen=4 * nsf)
-    o = O.Bpsk(do_fft=1, rate=rate, blen=4 * nsf, trace=nsf * nfr // (rate // 9600) + 8)
+    o = O.Bpsk(do_fft=1, rate=rate, blen=4 * nsf, trace=nsf * nfr // max(1, rate // 9600) + 8)
     bits, tr = [], []
     for k in range(nfr):
         fr = exact[2 * nsf * k:2 * nsf * (k + 1)].copy()

@@ -398,9 +398,13 @@ def test_oracle_mixed_radix_f64_transform_against_numpy():
     assert L.jo_fft_mixed_radices(4800, rad.ctypes.data) == 6 and list(rad[:6]) == [4, 4, 4, 3, 5, 5]
     assert L.jo_fft_mixed_radices(7000, rad.ctypes.data) == 6 and list(rad[:6]) == [4, 2, 5, 5, 5, 7]  # round 4: radix 7
     assert L.jo_fft_mixed_radices(4410, rad.ctypes.data) == 6 and list(rad[:6]) == [2, 3, 3, 5, 7, 7]  # a 44.1 kHz sound card's frame
-    assert L.jo_fft_mixed_radices(1100, rad.ctypes.data) == 0  # a factor 11
+    # round 5: any other prime factor, ascending, through the r-point DFT as its definition
+    assert L.jo_fft_mixed_radices(1100, rad.ctypes.data) == 4 and list(rad[:4]) == [4, 5, 5, 11]
+    assert L.jo_fft_mixed_radices(1102, rad.ctypes.data) == 3 and list(rad[:3]) == [2, 19, 29]  # an 11.025 kHz card's frame
+    assert L.jo_fft_mixed_radices(1103, rad.ctypes.data) == 1 and list(rad[:1]) == [1103]       # a prime frame: the DFT sum itself
+    assert L.jo_fft_mixed_radices(2 * 11 * 11 * 13, rad.ctypes.data) == 4 and list(rad[:4]) == [2, 11, 11, 13]
     rng = np.random.default_rng(12)
-    for n in (9600, 4800, 2400, 60, 15, 6, 4410, 7000, 49, 7, 2646):
+    for n in (9600, 4800, 2400, 60, 15, 6, 4410, 7000, 49, 7, 2646, 1102, 1100, 1103, 3146, 11, 800, 638):
         x = rng.standard_normal(2 * n)
         a = x.copy()
         L.jo_fft_f64(a.ctypes.data, n, 0, 0)
