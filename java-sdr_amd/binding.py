@@ -45,12 +45,12 @@ def lib():
         _lib.jsdr_last_error.restype = C.c_char_p
         _lib.jsdr_bpsk_profile_name.restype = C.c_char_p
         _lib.jsdr_demod_profile_name.restype = C.c_char_p
-        for fn in ("jsdr_bpsk_front_kernel", "jsdr_bpsk_tail_kernel", "jsdr_bpsk_fec_kernel"):
+        for fn in ("jsdr_bpsk_front_kernel", "jsdr_bpsk_tail_kernel", "jsdr_bpsk_fec_kernel", "jsdr_fft_kernel"):
             getattr(_lib, fn).restype = C.c_char_p
             getattr(_lib, fn).argtypes = [C.c_void_p]
         for name in EXPORTED_SYMBOLS:
             if name not in ("jsdr_last_error", "jsdr_bpsk_profile_name", "jsdr_demod_profile_name", "jsdr_bpsk_front_kernel",
-                            "jsdr_bpsk_tail_kernel", "jsdr_bpsk_fec_kernel"):
+                            "jsdr_bpsk_tail_kernel", "jsdr_bpsk_fec_kernel", "jsdr_fft_kernel"):
                 getattr(_lib, name).restype = C.c_int
     return _lib
 
@@ -205,6 +205,9 @@ class Fft:
 
     def set_cu_share(self, wgs_per_cu):
         _check(lib().jsdr_fft_set_cu_share(self.h, int(wgs_per_cu)), "jsdr_fft_set_cu_share")
+
+    def kernel_name(self):
+        return lib().jsdr_fft_kernel(self.h).decode()
 
     def last_launch(self):
         a, b = C.c_int64(), C.c_int64()

@@ -23,6 +23,7 @@ SOURCES = {
     "fft_psd.hip": [],
     "fft_mixed.hip": [],
     "fft_any.hip": ["-ffp-contract=off"],
+    "fft_rt.hip": [],
     "fir_phase.hip": ["-ffp-contract=off"],
     "fir_batch.hip": ["-ffp-contract=off"],
     "fec.hip": [],

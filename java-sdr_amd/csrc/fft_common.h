@@ -3,6 +3,7 @@
 #pragma once
 #include "common.h"
 #include <utility>
+#include <vector>
 
 namespace jsdr {
 
@@ -158,6 +159,11 @@ void mixed_twiddles(const MixedPlan &p, float2 *out);
 int mixed_launch(const MixedPlan &p, const FftArgs &a, int in_kind, int out_kind, int grid, hipStream_t st);
 // split2 plans: half-size spectra of `nframes` frames into tmp [2*nframes][n/2], then the combine pass
 int mixed_launch_split2(const MixedPlan &p, const FftArgs &a, int in_kind, int out_kind, int num_cu, hipStream_t st);
+
+// any other n = 2^a 3^b 5^c 7^d up to 9800 (fft_rt.hip): Stockham passes with a run-time radix plan
+bool rt_supported(int n);
+void rt_twiddles(int n, std::vector<float2> &w);
+int rt_launch(const FftArgs &a, int n, int in_kind, int out_kind, int num_cu, hipStream_t st);
 
 // any other frame size (fft_any.hip): the DFT itself, double accumulation
 bool dft_any_supported(int n);

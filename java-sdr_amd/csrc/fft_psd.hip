@@ -374,6 +374,7 @@ struct jsdr_fft {
     int num_cu = 256;
     bool mixed = false;  // non power-of-two frame: fft_mixed.hip
     MixedPlan mplan;
+    bool rt = false;      // any other 2^a 3^b 5^c 7^d frame up to 9800 samples: fft_rt.hip
     bool direct = false;  // any other frame size: fft_any.hip
     long long last_items = 0, last_grid = 0;  // jsdr_fft_last_launch
     int share_wgs_per_cu = 0;  // jsdr_fft_set_cu_share: workgroups per CU the batch kernel is held to (0: all it can use)
@@ -387,6 +388,16 @@ static int fft_run(jsdr_fft *h, const void *in_dev, int in_kind, int out_kind, l
     JSDR_REQUIRE(nframes >= 0, "fft: negative frame count");
     if (nframes == 0) return JSDR_OK;
     FftArgs a;
+    if (h->rt) {
+        a.in = in_dev;
+        a.out = out_dev;
+        a.tw = h->tw.p;
+        a.nframes = nframes;
+        a.rate = h->rate;
+        a.ic = ic;
+        a.qc = qc;
+        return rt_launch(a, h->n, in_kind, out_kind, h->num_cu, s);
+    }
     if (h->direct) {
         a.in = in_dev;
         a.out = out_dev;
@@ -456,8 +467,9 @@ int jsdr_fft_create(jsdr_fft **out, int n, int rate)
     MixedPlan mp;
     const bool pow2 = n >= 64 && n <= 8192 && (n & (n - 1)) == 0;
     const bool mixed = !pow2 && mixed_plan(n, mp);
-    const bool direct = !pow2 && !mixed && dft_any_supported(n);
-    JSDR_REQUIRE(pow2 || mixed || direct,
+    const bool rt = !pow2 && !mixed && rt_supported(n);
+    const bool direct = !pow2 && !mixed && !rt && dft_any_supported(n);
+    JSDR_REQUIRE(pow2 || mixed || rt || direct,
                  "jsdr_fft_create: n=%d unsupported (2 .. 20000 samples)", n);
     JSDR_REQUIRE(rate > 0, "jsdr_fft_create: rate must be positive");
     int dev = 0;
@@ -471,6 +483,20 @@ int jsdr_fft_create(jsdr_fft **out, int n, int rate)
     if (direct) {  // no tables: the twiddles are computed where they are used
         h->direct = true;
         if (h->in_stage.alloc((size_t)n * 8) != JSDR_OK || h->out_stage.alloc((size_t)n + 2) != JSDR_OK) {
+            jsdr_fft_destroy(h);
+            return JSDR_ERR;
+        }
+        *out = h;
+        return JSDR_OK;
+    }
+    if (rt) {
+        h->rt = true;
+        std::vector<float2> rtw;
+        rt_twiddles(n, rtw);
+        if (h->tw.alloc(rtw.size() ? rtw.size() : 1) != JSDR_OK || h->in_stage.alloc((size_t)n * 8) != JSDR_OK ||
+            h->out_stage.alloc((size_t)n + 2) != JSDR_OK ||
+            (rtw.size() && hipMemcpy(h->tw.p, rtw.data(), sizeof(float2) * rtw.size(), hipMemcpyHostToDevice) != hipSuccess)) {
+            set_error("jsdr_fft_create: run-time-plan setup failed");
             jsdr_fft_destroy(h);
             return JSDR_ERR;
         }
@@ -556,6 +582,12 @@ int jsdr_fft_set_cu_share(jsdr_fft *h, int wgs_per_cu)
     JSDR_REQUIRE(h && wgs_per_cu >= 0 && wgs_per_cu <= 16, "jsdr_fft_set_cu_share: bad argument");
     h->share_wgs_per_cu = wgs_per_cu;
     return JSDR_OK;
+}
+
+const char *jsdr_fft_kernel(jsdr_fft *h)
+{
+    if (!h) return "";
+    return h->rt ? "k_fft_rt" : h->direct ? "k_dft_any" : h->mixed ? (h->mplan.split2 ? "k_fft_mixed_dual" : "k_fft_mixed") : "k_fft";
 }
 
 int jsdr_fft_last_launch(jsdr_fft *h, int64_t *work_items, int64_t *workgroups)

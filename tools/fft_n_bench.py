@@ -25,4 +25,4 @@ for _ in range(5):
     f.batch_i16(d_raw, nframes, d_psd)
 t.stop()
 ms = t.elapsed_ms() / 5
-print(f"n={n}: {nframes} frames in {ms:.3f} ms = {nframes * n / ms / 1e6:.1f} Gsamples/s, {nframes * n * 8.0 / ms / 1e9:.2f} TB/s algorithmic")
+print(f"n={n} ({f.kernel_name()}): {nframes} frames in {ms:.3f} ms = {nframes * n / ms / 1e6:.1f} Gsamples/s, {nframes * n * 8.0 / ms / 1e9:.2f} TB/s algorithmic")
