@@ -122,6 +122,7 @@ void jo_bpsk_trace_enable(jo_bpsk_t *d, int64_t cap_pairs);
 void jo_bpsk_fft_probe_enable(jo_bpsk_t *d, int64_t cap_frames);
 int64_t jo_bpsk_fft_probe(const jo_bpsk_t *d, double *out, int64_t cap_frames);
 void jo_bpsk_fft_perturb(jo_bpsk_t *d, double scale, uint64_t seed);
+void jo_bpsk_decision_margins(const jo_bpsk_t *d, double *out /* [8] */);
 int64_t jo_bpsk_trace(const jo_bpsk_t *d, double *out, int64_t cap_pairs);
 /* optional trace of down-sampler outputs (after x HOWARD_FUDGE_FACTOR)           */
 int64_t jo_bpsk_trace_ds(const jo_bpsk_t *d, double *out, int64_t cap_pairs);

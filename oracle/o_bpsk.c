@@ -157,6 +157,17 @@ struct jo_bpsk {
     int64_t nprobe, capprobe;
     double perturb_scale;   /* 0: off; else every bin's re, im += scale * u * log2(n) * ||x||_2 * U(-1,1) */
     uint64_t perturb_state;
+    /* round 5: the same question one stage further -- the inverse transform's output feeds RxDownSample and, through the
+     * filters, the three decisions of RxDemodulate (energy2 > 100, di < 0, the 8-way dmNewPeak argmax, :544-545,:586-592).
+     * inv_err[0..1]: a bound on what two correct double FFTs can differ by in one real sample of this / the previous frame
+     * (inverse rounding + the forward transform's error in the 204 gathered bins), amplified through both FIRs for (fi,fq);
+     * dec[]: smallest margin of each decision in units of the error that bound allows in the compared quantity, and
+     * counts; errE: the bound carried through the energy IIRs.  With perturb_scale != 0 the inverse output is perturbed too. */
+    double inv_err[2];
+    double dec_margin[3];   /* di, energy2 vs 100, argmax gap */
+    int64_t dec_count[3];
+    double errE[SPB + 2];
+    uint64_t dec_hash[2];   /* rolling hashes of the energy2 > 100 outcomes and of the dmNewPeak sequence */
 };
 
 jo_bpsk_t *jo_bpsk_new(int rate, int blen, int size, int tuning, int do_fft, int do_up)
@@ -243,15 +254,37 @@ static void RxDemodulate(jo_bpsk_t *d, double i, double q)
 
     /* smoothed bit energy (:534-535) */
     d->energy1 = fi * fi + fq * fq;
+    double ey = 0.0; /* (instruments only) bound on |delta fi|, |delta fq| */
+    if (d->probe) {
+        double ds1 = 0.0, dm1 = 0.0;
+        for (int n = 0; n < DS_N; n++) ds1 += fabs(dsFilter[n]);
+        for (int n = 0; n < DM_N; n++) dm1 += fabs(dmFilter[n]);
+        ey = (d->inv_err[0] > d->inv_err[1] ? d->inv_err[0] : d->inv_err[1]) * ds1 * d->HOWARD_FUDGE_FACTOR * dm1;
+        d->errE[d->dmBitPos] = d->errE[d->dmBitPos] * (1.0 - BIT_SMOOTH1) + (2.0 * (fabs(fi) + fabs(fq)) * ey + 2.0 * ey * ey) * BIT_SMOOTH1;
+    }
     d->dmEnergy[d->dmBitPos] = (d->dmEnergy[d->dmBitPos] * (1.0 - BIT_SMOOTH1)) + (d->energy1 * BIT_SMOOTH1);
     /* at peak bit energy? decode (:537-575) */
     if (d->dmBitPos == d->dmPeakPos) {
         d->dmEnergyOut = (d->dmEnergyOut * (1.0 - BIT_SMOOTH2)) + (d->energy1 * BIT_SMOOTH2);
         double di = -(d->dmLastIQ[0] * fi + d->dmLastIQ[1] * fq);
         double dq = d->dmLastIQ[0] * fq - d->dmLastIQ[1] * fi;
+        const double err_d = ey * (fabs(d->dmLastIQ[0]) + fabs(d->dmLastIQ[1]) + fabs(fi) + fabs(fq)) + 2.0 * ey * ey; /* |delta di|, |delta dq| */
         d->dmLastIQ[0] = fi;
         d->dmLastIQ[1] = fq;
         d->energy2 = sqrt(di * di + dq * dq);
+        if (d->probe) {
+            d->dec_hash[0] = (d->dec_hash[0] * 0x100000001b3ull) ^ (uint64_t)(d->energy2 > 100.0);
+            if (err_d > 0.0) {
+                const double m2 = fabs(d->energy2 - 100.0) / (1.4142135623730951 * err_d);
+                if (d->dec_count[1] == 0 || m2 < d->dec_margin[1]) d->dec_margin[1] = m2;
+                d->dec_count[1]++;
+                if (d->energy2 > 100.0) {
+                    const double m1 = fabs(di) / err_d;
+                    if (d->dec_count[0] == 0 || m1 < d->dec_margin[0]) d->dec_margin[0] = m1;
+                    d->dec_count[0]++;
+                }
+            }
+        }
         if (d->energy2 > 100.0) {
             int bit = di < 0.0;
             memmove(d->dmFECCorr, d->dmFECCorr + 1, FEC_BITS - 1);
@@ -285,6 +318,18 @@ static void RxDemodulate(jo_bpsk_t *d, double i, double q)
             if (d->dmEnergy[n] > eMax) {
                 d->dmNewPeak = n;
                 eMax = d->dmEnergy[n];
+            }
+        }
+        if (d->probe) {
+            d->dec_hash[1] = (d->dec_hash[1] * 0x100000001b3ull) ^ (uint64_t)d->dmNewPeak;
+            int second = -1;
+            for (int n = 0; n < SPB; n++)
+                if (n != d->dmNewPeak && (second < 0 || d->dmEnergy[n] > d->dmEnergy[second])) second = n;
+            const double err = d->errE[d->dmNewPeak] + d->errE[second];
+            if (err > 0.0) {
+                const double m3 = (d->dmEnergy[d->dmNewPeak] - d->dmEnergy[second]) / err;
+                if (d->dec_count[2] == 0 || m3 < d->dec_margin[2]) d->dec_margin[2] = m3;
+                d->dec_count[2]++;
             }
         }
     }
@@ -406,7 +451,26 @@ static void doBufferFFT(jo_bpsk_t *d, const float *buf)
         r[7] = (double)samples;
     }
     memcpy(fftRev, fftFwd + 2 * (d->centreBin - 102), sizeof(double) * 2 * 204);
+    double ynorm = 0.0;
+    if (d->probe || d->perturb_scale != 0.0) {
+        for (int n = 0; n < 2 * 204; n++) ynorm += fftRev[n] * fftRev[n];
+        ynorm = sqrt(ynorm);
+        /* one real sample of the scaled inverse: its own rounding, u log2(n) ||Y||_2 / n, plus what the forward transform's
+         * error in the 204 gathered bins (each component within u log2(n) ||x||_2) adds: (1/n) sum |dY_k| */
+        d->inv_err[1] = d->inv_err[0];
+        d->inv_err[0] = 1.1102230246251565e-16 * log2((double)samples) * (ynorm + 204.0 * 1.4142135623730951 * xnorm) / (double)samples;
+    }
     jo_fft_f64(fftRev, samples, 1, 1);
+    if (d->perturb_scale != 0.0) {
+        const double bound = d->perturb_scale * 1.1102230246251565e-16 * log2((double)samples) * ynorm / (double)samples;
+        for (int n = 0; n < samples; n++) {
+            uint64_t z = (d->perturb_state += 0x9e3779b97f4a7c15ull);
+            z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+            z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+            z ^= z >> 31;
+            fftRev[2 * n] += bound * (((double)(z >> 11) * (1.0 / 9007199254740992.0)) * 2.0 - 1.0);
+        }
+    }
     for (int i = 0; i < samples; i++) RxDownSample(d, fftRev[2 * i], fftRev[2 * i]); /* Q dropped (:462) */
     free(fftFwd);
     free(fftRev);
@@ -484,6 +548,18 @@ int64_t jo_bpsk_fft_probe(const jo_bpsk_t *d, double *out, int64_t cap_frames)
     int64_t n = d->nprobe < cap_frames ? d->nprobe : cap_frames;
     if (out && n > 0) memcpy(out, d->probe, sizeof(double) * JO_BPSK_PROBE_N * (size_t)n);
     return d->nprobe;
+}
+
+/* out[0..2]: smallest margins (di, energy2 vs 100, argmax gap) in units of the error two correct double FFTs allow in that
+ * quantity; out[3..5]: decisions counted; out[6..7]: hashes of the threshold outcomes and of the dmNewPeak sequence */
+void jo_bpsk_decision_margins(const jo_bpsk_t *d, double *out)
+{
+    for (int i = 0; i < 3; i++) {
+        out[i] = d->dec_margin[i];
+        out[3 + i] = (double)d->dec_count[i];
+    }
+    out[6] = (double)(d->dec_hash[0] >> 11);
+    out[7] = (double)(d->dec_hash[1] >> 11);
 }
 
 void jo_bpsk_fft_perturb(jo_bpsk_t *d, double scale, uint64_t seed)

@@ -388,6 +388,16 @@ class Bpsk:
         f(self.h, out.ctypes.data, n)
         return out[:n]
 
+    def decision_margins(self):
+        """(fft_probe_enable first) smallest margins of di<0, energy2>100 and the 8-way argmax in units of the error two correct
+        double FFTs allow, their counts, and hashes of the threshold outcomes / the dmNewPeak sequence"""
+        out = np.zeros(8, np.float64)
+        lib().jo_bpsk_decision_margins.argtypes = [C.c_void_p, C.c_void_p]
+        lib().jo_bpsk_decision_margins.restype = None
+        lib().jo_bpsk_decision_margins(self.h, out.ctypes.data)
+        return dict(di=out[0], energy2=out[1], argmax=out[2], n_di=int(out[3]), n_energy2=int(out[4]), n_argmax=int(out[5]),
+                    hash_energy2=int(out[6]), hash_peak=int(out[7]))
+
     def fft_perturb(self, scale, seed):
         lib().jo_bpsk_fft_perturb.argtypes = [C.c_void_p, C.c_double, C.c_uint64]
         lib().jo_bpsk_fft_perturb(self.h, float(scale), int(seed))

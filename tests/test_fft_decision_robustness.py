@@ -12,6 +12,14 @@ forward error |X'_k - X_k| <= c u log2(n) ||x||_2 per bin (Higham, ASNA, thm 24.
 (x 1 and x 16, several seeds; the perturbed centre bin feeds the averages of the following frames, as a different FFT's
 would): the number of frames whose `centreBin` differs from the unperturbed run is counted.
 
+Round 5 takes the same question one stage further, to the BITS: the inverse transform's output
+(:459-463) feeds RxDownSample, both FIRs and RxDemodulate's three data-dependent decisions -- `energy2 > 100`, `di < 0`
+(:544-545) and the 8-way dmNewPeak argmax (:586-592).  The oracle carries a bound on what two correct double FFTs can differ
+by in one real sample (the inverse's own rounding plus the forward error in the 204 gathered bins) through the filters' tap
+sums and the energy IIRs, and records each decision's smallest margin in units of the error that bound allows in the
+compared quantity; and the inverse output is perturbed by its bound as well (x 1, x 16), the whole bit stream, the threshold
+outcomes and the peak sequence compared with the unperturbed run.
+
 Corpus: the six streams of the FFT-mode fixtures' recipe (clean, noisy, noise-only; both band halves) at 2048-sample frames,
 DBPSK + noise at the application's default frames 9600 and 19200 (192 kHz), and the reference's sine4410.raw."""
 import os
@@ -48,16 +56,26 @@ def run(rate, frame, do_up, iq, perturb=0.0, seed=0):
     if perturb:
         o.fft_perturb(perturb, seed)
     o.receive_i16(iq)
-    return o.fft_probe()
+    return o.fft_probe(), o.bits().copy(), o.decision_margins()
 
 
 def test_decisions_against_an_ffts_own_rounding_error():
     report = []
     total = changed1 = changed16 = 0
     worst1 = worst2 = np.inf
+    bits_total = 0
+    bitflips = {1.0: 0, 16.0: 0}
+    seqflips = {1.0: 0, 16.0: 0}
+    worst_dec = {"di": np.inf, "energy2": np.inf, "argmax": np.inf}
+    ndec = {"di": 0, "energy2": 0, "argmax": 0}
     for name, rate, frame, do_up, iq in corpus():
-        base = run(rate, frame, do_up, iq)
+        base, base_bits, base_m = run(rate, frame, do_up, iq)
         nfr = len(base)
+        bits_total += len(base_bits)
+        for k in worst_dec:
+            if base_m["n_" + k] > 0:
+                worst_dec[k] = min(worst_dec[k], base_m[k])
+                ndec[k] += base_m["n_" + k]
         # the error an FFT can put into a boxcar sum of 100 magnitudes (c = 1; |X| moves by at most |dX| <= sqrt(2) x the
         # per-component figure)
         esum = 100.0 * np.sqrt(2.0) * U * np.log2(base[:, 7]) * base[:, 6]
@@ -69,20 +87,33 @@ def test_decisions_against_an_ffts_own_rounding_error():
         for scale in (1.0, 16.0):
             worst = 0
             for seed in (1, 2, 3):
-                p = run(rate, frame, do_up, iq, perturb=scale, seed=seed)
+                p, pbits, pm = run(rate, frame, do_up, iq, perturb=scale, seed=seed)
                 worst = max(worst, int(np.count_nonzero(p[:, 5] != base[:, 5])))
+                nb = min(len(pbits), len(base_bits))
+                bitflips[scale] = max(bitflips[scale], int(np.count_nonzero(pbits[:nb] != base_bits[:nb])) + abs(len(pbits) - len(base_bits)))
+                seqflips[scale] += int(pm["hash_energy2"] != base_m["hash_energy2"]) + int(pm["hash_peak"] != base_m["hash_peak"])
             flips[scale] = worst
         total += nfr
         changed1 += flips[1.0]
         changed16 += flips[16.0]
         report.append("%-34s frames %4d  argmax margin min %.3g (x error)  rule margin min %.3g  centreBin changed: %d / %d (x1 / x16)"
-                      % (name, nfr, m1.min(initial=np.inf), m2.min(initial=np.inf), flips[1.0], flips[16.0]))
+                      "  | bits %5d  margins di %.3g  energy2 %.3g  peak argmax %.3g"
+                      % (name, nfr, m1.min(initial=np.inf), m2.min(initial=np.inf), flips[1.0], flips[16.0], len(base_bits),
+                         base_m["di"] if base_m["n_di"] else np.inf, base_m["energy2"] if base_m["n_energy2"] else np.inf,
+                         base_m["argmax"] if base_m["n_argmax"] else np.inf))
     text = "\n".join(report) + "\ntotal frames %d; centreBin decisions changed by a perturbation of 1 x / 16 x the bound: %d / %d; " \
         "smallest margins: argmax %.3g, rule %.3g (in units of the error an FFT can put into a boxcar sum)" % (
             total, changed1, changed16, worst1, worst2)
+    text += ("\nRxDemodulate's decisions behind the inverse transform (:544-545, :586-592): %d slicer decisions (di < 0), %d threshold "
+             "decisions (energy2 > 100), %d peak argmaxes; smallest margins in units of the error two correct double FFTs allow in the "
+             "compared quantity: di %.3g, energy2 %.3g, argmax %.3g; with the spectrum AND the inverse's output perturbed by 1 x / 16 x "
+             "their bounds: bits that differ (worst seed, of %d) %d / %d, threshold-outcome or peak sequences that differ (of %d runs each) %d / %d"
+             % (ndec["di"], ndec["energy2"], ndec["argmax"], worst_dec["di"], worst_dec["energy2"], worst_dec["argmax"], bits_total,
+                bitflips[1.0], bitflips[16.0], 3 * 2 * len(report), seqflips[1.0], seqflips[16.0]))
     print(text)
-    with open(os.path.join(os.path.dirname(GOLD), "..", "profiles", "r04_fft_decision_robustness.txt"), "w") as f:
+    with open(os.path.join(os.path.dirname(GOLD), "..", "profiles", "r05_fft_decision_robustness.txt"), "w") as f:
         f.write("tests/test_fft_decision_robustness.py (CPU, the C oracle)\n" + text + "\n")
     # what the parity claim rests on: no decision of the corpus sits within an FFT's rounding error of its alternative
     assert changed1 == 0 and changed16 == 0, text
     assert worst1 > 100.0 and worst2 > 100.0, text
+    assert bitflips[1.0] == 0 and bitflips[16.0] == 0 and seqflips[1.0] == 0 and seqflips[16.0] == 0, text
