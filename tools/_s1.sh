@@ -1,5 +1,5 @@
 set -u; mkdir -p gpurun_out; export TMPDIR=/tmp
-timeout -k 10 900 python -m pytest tests/test_gpu_fft.py -m gpu -q -x -p no:cacheprovider --timeout 600 > gpurun_out/r05_e_tests.log 2>&1; echo "tests rc=$?"
-tail -25 gpurun_out/r05_e_tests.log
-for n in 9600 4410 2205 3200 800 8820 1102; do timeout -k 10 120 python tools/fft_n_bench.py $n 1024 2>&1 | tail -1; done | tee gpurun_out/r05_e_fft_n_bench.txt
-python tools/latency_bench.py 2>&1 | tail -12
+rm -rf gpurun_out/sqp
+timeout -k 10 400 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --output-format csv -d gpurun_out/sqp -- python3 bench.py --serial --steps 2 --warmup 1 --no-cpu-baseline --no-validate > gpurun_out/sqp.log 2>&1
+python tools/pmc_summary.py gpurun_out/sqp > gpurun_out/r05_g_sq_counters_pipeline_serial.txt; rm -rf gpurun_out/sqp
+grep -A8 "^jsdr\|^void" gpurun_out/r05_g_sq_counters_pipeline_serial.txt | grep "^jsdr\|^void\|INSTS_VALU\|BUSY_CYCLES\|SQ_WAVES " 
