@@ -754,6 +754,144 @@ __device__ __attribute__((noinline)) void fm_pass_generic(LdsArr X, const double
     __syncthreads();
 }
 
+// ---- round 5: the 4410-sample frame of a 44.1 kHz card (2 . 3 . 3 . 5 . 7 . 7, the oracle's order) with compile-time passes.
+// fm_passr_real / fm_passr_band: fm_pass5_real / fm_pass5_band for any radix (the last pass of 4410 is a radix-7 one).
+template <int R, int NN, int PP, int COMPACT, class TW>
+__device__ __attribute__((noinline)) void fm_passr_real(LdsArr X, TW tw, double norm, int tid, const double *hist_)
+{
+    constexpr int nb = NN / R, ITERS = (nb + FM_T - 1) / FM_T;
+    static_assert(COMPACT == 1, "compact real samples");
+    double o[ITERS][R];
+#pragma unroll
+    for (int it = 0; it < ITERS; it++) {
+        const int b = it * FM_T + tid;
+        if (b < nb) {
+            const int k = b % PP;
+            double2 v[R];
+#pragma unroll
+            for (int j = 0; j < R; j++) {
+                v[j] = X[b + j * nb];
+                if (j >= 1) v[j] = cdmul(v[j], tw[k * j]);
+            }
+            dft_r<R>(v);  // (only the real parts are read: the imaginary halves have no reader and are not formed)
+#pragma unroll
+            for (int q = 0; q < R; q++) o[it][q] = v[q].x * norm;
+        }
+    }
+    FM_PASS_SYNC();
+    lds_f64 *Rb = reinterpret_cast<lds_f64 *>(X.p);
+#pragma unroll
+    for (int it = 0; it < ITERS; it++) {
+        const int b = it * FM_T + tid;
+        if (b < nb) {
+            const int k = b % PP;
+            const int j0 = (b - k) * R + k;
+#pragma unroll
+            for (int q = 0; q < R; q++) Rb[FM_RB0 + j0 + q * PP] = o[it][q];
+        }
+    }
+    if (hist_ != nullptr) {
+        const lds_f64 *hist = (const lds_f64 *)(unsigned)(unsigned long long)hist_;
+        if (tid < 26) Rb[FM_RB0 - 26 + tid] = hist[tid];
+    }
+    FM_PASS_SYNC();
+}
+
+template <int R, int NN, int PP, class TW>
+__device__ __attribute__((noinline)) void fm_passr_band(LdsArr X, TW tw, int need_end, int tid)
+{
+    constexpr int nb = NN / R, ITERS = (nb + FM_T - 1) / FM_T;
+    static_assert(PP == nb, "the last pass: one butterfly per k");
+    double2 v[ITERS][R];
+    unsigned need[ITERS];
+#pragma unroll
+    for (int it = 0; it < ITERS; it++) {
+        const int b = it * FM_T + tid;  // == k
+        need[it] = 0u;
+        if (b < nb) {
+#pragma unroll
+            for (int q = 0; q < R; q++)
+                if (b + q * PP < need_end) need[it] |= 1u << q;
+            if (need[it]) {  // (a butterfly none of whose outputs is read is not formed: its inputs are dead after this pass)
+#pragma unroll
+                for (int j = 0; j < R; j++) {
+                    v[it][j] = X[b + j * nb];
+                    if (j >= 1) v[it][j] = cdmul(v[it][j], tw[b * j]);
+                }
+                dft_r<R>(v[it]);
+            }
+        }
+    }
+    FM_PASS_SYNC();
+#pragma unroll
+    for (int it = 0; it < ITERS; it++) {
+        const int b = it * FM_T + tid;
+        if (b < nb) {
+#pragma unroll
+            for (int q = 0; q < R; q++)
+                if (need[it] & (1u << q)) X[b + q * PP] = v[it][q];
+        }
+    }
+    FM_PASS_SYNC();
+}
+
+// The first pass pair (R1, R2; strides 1 and R1) of the INVERSE transform straight from the 204 gathered bins: what
+// fm_pass2<R1, R2, NN, 1> computes on the zeroed, conjugated array of FUNcubeBPSKDemod.java:458 -- element i = conj(bin i) for
+// i < 204, (0.0, -0.0) elsewhere -- without that array ever being written: item g reads element g + j2 NN/(R1 R2) + j1 NN/R1,
+// which is a bin only for j1 = j2 = 0 and g < 204.  The same operations on the same operand values (the zeros included: a
+// zero's sign is whatever the general pass would have produced), one LDS write of the image instead of zero-fill + scatter +
+// read + write.  src: the spectrum image itself (X + centreBin - 102); every bin is in registers before the first store.
+template <int R1, int R2, int NN, class TW2>
+__device__ __attribute__((noinline)) void fm_inv_pair_from_bins(LdsArr X, LdsArr src, TW2 tw2, int tid)
+{
+    constexpr int RR = R1 * R2, ng = NN / RR, ITERS = (ng + FM_T - 1) / FM_T;
+    static_assert(ng >= 204 && FM_T >= 204, "item g < 204 holds bin g, in the first round");
+    double2 v[ITERS][R2][R1];
+#pragma unroll
+    for (int it = 0; it < ITERS; it++) {
+        const int g = it * FM_T + tid;
+        if (g < ng) {
+#pragma unroll
+            for (int j2 = 0; j2 < R2; j2++) {
+#pragma unroll
+                for (int j1 = 0; j1 < R1; j1++) v[it][j2][j1] = make_double2(0.0, -0.0);
+            }
+            if (it == 0 && g < 204) {
+                const double2 a = src[g];
+                v[it][0][0] = make_double2(a.x, -a.y);
+            }
+#pragma unroll
+            for (int j2 = 0; j2 < R2; j2++) dft_r<R1>(v[it][j2]);  // (stride 1: no twiddles in the first pass)
+#pragma unroll
+            for (int q1 = 0; q1 < R1; q1++) {
+                const int k2 = q1;  // k1 + q1 P with k1 = 0, P = 1
+                double2 w[R2];
+#pragma unroll
+                for (int j2 = 0; j2 < R2; j2++) {
+                    w[j2] = v[it][j2][q1];
+                    if (j2 >= 1) w[j2] = cdmul(w[j2], tw2[k2 * j2]);
+                }
+                dft_r<R2>(w);
+#pragma unroll
+                for (int q2 = 0; q2 < R2; q2++) v[it][q2][q1] = w[q2];
+            }
+        }
+    }
+    __syncthreads();  // every bin has been read from the image
+#pragma unroll
+    for (int it = 0; it < ITERS; it++) {
+        const int g = it * FM_T + tid;
+        if (g < ng) {
+            const LdsArr z = X + g * RR;
+#pragma unroll
+            for (int q2 = 0; q2 < R2; q2++)
+#pragma unroll
+                for (int q1 = 0; q1 < R1; q1++) z[q1 + q2 * R1] = v[it][q2][q1];
+        }
+    }
+    __syncthreads();
+}
+
 __device__ __forceinline__ const double2 *fm_table(const double2 *twL, const FftmArgs &a, int p, int P)
 {
     // the narrow tables sit in LDS: a pass that starts with a round trip to L2 for its twiddles costs ~2 us,
@@ -847,6 +985,23 @@ __device__ __forceinline__ void fm_forward(LdsArr X, const double2 *twL, const F
         else
             fm_pass<5, 4800, 960>(X, g + 1236, 4800, 960, 0u, tid);
         return;
+    }
+    if (a.f.n == 4410) {
+        // radices 2,3,3,5,7,7; table lengths 2,6,18,90,630,4410 at offsets 0,2,8,26,116,746, ALL in LDS (launch_front_fftm
+        // checks it): [2,3] [3,5] [7] [7] -- four LDS round trips with compile-time strides instead of the run-time plan's five
+        if constexpr (LDSTW) {
+            const LdsArr t = lds_arr(twL);
+            if (mode != FM_INV_REAL) fm_pass2<2, 3, 4410, 1>(X, t, t + 2, 4410, 1, 0u, tid);  // (the inverse's came from the bins)
+            fm_pass2<3, 5, 4410, 6>(X, t + 8, t + 26, 4410, 6, 0u, tid);
+            fm_pass<7, 4410, 90>(X, t + 116, 4410, 90, 0u, tid);
+            if (mode == FM_FWD_BAND)
+                fm_passr_band<7, 4410, 630>(X, t + 746, need_end, tid);
+            else if (mode == FM_INV_REAL)
+                fm_passr_real<7, 4410, 630, 1>(X, t + 746, norm, tid, hist);
+            else
+                fm_pass<7, 4410, 630>(X, t + 746, 4410, 630, 0u, tid);
+            return;
+        }
     }
     // any other frame: run-time plan, tables wherever fm_table finds them (flat accesses)
     int P = 1;
@@ -947,6 +1102,7 @@ __global__ __launch_bounds__(FM_T) void k_front_fftm(FftmArgs aa)
         int tf = tid;
         asm volatile("" : "+v"(tf));
         const bool fused_first = (n == 9600 || n == 4800);
+        const bool compact = fused_first || n == 4410;  // the inverse from the bins, compact real samples, windows as aligned runs
         if (n == 9600) {
             fm_first2_from_raw<9600, F32IN>(XL, raw + t0, rawf + t0, a.ic, a.qc, lds_arr(twL) + 4, tf);
         } else if (n == 4800) {
@@ -987,7 +1143,7 @@ __global__ __launch_bounds__(FM_T) void k_front_fftm(FftmArgs aa)
             __syncthreads();
         }
         PHASE(0)
-        fm_forward<true>(XL, twL, aa, tf, fused_first, fused_first ? FM_FWD_BAND : FM_FULL, end + 102);  // :422-423; bins < end + 102 are read
+        fm_forward<true>(XL, twL, aa, tf, fused_first, compact ? FM_FWD_BAND : FM_FULL, end + 102);  // :422-423; bins < end + 102 are read
         PHASE(1)
         // ---- |X| (:425-427) over the band the boxcar reads
         for (int i = pbase + tf; i < end - 24; i += FM_T) {
@@ -1072,13 +1228,15 @@ __global__ __launch_bounds__(FM_T) void k_front_fftm(FftmArgs aa)
         PHASE(2)
         // ---- 204 bins around the centre to bin 0 of a zeroed array (:458), inverse transform (:459) as
         // conj o forward o conj; only real parts are read afterwards, so the closing conjugation is dropped
-        if (fused_first) {
+        if (compact) {
             // default frames: passes 1-3 straight from the bins, last pass real parts only and already scaled by 1/n
             const LdsArr t64 = lds_arr(twL) + 20;  // the 64-entry table of pass 3
             if (n == 9600)
                 fm_inv_blocks128_9600<true>(XL, XL + (centreBin - 102), t64, lds_arr(twL) + 84, tf);
-            else
+            else if (n == 4800)
                 fm_inv_blocks<4800, true>(XL, XL + (centreBin - 102), t64, 1, t64, 2, tf);
+            else
+                fm_inv_pair_from_bins<2, 3, 4410>(XL, XL + (centreBin - 102), lds_arr(twL) + 2, tf);  // 4410: the first pair
             PHASE(3)
             fm_forward<true>(XL, twL, aa, tf, true, FM_INV_REAL, 0, norm, hist);
             PHASE(4)
@@ -1779,7 +1937,8 @@ int launch_front_fftm(const FftFrontArgs &a, int np, const int *rad, const int *
     }
     // the default frames' kernels address their tables by compile-time offsets (fm_forward)
     if ((a.n == 9600 && (aa.lds_tw != FM_LDS_TW_9600 || tw_off[5] != 596 || tw_off[6] != 2516)) ||
-        (a.n == 4800 && (aa.lds_tw != FM_LDS_TW_4800 || tw_off[4] != 276 || tw_off[5] != 1236))) {
+        (a.n == 4800 && (aa.lds_tw != FM_LDS_TW_4800 || tw_off[4] != 276 || tw_off[5] != 1236)) ||
+        (a.n == 4410 && (aa.lds_tw != 5156 || tw_off[1] != 2 || tw_off[2] != 8 || tw_off[3] != 26 || tw_off[4] != 116 || tw_off[5] != 746))) {
         set_error("launch_front_fftm: the twiddle tables of a default frame are not where the kernel expects them");
         return JSDR_ERR;
     }

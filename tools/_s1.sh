@@ -1,5 +1,4 @@
 set -u; mkdir -p gpurun_out; export TMPDIR=/tmp
-rm -rf gpurun_out/sqp
-timeout -k 10 400 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --output-format csv -d gpurun_out/sqp -- python3 bench.py --serial --steps 2 --warmup 1 --no-cpu-baseline --no-validate > gpurun_out/sqp.log 2>&1
-python tools/pmc_summary.py gpurun_out/sqp > gpurun_out/r05_g_sq_counters_pipeline_serial.txt; rm -rf gpurun_out/sqp
-grep -A8 "^jsdr\|^void" gpurun_out/r05_g_sq_counters_pipeline_serial.txt | grep "^jsdr\|^void\|INSTS_VALU\|BUSY_CYCLES\|SQ_WAVES " 
+for F in "4410 44100" "9600 96000" "4800 48000"; do set -- $F
+JSDR_FFT_PHASECLK=1 timeout -k 10 300 python bench.py --workload bpsk --fft-acquire --bpsk-frame $1 --rate $2 --streams 1024 --no-cpu-baseline --steps 2 --warmup 1 --no-validate 2>&1 | grep "phase\|metric" | cut -c1-120 | sed "s/^/$1: /"
+done | tee gpurun_out/r05_h_phase_clocks.txt
