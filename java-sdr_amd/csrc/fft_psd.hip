@@ -270,20 +270,24 @@ __device__ __forceinline__ void fft_frame(const FftArgs &a, long long frame, lon
     }
 }
 
-template <int N, int T, int FPB, int IN, int OUT, int R0, int R1, int R2, int R3>
+// TWG: the twiddle tables are read from global memory (L1 / L2) instead of a per-workgroup copy in LDS
+template <int N, int T, int FPB, int IN, int OUT, int R0, int R1, int R2, int R3, bool TWG = false>
 __global__ __launch_bounds__(T *FPB, (N == 2048 ? 4 : 1)) void k_fft(FftArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int FE = lds_frame_elems(N);
-    constexpr int TWN = tw_total(R0, R1, R2, R3);
-    float2 *tw_lds = reinterpret_cast<float2 *>(smem);                   // [TWN]
-    float2 *bufs = tw_lds + TWN;                                          // [FPB][FE]
+    constexpr int TWN = TWG ? 0 : tw_total(R0, R1, R2, R3);
+    float2 *tw_own = reinterpret_cast<float2 *>(smem);                    // [TWN]
+    float2 *bufs = tw_own + TWN;                                          // [FPB][FE]
     float *red_val = reinterpret_cast<float *>(bufs + (size_t)FPB * FE);  // [FPB*NW]
     int *red_idx = reinterpret_cast<int *>(red_val + FPB * ((T + 63) / 64));
+    const float2 *tw_lds = TWG ? a.tw : tw_own;
 
     const int tid_b = threadIdx.x;
-    for (int i = tid_b; i < TWN; i += T * FPB) tw_lds[i] = a.tw[i];
-    __syncthreads();
+    if constexpr (!TWG) {
+        for (int i = tid_b; i < TWN; i += T * FPB) tw_own[i] = a.tw[i];
+        __syncthreads();
+    }
 
     const int fib = tid_b / T;
     const int tid = tid_b - fib * T;
@@ -305,10 +309,10 @@ __global__ __launch_bounds__(T *FPB, (N == 2048 ? 4 : 1)) void k_fft(FftArgs a)
     }
 }
 
-template <int N, int FPB, int T, int R0, int R1, int R2, int R3>
+template <int N, int FPB, int T, int R0, int R1, int R2, int R3, bool TWG = false>
 constexpr size_t fft_lds_bytes()
 {
-    return sizeof(float2) * ((size_t)tw_total(R0, R1, R2, R3) + (size_t)FPB * lds_frame_elems(N)) +
+    return sizeof(float2) * ((TWG ? (size_t)0 : (size_t)tw_total(R0, R1, R2, R3)) + (size_t)FPB * lds_frame_elems(N)) +
            (sizeof(float) + sizeof(int)) * FPB * ((T + 63) / 64);
 }
 
@@ -320,27 +324,27 @@ struct Launcher {
     int radix[4] = {1, 1, 1, 1};
 };
 
-template <int N, int T, int FPB, int IN, int OUT, int R0, int R1, int R2, int R3>
+template <int N, int T, int FPB, int IN, int OUT, int R0, int R1, int R2, int R3, bool TWG = false>
 static void launch_impl(const FftArgs &a, int grid, hipStream_t s)
 {
-    constexpr size_t lds = fft_lds_bytes<N, FPB, T, R0, R1, R2, R3>();
-    hipLaunchKernelGGL((k_fft<N, T, FPB, IN, OUT, R0, R1, R2, R3>), dim3(grid), dim3(T * FPB), lds, s, a);
+    constexpr size_t lds = fft_lds_bytes<N, FPB, T, R0, R1, R2, R3, TWG>();
+    hipLaunchKernelGGL((k_fft<N, T, FPB, IN, OUT, R0, R1, R2, R3, TWG>), dim3(grid), dim3(T * FPB), lds, s, a);
 }
 
-template <int N, int T, int FPB, int R0, int R1, int R2, int R3>
+template <int N, int T, int FPB, int R0, int R1, int R2, int R3, bool TWG = false>
 static Launcher make_launcher(int in, int out)
 {
     Launcher l;
     l.frames_per_block = FPB;
     l.block = T * FPB;
-    l.lds_bytes = fft_lds_bytes<N, FPB, T, R0, R1, R2, R3>();
+    l.lds_bytes = fft_lds_bytes<N, FPB, T, R0, R1, R2, R3, TWG>();
     l.radix[0] = R0;
     l.radix[1] = R1;
     l.radix[2] = R2;
     l.radix[3] = R3;
-    if (in == IN_I16 && out == OUT_PSD) l.launch = launch_impl<N, T, FPB, IN_I16, OUT_PSD, R0, R1, R2, R3>;
-    if (in == IN_F32 && out == OUT_PSD) l.launch = launch_impl<N, T, FPB, IN_F32, OUT_PSD, R0, R1, R2, R3>;
-    if (in == IN_F32 && out == OUT_SPEC) l.launch = launch_impl<N, T, FPB, IN_F32, OUT_SPEC, R0, R1, R2, R3>;
+    if (in == IN_I16 && out == OUT_PSD) l.launch = launch_impl<N, T, FPB, IN_I16, OUT_PSD, R0, R1, R2, R3, TWG>;
+    if (in == IN_F32 && out == OUT_PSD) l.launch = launch_impl<N, T, FPB, IN_F32, OUT_PSD, R0, R1, R2, R3, TWG>;
+    if (in == IN_F32 && out == OUT_SPEC) l.launch = launch_impl<N, T, FPB, IN_F32, OUT_SPEC, R0, R1, R2, R3, TWG>;
     return l;
 }
 
@@ -352,6 +356,9 @@ static Launcher pick_launcher(int n, int in, int out)
         case 256: return make_launcher<256, 16, 16, 16, 16, 1, 1>(in, out);
         case 512: return make_launcher<512, 64, 4, 8, 8, 8, 1>(in, out);
         case 1024: return make_launcher<1024, 64, 4, 16, 8, 8, 1>(in, out);
+        // (round 5, measured and not kept -- profiles/r05_experiments.md: one frame per 128-thread workgroup with the tables in LDS
+        //  17.0-17.1 ms, one frame with the tables read from global memory (make_launcher<..., true>) 16.7-17.3, two frames with
+        //  global tables 17.05, against 15.8 for this form)
         case 2048: return make_launcher<2048, 128, 2, 16, 16, 8, 1>(in, out);
         case 4096: return make_launcher<4096, 256, 1, 16, 16, 16, 1>(in, out);
         case 8192: return make_launcher<8192, 512, 1, 16, 16, 8, 4>(in, out);

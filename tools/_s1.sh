@@ -1,4 +1,4 @@
 set -u; mkdir -p gpurun_out; export TMPDIR=/tmp
-for F in "4410 44100" "9600 96000" "4800 48000"; do set -- $F
-JSDR_FFT_PHASECLK=1 timeout -k 10 300 python bench.py --workload bpsk --fft-acquire --bpsk-frame $1 --rate $2 --streams 1024 --no-cpu-baseline --steps 2 --warmup 1 --no-validate 2>&1 | grep "phase\|metric" | cut -c1-120 | sed "s/^/$1: /"
-done | tee gpurun_out/r05_h_phase_clocks.txt
+echo "== fft alone"; bash tools/ab_env.sh "--workload fft --steps 10 --warmup 3" JSDR_FFT_FORM=0 JSDR_FFT_FORM=1 JSDR_FFT_FORM=2 JSDR_FFT_FORM=3 2>&1 | sed 's/validated.*//' 
+for f in 0 1 2 3; do grep -o '"ms_per_step": [0-9.]*' gpurun_out/abenv_JSDR_FFT_FORM=$f.log | tail -1 | sed "s/^/form $f /"; done
+echo "== pipeline serial"; bash tools/ab_env.sh "--serial --steps 8 --warmup 3" JSDR_FFT_FORM=0 JSDR_FFT_FORM=2
