@@ -68,4 +68,25 @@ final class HipNative {
     /** per-pixel-column means of I and Q for a panel bx pixels wide (:93-116): pix[c], avgi[c], avgq[c]; arrays of at
      *  least n+1 elements; returns the number of columns */
     static native int phaseColumns(long h, int bx, int[] pix, float[] avgi, float[] avgq);
+
+    // ---- one JVM, several GPUs: jsdr.java:479-483 hosts all its demodulators in one process (jsdr_group_*, include/jsdr_hip.h)
+    /** totalStreams lock-step FUNcubeBPSKDemod instances split into contiguous shards over ndev devices (0 .. ndev-1), one
+     *  native host thread per device; every device gets an input buffer of totalStreams/ndev x maxBatch samples.
+     *  flags: 1 = gather with device copies instead of RCCL, 2 = fft.receive's PSD beside the demodulators */
+    static native long groupCreate(int ndev, int rate, int samples, int tuning, int doFFT, int doUp, int totalStreams,
+                                   long maxBatch, int flags);
+    static native void groupDestroy(long g);
+    /** info7 = devices, streams per device, bytes per result slot, RCCL version (0: copies), then the slot's layout
+     *  (jsdr_bpsk_slot_info): offset of the bits, offset of the FECDecode entries, how many entries a slot holds */
+    static native void groupInfo(long g, long[] info7);
+    /** recordings (WAV or headerless int16 IQ dumps, JavaAudio.java:369-395 / recorder.java:66-74), one per stream, frames
+     *  [firstFrame, firstFrame + nframes) into the devices' input buffers; returns the frames really read, summed */
+    static native long groupLoadRecordings(long g, String[] paths, int channels, int rate, long firstFrame, long nframes);
+    /** FUNcubeBPSKDemod.receive over nsamples of every stream's loaded input, asynchronously on every device; the result
+     *  slots of all streams are gathered to every device (ncclAllGather over xGMI) */
+    static native void groupBatch(long g, long nsamples, int ic, int qc);
+    static native void groupSync(long g);
+    /** the result slot of global stream `stream` (counters, the call's bits, every FECDecode result: jsdr_bpsk_pack_slots'
+     *  layout) from device 0's gathered copy; slot.length >= info7[2] */
+    static native void groupReadSlot(long g, int stream, byte[] slot);
 }

@@ -52,6 +52,13 @@ typedef struct {
     float *avgi, *avgq;
 } phase_ctx;
 
+typedef struct {
+    jsdr_group *g;
+    int ndev, per_dev, total;
+    int64_t max_batch, slot_bytes;
+    int16_t **raw;  /* [ndev] device buffers [per_dev][2 * max_batch], each on its own device */
+} group_ctx;
+
 #define CTX(type, h) ((type *)(intptr_t)(h))
 
 static void throw_new(JNIEnv *e, const char *cls, const char *msg)
@@ -418,4 +425,163 @@ JNIEXPORT jint JNICALL Java_com_ashbysoft_java_1sdr_HipNative_phaseColumns(JNIEn
     (*e)->SetFloatArrayRegion(e, avgi, 0, ncol, x->avgi);
     (*e)->SetFloatArrayRegion(e, avgq, 0, ncol, x->avgq);
     return ncol;
+}
+
+/* ------------------------------------------------------------------ one JVM, several GPUs (jsdr.java:479-483; jsdr_group_*) */
+static void group_free(group_ctx *x)
+{
+    if (!x) return;
+    if (x->g) {
+        for (int d = 0; x->raw && d < x->ndev; d++) {
+            int dev = d;
+            if (jsdr_group_device(x->g, d, &dev, NULL, NULL) == JSDR_OK && jsdr_set_device(dev) == JSDR_OK && x->raw[d]) jsdr_free(x->raw[d]);
+        }
+        jsdr_group_destroy(x->g);
+    }
+    free(x->raw);
+    free(x);
+}
+
+JNIEXPORT jlong JNICALL Java_com_ashbysoft_java_1sdr_HipNative_groupCreate(JNIEnv *e, jclass c, jint ndev, jint rate, jint samples,
+                                                                          jint tuning, jint doFFT, jint doUp, jint totalStreams,
+                                                                          jlong maxBatch, jint flags)
+{
+    if (ndev < 1 || totalStreams < ndev || maxBatch < samples) {
+        throw_new(e, "java/lang/IllegalArgumentException", "groupCreate: ndev >= 1, totalStreams >= ndev, maxBatch >= samples");
+        return 0;
+    }
+    group_ctx *x = (group_ctx *)calloc(1, sizeof(*x));
+    if (!x) {
+        fail_msg(e, "groupCreate: out of memory");
+        return 0;
+    }
+    x->ndev = ndev;
+    x->total = totalStreams;
+    x->per_dev = totalStreams / ndev;
+    x->max_batch = maxBatch;
+    if (jsdr_group_create(&x->g, ndev, NULL, rate, samples, tuning, doFFT, doUp, totalStreams, maxBatch, flags) != JSDR_OK ||
+        jsdr_group_info(x->g, NULL, NULL, &x->slot_bytes, NULL) != JSDR_OK) {
+        fail(e);
+        x->g = NULL;
+        group_free(x);
+        return 0;
+    }
+    x->raw = (int16_t **)calloc((size_t)ndev, sizeof(*x->raw));
+    for (int d = 0; x->raw && d < ndev; d++) {
+        int dev = d;
+        if (jsdr_group_device(x->g, d, &dev, NULL, NULL) != JSDR_OK || jsdr_set_device(dev) != JSDR_OK ||
+            jsdr_malloc((void **)&x->raw[d], (size_t)x->per_dev * (size_t)maxBatch * 4) != JSDR_OK) {
+            fail(e);
+            group_free(x);
+            return 0;
+        }
+    }
+    if (!x->raw) {
+        fail_msg(e, "groupCreate: out of memory");
+        group_free(x);
+        return 0;
+    }
+    return (jlong)(intptr_t)x;
+}
+
+JNIEXPORT void JNICALL Java_com_ashbysoft_java_1sdr_HipNative_groupDestroy(JNIEnv *e, jclass c, jlong h)
+{
+    group_free(CTX(group_ctx, h));
+}
+
+JNIEXPORT void JNICALL Java_com_ashbysoft_java_1sdr_HipNative_groupInfo(JNIEnv *e, jclass c, jlong h, jlongArray info7)
+{
+    group_ctx *x = CTX(group_ctx, h);
+    if (null_handle(e, x, "groupInfo") || short_array(e, "groupInfo", (*e)->GetArrayLength(e, info7), 7)) return;
+    int nd = 0, per = 0, ver = 0, slot_bits = 0, nfec_max = 0;
+    int64_t sb = 0, bits_off = 0, fec_off = 0;
+    jsdr_bpsk *dem = NULL;
+    if (jsdr_group_info(x->g, &nd, &per, &sb, &ver) != JSDR_OK || jsdr_group_device(x->g, 0, NULL, &dem, NULL) != JSDR_OK ||
+        jsdr_bpsk_slot_info(dem, &sb, &bits_off, &fec_off, &slot_bits, &nfec_max) != JSDR_OK) {
+        fail(e);
+        return;
+    }
+    const jlong v[7] = {nd, per, sb, ver, bits_off, fec_off, nfec_max};
+    (*e)->SetLongArrayRegion(e, info7, 0, 7, v);
+}
+
+JNIEXPORT jlong JNICALL Java_com_ashbysoft_java_1sdr_HipNative_groupLoadRecordings(JNIEnv *e, jclass c, jlong h, jobjectArray paths,
+                                                                                  jint channels, jint rate, jlong firstFrame,
+                                                                                  jlong nframes)
+{
+    group_ctx *x = CTX(group_ctx, h);
+    if (null_handle(e, x, "groupLoadRecordings") || bad_length(e, "groupLoadRecordings: paths", (*e)->GetArrayLength(e, paths), x->total))
+        return -1;
+    if (nframes < 0 || nframes > x->max_batch) {
+        throw_new(e, "java/lang/IllegalArgumentException", "groupLoadRecordings: more frames than the group's maxBatch");
+        return -1;
+    }
+    const char **cp = (const char **)calloc((size_t)x->per_dev, sizeof(*cp));
+    jstring *js = (jstring *)calloc((size_t)x->per_dev, sizeof(*js));
+    int64_t *got = (int64_t *)calloc((size_t)x->per_dev, sizeof(*got));
+    jlong sum = -1;
+    if (cp && js && got) {
+        sum = 0;
+        for (int d = 0; d < x->ndev && sum >= 0; d++) {
+            int dev = d, ok = 1;
+            for (int s = 0; s < x->per_dev; s++) {  /* this device's shard of the global stream ids: contiguous */
+                js[s] = (jstring)(*e)->GetObjectArrayElement(e, paths, d * x->per_dev + s);
+                cp[s] = js[s] ? (*e)->GetStringUTFChars(e, js[s], NULL) : NULL;
+                if (!cp[s]) ok = 0;
+            }
+            if (ok && (jsdr_group_device(x->g, d, &dev, NULL, NULL) != JSDR_OK || jsdr_set_device(dev) != JSDR_OK ||
+                       jsdr_recordings_load(cp, x->per_dev, channels, rate, firstFrame, nframes, x->raw[d], 2 * x->max_batch, got, NULL) != JSDR_OK))
+                ok = -1;
+            for (int s = 0; s < x->per_dev; s++) {
+                if (cp[s]) (*e)->ReleaseStringUTFChars(e, js[s], cp[s]);
+                if (js[s]) (*e)->DeleteLocalRef(e, js[s]);
+                if (ok > 0) sum += got[s];
+            }
+            if (ok <= 0) {
+                if (ok < 0) fail(e);
+                else throw_new(e, "java/lang/IllegalArgumentException", "groupLoadRecordings: null path");
+                sum = -1;
+            }
+        }
+    } else {
+        fail_msg(e, "groupLoadRecordings: out of memory");
+    }
+    free(cp);
+    free(js);
+    free(got);
+    return sum;
+}
+
+JNIEXPORT void JNICALL Java_com_ashbysoft_java_1sdr_HipNative_groupBatch(JNIEnv *e, jclass c, jlong h, jlong nsamples, jint ic, jint qc)
+{
+    group_ctx *x = CTX(group_ctx, h);
+    if (null_handle(e, x, "groupBatch")) return;
+    if (nsamples < 0 || nsamples > x->max_batch) {
+        throw_new(e, "java/lang/IllegalArgumentException", "groupBatch: more samples than the group's maxBatch");
+        return;
+    }
+    if (jsdr_group_batch_i16(x->g, (const int16_t *const *)x->raw, 2 * x->max_batch, nsamples, ic, qc, NULL) != JSDR_OK) fail(e);
+}
+
+JNIEXPORT void JNICALL Java_com_ashbysoft_java_1sdr_HipNative_groupSync(JNIEnv *e, jclass c, jlong h)
+{
+    group_ctx *x = CTX(group_ctx, h);
+    if (null_handle(e, x, "groupSync")) return;
+    if (jsdr_group_sync(x->g) != JSDR_OK) fail(e);
+}
+
+JNIEXPORT void JNICALL Java_com_ashbysoft_java_1sdr_HipNative_groupReadSlot(JNIEnv *e, jclass c, jlong h, jint stream, jbyteArray slot)
+{
+    group_ctx *x = CTX(group_ctx, h);
+    if (null_handle(e, x, "groupReadSlot") || short_array(e, "groupReadSlot", (*e)->GetArrayLength(e, slot), (jsize)x->slot_bytes)) return;
+    uint8_t *buf = (uint8_t *)malloc((size_t)x->slot_bytes);
+    if (!buf) {
+        fail_msg(e, "groupReadSlot: out of memory");
+        return;
+    }
+    if (jsdr_group_read_slot(x->g, 0, stream, buf) != JSDR_OK)
+        fail(e);
+    else
+        (*e)->SetByteArrayRegion(e, slot, 0, (jsize)x->slot_bytes, (const jbyte *)buf);
+    free(buf);
 }

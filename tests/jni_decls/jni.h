@@ -22,6 +22,9 @@ typedef jarray jbyteArray;
 typedef jarray jintArray;
 typedef jarray jfloatArray;
 typedef jarray jdoubleArray;
+typedef jarray jlongArray;
+typedef jarray jobjectArray;
+typedef jobject jstring;
 
 #define JNIEXPORT __attribute__((visibility("default")))
 #define JNICALL
@@ -41,5 +44,10 @@ struct JNINativeInterface_ {
     void (*SetByteArrayRegion)(JNIEnv *env, jbyteArray array, jsize start, jsize len, const jbyte *buf);
     void (*SetFloatArrayRegion)(JNIEnv *env, jfloatArray array, jsize start, jsize len, const jfloat *buf);
     void (*SetDoubleArrayRegion)(JNIEnv *env, jdoubleArray array, jsize start, jsize len, const jdouble *buf);
+    void (*SetLongArrayRegion)(JNIEnv *env, jlongArray array, jsize start, jsize len, const jlong *buf);
+    jobject (*GetObjectArrayElement)(JNIEnv *env, jobjectArray array, jsize index);
+    const char *(*GetStringUTFChars)(JNIEnv *env, jstring str, jboolean *isCopy);
+    void (*ReleaseStringUTFChars)(JNIEnv *env, jstring str, const char *chars);
+    void (*DeleteLocalRef)(JNIEnv *env, jobject obj);
 };
 #endif

@@ -44,7 +44,7 @@ def jni_functions():
 
 def test_every_native_method_has_its_jni_function_and_vice_versa():
     nat, jni = native_methods(), jni_functions()
-    assert len(nat) == 22
+    assert len(nat) == 29  # 22 of the four plugin classes + 7 of the group (round 5)
     assert set(nat) == set(jni)
     for name, nargs in nat.items():
         assert jni[name] == nargs + 2, (name, nargs, jni[name])  # JNIEnv*, jclass + the Java arguments
@@ -53,7 +53,7 @@ def test_every_native_method_has_its_jni_function_and_vice_versa():
 def test_plugin_classes_call_only_declared_native_methods():
     nat = native_methods()
     used = set()
-    for fn in ("HipFft.java", "HipFUNcubeBPSKDemod.java", "HipDemod.java", "HipPhase.java"):
+    for fn in ("HipFft.java", "HipFUNcubeBPSKDemod.java", "HipDemod.java", "HipPhase.java", "HipDemodGroup.java"):
         src = strip_comments(open(os.path.join(JDIR, fn)).read())
         used |= set(re.findall(r"HipNative\.(\w+)\s*\(", src))
     assert used and used <= set(nat), used - set(nat)
