@@ -425,6 +425,9 @@ def main():
             raise SystemExit("--rate needs --workload bpsk (the pipeline line is BASELINE's 96 kHz configuration)")
         RATE = a.rate
     knobs = sorted(k for k in os.environ if k.startswith("JSDR_EXPERIMENT_") or k.startswith("JSDR_FAST_"))
+    if os.environ.get("JSDR_KNOBS") and os.environ.get("JSDR_BENCH_ALLOW_KNOBS") != "1":
+        # the library only listens to its tuning knobs with JSDR_KNOBS=1; a measured line must say so itself (tools/ab_*.sh do)
+        knobs.append("JSDR_KNOBS (without JSDR_BENCH_ALLOW_KNOBS=1)")
     if knobs:
         raise SystemExit(f"bench.py: {', '.join(knobs)} set -- experiment knobs make the product skip work / change what the fast "
                          "variant certifies; refusing to measure")

@@ -2704,7 +2704,7 @@ static void launch_front_t(const FrontArgs &fa, int nstreams, long long nds, hip
 static bool front_reg_enabled()
 {
     static const bool reg = [] {
-        const char *e = getenv("JSDR_FRONT_REG");  // JSDR_FRONT_REG=0: the generic kernel instead
+        const char *e = knob("JSDR_FRONT_REG");  // JSDR_FRONT_REG=0: the generic kernel instead
         return !e || atoi(e) != 0;
     }();
     return reg;
@@ -2776,7 +2776,7 @@ static int launch_fm_t(const FmArgs &a_in, bool mix, bool dc, bool fast, int nst
     a.ntiles = (int)ntiles;
     a.nstreams = nstreams;
     static const long long grid_cap = [] {
-        const char *e = getenv("JSDR_FM_GRID");  // tuning knob: total workgroups (default: one per tile)
+        const char *e = knob("JSDR_FM_GRID");  // tuning knob: total workgroups (default: one per tile)
         return e ? atoll(e) : 0LL;
     }();
     long long gx = ntiles * nstreams;
@@ -2906,11 +2906,11 @@ static int run_side(jsdr_bpsk *h, const SideJob &j)
         ta.sincos = h->sincos.p;
         ProfScope ps(h, PK_TAIL, ts);
         static const bool use_tail8 = [] {
-            const char *e = getenv("JSDR_TAIL8");  // JSDR_TAIL8=0: the one-wave-per-stream tail (A/B timing)
+            const char *e = knob("JSDR_TAIL8");  // JSDR_TAIL8=0: the one-wave-per-stream tail (A/B timing)
             return !e || atoi(e) != 0;
         }();
         static const bool force_tail8 = [] {
-            const char *e = getenv("JSDR_TAIL8");  // JSDR_TAIL8=2: k_tail8 whatever the number of streams (the tests' small handles)
+            const char *e = knob("JSDR_TAIL8");  // JSDR_TAIL8=2: k_tail8 whatever the number of streams (the tests' small handles)
             return e && atoi(e) == 2;
         }();
         h->tail_name = (h->variant == 0 || h->do_fft || !j.raw) && use_tail8 && (S >= 2048 || force_tail8) ? "k_tail8" : "k_tail";
@@ -2921,7 +2921,7 @@ static int run_side(jsdr_bpsk *h, const SideJob &j)
             //  decides: 1024 streams, FFT-acquire lines of round 4: locked 0.64 ms (k_tail) against 1.6, unlocked 5.6 against 3.5)
         {
             static const int wpb = [] {
-                const char *e = getenv("JSDR_TAIL8_WPB");  // JSDR_TAIL8_WPB=1: one-wave workgroups (A/B timing)
+                const char *e = knob("JSDR_TAIL8_WPB");  // JSDR_TAIL8_WPB=1: one-wave workgroups (A/B timing)
                 return e ? atoi(e) : 4;
             }();
             const unsigned waves = (unsigned)((S + 7) / 8);
@@ -2953,7 +2953,7 @@ static int run_side(jsdr_bpsk *h, const SideJob &j)
             if (((rs / 4) & 1) == 0) rs += 4;  // 4 * odd
             const size_t lds = (size_t)80 * rs + 16;
             static const bool use_t = [] {
-                const char *e = getenv("JSDR_SYNC_T");  // JSDR_SYNC_T=0: the strided kernel
+                const char *e = knob("JSDR_SYNC_T");  // JSDR_SYNC_T=0: the strided kernel
                 return !e || atoi(e) != 0;
             }();
             ProfScope ps(h, (use_t && lds <= 150 * 1024) ? PK_SYNCT : PK_SYNC, ts);  // timed under the name rocprof shows
@@ -3458,14 +3458,14 @@ int jsdr_bpsk_create(jsdr_bpsk **out, int rate, int nsamples_per_frame, int tuni
     // tools/ab_overlap_acq.sh / ab_env.sh: a step 14.0 vs 14.9 ms at n = 9600, 17.5 vs 18.1 at 4800, no difference at 19200;
     // round 4: 11.4 vs 12.15 at n = 2048 -- k_sync_t takes 5.1 ms beside k_front_fft against 0.11 alone -- 11.6 vs 12.5 at 4096)
     if (do_fft) h->overlap = false;
-    if (const char *e = getenv("JSDR_NO_OVERLAP")) h->overlap = atoi(e) == 0;
-    if (const char *e = getenv("JSDR_FM")) h->use_fm = atoi(e) != 0;
-    if (const char *e = getenv("JSDR_SCHED_PREFETCH")) h->prefetch_on = atoi(e) != 0;
+    if (const char *e = knob("JSDR_NO_OVERLAP")) h->overlap = atoi(e) == 0;
+    if (const char *e = knob("JSDR_FM")) h->use_fm = atoi(e) != 0;
+    if (const char *e = knob("JSDR_SCHED_PREFETCH")) h->prefetch_on = atoi(e) != 0;
     const size_t S = (size_t)nstreams;
     // FEC of a batch handle: the lane-per-block Viterbi (fec.hip, k_vitq) once there are enough blocks to fill waves of 64;
     // below that (and for the 1-stream receive() form, whose latency counts) one wave per block
     bool vitq = nstreams >= 256;
-    if (const char *e = getenv("JSDR_VITQ")) vitq = atoi(e) != 0 && nstreams > 1;
+    if (const char *e = knob("JSDR_VITQ")) vitq = atoi(e) != 0 && nstreams > 1;
     h->dm_stride = 64 + h->max_ds + 64;
     h->y_stride = h->max_ds;
     h->bitlog_stride = (HIST_BITS + h->max_bits + 64 + 15) & ~15LL;  // (rows 16-byte aligned: k_tail8 carries the register over in dwords)
@@ -3552,7 +3552,7 @@ int jsdr_bpsk_create(jsdr_bpsk **out, int rate, int nsamples_per_frame, int tuni
             jsdr_bpsk_destroy(h);
             return JSDR_ERR;
         }
-        if (const char *e = getenv("JSDR_FFT_PHASECLK"))
+        if (const char *e = knob("JSDR_FFT_PHASECLK"))
             if (atoi(e) != 0 && (h->phase_clk.alloc(8) != JSDR_OK || h->phase_clk.zero() != JSDR_OK)) h->phase_clk.release();
     }
     if (hipMemcpy(h->ds_taps_dev.p, bc.ds_taps, sizeof(double) * 27, hipMemcpyHostToDevice) != hipSuccess) {
@@ -3578,11 +3578,11 @@ int jsdr_bpsk_create(jsdr_bpsk **out, int rate, int nsamples_per_frame, int tuni
         t1 *= 1.00004;
         const double U = 1.1102230246251565e-16, HOWARD = 0.9 * 32768.0, dmax = HOWARD * t1;
         h->fast_ey = 1.01 * U * f1 * (131.0 * dmax + 56.0 * t1 * HOWARD + 4.0 * dmax);
-        if (const char *e = getenv("JSDR_FAST_MARGIN_SCALE")) {
+        if (const char *e = knob("JSDR_FAST_MARGIN_SCALE")) {
             const double v = atof(e);
             if (v >= 1.0) h->margin_scale = v;
         }
-        if (const char *e = getenv("JSDR_FAST_ARGMAX_SCALE")) {
+        if (const char *e = knob("JSDR_FAST_ARGMAX_SCALE")) {
             const double v = atof(e);
             if (v >= 1.0) h->argmax_scale = v;
         }
@@ -3790,7 +3790,7 @@ int jsdr_bpsk_receive_f32(jsdr_bpsk *h, const float *iq_host)
     // float takes the float kernels as before.
     const size_t nfl = 2 * (size_t)h->nsf;
     static const bool route = [] {
-        const char *e = getenv("JSDR_F32_AS_I16");  // JSDR_F32_AS_I16=0: float frames always take the float kernels (tests)
+        const char *e = knob("JSDR_F32_AS_I16");  // JSDR_F32_AS_I16=0: float frames always take the float kernels (tests)
         return !e || atoi(e) != 0;
     }();
     bool as_i16 = route && h->variant == 0 && h->pin && (h->n_in == 0 || !h->hist_is_float) && nfl * sizeof(int16_t) <= h->pin_bytes;

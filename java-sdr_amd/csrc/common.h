@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include "../../include/jsdr_hip.h"
@@ -33,6 +34,19 @@ void set_error(const char *fmt, ...);
 #define JSDR_LAUNCH_CHECK() JSDR_HIP_TRY(hipGetLastError())
 
 static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+// Tuning and test knobs (JSDR_TAIL8, JSDR_NO_OVERLAP, JSDR_FFT_GRID_ABS, ... : A/B timing in tools/, forcing a kernel in tests/)
+// are read through this: the library is DEAF to all of them unless JSDR_KNOBS=1 is set as well, so a stray variable in a
+// production environment changes nothing (ADVICE / VERDICT r4: "17 getenv knobs live in the shipped library").  bench.py
+// refuses to measure with JSDR_KNOBS set unless it is told so (--allow-knobs, used by tools/ab_*.sh only).
+static inline const char *knob(const char *name)
+{
+    static const bool on = [] {
+        const char *e = getenv("JSDR_KNOBS");
+        return e && e[0] == '1' && e[1] == 0;
+    }();
+    return on ? getenv(name) : nullptr;
+}
 
 // RAII-less device buffer (handles own them and free in destroy)
 template <class T>

@@ -659,7 +659,7 @@ static int demod_run(jsdr_demod *h, const int16_t *raw_dev, const float *rawf_de
     // every mode but AM, frames of up to 5 tiles (the reference's 9600-sample default included): one kernel from
     // raw samples to int16 audio; JSDR_DEMOD_FUSED=0 keeps the three-kernel path for A/B runs
     static const bool fused_ok = [] {
-        const char *e = getenv("JSDR_DEMOD_FUSED");
+        const char *e = knob("JSDR_DEMOD_FUSED");
         return !(e && e[0] == '0');
     }();
     const bool fused = fused_ok && h->mode != MODE_AM && tiles_per_frame <= 5;

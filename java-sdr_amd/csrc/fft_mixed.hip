@@ -491,7 +491,7 @@ int mixed_launch_split2(const MixedPlan &p, const FftArgs &a, int in_kind, int o
     FftArgs h = a;
     h.split = 1;  // half transform hf reads the even (hf even) / odd samples of frame hf >> 1
     const float2 *wcomb = a.tw + p.half_tw_count;
-    static const int mgrid = [] { const char *e = getenv("JSDR_MIXED_GRID"); return e ? atoi(e) : 16; }();
+    static const int mgrid = [] { const char *e = knob("JSDR_MIXED_GRID"); return e ? atoi(e) : 16; }();
     const long long cap = (long long)num_cu * mgrid;
     const unsigned grid = (unsigned)(a.nframes < cap ? a.nframes : cap);
     auto go = [&](auto kern) -> int {

@@ -425,7 +425,7 @@ static int fft_run(jsdr_fft *h, const void *in_dev, int in_kind, int out_kind, l
         a.qc = qc;
         if (h->mplan.split2)
             return mixed_launch_split2(h->mplan, a, in_kind, out_kind, h->num_cu, s);
-        static const int mgrid = [] { const char *e = getenv("JSDR_MIXED_GRID"); return e ? atoi(e) : 16; }();  // workgroups per CU: shorter workgroups balance the tail (2: 3.84, 16: 3.56 ms at n = 9600)
+        static const int mgrid = [] { const char *e = knob("JSDR_MIXED_GRID"); return e ? atoi(e) : 16; }();  // workgroups per CU: shorter workgroups balance the tail (2: 3.84, 16: 3.56 ms at n = 9600)
         long long cap = (long long)h->num_cu * mgrid;
         return mixed_launch(h->mplan, a, in_kind, out_kind, (int)(nframes < cap ? nframes : cap), s);
     }
@@ -444,13 +444,13 @@ static int fft_run(jsdr_fft *h, const void *in_dev, int in_kind, int out_kind, l
     if (per_cu < 1) per_cu = 1;
     if (per_cu * l.block > 2048) per_cu = 2048 / l.block;
     static const int mult = [] {
-        const char *e = getenv("JSDR_FFT_GRID_MULT");  // tuning knob: workgroups per resident slot
+        const char *e = knob("JSDR_FFT_GRID_MULT");  // tuning knob: workgroups per resident slot
         const int v = e ? atoi(e) : 0;
         return v > 0 ? v : 4;
     }();
     long long cap = (long long)h->num_cu * per_cu * mult;
     static const int abs_grid = [] {
-        const char *e = getenv("JSDR_FFT_GRID_ABS");  // tuning knob: total workgroups (co-residency experiments: 2 per CU = 512)
+        const char *e = knob("JSDR_FFT_GRID_ABS");  // tuning knob: total workgroups (co-residency experiments: 2 per CU = 512)
         return e ? atoi(e) : 0;
     }();
     if (abs_grid > 0) cap = abs_grid;

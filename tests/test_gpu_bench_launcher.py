@@ -16,6 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def run_bench(extra, env_extra):
     env = dict(os.environ, **env_extra)
+    env.pop("JSDR_KNOBS", None)  # (conftest switches the library's test knobs on for the test process; bench.py refuses to measure with them)
     env.pop("WORLD_SIZE", None)
     env.pop("RANK", None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, env=env, capture_output=True, text=True,

@@ -166,3 +166,20 @@ def test_native_width_tail8_and_batch_fec_against_the_oracle():
     assert (nfec == 1).all(), np.flatnonzero(nfec != 1)[:10]
     for s in sampled:
         check_stream_against_oracle(dem, d_iq, L, s, bits[s], trace[s], fec[s])
+
+
+def test_library_is_deaf_to_its_knobs_without_the_master_switch():
+    """JSDR_TAIL8=2 forces k_tail8 on small handles -- but only when JSDR_KNOBS=1 is set as well (the tests' conftest sets it):
+    a stray tuning variable in a production environment must change nothing"""
+    import os
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); import numpy as np, java_sdr_amd as J\n"
+            "d = J.Bpsk(nstreams=2, max_batch_samples=4096); b = J.DeviceBuffer(2 * 4096 * 4); b.zero()\n"
+            "d.batch_i16(b, 2 * 4096, 4096); print(d.tail_kernel_name())" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ, JSDR_TAIL8="2")
+    env.pop("JSDR_KNOBS", None)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("k_tail"), r.stdout + r.stderr
+    r = subprocess.run([sys.executable, "-c", code], env=dict(env, JSDR_KNOBS="1"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("k_tail8"), r.stdout + r.stderr

@@ -24,9 +24,15 @@ def test_bench_refuses_experiment_knobs_and_reports_missing_gpu():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, JSDR_EXPERIMENT_SKIP_FEC="1")
+    env.pop("JSDR_KNOBS", None)
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0"], env=env,
                        capture_output=True, text=True)
     assert r.returncode != 0 and "JSDR_EXPERIMENT_SKIP_FEC" in (r.stderr + r.stdout)
+    # the library's tuning knobs only work with JSDR_KNOBS=1, and with that set bench.py does not measure unless told to
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0"],
+                       env={k: v for k, v in dict(env, JSDR_KNOBS="1").items() if k != "JSDR_EXPERIMENT_SKIP_FEC"},
+                       capture_output=True, text=True)
+    assert r.returncode != 0 and "JSDR_KNOBS" in (r.stderr + r.stdout)
     import java_sdr_amd as J
     if not J.have_gpu():
         env.pop("JSDR_EXPERIMENT_SKIP_FEC")

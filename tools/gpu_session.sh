@@ -3,6 +3,7 @@
 # gpurun_out/; a step that TIMES OUT (124/137) ends the session (no further GPU work after a kill),
 # an ordinary failure (assert, non-zero exit) is logged and the session goes on.
 #   usage: tools/gpu_session.sh step [step ...]   steps: tests micro bench_small bench bench_fft bench_bpsk prof pmc
+export JSDR_KNOBS=1 JSDR_BENCH_ALLOW_KNOBS=1  # the library listens to its tuning knobs only with JSDR_KNOBS=1; bench.py measures with them only when told
 set -u
 mkdir -p gpurun_out
 export TMPDIR=/tmp
