@@ -21,11 +21,11 @@ step() { # name timeout cmd...
 step bench 500 python bench.py --steps 20 --warmup 5
 line $O/${T}_bench.log > $O/${T}_bench.json
 rm -rf $O/prof_$T $O/pmc_rd_$T $O/pmc_wr_$T
-step prof 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$T -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline
+step prof 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$T -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-compare-serial
 line $O/${T}_prof.log > $O/${T}_bench_under_rocprof.json
 cp "$(find $O/prof_$T -name '*kernel_stats.csv' | head -1)" $O/${T}_kernel_stats.csv
-step pmc_rd 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_rd_$T -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-validate
-step pmc_wr 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_wr_$T -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-validate
+step pmc_rd 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_rd_$T -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-validate --no-compare-serial
+step pmc_wr 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_wr_$T -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-validate --no-compare-serial
 python tools/pmc_traffic.py $O/pmc_rd_$T $O/pmc_wr_$T $O/${T}_pmc_traffic.json 8589934592 > /dev/null
 python - "$O" "$T" <<'PY'
 import collections, csv, glob, sys
@@ -66,5 +66,10 @@ step b_fir65_1 300 python bench.py --workload fir --fir-taps 65 --fir-decim 1 --
 JSDR_BENCH_SAME_DEVICE=1 JSDR_BENCH_BACKEND=gloo step b_n2_rehearsal 400 python bench.py --gpus 2 --streams 512 --steps 5 --warmup 2 $B
 line $O/${T}_b_n2_rehearsal.log > $O/${T}_b_n2_rehearsal.json
 step latency 200 python tools/latency_bench.py; cp $O/${T}_latency.log $O/${T}_single_stream_latency.txt
+# fft.receive at the frame sizes other audio rates give (k_fft_rt / k_dft_any) against the 9600-sample default
+for n in 9600 4800 19200 4410 2205 3200 800 8820 1102; do timeout -k 10 120 python tools/fft_n_bench.py $n 1024 2>&1 | tail -1; done > $O/${T}_fft_n_bench.txt
+# config 5 behind the C ABI alone: the C++ harness, one process, jsdr_group_* (RCCL with one rank here; 8 members on one device with copies)
+step harness_n1 300 java-sdr_amd/host/jsdr_harness --gpus 1 --streams 8192 --psd --steps 10 --warmup 3; grep '^{"harness' $O/${T}_harness_n1.log > $O/${T}_harness_n1.json
+step harness_n8 300 java-sdr_amd/host/jsdr_harness --gpus 8 --streams 8192 --same-device --copy-gather --steps 5 --warmup 2; grep '^{"harness' $O/${T}_harness_n8.log > $O/${T}_harness_n8_rehearsal.json
 rm -f $O/${T}_*.log.tmp
 echo "profile set $T done" | tee -a $O/session.log
