@@ -337,6 +337,13 @@ static void group_free(Group *g)
             r->th.join();
         }
     }
+    // nothing of any device may still be in flight when a communicator, a handle or a buffer goes away
+    for (Rank *r : g->ranks) {
+        (void)hipSetDevice(r->dev);
+        if (r->gather) (void)hipStreamSynchronize(r->gather);
+        if (r->main) (void)hipStreamSynchronize(r->main);
+        if (r->psd) (void)hipStreamSynchronize(r->psd);
+    }
     for (Rank *r : g->ranks) {
         (void)hipSetDevice(r->dev);
         if (r->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(r->comm);
