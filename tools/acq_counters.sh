@@ -22,8 +22,9 @@ step() { # name timeout cmd...
 }
 SQ1="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS"
 SQ2="SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"
-for F in $FRAMES; do
-  ARGS="--workload bpsk --fft-acquire --bpsk-frame $F --streams 1024 --no-cpu-baseline"
+for FR in $FRAMES; do  # a frame size, or size@rate (4410@44100)
+  F=${FR%@*}; RATE=96000; case $FR in *@*) RATE=${FR#*@};; esac
+  ARGS="--workload bpsk --fft-acquire --bpsk-frame $F --rate $RATE --streams 1024 --no-cpu-baseline"
   step acq${F} 300 python bench.py $ARGS --steps 5 --warmup 2
   line $O/${T}_acq${F}.log > $O/${T}_acq${F}.json
   PA="$ARGS --steps 2 --warmup 1 --no-validate"
