@@ -503,11 +503,16 @@ def main():
     # (measured, one session each: 34.1 against 35.2 ms at 8192 streams -- but 19.8 against 17.9 at 4096, 10.2 / 9.5 at 2048,
     #  5.9 / 5.1 at 1024, and 35.7 against 33.1 with the fast variant's kernels: the split pays only for the full single-GPU
     #  batch of the exact variant, which is where it is used)
-    side_by_side = (a.workload == "pipeline" and fft is not None and dem is not None and not a.serial and not a.psd_stream
-                    and not a.fft_acquire and RATE == 96000 and a.variant == "exact" and (S >= 8192 or a.side_by_side))
+    # WHERE the split pays is the library's knowledge (jsdr_bpsk_pair_shares: exact variant, tune mode, 96 kHz, 2048-sample frames, from
+    # 8192 streams per device -- ADVICE r4: the policy lives in the library, jsdr_group_* asks the same function); --side-by-side
+    # forces the 2 + 1 split on a smaller batch for A/B runs
+    shares = dem.pair_shares() if (a.workload == "pipeline" and fft is not None and dem is not None) else (0, 0)
+    if a.side_by_side and shares == (0, 0) and not a.fft_acquire and a.variant == "exact":
+        shares = (2, 1)
+    side_by_side = shares != (0, 0) and not a.serial and not a.psd_stream
     if side_by_side:
-        fft.set_cu_share(2)
-        dem.set_cu_share(1)
+        fft.set_cu_share(shares[0])
+        dem.set_cu_share(shares[1])
     psd_stream = J.Stream() if (fft is not None and dem is not None and (a.psd_stream or side_by_side)) else None
     ps = psd_stream.ptr if psd_stream else ms_
     fir_taps = d_fir = None
@@ -736,8 +741,8 @@ def main():
             serial_step()
         sync()
         roofline["one_after_the_other_ms_per_step"] = round((time.perf_counter() - ts) / 5 * 1e3, 4)
-        fft.set_cu_share(2)
-        dem.set_cu_share(1)
+        fft.set_cu_share(shares[0])
+        dem.set_cu_share(shares[1])
 
     # ---- validation outside the timed region: every sampled stream decodes what it was sent
     validated = None

@@ -188,6 +188,11 @@ int jsdr_bpsk_receive_i16(jsdr_bpsk *h, const int16_t *raw_host, int ic, int qc)
 int jsdr_bpsk_batch_i16(jsdr_bpsk *h, const int16_t *raw_dev, int64_t stream_stride_i16,
                         int64_t nsamples, int ic, int qc, void *stream);
 int jsdr_bpsk_set_cu_share(jsdr_bpsk *h, int wgs_per_cu); /* see jsdr_fft_set_cu_share; applies to the tune-mode front-end kernel */
+/* The library's own answer to "should fft.receive and this demodulator, fed the same batch on two streams, share the CUs?":
+ * the shares to pass to jsdr_fft_set_cu_share / jsdr_bpsk_set_cu_share (2 and 1 where the split was measured to pay: the
+ * exact variant's tune-mode kernel, 96 kHz, 2048-sample frames, 8192 streams and more per device), 0 and 0 everywhere else.
+ * bench.py and jsdr_group_* ask this instead of carrying the rule themselves. */
+int jsdr_bpsk_pair_shares(jsdr_bpsk *h, int *fft_wgs_per_cu, int *bpsk_wgs_per_cu);
 /* diagnostics: tiles x streams of the last tune-mode front-end launch (k_fm) and the workgroups that strode over them */
 int jsdr_bpsk_last_launch(jsdr_bpsk *h, int64_t *work_items, int64_t *workgroups);
 /* wait until every kernel of the calls made so far has finished (the 9600 Hz tail and the FEC decoder run on

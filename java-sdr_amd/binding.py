@@ -489,6 +489,12 @@ class Bpsk:
     def set_cu_share(self, wgs_per_cu):
         _check(lib().jsdr_bpsk_set_cu_share(self.h, int(wgs_per_cu)), "jsdr_bpsk_set_cu_share")
 
+    def pair_shares(self):
+        """(fft share, bpsk share) the library recommends for running fft.receive beside this demodulator; (0, 0): one after the other"""
+        a, b = C.c_int(), C.c_int()
+        _check(lib().jsdr_bpsk_pair_shares(self.h, C.byref(a), C.byref(b)), "jsdr_bpsk_pair_shares")
+        return a.value, b.value
+
     def last_launch(self):
         a, b = C.c_int64(), C.c_int64()
         _check(lib().jsdr_bpsk_last_launch(self.h, C.byref(a), C.byref(b)), "jsdr_bpsk_last_launch")

@@ -3743,6 +3743,18 @@ int jsdr_bpsk_set_cu_share(jsdr_bpsk *h, int wgs_per_cu)
     return JSDR_OK;
 }
 
+int jsdr_bpsk_pair_shares(jsdr_bpsk *h, int *fft_wgs_per_cu, int *bpsk_wgs_per_cu)
+{
+    JSDR_REQUIRE(h && fft_wgs_per_cu && bpsk_wgs_per_cu, "jsdr_bpsk_pair_shares: null argument");
+    // measured (DESIGN.md "the step", profiles/r04_experiments.md, r05_j_bench.json): the 2 + 1 split pays for the exact variant's
+    // tune-mode kernel at 96 kHz / 2048-sample frames from 8192 streams per device (33.5 against 35.1 ms); at 4096 / 2048 / 1024
+    // streams it is slower than one after the other (19.8 / 10.2 / 5.9 against 17.9 / 9.5 / 5.1), and so it is with the fast variant
+    const bool pays = !h->do_fft && h->rate == 96000 && h->nsf == 2048 && h->variant == 0 && h->nstreams >= 8192;
+    *fft_wgs_per_cu = pays ? 2 : 0;
+    *bpsk_wgs_per_cu = pays ? 1 : 0;
+    return JSDR_OK;
+}
+
 int jsdr_bpsk_last_launch(jsdr_bpsk *h, int64_t *work_items, int64_t *workgroups)
 {
     JSDR_REQUIRE(h && work_items && workgroups, "jsdr_bpsk_last_launch: null argument");

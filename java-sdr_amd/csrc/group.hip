@@ -300,11 +300,13 @@ static int rank_create(void *p, int index)
         JSDR_HIP_TRY(hipStreamCreateWithFlags(&r->psd, hipStreamNonBlocking));
         if (jsdr_fft_create(&r->fft, a->frame, a->rate) != JSDR_OK) return JSDR_ERR;
     }
-    // fft.receive and FUNcubeBPSKDemod.receive over the same batch: from 8192 streams per device the two batch kernels run
-    // SIDE BY SIDE on the device's PSD and main streams, each held to its share of every CU (include/jsdr_hip.h,
-    // jsdr_fft_set_cu_share: measured 34.8 against 36.0 ms a step in one session; slower below that size, so not there)
-    if (g->with_psd && g->streams_per_dev >= 8192 && !a->do_fft && a->rate == 96000 && a->frame == 2048) {
-        if (jsdr_fft_set_cu_share(r->fft, 2) != JSDR_OK || jsdr_bpsk_set_cu_share(r->dem, 1) != JSDR_OK) return JSDR_ERR;
+    // fft.receive and FUNcubeBPSKDemod.receive over the same batch: where the library says the CU split pays (jsdr_bpsk_pair_shares:
+    // from 8192 streams per device) the two batch kernels run SIDE BY SIDE on the device's PSD and main streams
+    if (g->with_psd) {
+        int sf = 0, sd = 0;
+        if (jsdr_bpsk_pair_shares(r->dem, &sf, &sd) != JSDR_OK || jsdr_fft_set_cu_share(r->fft, sf) != JSDR_OK ||
+            jsdr_bpsk_set_cu_share(r->dem, sd) != JSDR_OK)
+            return JSDR_ERR;
     }
     int64_t sb = 0;
     if (jsdr_bpsk_slot_info(r->dem, &sb, nullptr, nullptr, nullptr, nullptr) != JSDR_OK) return JSDR_ERR;
