@@ -249,3 +249,26 @@ def test_fft_linearity_property_at_full_batch_size():
     for k in (0, 1, 777, 4095):
         assert np.array_equal(f.receive_raw(raw[k]), psd[k])
         check_psd(psd[k], O.fft_receive(O.convert_i16(raw[k]), 96000), n)
+
+
+def test_fft_run_time_plan_at_random_smooth_sizes():
+    """k_fft_rt takes ANY n = 2^a 3^b 5^c 7^d up to 9800 (audio-rate is a free integer, JavaAudio.java:49,58-59): forty sizes drawn
+    from all of them -- every radix mix, plans of two to eight passes, the composite radices from 4000 samples -- spectrum within
+    1e-5 of the peak of the exact DFT, batch of three frames each"""
+    smooth = sorted({2 ** a * 3 ** b * 5 ** c * 7 ** d for a in range(14) for b in range(9) for c in range(6) for d in range(5)
+                     if 6 <= 2 ** a * 3 ** b * 5 ** c * 7 ** d <= 9800})
+    rng = np.random.default_rng(2024)
+    picks = [n for n in rng.choice(smooth, 48, replace=False) if (n & (n - 1)) != 0 and n not in (9600, 4800)][:40]
+    picks += [9800, 9604, 8750, 4000, 4116, 3969]  # the largest, 2^2 7^4, 2 5^4 7, the merge threshold, 2^2 3 7^3, 3^4 7^2
+    for n in picks:
+        f = J.Fft(int(n), 10 * int(n))
+        if f.kernel_name() != "k_fft_rt":
+            assert int(n) in (7, 9, 14, 15, 21, 25, 35, 49, 6, 10) or n < 12, (n, f.kernel_name())  # one-pass plans go to k_dft_any
+            continue
+        bufs = (rng.standard_normal((3, 2 * int(n))) * 0.25).astype(np.float32)
+        bufs[0, 0::2] += np.float32(0.5) * np.cos(2 * np.pi * (int(n) // 5) * np.arange(int(n)) / int(n)).astype(np.float32)
+        spec = f.spectrum(bufs).astype(np.float64)
+        for k in range(3):
+            want = np.fft.fft(bufs[k, 0::2].astype(np.float64) + 1j * bufs[k, 1::2].astype(np.float64))
+            got = spec[k, 0::2] + 1j * spec[k, 1::2]
+            assert np.abs(got - want).max() <= FFT_RTOL * np.abs(want).max(), n

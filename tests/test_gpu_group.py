@@ -140,3 +140,28 @@ def test_harness_gpus_mode(args):
     assert j["streams_without_decoded_frame"] == 0 and j["decoded_frames_matching_no_sent_payload"] == 0
     assert j["decoded_frames"] >= j["total_streams"]
     assert (j["rccl_version"] > 0) == (j["gather"] == "ncclAllGather")
+
+
+def test_group_in_fft_acquire_mode_equals_a_single_handle():
+    """the group carries whatever demodulator configuration it is given: FFT-acquire mode (bpsk-dofft) at the default 2048-sample
+    frame, three members on one device -- every gathered byte equals a plain 6-stream handle's slots"""
+    n = 2048 * 36
+    chunks = [2048 * 20, 2048 * 16]
+    iq = [O.make_dbpsk_stream(61, s, n, carrier_hz=13200.0 + 90.0 * s, noise_sigma=500.0 + 200 * s)[0] for s in range(6)]
+    d = J.Bpsk(nstreams=6, max_batch_samples=max(chunks), do_fft=1)
+    d_iq = J.DeviceBuffer.from_host(np.concatenate(iq))
+    info = d.slot_info()
+    g = J.Group(3, 6, max(chunks), devices=[0, 0, 0], do_fft=1, gather_copy=True)
+    bufs = [J.DeviceBuffer.from_host(np.concatenate(iq[2 * r:2 * r + 2])) for r in range(3)]
+    pos = 0
+    for c in chunks:
+        d.batch_i16(d_iq.ptr + 4 * pos, 2 * n, c)
+        slots = J.DeviceBuffer(6 * info["slot_bytes"])
+        d.pack_slots(slots)
+        want = slots.to_host(np.uint8).reshape(6, info["slot_bytes"])
+        g.batch_i16([b.ptr + 4 * pos for b in bufs], 2 * n, c)
+        for r in range(3):
+            assert np.array_equal(g.gathered(r), want), (pos, r)
+        pos += c
+    _, view = g.device(1)
+    assert view.counters(0)["centreBin"] == d.counters(2)["centreBin"]
