@@ -21,11 +21,11 @@ step() { # name timeout cmd...
 step bench 500 python bench.py --steps 20 --warmup 5
 line $O/${T}_bench.log > $O/${T}_bench.json
 rm -rf $O/prof_$T $O/pmc_rd_$T $O/pmc_wr_$T
-step prof 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$T -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-compare-serial
+step prof 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$T -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-compare-serial --no-autotune
 line $O/${T}_prof.log > $O/${T}_bench_under_rocprof.json
 cp "$(find $O/prof_$T -name '*kernel_stats.csv' | head -1)" $O/${T}_kernel_stats.csv
-step pmc_rd 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_rd_$T -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-validate --no-compare-serial
-step pmc_wr 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_wr_$T -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-validate --no-compare-serial
+step pmc_rd 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_rd_$T -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-validate --no-compare-serial --no-autotune
+step pmc_wr 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_wr_$T -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-validate --no-compare-serial --no-autotune
 python tools/pmc_traffic.py $O/pmc_rd_$T $O/pmc_wr_$T $O/${T}_pmc_traffic.json 8589934592 > /dev/null
 python - "$O" "$T" <<'PY'
 import collections, csv, glob, sys
