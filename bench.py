@@ -76,6 +76,10 @@ def parse():
     ap.add_argument("--variant", default="exact", choices=["exact", "fast"],
                     help="demodulator arithmetic: exact-order FP64 (default) or FMA-contracted FP64 with margin-certified decisions")
     ap.add_argument("--side-by-side", action="store_true", help="pipeline workload: the CU split below 8192 streams per GPU as well")
+    ap.add_argument("--dist-single", action="store_true",
+                    help="rehearsal: --gpus 1 through the DISTRIBUTED code path -- torch.distributed with the RCCL backend and ONE rank "
+                         "(process-group init on the device, gather stream, all_gather_into_tensor, the gather check): the closest a "
+                         "one-GPU box gets to the driver's N > 1 run with the real backend")
     ap.add_argument("--no-autotune", action="store_true",
                     help="pipeline workload where the CU split may pay (8192 streams per GPU): run side by side without first timing three "
                          "steps of each form after the warm-up (profile runs: one form only)")
@@ -440,7 +444,24 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
     torch = None
-    if N > 1:
+    D = N > 1 or a.dist_single  # the distributed code path
+    if a.dist_single and N == 1 and "WORLD_SIZE" not in os.environ:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        world = 1
+    saved_stdout = None
+    if D and "WORLD_SIZE" in os.environ:
+        # RCCL prints a banner ("RCCL version : ...", "Librccl path : ...") on STDOUT when its first communicator comes up, from every
+        # rank; the contract is ONE JSON line on rank 0's stdout.  So in the distributed path file descriptor 1 points at stderr for
+        # the whole run and is put back only around rank 0's JSON line.
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+    if D:
         if "WORLD_SIZE" not in os.environ:
             # the bare command (`python bench.py --gpus N`): this process has made no GPU call yet and never will --
             # it starts one fresh child per rank and relays rank 0's JSON line
@@ -468,7 +489,7 @@ def main():
 
     if not J.have_gpu():
         raise SystemExit("bench.py: no HIP device (libjsdr_hip.so has no CPU fallback)")
-    if J.lib().jsdr_set_device((0 if os.environ.get("JSDR_BENCH_SAME_DEVICE", "0") == "1" else local_rank) if N > 1 else 0) != 0:
+    if J.lib().jsdr_set_device((0 if os.environ.get("JSDR_BENCH_SAME_DEVICE", "0") == "1" else local_rank) if D else 0) != 0:
         raise SystemExit(J.lib().jsdr_last_error())
 
     if a.streams > 0:
@@ -538,7 +559,7 @@ def main():
         amfm.weights(3000, 15000)
         d_audio = J.DeviceBuffer(S * L * 4)
     slots = gathered = gstream = None
-    if dem is not None and N > 1:
+    if dem is not None and D:
         # the gather runs on its own stream: packing waits there for the side-stream tail of this step, so the
         # next step's FFT / front end on the main stream is not serialised behind it
         gstream = torch.cuda.Stream()
@@ -575,7 +596,7 @@ def main():
             amfm.batch_i16(d_iq, 2 * L, L, d_audio, 2 * L, stream=ms_)
         if dem is not None:
             dem.batch_i16(d_iq, 2 * L, L, stream=ms_)
-            if N > 1:
+            if D:
                 dem.pack_slots(slots.data_ptr(), stream=gstream.cuda_stream)
                 with torch.cuda.stream(gstream):
                     dist.all_gather_into_tensor(gathered, slots)  # == sharding.all_gather_slots, reused buffer
@@ -586,7 +607,7 @@ def main():
         main_stream.sync()
         if dem is not None:
             dem.sync()  # the tail / FEC of the last step run on the handle's side stream
-        if N > 1:
+        if D:
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
@@ -601,7 +622,7 @@ def main():
     # each form after the warm-up decide which one the timed region runs; both figures go into the record.
     extra_calls = 0
     autotune = None
-    if side_by_side and N == 1 and not a.no_autotune:
+    if side_by_side and N == 1 and not D and not a.no_autotune:
         def probe(sbs, k=3):
             set_form(sbs)
             step(0, False)
@@ -632,7 +653,7 @@ def main():
     if dem is not None:
         dem.profile_enable(False)
     per_rank_ms = None
-    if N > 1:
+    if D:
         per_rank = [None] * N
         dist.all_gather_object(per_rank, dt)
         per_rank_ms = [round(v / a.steps * 1e3, 4) for v in per_rank]
@@ -759,7 +780,7 @@ def main():
     calls_made = a.warmup + a.steps + extra_calls
     if autotune is not None:
         roofline["autotune"] = autotune
-    if shares != (0, 0) and psd_stream is not None and not a.serial and not a.psd_stream and N == 1 and a.compare_serial:
+    if shares != (0, 0) and psd_stream is not None and not a.serial and not a.psd_stream and N == 1 and not D and a.compare_serial:
         # the OTHER form, five steps right after the timed region
         calls_made += 7
         ran = form["sbs"]
@@ -839,7 +860,7 @@ def main():
 
     # ---- N > 1: the gathered buffer of the LAST timed step against this rank's own results
     gather_check = None
-    if dem is not None and N > 1:
+    if dem is not None and D:
         import hashlib
         info = dem.slot_info()
         sb = info["slot_bytes"]
@@ -896,7 +917,7 @@ def main():
                        "rate_hz": RATE, "frame": a.bpsk_frame if a.workload == "bpsk" else N_FFT, "input_bytes_per_gpu": S * L * 4,
                        "variant": variant_text(a), "streams": stream_text(a, (psd_stream is not None) and (form["sbs"] or a.psd_stream), dem),
                        "parallelism": f"{N * S} streams sharded contiguously over {N} GPU(s)" +
-                                      (f", one all-gather of result slots per step ({backend_text()})" if N > 1 else "")},
+                                      (f", one all-gather of result slots per step ({backend_text()})" if D else "")},
             "roofline": roofline,
             "hbm_read_roofline_frac": round(total / dt * 4.0 / (N * HBM_PEAK_GBS * 1e9), 4),
             "validated": validated,
@@ -911,8 +932,13 @@ def main():
             out["certification"] = cert
         if N == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.workload if a.workload != "demod" else "demod:" + a.demod_mode, L, a.cpu_seconds)
+        sys.stdout.flush()
+        if saved_stdout is not None:
+            os.dup2(saved_stdout, 1)
         print(json.dumps(out), flush=True)
-    if N > 1:
+        if saved_stdout is not None:
+            os.dup2(2, 1)
+    if D:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -70,3 +70,26 @@ def test_bare_command_fails_when_a_rank_fails():
     r, lines = run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0", "--total-streams", "7", "--no-cpu-baseline"],
                          {"JSDR_BENCH_SAME_DEVICE": "1", "JSDR_BENCH_BACKEND": "gloo"})
     assert r.returncode != 0 and not lines
+
+
+def test_distributed_path_with_the_real_backend_and_one_rank():
+    """`--gpus 1 --dist-single`: torch.distributed with the RCCL backend and ONE rank -- process-group init on the device, the
+    gather stream, all_gather_into_tensor, the gather check -- the closest a one-GPU box gets to the driver's N > 1 run.  Rank 0's
+    stdout must hold the JSON line and nothing else (RCCL prints a banner on stdout when its first communicator comes up)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop("JSDR_KNOBS", None)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--dist-single", "--streams", "256", "--steps", "3",
+                        "--warmup", "1", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    j = json.loads(lines[0])
+    assert j["validated"] is True and j["n_gpus"] == 1
+    assert j["gather_check"]["all_ranks_ok"] is True and j["gather_check"]["validated_per_rank"] == [True]
+    assert "RCCL" in j["config"]["parallelism"]
