@@ -2691,12 +2691,7 @@ static void launch_front_t(const FrontArgs &fa, int nstreams, long long nds, hip
     long long gx = (ntiles + WAVES - 1) / WAVES;
     if (gx > 2048) gx = 2048;
     if (gx < 1) gx = 1;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_front<D, RD, F32IN, MIX>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_done = true;
-    }
+    (void)ensure_dynamic_lds(reinterpret_cast<const void *>(k_front<D, RD, F32IN, MIX>), lds);
     hipLaunchKernelGGL((k_front<D, RD, F32IN, MIX>), dim3((unsigned)gx, (unsigned)nstreams), dim3(64 * WAVES), lds, st,
                        fa);
 }
@@ -2787,22 +2782,12 @@ static int launch_fm_t(const FmArgs &a_in, bool mix, bool dc, bool fast, int nst
     const dim3 grid((unsigned)gx), block(FM_THREADS);
 #define JSDR_FM_LAUNCH(MIX, DC, FAST)                                                                           \
     do {                                                                                                        \
-        static bool attr_done = false;                                                                          \
-        if (!attr_done) {                                                                                       \
-            JSDR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fm<D, R, MIX, DC, FAST>),         \
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));            \
-            attr_done = true;                                                                                   \
-        }                                                                                                       \
+        JSDR_LDS_ATTR((k_fm<D, R, MIX, DC, FAST>), lds);                                                        \
         hipLaunchKernelGGL((k_fm<D, R, MIX, DC, FAST>), grid, block, lds, st, a);                               \
     } while (0)
 #define JSDR_FM_LAUNCH_SMALL(MIX, DC)                                                                           \
     do {                                                                                                        \
-        static bool attr_done = false;                                                                          \
-        if (!attr_done) {                                                                                       \
-            JSDR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fm<D, R, MIX, DC, false, true>),  \
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));            \
-            attr_done = true;                                                                                   \
-        }                                                                                                       \
+        JSDR_LDS_ATTR((k_fm<D, R, MIX, DC, false, true>), lds);                                                 \
         hipLaunchKernelGGL((k_fm<D, R, MIX, DC, false, true>), grid, block, lds, st, a);                        \
     } while (0)
     if (!fast && a.nds <= FM_THREADS && ntiles == 1) {  // a short call (receive()): the one-output-per-thread matched half
@@ -2958,11 +2943,7 @@ static int run_side(jsdr_bpsk *h, const SideJob &j)
             }();
             ProfScope ps(h, (use_t && lds <= 150 * 1024) ? PK_SYNCT : PK_SYNC, ts);  // timed under the name rocprof shows
             if (use_t && lds <= 150 * 1024) {
-                static size_t attr_for = 0;
-                if (attr_for < lds) {
-                    JSDR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sync_t), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                    attr_for = lds;
-                }
+                JSDR_LDS_ATTR(k_sync_t, lds);
                 SyncFinArgs sf;
                 sf.trig_count = h->trig_count.p;
                 sf.trig_bits = h->trig_bits.p;
@@ -3355,14 +3336,8 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
         ma.tile0 = b0;
         long long ntiles = (g_first + nds - b0 + 4159) / 4160;
         const size_t lds = (64 + 4160) * sizeof(double2);
-        static bool attr_done = false;
-        if (!attr_done) {
-            JSDR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_matched<false>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            JSDR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_matched<true>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_done = true;
-        }
+        JSDR_LDS_ATTR(k_matched<false>, lds);
+        JSDR_LDS_ATTR(k_matched<true>, lds);
         {
             ProfScope ps(h, PK_MATCHED, st);
             hipLaunchKernelGGL(k_matched<false>, dim3((unsigned)ntiles, (unsigned)S), dim3(512), lds, st, ma);

@@ -658,12 +658,7 @@ static int launch_front_fft_t(const FftFrontArgs &a, int nstreams, hipStream_t s
     constexpr int N = 1 << LOGN;
     constexpr size_t lds = sizeof(double2) * ((size_t)N + (N >> 3) + 64) + sizeof(double) * (32 + 32 + 4) + 32 + 64 +
                            (N >= 2048 ? 0 : sizeof(double) * (size_t)N);
-    static bool attr_set = false;
-    if (!attr_set) {
-        JSDR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_front_fft<LOGN, F32IN>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    JSDR_LDS_ATTR((k_front_fft<LOGN, F32IN>), lds);
     hipLaunchKernelGGL((k_front_fft<LOGN, F32IN>), dim3((unsigned)nstreams), dim3(256), lds, st, a);
     JSDR_LAUNCH_CHECK();
     return JSDR_OK;

@@ -1944,16 +1944,10 @@ int launch_front_fftm(const FftFrontArgs &a, int np, const int *rad, const int *
     }
     const size_t lds = fixed + sizeof(double2) * (size_t)aa.lds_tw;
     const bool f32 = a.rawf != nullptr;
-    static size_t attr_for[2] = {0, 0};
-    if (attr_for[f32] < lds) {
-        if (f32)
-            JSDR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_front_fftm<true>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        else
-            JSDR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_front_fftm<false>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_for[f32] = lds;
-    }
+    if (f32)
+        JSDR_LDS_ATTR(k_front_fftm<true>, lds);
+    else
+        JSDR_LDS_ATTR(k_front_fftm<false>, lds);
     if (f32)
         hipLaunchKernelGGL(k_front_fftm<true>, dim3((unsigned)nstreams), dim3(FM_T), lds, st, aa);
     else
@@ -2025,16 +2019,10 @@ int launch_front_fft2x(const FftFrontArgs &a, int np, const int *rad, const int 
     aa.r0_stride = (long long)fft2x_scratch_r0(a.n);
     const size_t lds = sizeof(double2) * (size_t)(a.n / 2) + sizeof(double) * (64 + 16) + sizeof(int) * 16 + sizeof(double2) * 204 + 64;
     const bool f32 = a.rawf != nullptr;
-    static size_t attr_for[2] = {0, 0};
-    if (attr_for[f32] < lds) {
-        if (f32)
-            JSDR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_front_fft2x<true>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        else
-            JSDR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_front_fft2x<false>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_for[f32] = lds;
-    }
+    if (f32)
+        JSDR_LDS_ATTR(k_front_fft2x<true>, lds);
+    else
+        JSDR_LDS_ATTR(k_front_fft2x<false>, lds);
     if (f32)
         hipLaunchKernelGGL(k_front_fft2x<true>, dim3((unsigned)nstreams), dim3(FM_T), lds, st, aa);
     else

@@ -35,6 +35,15 @@ void set_error(const char *fmt, ...);
 
 static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
+// A kernel whose dynamic LDS exceeds the default needs hipFuncAttributeMaxDynamicSharedMemorySize -- per DEVICE: a process that hosts
+// several GPUs (jsdr_group_*, one host thread per device) must set it on each of them, and from whichever thread gets there first.
+// Remembers (device, kernel) -> bytes under a mutex and calls hipFuncSetAttribute only when a larger size comes along.
+int ensure_dynamic_lds(const void *kernel, size_t bytes);
+#define JSDR_LDS_ATTR(kernel, bytes)                                                                       \
+    do {                                                                                                   \
+        if (::jsdr::ensure_dynamic_lds(reinterpret_cast<const void *>(kernel), (bytes)) != JSDR_OK) return JSDR_ERR; \
+    } while (0)
+
 // Tuning and test knobs (JSDR_TAIL8, JSDR_NO_OVERLAP, JSDR_FFT_GRID_ABS, ... : A/B timing in tools/, forcing a kernel in tests/)
 // are read through this: the library is DEAF to all of them unless JSDR_KNOBS=1 is set as well, so a stray variable in a
 // production environment changes nothing (ADVICE / VERDICT r4: "17 getenv knobs live in the shipped library").  bench.py

@@ -135,12 +135,7 @@ int dft_any_launch(const FftArgs &a, int n, int in_kind, int out_kind, int num_c
     const dim3 grid((unsigned)a.nframes, (unsigned)((n + bins - 1) / bins)), block(DFT_T);
 #define JSDR_DFT_LAUNCH(IN, OUT)                                                                                      \
     do {                                                                                                              \
-        static size_t attr_for = 0;                                                                                   \
-        if (attr_for < lds) {                                                                                         \
-            JSDR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_dft_any<IN, OUT>),                      \
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                  \
-            attr_for = lds;                                                                                           \
-        }                                                                                                             \
+        JSDR_LDS_ATTR((k_dft_any<IN, OUT>), lds);                                                                     \
         hipLaunchKernelGGL((k_dft_any<IN, OUT>), grid, block, lds, st, a, n, bins);                                   \
     } while (0)
     JSDR_REQUIRE(a.nframes <= 0x7fffffffLL, "fft: too many frames for one launch");

@@ -386,12 +386,7 @@ template <int N, int T, int R0, int R1, int R2, int R3, int R4>
 static int mixed_launch_t(const MixedPlan &p, const FftArgs &a, int in_kind, int out_kind, int grid, hipStream_t st)
 {
     auto go = [&](auto kern) -> int {
-        static bool attr_done = false;
-        if (!attr_done) {
-            JSDR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));
-            attr_done = true;
-        }
+        JSDR_LDS_ATTR(kern, p.lds_bytes);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(T), p.lds_bytes, st, a);
         JSDR_LAUNCH_CHECK();
         return JSDR_OK;
@@ -495,11 +490,7 @@ int mixed_launch_split2(const MixedPlan &p, const FftArgs &a, int in_kind, int o
     const long long cap = (long long)num_cu * mgrid;
     const unsigned grid = (unsigned)(a.nframes < cap ? a.nframes : cap);
     auto go = [&](auto kern) -> int {
-        static bool attr_done = false;
-        if (!attr_done) {
-            JSDR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_done = true;
-        }
+        JSDR_LDS_ATTR(kern, lds);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(T), lds, st, h, wcomb);
         JSDR_LAUNCH_CHECK();
         return JSDR_OK;

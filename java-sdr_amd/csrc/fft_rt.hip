@@ -398,11 +398,7 @@ int rt_launch(const FftArgs &a, int n, int in_kind, int out_kind, int num_cu, hi
     const long long cap = (long long)num_cu * (per_cu < 1 ? 1 : per_cu) * 4;
     const unsigned grid = (unsigned)(a.nframes < cap ? a.nframes : cap);
     auto go = [&](auto kern) -> int {
-        static size_t attr_for = 0;
-        if (attr_for < lds) {
-            JSDR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_for = lds;
-        }
+        JSDR_LDS_ATTR(kern, lds);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(RT_T), lds, st, a, p);
         JSDR_LAUNCH_CHECK();
         return JSDR_OK;

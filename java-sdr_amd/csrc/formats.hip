@@ -148,12 +148,7 @@ int jsdr_waterfall_lines(const float *psd_dev, int64_t nframes, int n, int width
     JSDR_REQUIRE(n > 0 && width > 0, "jsdr_waterfall_lines: n=%d width=%d must be positive", n, width);
     JSDR_REQUIRE(nframes >= 0, "jsdr_waterfall_lines: negative frame count");
     JSDR_REQUIRE((size_t)n * sizeof(float) <= 128 * 1024, "jsdr_waterfall_lines: n=%d bins exceed the 128 KB LDS image", n);
-    static size_t lds_allowed = 64 * 1024;
-    if ((size_t)n * sizeof(float) > lds_allowed) {  // e.g. n = 19200, the 192 kHz default frame
-        JSDR_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_waterfall), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         128 * 1024));
-        lds_allowed = 128 * 1024;
-    }
+    if ((size_t)n * sizeof(float) > 64 * 1024) JSDR_LDS_ATTR(k_waterfall, 128 * 1024);  // e.g. n = 19200, the 192 kHz default frame
     // (the reference would throw ArrayIndexOutOfBounds past the bins; (int)((width-1)*step) + (int)step <= n always)
     if (nframes == 0) return JSDR_OK;
     const long long cap = 256LL * 8 * 4;  // 8 workgroups per CU resident, a few rounds

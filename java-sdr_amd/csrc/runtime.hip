@@ -2,6 +2,9 @@
 // int16->float conversion kernel (JavaAudio.java:276-293).
 #include "common.h"
 #include <stdarg.h>
+#include <map>
+#include <mutex>
+#include <utility>
 
 namespace jsdr {
 
@@ -13,6 +16,21 @@ void set_error(const char *fmt, ...)
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+int ensure_dynamic_lds(const void *kernel, size_t bytes)
+{
+    static std::mutex mu;
+    static std::map<std::pair<int, const void *>, size_t> have;
+    int dev = 0;
+    JSDR_HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(mu);
+    size_t &cur = have[std::make_pair(dev, kernel)];
+    if (cur < bytes) {
+        JSDR_HIP_TRY(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        cur = bytes;
+    }
+    return JSDR_OK;
 }
 
 struct Timer {
