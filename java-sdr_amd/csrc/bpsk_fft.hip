@@ -306,8 +306,11 @@ __device__ __forceinline__ void fft_rest(double2 *X, const double2 *TsL, const d
     __syncthreads();
 }
 
+#ifndef JSDR_FF_MINWG11
+#define JSDR_FF_MINWG11 4  // (probe builds: 3 = 170 VGPRs and three workgroups a CU at n = 2048)
+#endif
 template <int LOGN, bool F32IN>
-__global__ __launch_bounds__(256, (LOGN <= 11 ? 4 : (LOGN == 12 ? 2 : 1))) void k_front_fft(FftFrontArgs a)
+__global__ __launch_bounds__(256, (LOGN <= 11 ? JSDR_FF_MINWG11 : (LOGN == 12 ? 2 : 1))) void k_front_fft(FftFrontArgs a)
 {
     constexpr int N = 1 << LOGN;
     constexpr int XSLOTS = N + (N >> 3);
