@@ -217,6 +217,40 @@ def validate_acquire(J, dem, d_iq, S, L, ncalls, frame, rate, prefer=(), do_fft=
                      "of_them_without_a_decoded_frame_in_the_oracle_too": lost}
 
 
+def validate_demod(J, d_iq, d_audio, S, L, ncalls, mode, rate):
+    """demod.java's chain (demod.java:398-483) is stateful from frame to frame (filter ring, carrier phase, the running mean of the AM
+    detector): sampled streams are replayed through the oracle over ALL calls of the run, frame by frame, and the LAST call's int16
+    audio must be bit-identical.  Outside the timed region."""
+    import threading
+    import oracle_lib as O
+    idx = sorted(set(int(v) for v in np.linspace(0, S - 1, 4)))
+    bad = []
+
+    def one(st):
+        raw = d_iq.to_host(np.int16, 2 * L, offset_bytes=st * L * 4)
+        buf = O.convert_i16(raw)
+        o = O.Demod(rate)
+        o.configure(mode, 1, 1, 1)
+        o.weights(3000, 15000)
+        nfr = L // N_FFT
+        last = None
+        for k in range(ncalls):
+            outs = [o.receive(buf[2 * f * N_FFT:2 * (f + 1) * N_FFT]) for f in range(nfr)]
+            if k == ncalls - 1:
+                last = np.concatenate(outs)
+        got = d_audio.to_host(np.int16, 2 * L, offset_bytes=st * L * 4)
+        if not np.array_equal(got, last):
+            bad.append(st)
+
+    th = [threading.Thread(target=one, args=(st,)) for st in idx]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    return not bad, {"streams_compared_with_the_oracle": len(idx), "calls_replayed": ncalls, "streams_that_differ": sorted(bad),
+                     "int16_audio_samples_per_stream": 2 * L}
+
+
 def validate_fir(J, d_iq, d_fir, S, L, taps, decim, scale):
     """sampled streams of the batch against the oracle's RxDownSample operator (FUNcubeBPSKDemod.java:466-492): every
     output of the stream bit-identical.  Outside the timed region."""
@@ -850,6 +884,9 @@ def main():
         validated = bool(ok_f) if dem is None else bool(validated and ok_f)
     if fir_taps is not None and not a.no_validate:
         validated, vstats = validate_fir(J, d_iq, d_fir, S, L, fir_taps, a.fir_decim, 0.9 * 32768.0)
+    if amfm is not None and not a.no_validate:
+        J.binding.stream_sync(None)
+        validated, vstats = validate_demod(J, d_iq, d_audio, S, L, a.warmup + a.steps, DEMOD_MODES[a.demod_mode], RATE)
     if dem is not None and a.variant == "fast":
         cert = dem.cert_stats()
         if cert["streams_uncertified"] > 0 and validated:
