@@ -806,7 +806,9 @@ def main():
                 e.pop("binding_limit", None)
                 e["note"] = "concurrent with the other kernel of the pair: its launch time is time it SHARED the chip"
     if a.workload in ("pipeline", "bpsk") and not a.fft_acquire:
-        roofline["note"] = ("the exact-order demodulator is FP64-issue bound, not HBM bound: see per_kernel[k_fm].fp64_issue_frac "
+        roofline["note"] = ("the exact-order demodulator is FP64-issue bound, not HBM bound: " +
+                            ("its per-kernel figures exist when it runs alone (bench.py --serial: per_kernel[k_fm].fp64_issue_frac) "
+                             if side_by_side else "see per_kernel[k_fm].fp64_issue_frac ") +
                             f"(368 separately rounded operations per 9600 Hz sample against {FP64_ISSUE_TOPS} T lane-ops/s measured)")
 
     # ---- --compare-serial: the same pipeline one after the other, on this box, right after the timed region (boxes differ by
