@@ -87,7 +87,7 @@ int jsdr_fft_set_cu_share(jsdr_fft *h, int wgs_per_cu);
  * workgroups that strode over them.  workgroups < work_items means the persistent-stride path ran (the tests assert it). */
 int jsdr_fft_last_launch(jsdr_fft *h, int64_t *work_items, int64_t *workgroups);
 /* which kernel serves the handle's frame size: "k_fft" (powers of two 64 .. 8192), "k_fft_mixed" (9600 / 4800), "k_fft_mixed_dual"
- * (19200), "k_fft_rt" (any other 2^a 3^b 5^c 7^d up to 9800: 4410, 2205, 3200, 800 ...), "k_dft_any" (everything else up to 20 000) */
+ * (19200), "k_fft_rt" (any other composite frame up to 9800: 4410, 2205, 3200, 800, 1102 ...), "k_dft_any" (primes, and everything else up to 20 000) */
 const char *jsdr_fft_kernel(jsdr_fft *h);
 int jsdr_fft_batch_i16(jsdr_fft *h, const int16_t *raw_dev, int64_t nframes, int ic, int qc,
                        float *psd_dev, void *stream);

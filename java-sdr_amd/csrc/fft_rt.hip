@@ -22,7 +22,15 @@ struct RtPlan {
     int n, np;
     int rad[RT_MAXPASS];
     int tw_off[RT_MAXPASS];  // pass p's table at tw + tw_off[p], P_p * r_p entries (pass 0 has none)
+    int wr_off[RT_MAXPASS];  // a prime radix above 7: W[m] = exp(-2 pi i m / r), m < r, at tw + wr_off[p]
 };
+
+// radices with a butterfly of their own; everything else (a prime above 7: 1102 = 2 . 19 . 29 at 11.025 kHz) takes rt_pass_generic
+__host__ __device__ inline bool rt_special(int r)
+{
+    return r == 2 || r == 3 || r == 4 || r == 5 || r == 6 || r == 7 || r == 8 || r == 9 || r == 10 || r == 14 || r == 15 || r == 16 ||
+           r == 21 || r == 25;
+}
 
 __device__ __forceinline__ void rt_dft7(float2 *x)
 {
@@ -217,6 +225,65 @@ __device__ __forceinline__ void rt_pass(const FftArgs &a, long long frame, int n
     }
 }
 
+// A pass whose radix is a prime above 7 (round 5): one thread per OUTPUT, out[(b - k) r + k + q P] = sum_j v_j W[(j q) mod r] with
+// v_j = in[b + j nb] (x T[k j] for j >= 1, P > 1) -- the DFT's definition, O(n r) a pass, image to image.  19 + 29 terms per
+// output at n = 1102 instead of the 1102 of the O(n^2) kernel.
+__device__ __forceinline__ void rt_pass_generic(int n, int P, int r, const float2 *__restrict__ tw, const float2 *__restrict__ wr,
+                                                const float2 *src, float2 *dst, int tid)
+{
+    const int nb = n / r;
+    for (int o = tid; o < n; o += RT_T) {
+        const int q = o / nb, b = o - q * nb;
+        const int k = b % P;
+        float2 acc = src[b];
+        int m = 0;
+        for (int j = 1; j < r; j++) {
+            m += q;
+            if (m >= r) m -= r;
+            float2 v = src[b + j * nb];
+            if (P > 1) v = cmul(v, tw[k * j]);
+            acc = cadd(acc, cmul(v, wr[m]));
+        }
+        dst[(b - k) * r + k + q * P] = acc;
+    }
+}
+
+// the frame into an LDS image, converted (a plan whose FIRST radix has no butterfly of its own: 143 = 11 . 13)
+template <int IN>
+__device__ __forceinline__ void rt_load(const FftArgs &a, long long frame, int n, float2 *dst, int tid)
+{
+    for (int t = tid; t < n; t += RT_T) {
+        if constexpr (IN == IN_I16) {
+            const int w = (reinterpret_cast<const int *>(a.in) + frame * n)[t];
+            const int si = java_short_add((int)(short)(w & 0xffff), a.ic);
+            const int sq = java_short_add(w >> 16, a.qc);
+            dst[t] = make_float2(i16_to_float_java(si), i16_to_float_java(sq));
+        } else {
+            dst[t] = (reinterpret_cast<const float2 *>(a.in) + frame * n)[t];
+        }
+    }
+}
+
+// PSD / first maximum (or the spectrum) from an LDS image (a plan whose LAST radix has no butterfly of its own)
+template <int OUT>
+__device__ __forceinline__ void rt_epilogue(const FftArgs &a, long long frame, int n, const float2 *src, int tid, Best &best)
+{
+    const float cf = (2.0f / (float)n) * (2.0f / (float)n);
+    for (int bin = tid; bin < n; bin += RT_T) {
+        const float2 x = src[bin];
+        if constexpr (OUT == OUT_SPEC) {
+            (reinterpret_cast<float2 *>(a.out) + frame * n)[bin] = x;
+        } else {
+            const float db = 3.0102999566398120f * __log2f((x.x * x.x + x.y * x.y) * cf);  // fft.java:207
+            (a.out + frame * (n + 2))[bin] = db;
+            if (db > best.v || (db == best.v && bin < best.k)) {
+                best.v = db;
+                best.k = bin;
+            }
+        }
+    }
+}
+
 // FULL: the composite radices as well.  They are a kernel of their own: a switch that holds a 25-point butterfly gives EVERY
 // plan that kernel's register count (3200 = 16.8.5.5: 5.3 ms per 2^30 samples in the small kernel, 6.8 in the full one).
 template <int IN, int OUT, bool FIRST, bool LAST, bool FULL>
@@ -262,20 +329,34 @@ __global__ __launch_bounds__(RT_T) void k_fft_rt(FftArgs a, RtPlan p)
         best.v = -3.402823466e+38f;
         best.k = 0x7fffffff;
         float2 *src = img0, *dst = img1;
-        int P = 1;
-        // (a one-pass plan -- n = 2, 3, 5, 7, 16 ... -- is first and last at once: it is not given to this kernel, rt_plan asks for two)
-        rt_pass_any<IN, OUT, true, false, FULL>(p.rad[0], a, frame, n, 1, a.tw, src, dst, tid, best);
-        P = p.rad[0];
+        int P = 1, q0 = 0;
+        // (a one-pass plan is first and last at once: it is not given to this kernel, rt_plan asks for two)
+        if (rt_special(p.rad[0])) {
+            rt_pass_any<IN, OUT, true, false, FULL>(p.rad[0], a, frame, n, 1, a.tw, src, dst, tid, best);
+            P = p.rad[0];
+            q0 = 1;
+        } else {
+            rt_load<IN>(a, frame, n, dst, tid);
+        }
         __syncthreads();
-        for (int q = 1; q + 1 < p.np; q++) {
+        const bool last_fused = rt_special(p.rad[p.np - 1]);
+        const int qend = last_fused ? p.np - 1 : p.np;  // passes [q0, qend) go image to image
+        for (int q = q0; q < qend; q++) {
             float2 *t = src;
             src = dst;
             dst = t;
-            rt_pass_any<IN, OUT, false, false, FULL>(p.rad[q], a, frame, n, P, a.tw + p.tw_off[q], src, dst, tid, best);
-            P *= p.rad[q];
+            const int r = p.rad[q];
+            if (rt_special(r))
+                rt_pass_any<IN, OUT, false, false, FULL>(r, a, frame, n, P, a.tw + p.tw_off[q], src, dst, tid, best);
+            else
+                rt_pass_generic(n, P, r, a.tw + p.tw_off[q], a.tw + p.wr_off[q], src, dst, tid);
+            P *= r;
             __syncthreads();
         }
-        rt_pass_any<IN, OUT, false, true, FULL>(p.rad[p.np - 1], a, frame, n, P, a.tw + p.tw_off[p.np - 1], dst, nullptr, tid, best);
+        if (last_fused)
+            rt_pass_any<IN, OUT, false, true, FULL>(p.rad[p.np - 1], a, frame, n, P, a.tw + p.tw_off[p.np - 1], dst, nullptr, tid, best);
+        else
+            rt_epilogue<OUT>(a, frame, n, dst, tid, best);
         if constexpr (OUT == OUT_PSD) {
             float bestv = best.v;
             int bestk = best.k;
@@ -319,7 +400,7 @@ __global__ __launch_bounds__(RT_T) void k_fft_rt(FftArgs a, RtPlan p)
 
 // radix plan: 16, 8, 4, 2 while they divide (largest first), then 3s, 5s, 7s; false if n has another factor, is too small
 // to need two passes, or does not fit two LDS images
-bool rt_plan(int n, int *np_out, int *rad, int *tw_off, size_t *tw_count)
+bool rt_plan(int n, int *np_out, int *rad, int *tw_off, size_t *tw_count, int *wr_off = nullptr)
 {
     if (n < 6 || n > RT_NMAX) return false;
     int m = n, c = 0;
@@ -335,7 +416,16 @@ bool rt_plan(int n, int *np_out, int *rad, int *tw_off, size_t *tw_count)
         while (m % q == 0 && no < 16) { odd[no++] = q; m /= q; }
     const bool two = (m % 2 == 0);
     if (two) m /= 2;
-    if (m != 1) return false;
+    // what is left are primes above 7 (ascending): passes of that radix by the DFT's definition, behind the others
+    int big[8], nbig = 0;
+    for (int q = 11; m > 1; q += 2) {
+        if (q * q > m) q = m;
+        while (m % q == 0) {
+            if (nbig == 8) return false;
+            big[nbig++] = q;
+            m /= q;
+        }
+    }
     int lo = 0, hi = no - 1;
     const bool merge = n >= 4000;  // (below, the four- and five-pass plans of the small kernel are the faster ones)
     if (two) {
@@ -351,13 +441,25 @@ bool rt_plan(int n, int *np_out, int *rad, int *tw_off, size_t *tw_count)
             rad[c++] = odd[lo++];
         }
     }
-    if (lo <= hi || c < 2) return false;
+    if (lo <= hi) return false;
+    for (int i = 0; i < nbig; i++) {
+        if (c == RT_MAXPASS) return false;
+        rad[c++] = big[i];
+    }
+    if (c < 2) return false;
     size_t o = 0;
     int P = 1;
     for (int p = 0; p < c; p++) {
         tw_off[p] = (int)o;
         if (p >= 1) o += (size_t)P * rad[p];
         P *= rad[p];
+    }
+    for (int p = 0; p < c; p++) {
+        if (wr_off) wr_off[p] = 0;
+        if (!rt_special(rad[p])) {
+            if (wr_off) wr_off[p] = (int)o;
+            o += (size_t)rad[p];
+        }
     }
     *np_out = c;
     *tw_count = o;
@@ -367,11 +469,17 @@ bool rt_plan(int n, int *np_out, int *rad, int *tw_off, size_t *tw_count)
 // T_p[m] = exp(-2 pi i m/(P r)), m < P r: long double, one rounding to float
 void rt_twiddles(int n, std::vector<float2> &w)
 {
-    int np = 0, rad[RT_MAXPASS], off[RT_MAXPASS];
+    int np = 0, rad[RT_MAXPASS], off[RT_MAXPASS], woff[RT_MAXPASS];
     size_t cnt = 0;
     w.clear();
-    if (!rt_plan(n, &np, rad, off, &cnt)) return;
+    if (!rt_plan(n, &np, rad, off, &cnt, woff)) return;
     w.resize(cnt);
+    for (int p = 0; p < np; p++)
+        if (!rt_special(rad[p]))
+            for (int m = 0; m < rad[p]; m++) {
+                const long double ang = -2.0L * 3.14159265358979323846264338327950288L * (long double)m / (long double)rad[p];
+                w[(size_t)woff[p] + m] = make_float2((float)cosl(ang), (float)sinl(ang));
+            }
     int P = rad[0];
     for (int p = 1; p < np; p++) {
         const int len = P * rad[p];
@@ -388,11 +496,11 @@ int rt_launch(const FftArgs &a, int n, int in_kind, int out_kind, int num_cu, hi
     RtPlan p;
     size_t cnt = 0;
     p.n = n;
-    if (!rt_plan(n, &p.np, p.rad, p.tw_off, &cnt)) {
+    if (!rt_plan(n, &p.np, p.rad, p.tw_off, &cnt, p.wr_off)) {
         set_error("fft: no run-time radix plan for n=%d", n);
         return JSDR_ERR;
     }
-    for (int i = p.np; i < RT_MAXPASS; i++) p.rad[i] = 1, p.tw_off[i] = 0;
+    for (int i = p.np; i < RT_MAXPASS; i++) p.rad[i] = 1, p.tw_off[i] = 0, p.wr_off[i] = 0;
     const size_t lds = sizeof(float2) * 2 * (size_t)n + (sizeof(float) + sizeof(int)) * (RT_T / 64) + 16;
     const long long per_cu = (long long)(160 * 1024 / lds) < 8 ? (long long)(160 * 1024 / lds) : 8;
     const long long cap = (long long)num_cu * (per_cu < 1 ? 1 : per_cu) * 4;
@@ -404,7 +512,7 @@ int rt_launch(const FftArgs &a, int n, int in_kind, int out_kind, int num_cu, hi
         return JSDR_OK;
     };
     bool full = false;
-    for (int i = 0; i < p.np; i++) full |= (p.rad[i] == 6 || p.rad[i] > 8) && p.rad[i] != 16;
+    for (int i = 0; i < p.np; i++) full |= rt_special(p.rad[i]) && (p.rad[i] == 6 || p.rad[i] > 8) && p.rad[i] != 16;
     if (full) {
         if (in_kind == IN_I16 && out_kind == OUT_PSD) return go(k_fft_rt<IN_I16, OUT_PSD, true>);
         if (in_kind == IN_F32 && out_kind == OUT_PSD) return go(k_fft_rt<IN_F32, OUT_PSD, true>);

@@ -179,7 +179,9 @@ def test_fft_rejects_unsupported_sizes():
 @pytest.mark.parametrize("n,rate", [(4410, 44100), (2205, 22050), (3200, 32000), (1102, 11025), (8820, 88200), (17640, 176400),
                                     (9601, 96010), (16384, 96000), (100, 1000), (37, 370),
                                     # round 5: 2^a 3^b 5^c 7^d frames leave the O(n^2) kernel (run-time radix plan, fft_rt.hip)
-                                    (800, 8000), (1600, 16000), (2400, 24000), (1200, 12000), (9800, 98000), (12, 120), (343, 3430), (630, 6300)])
+                                    (800, 8000), (1600, 16000), (2400, 24000), (1200, 12000), (9800, 98000), (12, 120), (343, 3430), (630, 6300),
+                                    # ... and every other composite frame: primes above 7 as passes of that radix (11.025 kHz: 1102 = 2.19.29)
+                                    (143, 1430), (1100, 11000), (3146, 31460), (551, 5510), (9782, 97820)])
 def test_fft_any_frame_size(n, rate):
     """the reference's audio-rate is a free integer and its frame rate / 10 (JavaAudio.java:49,59; JTransforms takes any n,
     fft.java:67,194): 44.1 kHz -> 4410 = 2.3^2.5.7^2 (the reference's own sine4410.wav), 11.025 kHz -> 1102 = 2.19.29,
@@ -194,11 +196,10 @@ def test_fft_any_frame_size(n, rate):
     bufs[1] = (rng.standard_normal(2 * n) * 0.2).astype(np.float32)
     bufs[2, 0::2] = 0.4 * np.cos(2 * np.pi * (n / 5.0 + 0.25) * t / n)
     f = J.Fft(n, rate)
-    m = n
-    for p in (2, 3, 5, 7):
-        while m % p == 0:
-            m //= p
-    assert f.kernel_name() == ("k_fft_rt" if (m == 1 and 6 <= n <= 9800) else "k_dft_any"), f.kernel_name()
+    # k_fft_rt: any composite n up to 9800 (primes above 7 through a pass that is the DFT's definition: 1102 = 2.19.29); k_dft_any: primes
+    # and frames above 9800 samples
+    prime = all(n % q for q in range(2, int(n ** 0.5) + 1))
+    assert f.kernel_name() == ("k_dft_any" if (prime or n > 9800) else "k_fft_rt"), f.kernel_name()
     spec = f.spectrum(bufs).astype(np.float64)
     for k in range(3):
         want = np.fft.fft(bufs[k, 0::2].astype(np.float64) + 1j * bufs[k, 1::2].astype(np.float64))
