@@ -160,12 +160,13 @@ int mixed_launch(const MixedPlan &p, const FftArgs &a, int in_kind, int out_kind
 // split2 plans: half-size spectra of `nframes` frames into tmp [2*nframes][n/2], then the combine pass
 int mixed_launch_split2(const MixedPlan &p, const FftArgs &a, int in_kind, int out_kind, int num_cu, hipStream_t st);
 
-// any other n = 2^a 3^b 5^c 7^d up to 9800 (fft_rt.hip): Stockham passes with a run-time radix plan
+// any other composite n up to 9800 (fft_rt.hip): Stockham passes with a run-time radix plan (2^a 3^b 5^c 7^d in registers,
+// a larger prime factor as a pass of that radix by the DFT's definition)
 bool rt_supported(int n);
 void rt_twiddles(int n, std::vector<float2> &w);
 int rt_launch(const FftArgs &a, int n, int in_kind, int out_kind, int num_cu, hipStream_t st);
 
-// any other frame size (fft_any.hip): the DFT itself, double accumulation
+// what is left -- prime frame sizes, frames above 9800 samples (fft_any.hip): the DFT itself, double accumulation
 bool dft_any_supported(int n);
 int dft_any_launch(const FftArgs &a, int n, int in_kind, int out_kind, int num_cu, hipStream_t st);
 
