@@ -982,7 +982,11 @@ __global__ __launch_bounds__(FM_THREADS, JSDR_FM_MINWAVES) void k_fm(FmArgs a)
     const int s = (int)(work / a.ntiles);
     const long long G = a.tile0 + (long long)(65 * FM_NB) * (work % a.ntiles);
     const int jrel0 = (int)(G - 64 - a.g_first);  // call-relative output index of X[0] (negative in the first tile)
+#ifdef JSDR_X_FM_SMALLSET  // timing probe (round 5): every stream reads one of 16 streams' samples -- 64 MB, served by the memory-side cache
+    const int *raw = a.raw + (long long)(s & 15) * a.stride_pairs;
+#else
     const int *raw = a.raw + (long long)s * a.stride_pairs;
+#endif
     const int *edges = a.edges + (long long)s * (4 * FM_EDGE);
     const double2 *dmh_old = a.dmh_old + (long long)s * 64;
     const int Lm1 = a.nsamples - 1, nds = a.nds, P = a.tper;

@@ -83,7 +83,12 @@ __device__ __forceinline__ void fft_fetch(const FftArgs &a, long long frame, int
 {
     constexpr int NB = N / R;
     static_assert(NB == T, "one first-pass butterfly per thread");
-    const typename RawPoint<IN>::type *src = reinterpret_cast<const typename RawPoint<IN>::type *>(a.in) + frame * N;
+    const typename RawPoint<IN>::type *src = reinterpret_cast<const typename RawPoint<IN>::type *>(a.in) +
+#ifdef JSDR_X_FFT_SMALLSET  // timing probe (round 5): every frame reads one of 8192 frames -- 64 MB, served by the memory-side cache
+        (frame & 8191) * N;
+#else
+        frame * N;
+#endif
 #pragma unroll
     for (int r = 0; r < R; r++) {
 #ifdef JSDR_X_FFT_NOLOAD  // timing experiment: no input loads (wrong data)
