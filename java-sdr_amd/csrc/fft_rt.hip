@@ -235,16 +235,21 @@ __device__ __forceinline__ void rt_pass_generic(int n, int P, int r, const float
     for (int o = tid; o < n; o += RT_T) {
         const int q = o / nb, b = o - q * nb;
         const int k = b % P;
-        float2 acc = src[b];
+        // (the r terms are summed in double: a float sum's rounding grows with r -- 2 x 4099 samples: 1.3e-3 dB off in bins 60 dB
+        //  below the peak -- and FP64 adds cost this chip what FP32 adds do)
+        const float2 x0 = src[b];
+        double ax = x0.x, ay = x0.y;
         int m = 0;
         for (int j = 1; j < r; j++) {
             m += q;
             if (m >= r) m -= r;
             float2 v = src[b + j * nb];
             if (P > 1) v = cmul(v, tw[k * j]);
-            acc = cadd(acc, cmul(v, wr[m]));
+            v = cmul(v, wr[m]);
+            ax += (double)v.x;
+            ay += (double)v.y;
         }
-        dst[(b - k) * r + k + q * P] = acc;
+        dst[(b - k) * r + k + q * P] = make_float2((float)ax, (float)ay);
     }
 }
 
@@ -417,15 +422,19 @@ bool rt_plan(int n, int *np_out, int *rad, int *tw_off, size_t *tw_count, int *w
     const bool two = (m % 2 == 0);
     if (two) m /= 2;
     // what is left are primes above 7 (ascending): passes of that radix by the DFT's definition, behind the others
-    int big[8], nbig = 0;
+    int big[8], nbig = 0, big_sum = 0;
     for (int q = 11; m > 1; q += 2) {
         if (q * q > m) q = m;
         while (m % q == 0) {
             if (nbig == 8) return false;
             big[nbig++] = q;
+            big_sum += q;
             m /= q;
         }
     }
+    // ... while they are small beside n: a term of such a pass costs ~4-7 x a term of k_dft_any's tuned sum (measured per 2^30
+    // samples: 2 x 4099: 15.8 s here against 4.3 s there; 97 x 101: 0.62 against ~5.1; 2 x 19 x 29: 0.06 against 0.58)
+    if (8 * big_sum > n) return false;
     int lo = 0, hi = no - 1;
     const bool merge = n >= 4000;  // (below, the four- and five-pass plans of the small kernel are the faster ones)
     if (two) {

@@ -33,6 +33,28 @@ def check_psd(got, ref, n):
     assert abs(got[n + 1] - ref[n + 1]) < 1e-3
 
 
+def prime_factors(n):
+    out, q = [], 2
+    while q * q <= n:
+        while n % q == 0:
+            out.append(q)
+            n //= q
+        q += 1
+    if n > 1:
+        out.append(n)
+    return out
+
+
+def expected_kernel(n):
+    """which kernel serves a frame that is neither a power of two nor 4800 / 9600 / 19200 (fft_rt.hip rt_plan): k_fft_rt for a
+    composite n up to 9800 whose prime factors above 7 are small beside it (8 x their sum <= n), k_dft_any for the rest"""
+    pf = prime_factors(n)
+    big = sum(q for q in pf if q > 7)
+    if len(pf) < 2 or n > 9800 or n < 6 or 8 * big > n:
+        return "k_dft_any"
+    return "k_fft_rt"
+
+
 def test_convert_all_65536_values_bit_exact():
     raw = np.arange(-32768, 32768, dtype=np.int32).astype(np.int16)
     iq = np.stack([raw, raw[::-1]], axis=1).reshape(-1)
@@ -198,8 +220,7 @@ def test_fft_any_frame_size(n, rate):
     f = J.Fft(n, rate)
     # k_fft_rt: any composite n up to 9800 (primes above 7 through a pass that is the DFT's definition: 1102 = 2.19.29); k_dft_any: primes
     # and frames above 9800 samples
-    prime = all(n % q for q in range(2, int(n ** 0.5) + 1))
-    assert f.kernel_name() == ("k_dft_any" if (prime or n > 9800) else "k_fft_rt"), f.kernel_name()
+    assert f.kernel_name() == expected_kernel(n), f.kernel_name()
     spec = f.spectrum(bufs).astype(np.float64)
     for k in range(3):
         want = np.fft.fft(bufs[k, 0::2].astype(np.float64) + 1j * bufs[k, 1::2].astype(np.float64))
@@ -273,3 +294,28 @@ def test_fft_run_time_plan_at_random_smooth_sizes():
             want = np.fft.fft(bufs[k, 0::2].astype(np.float64) + 1j * bufs[k, 1::2].astype(np.float64))
             got = spec[k, 0::2] + 1j * spec[k, 1::2]
             assert np.abs(got - want).max() <= FFT_RTOL * np.abs(want).max(), n
+
+
+def test_fft_run_time_plan_at_random_sizes_with_large_prime_factors():
+    """... and any OTHER composite frame up to 9800 samples: a prime factor above 7 becomes a pass of that radix by the DFT's
+    definition (k_fft_rt's rt_pass_generic, summed in double) while such factors are small beside n; the rest stays with
+    k_dft_any.  Sizes drawn from all composites that are not 7-smooth, plus the corners: a huge prime radix (2 x 4099), two
+    large primes (97 x 101), a prime squared (97^2), a prime cubed (19^3), the largest such n, the smallest."""
+    rng = np.random.default_rng(77)
+    cand = [n for n in range(22, 9801) if len(prime_factors(n)) >= 2 and max(prime_factors(n)) > 7]
+    picks = [int(n) for n in rng.choice(cand, 30, replace=False)] + [2 * 4099, 97 * 101, 97 * 97, 19 ** 3, 9799, 9798, 22, 26, 4 * 2447, 8 * 11, 16 * 11]
+    seen = set()
+    for n in picks:
+        f = J.Fft(n, 10 * n)
+        assert f.kernel_name() == expected_kernel(n), (n, prime_factors(n), f.kernel_name())
+        seen.add(f.kernel_name())
+        bufs = (rng.standard_normal((3, 2 * n)) * 0.25).astype(np.float32)
+        bufs[0, 0::2] += np.float32(0.5) * np.cos(2 * np.pi * (n // 5) * np.arange(n) / n).astype(np.float32)
+        spec = f.spectrum(bufs).astype(np.float64)
+        psd = np.stack([f.receive(bufs[k]) for k in range(3)])
+        for k in range(3):
+            want = np.fft.fft(bufs[k, 0::2].astype(np.float64) + 1j * bufs[k, 1::2].astype(np.float64))
+            got = spec[k, 0::2] + 1j * spec[k, 1::2]
+            assert np.abs(got - want).max() <= FFT_RTOL * np.abs(want).max(), (n, prime_factors(n))
+            check_psd(psd[k], O.fft_receive(bufs[k], 10 * n), n)
+    assert seen == {"k_fft_rt", "k_dft_any"}
