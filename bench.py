@@ -91,6 +91,10 @@ def parse():
     ap.add_argument("--serial", action="store_true",
                     help="pipeline workload: PSD then demodulator on ONE stream, each kernel with the whole chip (the default until round 4). "
                          "Default now, from 8192 streams per GPU: side by side on two streams with the CU shares set (jsdr_fft_set_cu_share 2, jsdr_bpsk_set_cu_share 1)")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="N = 1: do not count the HBM traffic in this run (two child runs of this command under rocprofv3 --pmc, "
+                         "about a minute); roofline.traffic then comes from the stored table under profiles/")
+    ap.add_argument("--live-traffic-timeout", type=float, default=240.0, help="seconds one counter pass may take")
     ap.add_argument("--psd-stream", action="store_true",
                     help="PSD kernel on a HIP stream of its own beside the demodulator (measured: within 2 %% of the default, "
                          "one after the other on one stream, whose per-kernel times are not inflated by the overlap)")
@@ -458,6 +462,57 @@ def launch_ranks(N):
     return rc
 
 
+def live_traffic_table(a, samples_per_launch):
+    """HBM bytes per kernel launch COUNTED IN THIS RUN: this very command (two steps after one warm-up, no validation, no CPU leg)
+    as a child process under `rocprofv3 --pmc FETCH_SIZE` and once more under `--pmc WRITE_SIZE` -- separate passes, as
+    MI355X_MICROARCH.md prescribes -- before this process makes its first GPU call (so the child has the whole HBM, and nothing
+    here is an exec from a process that holds the GPU).  None when the profiler is missing, fails or takes too long: the
+    line then carries the stored table (profiles/pmc_traffic*.json) and says so."""
+    import shutil
+    import signal
+    import subprocess
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import pmc_traffic
+    except Exception:
+        return None
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None
+    child = [x for x in sys.argv[1:]] + ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-validate", "--no-compare-serial",
+                                         "--no-autotune", "--no-live-traffic"]
+    tmp = tempfile.mkdtemp(prefix="jsdr_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", JSDR_BENCH_CHILD="1")
+    t0 = time.perf_counter()
+    try:
+        dirs = {}
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            with open(os.path.join(tmp, counter + ".log"), "w") as log:
+                pr = subprocess.Popen([prof, "--pmc", counter, "--output-format", "csv", "-d", d, "--", "python3",
+                                       os.path.join(ROOT, "bench.py")] + child, cwd="/tmp", env=env, stdout=log, stderr=log,
+                                      start_new_session=True)
+                try:
+                    rc = pr.wait(timeout=a.live_traffic_timeout)
+                except subprocess.TimeoutExpired:
+                    os.killpg(pr.pid, signal.SIGKILL)  # the process group this function started, nothing else
+                    pr.wait()
+                    return None
+            if rc != 0:
+                return None
+            dirs[counter] = d
+        tab = pmc_traffic.table(dirs["FETCH_SIZE"], dirs["WRITE_SIZE"], samples_per_launch)
+        if not any(k.startswith("k_") for k in tab):
+            return None
+        tab["_seconds"] = round(time.perf_counter() - t0, 1)
+        return tab
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def main():
     global RATE
     a = parse()
@@ -518,6 +573,14 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index), **kw)
         else:
             dist.init_process_group(backend, **kw)
+    live_tab = None
+    under_profiler = any(k.startswith("ROCPROF") or k.startswith("ROCP_") for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+    if (N == 1 and not D and not a.no_live_traffic and os.environ.get("JSDR_BENCH_CHILD") != "1" and not under_profiler and
+            os.environ.get("JSDR_BENCH_LIVE_TRAFFIC", "1") != "0" and os.path.exists("/dev/kfd")):
+        # (before this process's first GPU call; not when this run is itself being profiled, not for the A/B tooling's runs)
+        S_ = a.streams if a.streams > 0 else a.total_streams
+        L_ = (a.samples // a.bpsk_frame) * a.bpsk_frame if a.bpsk_frame != N_FFT else a.samples
+        live_tab = live_traffic_table(a, S_ * L_)
     import java_sdr_amd as J
     from java_sdr_amd import sharding as SH
 
@@ -730,13 +793,23 @@ def main():
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if a.fft_acquire and os.path.exists(os.path.join(ROOT, "profiles", f"pmc_traffic_acq{a.bpsk_frame}.json")):
         pmc = os.path.join(ROOT, "profiles", f"pmc_traffic_acq{a.bpsk_frame}.json")
+    stored_tab = None
     if os.path.exists(pmc):
         try:
-            tab = json.load(open(pmc))
-            per = tab.get(dom, {}).get("hbm_bytes_per_launch")  # measured at tab["_samples_per_launch"] samples a launch
-            traffic = int(per * (S * L) / tab.get("_samples_per_launch", 1024 * 1048576)) if per else None
+            stored_tab = json.load(open(pmc))
         except Exception:
-            traffic = None
+            stored_tab = None
+    tab = live_tab if live_tab is not None else stored_tab
+    if tab:
+        per = tab.get(dom, {}).get("hbm_bytes_per_launch")  # measured at tab["_samples_per_launch"] samples a launch
+        traffic = int(per * (S * L) / tab.get("_samples_per_launch", 1024 * 1048576)) if per else None
+    if live_tab is not None:
+        traffic_source = (f"counted in THIS run ({live_tab['_seconds']} s): this command (--steps 2 --warmup 1) as a child process under "
+                          "rocprofv3 --pmc FETCH_SIZE and again under --pmc WRITE_SIZE (separate passes; gfx950 correction 2 x FETCH + WRITE), "
+                          "mean per launch")
+    else:
+        traffic_source = (os.path.relpath(pmc, ROOT) + ": separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                          "workload (gfx950 correction 2 x FETCH + WRITE), scaled by streams x samples; not counted in this run")
     nds_per_launch = S * (L // (RATE // 9600))  # 9600 Hz samples one launch of the demodulator's kernels covers
 
     def kernel_entry(k, v):
@@ -760,9 +833,7 @@ def main():
     # the dominant kernel is "binding_limit" (and per kernel in per_kernel[...]["bound"])
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "traffic_source": (os.path.relpath(pmc, ROOT) + ": separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                                   "workload (gfx950 correction 2 x FETCH + WRITE), scaled by streams x samples; not counted in this run")
-                if traffic is not None else None,
+                "traffic_source": traffic_source if traffic is not None else None,
                 "binding_limit": KERNEL_LIMIT.get(dom, KERNEL_BOUND.get(dom, "hbm")),
                 "avg_launch_ms": round(dom_ms, 4), "algorithmic_bytes_per_launch": int(alg_bytes),
                 "kernels_ms_per_step": {k: round(v[0] / v[1], 4) for k, v in sorted(kern.items())},
@@ -770,6 +841,11 @@ def main():
                 # with whatever the side stream's kernels took from it)
                 "per_kernel": {k: kernel_entry(k, v) for k, v in sorted(kern.items())
                                if v[0] / v[1] > 0.02 * dom_ms}}  # (not the helper kernels)
+    if tab:
+        # HBM bytes per launch of every kernel of a step (not the input generator's: k_synth_*, k_fec_encode run once, before the timed region)
+        roofline["traffic_per_kernel"] = {k: int(v["hbm_bytes_per_launch"] * (S * L) / tab.get("_samples_per_launch", 1024 * 1048576))
+                                          for k, v in sorted(tab.items()) if isinstance(v, dict) and "hbm_bytes_per_launch" in v
+                                          and not k.startswith("k_synth") and k != "k_fec_encode"}
     if side_by_side:
         # k_fft and k_fm run CONCURRENTLY: each one's launch duration is the time it shared the chip with the other, not a time
         # it had the HBM to itself -- so the PAIR is the unit that is priced: the step's algorithmic bytes
@@ -788,16 +864,12 @@ def main():
         roofline["step_frac"] = roofline["frac"]
         roofline["binding_limit"] = ("VALU issue of the pair: k_fm's separately rounded FP64 operations and k_fft's packed FP32 butterflies "
                                      "share every SIMD (profiles/r05_*: k_fm alone issues VALU for 90 % of its cycles)")
-        tab = None
-        try:
-            tab = json.load(open(pmc))
-        except Exception:
-            pass
         if tab:
             # every kernel of a step (not the input generator's: k_synth_*, k_fec_encode run once, before the timed region)
             per = sum(v.get("hbm_bytes_per_launch", 0) for k, v in tab.items()
                       if isinstance(v, dict) and not k.startswith("k_synth") and k != "k_fec_encode")
             roofline["traffic"] = int(per * (S * L) / tab.get("_samples_per_launch", 1024 * 1048576)) if per else None
+            roofline["traffic_source"] = traffic_source if roofline["traffic"] is not None else None
         for k in ("k_fft", fm):
             if k in roofline["per_kernel"]:
                 e = roofline["per_kernel"][k]

@@ -93,3 +93,38 @@ def test_distributed_path_with_the_real_backend_and_one_rank():
     assert j["validated"] is True and j["n_gpus"] == 1
     assert j["gather_check"]["all_ranks_ok"] is True and j["gather_check"]["validated_per_rank"] == [True]
     assert "RCCL" in j["config"]["parallelism"]
+
+
+def test_roofline_traffic_is_counted_in_the_run_itself():
+    """`python bench.py` at N = 1 counts the HBM bytes it reports: the same command as a child process under rocprofv3 --pmc
+    FETCH_SIZE and again under --pmc WRITE_SIZE before the timed run ('roofline.traffic is a stored constant').
+    A small pipeline batch: the source says so, the per-kernel table holds the step's kernels, and the PSD kernel's bytes are its
+    algorithmic ones (4 B in + 4 B out per sample) within what the counters' granularity allows."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("JSDR_KNOBS", "JSDR_BENCH_LIVE_TRAFFIC", "JSDR_BENCH_ALLOW_KNOBS"):
+        env.pop(k, None)
+    S, L = 256, 1048576
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--streams", str(S), "--samples", str(L), "--steps", "2",
+                        "--warmup", "1", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[:2000]
+    out = json.loads(lines[0])
+    rf = out["roofline"]
+    assert out["validated"] is True
+    assert rf["traffic_source"].startswith("counted in THIS run"), rf["traffic_source"]
+    assert rf["traffic"] and rf["traffic"] > 0
+    # the same command with the counting switched off: the stored table, and the line says that instead
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--streams", str(S), "--samples", str(L), "--steps", "2",
+                         "--warmup", "1", "--no-cpu-baseline", "--no-live-traffic", "--serial"], env=env, capture_output=True, text=True, timeout=600)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    rf2 = json.loads([ln for ln in r2.stdout.splitlines() if ln.strip()][0])["roofline"]
+    assert "not counted in this run" in rf2["traffic_source"]
+    # one after the other the line prices its longest kernel: k_fm (4 B of int16 IQ in, 16 B of (fi,fq) out per 9600 Hz sample) or
+    # k_fft (4 B in, 4 B of PSD out per sample)
+    alg = S * L * (5.6 if rf2["kernel"] == "k_fm" else 8.0)
+    assert rf2["kernel"] in ("k_fm", "k_fft") and 0.9 * alg < rf2["traffic"] < 1.3 * alg, (rf2["kernel"], rf2["traffic"], alg)
+    # ... and the counted table of the first run agrees with it kernel by kernel
+    per = rf["traffic_per_kernel"]
+    assert 0.9 * S * L * 8.0 < per["k_fft"] < 1.3 * S * L * 8.0 and 0.9 * S * L * 5.6 < per["k_fm"] < 1.3 * S * L * 5.6, per

@@ -1,7 +1,7 @@
 #!/bin/bash
 # tools/ab_acq.sh <frame> <lib...> -- the same FFT-acquire bench line with several builds of the library, in ONE session
 # (boxes differ by several percent; only numbers of one session compare), each twice, interleaved
-export JSDR_KNOBS=1 JSDR_BENCH_ALLOW_KNOBS=1  # the library listens to its tuning knobs only with JSDR_KNOBS=1; bench.py measures with them only when told
+export JSDR_KNOBS=1 JSDR_BENCH_ALLOW_KNOBS=1 JSDR_BENCH_LIVE_TRAFFIC=0  # the library listens to its tuning knobs only with JSDR_KNOBS=1; bench.py measures with them only when told
 mkdir -p gpurun_out; export TMPDIR=/tmp
 F=$1; shift
 for rep in 1 2; do

@@ -1,7 +1,7 @@
 #!/bin/bash
 # tools/ab_acq_noov.sh <frame> <lib...> -- as ab_acq.sh, but with the side stream off (JSDR_NO_OVERLAP=1): the front-end
 # kernel's own time, not stretched by the tail / sync / FEC kernels of the previous step running beside it
-export JSDR_KNOBS=1 JSDR_BENCH_ALLOW_KNOBS=1  # the library listens to its tuning knobs only with JSDR_KNOBS=1; bench.py measures with them only when told
+export JSDR_KNOBS=1 JSDR_BENCH_ALLOW_KNOBS=1 JSDR_BENCH_LIVE_TRAFFIC=0  # the library listens to its tuning knobs only with JSDR_KNOBS=1; bench.py measures with them only when told
 mkdir -p gpurun_out; export TMPDIR=/tmp
 F=$1; shift
 for rep in 1 2; do

@@ -1,7 +1,7 @@
 #!/bin/bash
 # tools/ab_r03.sh <tag> -- the default bench line of the round-3 tree (.r03tree, a scratch export of that round's last commit with
 # its own built library) and of this tree, three times each, interleaved, on ONE box: boxes differ by ~1 ms on this line
-export JSDR_KNOBS=1 JSDR_BENCH_ALLOW_KNOBS=1  # the library listens to its tuning knobs only with JSDR_KNOBS=1; bench.py measures with them only when told
+export JSDR_KNOBS=1 JSDR_BENCH_ALLOW_KNOBS=1 JSDR_BENCH_LIVE_TRAFFIC=0  # the library listens to its tuning knobs only with JSDR_KNOBS=1; bench.py measures with them only when told
 set -u
 T=${1:-rXX}; O=$PWD/gpurun_out; mkdir -p $O
 line() { grep '^{"metric' "$1" | tail -1; }

@@ -3,7 +3,7 @@
 # k_front_fft2x) at 1024 streams x 2^20 samples: the bench line, two SQ counter passes, the FETCH_SIZE / WRITE_SIZE
 # passes (separate runs, as the guide prescribes) and the per-phase clocks.  Everything lands under gpurun_out/<tag>_*.
 #   gpurun --timeout 1100 -- 'bash tools/acq_counters.sh r03_a 2048 9600 19200'
-export JSDR_KNOBS=1 JSDR_BENCH_ALLOW_KNOBS=1  # the library listens to its tuning knobs only with JSDR_KNOBS=1; bench.py measures with them only when told
+export JSDR_KNOBS=1 JSDR_BENCH_ALLOW_KNOBS=1 JSDR_BENCH_LIVE_TRAFFIC=0  # the library listens to its tuning knobs only with JSDR_KNOBS=1; bench.py measures with them only when told
 set -u
 T=${1:-rXX}; shift
 FRAMES=${*:-2048 9600 19200}

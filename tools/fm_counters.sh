@@ -2,7 +2,7 @@
 # tools/fm_counters.sh <tag> -- SQ counters of k_fm ALONE (--workload bpsk, no side stream), exact and fast variant, on
 # the current code: three passes each (issue, waits, instruction mix).  Summaries land in gpurun_out/<tag>_sq_counters_k_fm_*.
 #   gpurun --timeout 1100 -- 'bash tools/fm_counters.sh r05_a'
-export JSDR_KNOBS=1 JSDR_BENCH_ALLOW_KNOBS=1  # the library listens to its tuning knobs only with JSDR_KNOBS=1; bench.py measures with them only when told
+export JSDR_KNOBS=1 JSDR_BENCH_ALLOW_KNOBS=1 JSDR_BENCH_LIVE_TRAFFIC=0  # the library listens to its tuning knobs only with JSDR_KNOBS=1; bench.py measures with them only when told
 set -u
 T=${1:-rXX}
 mkdir -p gpurun_out; export TMPDIR=/tmp

@@ -3,7 +3,7 @@
 # gpurun_out/; a step that TIMES OUT (124/137) ends the session (no further GPU work after a kill),
 # an ordinary failure (assert, non-zero exit) is logged and the session goes on.
 #   usage: tools/gpu_session.sh step [step ...]   steps: tests micro bench_small bench bench_fft bench_bpsk prof pmc
-export JSDR_KNOBS=1 JSDR_BENCH_ALLOW_KNOBS=1  # the library listens to its tuning knobs only with JSDR_KNOBS=1; bench.py measures with them only when told
+export JSDR_KNOBS=1 JSDR_BENCH_ALLOW_KNOBS=1 JSDR_BENCH_LIVE_TRAFFIC=0  # the library listens to its tuning knobs only with JSDR_KNOBS=1; bench.py measures with them only when told
 set -u
 mkdir -p gpurun_out
 export TMPDIR=/tmp
@@ -28,7 +28,7 @@ for step in "$@"; do
     micro)       run micro_build 120 hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -o /tmp/mb_fp64 tools/microbench_fp64.hip
                  run micro 120 /tmp/mb_fp64 ;;
     bench_small) run bench_small 300 python bench.py --steps 3 --warmup 1 --streams 128 --samples 1048576 --cpu-seconds 3 ;;
-    bench)       run bench 600 python bench.py ;;
+    bench)       JSDR_BENCH_LIVE_TRAFFIC=1 run bench 900 python bench.py ;;
     tests_demod) run tests_demod 600 python -m pytest tests/test_gpu_demod.py -m gpu -q -x -p no:cacheprovider --timeout 600 ;;
     tests_fft)   run tests_fft 900 python -m pytest tests/test_gpu_fft.py -m gpu -q -x -p no:cacheprovider --timeout 800 ;;
     tests_misc)  run tests_misc 600 python -m pytest tests/test_gpu_fir_phase_fec.py tests/test_gpu_host.py -m gpu -q -x -p no:cacheprovider --timeout 600 ;;

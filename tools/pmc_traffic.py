@@ -25,17 +25,24 @@ def per_kernel(d, counter):
     return {k: sum(v) / len(v) for k, v in acc.items()}
 
 
-samples = int(sys.argv[4]) if len(sys.argv) > 4 else 1024 * 1048576  # IQ samples one launch of the batch kernels covers
-fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
-write = per_kernel(sys.argv[2], "WRITE_SIZE")
-out = {"_samples_per_launch": samples, "_note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (tools/gpu_session.sh pmc_rd pmc_wr), "
-                "bench.py --steps 2 --warmup 1, per launch of _samples_per_launch IQ samples.  Counter unit = KiB.  Per MI355X_MICROARCH.md the gfx950 "
-                "FETCH_SIZE reports half the bytes of coalesced streaming reads: hbm_bytes = 2*FETCH + WRITE "
-                "(calibration: k_synth_dbpsk writes exactly 4.295e9 B; k_fft reads 4.295e9 B of int16 IQ)."}
-for k in sorted(set(fetch) | set(write)):
-    if k.startswith('_'):
-        continue
-    f, w = fetch.get(k, 0.0), write.get(k, 0.0)
-    out[k] = {"fetch_size_bytes_raw": int(f), "write_size_bytes": int(w), "hbm_bytes_per_launch": int(2 * f + w)}
-json.dump(out, open(sys.argv[3], "w"), indent=1)
-print(json.dumps({k: v["hbm_bytes_per_launch"] for k, v in out.items() if not k.startswith("_")}))
+def table(fetch_dir, write_dir, samples):
+    """per-kernel {fetch raw, write, hbm bytes per launch} from the two passes' output directories"""
+    fetch = per_kernel(fetch_dir, "FETCH_SIZE")
+    write = per_kernel(write_dir, "WRITE_SIZE")
+    out = {"_samples_per_launch": samples, "_note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (tools/gpu_session.sh pmc_rd pmc_wr), "
+                    "bench.py --steps 2 --warmup 1, per launch of _samples_per_launch IQ samples.  Counter unit = KiB.  Per MI355X_MICROARCH.md the gfx950 "
+                    "FETCH_SIZE reports half the bytes of coalesced streaming reads: hbm_bytes = 2*FETCH + WRITE "
+                    "(calibration: k_synth_dbpsk writes exactly 4.295e9 B; k_fft reads 4.295e9 B of int16 IQ)."}
+    for k in sorted(set(fetch) | set(write)):
+        if k.startswith('_'):
+            continue
+        f, w = fetch.get(k, 0.0), write.get(k, 0.0)
+        out[k] = {"fetch_size_bytes_raw": int(f), "write_size_bytes": int(w), "hbm_bytes_per_launch": int(2 * f + w)}
+    return out
+
+
+if __name__ == "__main__":
+    samples = int(sys.argv[4]) if len(sys.argv) > 4 else 1024 * 1048576  # IQ samples one launch of the batch kernels covers
+    out = table(sys.argv[1], sys.argv[2], samples)
+    json.dump(out, open(sys.argv[3], "w"), indent=1)
+    print(json.dumps({k: v["hbm_bytes_per_launch"] for k, v in out.items() if not k.startswith("_")}))

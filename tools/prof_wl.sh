@@ -1,6 +1,6 @@
 #!/bin/bash
 # tools/prof_wl.sh <tag> "<bench args>" [VAR=val ...] -- rocprofv3 --kernel-trace --stats of one bench line; prints the per-kernel table
-export JSDR_KNOBS=1 JSDR_BENCH_ALLOW_KNOBS=1  # the library listens to its tuning knobs only with JSDR_KNOBS=1; bench.py measures with them only when told
+export JSDR_KNOBS=1 JSDR_BENCH_ALLOW_KNOBS=1 JSDR_BENCH_LIVE_TRAFFIC=0  # the library listens to its tuning knobs only with JSDR_KNOBS=1; bench.py measures with them only when told
 mkdir -p gpurun_out; export TMPDIR=/tmp
 T=$1; A=$2; shift 2
 rm -rf gpurun_out/prof_$T

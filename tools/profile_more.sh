@@ -1,7 +1,7 @@
 #!/bin/bash
 # tools/profile_more.sh <tag> -- rocprofv3 --kernel-trace --stats of the other workloads' bench lines (fft, fir, bpsk, the three
 # FFT-acquire frame sizes) and a 200-step soak of the default pipeline; summaries under gpurun_out/<tag>_*
-export JSDR_KNOBS=1 JSDR_BENCH_ALLOW_KNOBS=1  # the library listens to its tuning knobs only with JSDR_KNOBS=1; bench.py measures with them only when told
+export JSDR_KNOBS=1 JSDR_BENCH_ALLOW_KNOBS=1 JSDR_BENCH_LIVE_TRAFFIC=0  # the library listens to its tuning knobs only with JSDR_KNOBS=1; bench.py measures with them only when told
 set -u
 T=${1:-rXX}
 mkdir -p gpurun_out; export TMPDIR=/tmp

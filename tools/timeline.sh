@@ -1,7 +1,7 @@
 #!/bin/bash
 # tools/timeline.sh <tag> "<bench args>" [VAR=val ...] -- rocprofv3 --kernel-trace of one bench line; prints when every kernel of the
 # last two steps started and ended (which kernels really run beside which)
-export JSDR_KNOBS=1 JSDR_BENCH_ALLOW_KNOBS=1  # the library listens to its tuning knobs only with JSDR_KNOBS=1; bench.py measures with them only when told
+export JSDR_KNOBS=1 JSDR_BENCH_ALLOW_KNOBS=1 JSDR_BENCH_LIVE_TRAFFIC=0  # the library listens to its tuning knobs only with JSDR_KNOBS=1; bench.py measures with them only when told
 mkdir -p gpurun_out; export TMPDIR=/tmp
 T=$1; A=$2; shift 2
 rm -rf gpurun_out/tl_$T
