@@ -16,7 +16,10 @@ per rank instead ("scaling": "weak").  Every step ends with one all-gather of th
 slots over xGMI.  value = samples processed by all ranks / max-over-ranks time.
 
 The JSON line also carries
-    roofline     : dominant kernel (HIP events recorded on the launch stream inside the timed region)
+    roofline     : dominant kernel (HIP events recorded on the launch stream inside the timed region); at N = 1 its `traffic`
+                   (HBM bytes per launch) is COUNTED IN THE RUN: before its first GPU call this process runs its own command
+                   line (two steps, no validation) as a child under `rocprofv3 --pmc FETCH_SIZE` and again under `--pmc
+                   WRITE_SIZE` (live_traffic_table; ~6 s; --no-live-traffic, or a failing profiler: the stored table under profiles/)
     cpu_baseline : the plain-C oracle (oracle/, a restatement of the Java arithmetic: kind "port") on the
                    host cores, bounded sample, rank 0 at N=1 only.
 """
