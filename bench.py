@@ -469,8 +469,11 @@ def live_traffic_table(a, samples_per_launch):
     """HBM bytes per kernel launch COUNTED IN THIS RUN: this very command (two steps after one warm-up, no validation, no CPU leg)
     as a child process under `rocprofv3 --pmc FETCH_SIZE` and once more under `--pmc WRITE_SIZE` -- separate passes, as
     MI355X_MICROARCH.md prescribes -- before this process makes its first GPU call (so the child has the whole HBM, and nothing
-    here is an exec from a process that holds the GPU).  None when the profiler is missing, fails or takes too long: the
-    line then carries the stored table (profiles/pmc_traffic*.json) and says so."""
+    here is an exec from a process that holds the GPU).  Returns (table, None), or (None, why) when the profiler is missing,
+    fails or takes too long: the line then carries the stored table (profiles/pmc_traffic*.json) and says why.  A child that
+    overruns is asked to stop (SIGTERM to the process group this function started) and waited for; if it has to be KILLED it may
+    have died in the middle of a kernel, and this process then does no GPU work at all (the repository's own session rule:
+    tools/gpu_session.sh) -- it exits non-zero."""
     import shutil
     import signal
     import subprocess
@@ -478,11 +481,14 @@ def live_traffic_table(a, samples_per_launch):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     try:
         import pmc_traffic
-    except Exception:
-        return None
+    except Exception as ex:
+        return None, f"tools/pmc_traffic.py not importable ({ex})"
     prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(prof):
-        return None
+        return None, "rocprofv3 not found"
+    # the child runs under the PARENT's interpreter (a real ELF binary: the program right after `--` must not be a launcher that
+    # re-execs, and a different python3 on PATH may lack this process's packages)
+    py = os.path.realpath(sys.executable) if sys.executable else "python3"
     child = [x for x in sys.argv[1:]] + ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-validate", "--no-compare-serial",
                                          "--no-autotune", "--no-live-traffic"]
     tmp = tempfile.mkdtemp(prefix="jsdr_pmc_", dir="/tmp")
@@ -493,25 +499,37 @@ def live_traffic_table(a, samples_per_launch):
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(tmp, counter)
             with open(os.path.join(tmp, counter + ".log"), "w") as log:
-                pr = subprocess.Popen([prof, "--pmc", counter, "--output-format", "csv", "-d", d, "--", "python3",
+                pr = subprocess.Popen([prof, "--pmc", counter, "--output-format", "csv", "-d", d, "--", py,
                                        os.path.join(ROOT, "bench.py")] + child, cwd="/tmp", env=env, stdout=log, stderr=log,
                                       start_new_session=True)
                 try:
                     rc = pr.wait(timeout=a.live_traffic_timeout)
                 except subprocess.TimeoutExpired:
-                    os.killpg(pr.pid, signal.SIGKILL)  # the process group this function started, nothing else
-                    pr.wait()
-                    return None
+                    os.killpg(pr.pid, signal.SIGTERM)  # the process group this function started, nothing else
+                    try:
+                        pr.wait(timeout=30)
+                    except subprocess.TimeoutExpired:
+                        os.killpg(pr.pid, signal.SIGKILL)
+                        pr.wait()
+                        raise SystemExit(f"bench.py: the --pmc {counter} child neither finished in {a.live_traffic_timeout:.0f} s nor "
+                                         "stopped on SIGTERM and had to be killed, possibly inside a kernel: no measurement on "
+                                         "this GPU from this process (re-run with --no-live-traffic)")
+                    return None, f"the --pmc {counter} pass took more than {a.live_traffic_timeout:.0f} s and was stopped (SIGTERM, exited)"
             if rc != 0:
-                return None
+                tail = ""
+                try:
+                    tail = open(os.path.join(tmp, counter + ".log")).read()[-300:].replace("\n", " | ")
+                except OSError:
+                    pass
+                return None, f"the --pmc {counter} pass exited with {rc}: {tail}"
             dirs[counter] = d
         tab = pmc_traffic.table(dirs["FETCH_SIZE"], dirs["WRITE_SIZE"], samples_per_launch)
         if not any(k.startswith("k_") for k in tab):
-            return None
+            return None, "the counter output names no kernel of this library"
         tab["_seconds"] = round(time.perf_counter() - t0, 1)
-        return tab
-    except Exception:
-        return None
+        return tab, None
+    except Exception as ex:
+        return None, f"{type(ex).__name__}: {ex}"
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
@@ -576,14 +594,16 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index), **kw)
         else:
             dist.init_process_group(backend, **kw)
-    live_tab = None
+    live_tab, live_why = None, None
     under_profiler = any(k.startswith("ROCPROF") or k.startswith("ROCP_") for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
     if (N == 1 and not D and not a.no_live_traffic and os.environ.get("JSDR_BENCH_CHILD") != "1" and not under_profiler and
             os.environ.get("JSDR_BENCH_LIVE_TRAFFIC", "1") != "0" and os.path.exists("/dev/kfd")):
         # (before this process's first GPU call; not when this run is itself being profiled, not for the A/B tooling's runs)
         S_ = a.streams if a.streams > 0 else a.total_streams
         L_ = (a.samples // a.bpsk_frame) * a.bpsk_frame if a.bpsk_frame != N_FFT else a.samples
-        live_tab = live_traffic_table(a, S_ * L_)
+        live_tab, live_why = live_traffic_table(a, S_ * L_)
+        if live_tab is None:
+            print(f"[bench] roofline.traffic falls back to the stored table: {live_why}", file=sys.stderr)
     import java_sdr_amd as J
     from java_sdr_amd import sharding as SH
 
@@ -812,7 +832,8 @@ def main():
                           "mean per launch")
     else:
         traffic_source = (os.path.relpath(pmc, ROOT) + ": separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                          "workload (gfx950 correction 2 x FETCH + WRITE), scaled by streams x samples; not counted in this run")
+                          "workload (gfx950 correction 2 x FETCH + WRITE), scaled by streams x samples; not counted in this run" +
+                          (f" ({live_why})" if live_why else ""))
     nds_per_launch = S * (L // (RATE // 9600))  # 9600 Hz samples one launch of the demodulator's kernels covers
 
     def kernel_entry(k, v):

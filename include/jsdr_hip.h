@@ -36,6 +36,7 @@ const char *jsdr_last_error(void);
 int jsdr_version(void);                       /* ABI version, currently 1 */
 int jsdr_device_count(int *count);
 int jsdr_set_device(int device);
+int jsdr_get_device(int *device);            /* the calling thread's current device (to restore after a per-device loop) */
 int jsdr_device_name(char *buf, int cap);     /* gcnArchName of the current device */
 int jsdr_malloc(void **dev, size_t bytes);
 int jsdr_free(void *dev);

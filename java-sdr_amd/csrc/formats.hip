@@ -185,6 +185,7 @@ int jsdr_recordings_load(const char *const *paths, int nstreams, int channels, i
                  (long long)stream_stride_i16, (long long)nframes);
     hipStream_t st = as_stream(stream);
     std::vector<int16_t> widen;
+    bool padded = false;
     for (int s = 0; s < nstreams; s++) {
         JSDR_REQUIRE(paths[s], "jsdr_recordings_load: null path for stream %d", s);
         Mapped m;
@@ -218,9 +219,16 @@ int jsdr_recordings_load(const char *const *paths, int nstreams, int channels, i
             // the source is unmapped (or reused) when this iteration ends
             JSDR_HIP_TRY(hipStreamSynchronize(st));
         }
-        if (have < nframes) JSDR_HIP_TRY(hipMemsetAsync(dst + 2 * have, 0, (size_t)(nframes - have) * 4, st));
+        if (have < nframes) {
+            JSDR_HIP_TRY(hipMemsetAsync(dst + 2 * have, 0, (size_t)(nframes - have) * 4, st));
+            padded = true;
+        }
         if (frames_loaded) frames_loaded[s] = have;
     }
+    // The zero padding of a short or exhausted recording was only ENQUEUED on `st` (the legacy null stream when the caller
+    // passes none): a consumer on a non-blocking stream of its own -- the group's device threads -- is not ordered behind
+    // it and would read the previous block's samples.  The copies above are complete when this returns; so is the padding.
+    if (padded) JSDR_HIP_TRY(hipStreamSynchronize(st));
     return JSDR_OK;
 }
 

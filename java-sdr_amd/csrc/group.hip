@@ -28,6 +28,7 @@ struct Rccl {
     void *so = nullptr;
     int (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
     int (*CommDestroy)(ncclComm_t) = nullptr;
+    int (*CommAbort)(ncclComm_t) = nullptr;  // optional: frees a communicator whose collective will never complete
     int (*AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
     int (*GetVersion)(int *) = nullptr;
@@ -51,6 +52,7 @@ static int rccl_load()
     r.so = so;
     r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(dlsym(so, "ncclCommInitAll"));
     r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(so, "ncclCommDestroy"));
+    r.CommAbort = reinterpret_cast<decltype(r.CommAbort)>(dlsym(so, "ncclCommAbort"));
     r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(so, "ncclAllGather"));
     r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(so, "ncclGetErrorString"));
     r.GetVersion = reinterpret_cast<decltype(r.GetVersion)>(dlsym(so, "ncclGetVersion"));
@@ -86,6 +88,7 @@ struct Rank {
     jsdr_fft *fft = nullptr;
     hipStream_t main = nullptr, psd = nullptr, gather = nullptr;
     uint8_t *slots = nullptr, *gathered = nullptr;
+    int64_t slot_bytes = 0;
     hipEvent_t ev_packed = nullptr, ev_pulled = nullptr;
     bool pulled_once = false;
     ncclComm_t comm = nullptr;
@@ -104,6 +107,10 @@ struct Group {
     int arrived = 0, generation = 0;
     bool step_failed = false, step_failed_latched = false;
     long long steps = 0;
+    // a collective that failed on ONE rank leaves the others' gather streams waiting for a peer that never joins: from then
+    // on nobody waits on a gather stream any more (sync / destroy), the communicators are aborted rather than destroyed, and
+    // every later batch call is refused
+    std::atomic<bool> broken{false};
 };
 
 static void rank_fail(Rank *r, const char *what)
@@ -135,11 +142,25 @@ static void run_batch(Rank *r, const Job &j)
     Group *g = r->g;
     bool failed = false;
     const int S = g->streams_per_dev;
+    if (g->broken.load()) {
+        r->status = JSDR_ERR;
+        snprintf(r->err, sizeof(r->err), "jsdr_group rank %d: the group is broken (an earlier collective failed on some rank); destroy it", r->index);
+        step_barrier(g, true);
+        return;
+    }
     if (g->with_psd && j.psd) {
-        if (jsdr_fft_batch_i16(r->fft, j.raw, (int64_t)S * (j.nsamples / g->frame), j.ic, j.qc, j.psd, r->psd) != JSDR_OK) {
-            rank_fail(r, "jsdr_fft_batch_i16");
-            failed = true;
+        // raw is [S][stride]: only when the streams lie back to back (stride == 2 nsamples int16) are their frames ONE run;
+        // otherwise (the chunked calls of a longer buffer, the JNI's 2 max_batch stride) the transform goes stream by stream
+        const int64_t nf = j.nsamples / g->frame;
+        if (j.stride == 2 * j.nsamples) {
+            if (jsdr_fft_batch_i16(r->fft, j.raw, (int64_t)S * nf, j.ic, j.qc, j.psd, r->psd) != JSDR_OK) failed = true;
+        } else {
+            for (int s = 0; s < S && !failed; s++)
+                if (jsdr_fft_batch_i16(r->fft, j.raw + (int64_t)s * j.stride, nf, j.ic, j.qc,
+                                       j.psd + (int64_t)s * nf * (g->frame + 2), r->psd) != JSDR_OK)
+                    failed = true;
         }
+        if (failed) rank_fail(r, "jsdr_fft_batch_i16");
     }
     if (!failed && jsdr_bpsk_batch_i16(r->dem, j.raw, j.stride, j.nsamples, j.ic, j.qc, r->main) != JSDR_OK) {
         rank_fail(r, "jsdr_bpsk_batch_i16");
@@ -176,11 +197,19 @@ static void run_batch(Rank *r, const Job &j)
     }
     const size_t seg = (size_t)S * (size_t)g->slot_bytes;
     if (!g->copy_gather) {
+        // Every device thread calls ncclAllGather on ITS OWN communicator, without ncclGroupStart / ncclGroupEnd.  That is the
+        // form rccl.h prescribes for this layout ("Collective communication operations must be called separately for each
+        // communicator in a communicator clique ... each call has to be done from a different thread or process, or need to
+        // use Group Semantics", rccl.h:522-529; the group calls are for "managing multiple GPUs from a single thread", :899) --
+        // one thread per communicator is the first alternative, the rendezvous above guarantees every thread gets here.
         const int rc = g_rccl.AllGather(r->slots, r->gathered, seg, NCCL_UINT8, r->comm, r->gather);
         if (rc != 0) {
             r->status = JSDR_ERR;
             snprintf(r->err, sizeof(r->err), "jsdr_group rank %d: ncclAllGather: %s", r->index, g_rccl.GetErrorString(rc));
         }
+        // a collective that one rank could not enqueue never completes on the others: everybody learns of it HERE, before
+        // anyone waits on a gather stream
+        if (!step_barrier(g, rc != 0)) g->broken.store(true);
     } else {
         // every rank PULLS every rank's segment into its own gathered buffer on its own gather stream, after that rank's
         // packing (event recorded before the rendezvous above)
@@ -213,7 +242,10 @@ static void run_sync(Rank *r)
         rank_fail(r, "sync");
     }
     if (jsdr_bpsk_sync(r->dem) != JSDR_OK) rank_fail(r, "jsdr_bpsk_sync");
-    if (hipStreamSynchronize(r->gather) != hipSuccess) {
+    if (r->g->broken.load()) {
+        set_error("the group is broken: a collective failed on some rank, the gather streams are not waited for");
+        rank_fail(r, "sync");
+    } else if (hipStreamSynchronize(r->gather) != hipSuccess) {
         set_error("hipStreamSynchronize(gather) failed");
         rank_fail(r, "sync");
     }
@@ -310,11 +342,12 @@ static int rank_create(void *p, int index)
     }
     int64_t sb = 0;
     if (jsdr_bpsk_slot_info(r->dem, &sb, nullptr, nullptr, nullptr, nullptr) != JSDR_OK) return JSDR_ERR;
-    g->slot_bytes = sb;  // equal on every rank (same configuration)
+    r->slot_bytes = sb;  // (the creating thread copies rank 0's into the group once every rank is done: no shared write here)
     const size_t seg = (size_t)g->streams_per_dev * (size_t)sb;
-    JSDR_HIP_TRY(hipMalloc((void **)&r->slots, seg));
-    JSDR_HIP_TRY(hipMalloc((void **)&r->gathered, seg * (size_t)g->ndev));
-    JSDR_HIP_TRY(hipMemset(r->gathered, 0, seg * (size_t)g->ndev));
+    JSDR_HIP_TRY(hipMalloc((void **)&r->slots, seg > 64 ? seg : 64));
+    const size_t gbytes = (seg > 64 ? seg : 64) * (size_t)g->ndev;
+    JSDR_HIP_TRY(hipMalloc((void **)&r->gathered, gbytes));
+    JSDR_HIP_TRY(hipMemset(r->gathered, 0, gbytes));
     if (g->copy_gather) {
         for (Rank *o : g->ranks)
             if (o->dev != r->dev) {
@@ -326,6 +359,77 @@ static int rank_create(void *p, int index)
                 }
             }
     }
+    return JSDR_OK;
+}
+
+// Create-time self-test of the gather path: every device contributes 64 bytes that name its rank, one all-gather over the
+// communicators (or the copy gather's pulls) moves them, and every device checks every segment -- so that a machine whose
+// RCCL cannot connect its devices fails HERE, with a message that says so, and not in the first step's slot check.
+static int rank_selftest(void *p, int index)
+{
+    Group *g = static_cast<Group *>(p);
+    Rank *r = g->ranks[index];
+    const size_t seg = 64;
+    uint8_t mine[64];
+    for (int i = 0; i < 64; i++) mine[i] = (uint8_t)(0xA5 ^ (index * 37 + i));
+    bool failed = false;
+    if (hipMemcpy(r->slots, mine, seg, hipMemcpyHostToDevice) != hipSuccess) failed = true;
+    if (!failed && g->copy_gather && hipEventRecord(r->ev_packed, r->gather) != hipSuccess) failed = true;
+    if (failed) {
+        set_error("copying the test pattern to the device failed");
+        rank_fail(r, "self-test");
+    }
+    if (!step_barrier(g, failed)) {
+        if (!failed) {
+            r->status = JSDR_ERR;
+            snprintf(r->err, sizeof(r->err), "jsdr_group rank %d: another rank failed before the gather; step abandoned", r->index);
+        }
+        return r->status;
+    }
+    if (!g->copy_gather) {
+        const int rc = g_rccl.AllGather(r->slots, r->gathered, seg, NCCL_UINT8, r->comm, r->gather);
+        if (rc != 0) {
+            set_error("ncclAllGather: %s", g_rccl.GetErrorString(rc));
+            rank_fail(r, "self-test");
+        }
+        if (!step_barrier(g, rc != 0)) {  // (see run_batch: nobody waits for a collective some rank did not enqueue)
+            g->broken.store(true);
+            if (r->status == JSDR_OK) {
+                r->status = JSDR_ERR;
+                snprintf(r->err, sizeof(r->err), "jsdr_group rank %d: another rank failed before the gather; step abandoned", r->index);
+            }
+            return JSDR_ERR;
+        }
+    } else {
+        for (Rank *o : g->ranks) {
+            hipError_t e = hipStreamWaitEvent(r->gather, o->ev_packed, 0);
+            if (e == hipSuccess) e = hipMemcpyAsync(r->gathered + (size_t)o->index * seg, o->slots, seg, hipMemcpyDeviceToDevice, r->gather);
+            if (e != hipSuccess) {
+                set_error("copy gather from rank %d: %s", o->index, hipGetErrorString(e));
+                rank_fail(r, "self-test");
+                break;
+            }
+        }
+    }
+    std::vector<uint8_t> got(seg * (size_t)g->ndev);
+    bool ok = r->status == JSDR_OK && hipStreamSynchronize(r->gather) == hipSuccess &&
+              hipMemcpy(got.data(), r->gathered, got.size(), hipMemcpyDeviceToHost) == hipSuccess;
+    if (g->copy_gather) step_barrier(g, false);  // nobody overwrites its 64 bytes while another rank may still pull them
+    if (r->status != JSDR_OK) return JSDR_ERR;
+    if (!ok) {
+        set_error("waiting for / reading back the gathered test pattern failed");
+        rank_fail(r, "self-test");
+        return JSDR_ERR;
+    }
+    for (int o = 0; o < g->ndev; o++)
+        for (int i = 0; i < 64; i++)
+            if (got[(size_t)o * seg + i] != (uint8_t)(0xA5 ^ (o * 37 + i))) {
+                set_error("device index %d received byte %d of rank %d's segment as 0x%02x, expected 0x%02x: the gather between the devices does not work",
+                          index, i, o, got[(size_t)o * seg + i], (uint8_t)(0xA5 ^ (o * 37 + i)));
+                rank_fail(r, "self-test");
+                return JSDR_ERR;
+            }
+    (void)hipMemset(r->gathered, 0, got.size());
     return JSDR_OK;
 }
 
@@ -342,13 +446,14 @@ static void group_free(Group *g)
     // nothing of any device may still be in flight when a communicator, a handle or a buffer goes away
     for (Rank *r : g->ranks) {
         (void)hipSetDevice(r->dev);
-        if (r->gather) (void)hipStreamSynchronize(r->gather);
+        if (r->gather && !g->broken.load()) (void)hipStreamSynchronize(r->gather);
         if (r->main) (void)hipStreamSynchronize(r->main);
         if (r->psd) (void)hipStreamSynchronize(r->psd);
     }
     for (Rank *r : g->ranks) {
         (void)hipSetDevice(r->dev);
-        if (r->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(r->comm);
+        if (r->comm && g->broken.load() && g_rccl.CommAbort) (void)g_rccl.CommAbort(r->comm);
+        else if (r->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(r->comm);
         if (r->dem) (void)jsdr_bpsk_destroy(r->dem);
         if (r->fft) (void)jsdr_fft_destroy(r->fft);
         if (r->slots) (void)hipFree(r->slots);
@@ -434,6 +539,27 @@ int jsdr_group_create(jsdr_group **out, int ndev, const int *devices, int rate, 
             return JSDR_ERR;
         }
         for (int i = 0; i < ndev; i++) g->ranks[i]->comm = comms[i];
+    }
+    (void)hipSetDevice(prev);
+    g->slot_bytes = g->ranks[0]->slot_bytes;
+    for (Rank *r : g->ranks)
+        if (r->slot_bytes != g->slot_bytes) {
+            set_error("jsdr_group_create: rank %d packs %lld-byte slots, rank 0 %lld", r->index, (long long)r->slot_bytes, (long long)g->slot_bytes);
+            group_free(g);
+            return JSDR_ERR;
+        }
+    // the gather path, exercised once before the first step (64 bytes per device)
+    for (auto &j : jobs) {
+        j.kind = Job::CALL;
+        j.fn = rank_selftest;
+        j.arg = g;
+    }
+    if (post_all(g, jobs) != JSDR_OK) {
+        const std::string why = jsdr_last_error();
+        group_free(g);
+        (void)hipSetDevice(prev);
+        set_error("jsdr_group_create: gather self-test failed: %s", why.c_str());
+        return JSDR_ERR;
     }
     (void)hipSetDevice(prev);
     jsdr_group *h = new jsdr_group();

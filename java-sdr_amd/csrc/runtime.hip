@@ -81,6 +81,13 @@ int jsdr_set_device(int device)
     return JSDR_OK;
 }
 
+int jsdr_get_device(int *device)
+{
+    JSDR_REQUIRE(device, "jsdr_get_device: null argument");
+    JSDR_HIP_TRY(hipGetDevice(device));
+    return JSDR_OK;
+}
+
 int jsdr_device_name(char *buf, int cap)
 {
     JSDR_REQUIRE(buf && cap > 0, "jsdr_device_name: bad buffer");

@@ -432,11 +432,16 @@ static void group_free(group_ctx *x)
 {
     if (!x) return;
     if (x->g) {
+        /* handles do not remember their device: the JVM thread that called must come back on the device it was on, or its
+         * single-GPU plugin handles (created on device 0) would launch on the last device of the loop */
+        int prev = -1;
+        (void)jsdr_get_device(&prev);
         for (int d = 0; x->raw && d < x->ndev; d++) {
             int dev = d;
             if (jsdr_group_device(x->g, d, &dev, NULL, NULL) == JSDR_OK && jsdr_set_device(dev) == JSDR_OK && x->raw[d]) jsdr_free(x->raw[d]);
         }
         jsdr_group_destroy(x->g);
+        if (prev >= 0) (void)jsdr_set_device(prev);
     }
     free(x->raw);
     free(x);
@@ -467,15 +472,19 @@ JNIEXPORT jlong JNICALL Java_com_ashbysoft_java_1sdr_HipNative_groupCreate(JNIEn
         return 0;
     }
     x->raw = (int16_t **)calloc((size_t)ndev, sizeof(*x->raw));
+    int prev = -1;
+    (void)jsdr_get_device(&prev);
     for (int d = 0; x->raw && d < ndev; d++) {
         int dev = d;
         if (jsdr_group_device(x->g, d, &dev, NULL, NULL) != JSDR_OK || jsdr_set_device(dev) != JSDR_OK ||
             jsdr_malloc((void **)&x->raw[d], (size_t)x->per_dev * (size_t)maxBatch * 4) != JSDR_OK) {
             fail(e);
+            if (prev >= 0) (void)jsdr_set_device(prev);
             group_free(x);
             return 0;
         }
     }
+    if (prev >= 0) (void)jsdr_set_device(prev);  /* the calling JVM thread stays on the device it came with */
     if (!x->raw) {
         fail_msg(e, "groupCreate: out of memory");
         group_free(x);
@@ -521,6 +530,8 @@ JNIEXPORT jlong JNICALL Java_com_ashbysoft_java_1sdr_HipNative_groupLoadRecordin
     int64_t *got = (int64_t *)calloc((size_t)x->per_dev, sizeof(*got));
     jlong sum = -1;
     if (cp && js && got) {
+        int prev = -1;
+        (void)jsdr_get_device(&prev);
         sum = 0;
         for (int d = 0; d < x->ndev && sum >= 0; d++) {
             int dev = d, ok = 1;
@@ -543,6 +554,7 @@ JNIEXPORT jlong JNICALL Java_com_ashbysoft_java_1sdr_HipNative_groupLoadRecordin
                 sum = -1;
             }
         }
+        if (prev >= 0) (void)jsdr_set_device(prev);
     } else {
         fail_msg(e, "groupLoadRecordings: out of memory");
     }

@@ -102,6 +102,19 @@ def test_group_with_psd_and_error_paths():
         f.batch_i16(bufs[r], 80, ref)
         J.binding.stream_sync()
         assert psds[r].to_host(np.float32).tobytes() == ref.to_host(np.float32).tobytes()
+    # a PSD call over PART of the buffers (stride != 2 nsamples: the chunked calls of a longer buffer, the JNI's 2 max_batch
+    # stride): every stream's frames are taken from ITS row, not from one contiguous run
+    half = n // 2
+    psds2 = [J.DeviceBuffer(2 * 20 * 2050 * 4) for _ in range(2)]
+    g.batch_i16([b.ptr + 4 * half for b in bufs], 2 * n, half, psd_devs=psds2)
+    g.sync()
+    for r in range(2):
+        got = psds2[r].to_host(np.float32).reshape(2, 20, 2050)
+        for s in range(2):
+            ref = J.DeviceBuffer(20 * 2050 * 4)
+            f.batch_i16(bufs[r].ptr + 4 * (s * n + half), 20, ref)
+            J.binding.stream_sync()
+            assert got[s].tobytes() == ref.to_host(np.float32).tobytes(), (r, s)
     # a call every member refuses (more samples than the handles were sized for): reported, nobody hangs, the group lives on
     with pytest.raises(J.JsdrError, match="rank"):
         g.batch_i16(bufs, 2 * n, 2 * n)
@@ -115,6 +128,31 @@ def test_group_with_psd_and_error_paths():
     # RCCL takes a device once
     with pytest.raises(J.JsdrError, match="twice"):
         J.Group(2, 4, n, devices=[0, 0])
+
+
+def test_group_block_of_a_recording_shorter_than_the_block(tmp_path):
+    """HipDemodGroup.decodeBlock's last block: jsdr_recordings_load pads a short recording with zeros on the
+    NULL stream, the group's device threads demodulate on non-blocking streams of their own -- the padding must be in
+    place when the load returns, or the kernels read the previous block's samples."""
+    n = 2048 * 24
+    iq = streams(2, n, seed=11)
+    short = n // 2 + 123
+    paths = []
+    for s in range(2):
+        p = tmp_path / f"s{s}.raw"
+        iq[s][:2 * short].astype("<i2").tofile(p)
+        paths.append(str(p))
+    g = J.Group(1, 2, n, devices=[0], gather_copy=True)
+    stale = np.concatenate(streams(2, n, seed=12))  # what the previous block left in the buffer
+    for trial in range(3):
+        buf = J.DeviceBuffer.from_host(stale)
+        got = J.recordings_load(paths, 2, 96000, 0, n, buf, 2 * n)
+        assert got == [short, short]
+        g.batch_i16([buf], 2 * n, n)
+    g.sync()
+    padded = [np.concatenate([iq[s][:2 * short], np.zeros(2 * (n - short), np.int16)]) for s in range(2)]
+    _, info, ref = reference_slots(padded, n, [n, n, n])
+    assert np.array_equal(g.gathered(0).reshape(2, info["slot_bytes"]), ref[2])
 
 
 # ------------------------------------------------------------------ the C++ harness's --gpus mode: config 5 with no Python in the process
