@@ -32,6 +32,7 @@ SOURCES = {
     "demod.hip": ["-ffp-contract=off"],
     "bpsk.hip": ["-ffp-contract=off"],
     "bpsk_fft.hip": ["-ffp-contract=off"],
+    "bpsk_acq.hip": ["-ffp-contract=off"],
     "bpsk_fftm.hip": ["-ffp-contract=off"],
     "group.hip": [],
 }

@@ -2464,6 +2464,11 @@ struct jsdr_bpsk {
     int fm_np = 0, fm_rad[12] = {0}, fm_off[12] = {0}, fm_off1[12] = {0};
     DevBuf<double2> fft2x_ek;  // per-stream scratch of the 2 m front end
     DevBuf<double> fft2x_r0;
+    // round 6: the three-phase front end (bpsk_acq.hip) for calls of two or more frames per stream -- what its phases hand each
+    // other, for nstreams x acq_chunk frames; allocated at the first such call
+    DevBuf<unsigned char> acq_scratch;
+    int acq_chunk = 0;
+    int acq_mode = -1;  // JSDR_ACQ3 (tests, A/B): 0 never, 1 whenever the frame size allows (also for one frame a call); -1: from two frames a call
     long long last_nds = 0;
     int last_y = 0;
     hipStream_t last_stream = 0;
@@ -2477,9 +2482,11 @@ struct jsdr_bpsk {
     std::vector<hipEvent_t> prof_pool;
 };
 
-enum { PK_FRONT = 0, PK_HIST, PK_MATCHED, PK_DMHIST, PK_TAIL, PK_SYNC, PK_SYNCFIN, PK_FEC, PK_FM, PK_SYNCT, PK_PREP, PK_COUNT };
+enum { PK_FRONT = 0, PK_HIST, PK_MATCHED, PK_DMHIST, PK_TAIL, PK_SYNC, PK_SYNCFIN, PK_FEC, PK_FM, PK_SYNCT, PK_PREP,
+       PK_ACQ_FWD, PK_ACQ_SCAN, PK_ACQ_INV, PK_ACQ_EDGES, PK_COUNT };
 static const char *const kProfNames[PK_COUNT] = {"k_front", "k_hist_in", "k_matched", "k_dm_history", "k_tail", "k_sync",
-                                                 "k_sync_fin", "k_fec_bpsk", "k_fm", "k_sync_t", "k_fm_prep"};
+                                                 "k_sync_fin", "k_fec_bpsk", "k_fm", "k_sync_t", "k_fm_prep",
+                                                 "k_acq_fwd", "k_acq_scan", "k_acq_inv", "k_acq_edges"};
 
 static hipEvent_t prof_event(jsdr_bpsk *h)
 {
@@ -2513,6 +2520,25 @@ struct ProfScope {
         }
     }
 };
+
+// the three-phase front end's launches (bpsk_acq.hip) under the same timing scopes
+struct AcqProfCtx {
+    jsdr_bpsk *h;
+    hipEvent_t a[4];
+};
+static void acq_prof_mark(void *ctx, int phase, bool begin, hipStream_t st)
+{
+    AcqProfCtx *c = static_cast<AcqProfCtx *>(ctx);
+    if (!c->h->prof_on) return;
+    if (begin) {
+        c->a[phase] = prof_event(c->h);
+        (void)hipEventRecord(c->a[phase], st);
+    } else {
+        hipEvent_t b = prof_event(c->h);
+        (void)hipEventRecord(b, st);
+        c->h->prof_recs.push_back({PK_ACQ_FWD + phase, c->a[phase], b});
+    }
+}
 
 static const double JPI = 3.14159265358979323846;
 
@@ -3204,11 +3230,42 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
         xa.nds = nds;
         xa.ds_taps = h->ds_taps_dev.p;
         xa.phase_clk = h->phase_clk.p;
+        // round 6: frames of 2^k samples, two or more per stream in the call: three phases over FRAMES (bpsk_acq.hip); a call of
+        // one frame per stream (a live receive()) keeps the fused kernel -- one launch instead of four
+        const bool three = !h->fft_2x && !h->fft_mixed && acq3_supported(h->nsf) && h->acq_mode != 0 && (xa.nframes >= 2 || h->acq_mode == 1);
+        if (three) {
+            const size_t per = acq3_frame_bytes(h->nsf, h->do_up) + 64;
+            if (!h->acq_scratch.p) {
+                // sized for the largest call the handle takes, capped (JSDR_ACQ_SCRATCH_MB, default 6 GiB): longer calls go in
+                // several launches of acq_chunk frames per stream
+                long long cap_mb = 6144;
+                if (const char *e = knob("JSDR_ACQ_SCRATCH_MB")) cap_mb = atoll(e) > 0 ? atoll(e) : cap_mb;
+                long long fmax = h->max_batch / h->nsf;
+                if (fmax < 1) fmax = 1;
+                long long chunk = (cap_mb << 20) / (long long)(per * (size_t)S);
+                if (chunk < 1) chunk = 1;
+                if (chunk > fmax) chunk = fmax;
+                if (const char *e = knob("JSDR_ACQ_CHUNK")) chunk = atoll(e) > 0 && atoll(e) < chunk ? atoll(e) : chunk;
+                if (h->acq_scratch.alloc(per * (size_t)S * (size_t)chunk) != JSDR_OK) return JSDR_ERR;
+                h->acq_chunk = (int)chunk;
+                int dev = 0, cus = 0;
+                JSDR_HIP_TRY(hipGetDevice(&dev));
+                JSDR_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+                h->num_cu = cus > 0 ? cus : 256;
+            }
+            h->front_name = "k_acq_fwd";
+            AcqProfCtx pc{h, {nullptr, nullptr, nullptr, nullptr}};
+            AcqProf prof;
+            prof.ctx = &pc;
+            prof.mark = acq_prof_mark;
+            if (launch_acq3(xa, S, h->acq_scratch.p, h->acq_scratch.n, h->acq_chunk, h->num_cu, st, prof) != JSDR_OK) return JSDR_ERR;
+        } else {
         ProfScope ps(h, PK_FRONT, st);
         h->front_name = h->fft_2x ? "k_front_fft2x" : (h->fft_mixed ? "k_front_fftm" : "k_front_fft");
         const int frc = h->fft_2x ? launch_front_fft2x(xa, h->fm_np, h->fm_rad, h->fm_off, h->fm_off1, h->fft2x_ek.p, h->fft2x_r0.p, S, st)
                                   : (h->fft_mixed ? launch_front_fftm(xa, h->fm_np, h->fm_rad, h->fm_off, h->fm_off1, h->fft2x_ek.p, S, st) : launch_front_fft(xa, S, st));
         if (frc != JSDR_OK) return JSDR_ERR;
+        }
     } else if (nds > 0 && fm_ok) {
         // wait for the tail that last read y[y_cur] (two calls ago) before the fused kernel overwrites it
         if (h->overlap && h->tail_pending[h->y_cur]) {
@@ -3531,6 +3588,7 @@ int jsdr_bpsk_create(jsdr_bpsk **out, int rate, int nsamples_per_frame, int tuni
             jsdr_bpsk_destroy(h);
             return JSDR_ERR;
         }
+        if (const char *e = knob("JSDR_ACQ3")) h->acq_mode = atoi(e) != 0 ? 1 : 0;
         if (const char *e = knob("JSDR_FFT_PHASECLK"))
             if (atoi(e) != 0 && (h->phase_clk.alloc(8) != JSDR_OK || h->phase_clk.zero() != JSDR_OK)) h->phase_clk.release();
     }
@@ -3639,6 +3697,7 @@ int jsdr_bpsk_destroy(jsdr_bpsk *h)
     h->fft_tw.release();
     h->fft2x_ek.release();
     h->fft2x_r0.release();
+    h->acq_scratch.release();
     h->vco_cs.release();
 #ifdef JSDR_X_T8CLK
     {

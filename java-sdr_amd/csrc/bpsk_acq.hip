@@ -1,0 +1,880 @@
+// bpsk_acq.hip -- FUNcubeBPSKDemod FFT-acquire front end, doBufferFFT (FUNcubeBPSKDemod.java:406-464), in THREE PHASES
+// (round 6).  What the reference's frame loop carries from frame to frame is three numbers (avePeakPower, aveCentreBin,
+// centreBin, :403-405, updated at :444-453) and the down-sampler's 26-sample history (:466-492).  Everything else is a
+// pure function of the frame:
+//   phase A  k_acq_fwd   one (stream, frame) per workgroup pass, any number in flight: forward transform (:416-423), |X| on the
+//                        searched band (:425-427), the 100-wide boxcar and its first maximum (:433-443).  Leaves per frame:
+//                        the spectrum bins a gather can reach, the boxcar sums of the band, (maxBin, binPos).
+//   phase B  k_acq_scan  one wave per stream, sequential over the call's frames: :444-453 exactly (clamps, float-valued
+//                        factors, avePsd[centreBin] read from phase A's band -- zero outside the loop's range, as Java's
+//                        `new double[]` leaves it).  Leaves centreBin per frame and the state.
+//   phase C  k_acq_inv   one (stream, frame) per workgroup pass: the 204 bins around the frame's centre to bin 0 (:458),
+//                        inverse transform (:459), RxDownSample(re, re) (:461-463, :470-492) for every window that lies
+//                        inside the frame, the VCO mix (:515-516).  Leaves the frame's first and last 26 real samples.
+//   edges    k_acq_edges the few windows per frame that reach back into the previous frame (or, for the call's first
+//                        frame, into the stream's history), and the history the call leaves.
+// The grid is FRAMES, not streams: occupancy no longer depends on the number of streams (one recorded stream of 512 frames
+// fills the chip), the kernels of the two transforms are separate and simpler than the fused front end (k_front_fft sat at
+// its 128-VGPR cap and spilled), and a thread holds 16 points (two waves per 2048-sample frame, four radix-2 stages per LDS
+// round trip instead of three).
+//
+// Compiled with -ffp-contract=off.  The transform is the oracle's radix-2 decimation-in-time network (oracle/o_fft.c
+// jo_fft_f64) on the same twiddle table, butterfly for butterfly:
+//     t = w*b (tr = wr*br - wi*bi, ti = wr*bi + wi*br), a' = a + t, b' = a - t
+// only the grouping of the stages into passes differs -- spectra, centre bins and everything downstream are bit-identical
+// to the oracle and to k_front_fft (which keeps serving calls of ONE frame per stream: a live receive()).
+#include "bpsk_fft.h"
+#include <math.h>
+
+namespace jsdr {
+
+// ---- LDS image of a frame: element e at 16-byte slot (e & ~15) | ((e & 15) ^ key(e >> 4)), key(r) = (r ^ r>>4 ^ r>>8) & 15.
+// Every pass reads / writes elements e0 | (H m), m = 0..2^G-1, lanes over e0: within a row of 16 the XOR is a permutation
+// (consecutive lanes -> distinct bank groups), and rows that differ in ANY nibble get different keys, so the first pass --
+// a lane owns a whole row, eight lanes of a store are eight rows apart in bits 4.. after the bit reversal of the coalesced
+// loads -- stores conflict-free as well.  No padding: four 2048-sample frames are 128 KB of a CU's 160.
+__host__ __device__ constexpr int acq_key(int row) { return (row ^ (row >> 4) ^ (row >> 8)) & 15; }
+__device__ __forceinline__ int acq_slot(int e) { return (e & ~15) | ((e & 15) ^ acq_key(e >> 4)); }
+// element e0 | HM, HM a multiple of 16 whose bits are clear in e0 (every pass: e0 = base + j, HM = H m): the key splits into
+// key(e0 >> 4) ^ key(HM >> 4), and with m an unrolled loop index the second half folds to a constant
+__device__ __forceinline__ int acq_slot_hm(int e0, int HM)
+{
+    return ((e0 & ~15) + HM) | (((e0 & 15) ^ acq_key(e0 >> 4)) ^ acq_key(HM >> 4));
+}
+
+template <int BITS>
+__device__ __forceinline__ int acq_brev(int x)
+{
+    return BITS == 0 ? 0 : (int)(__brev((unsigned)x) >> (32 - (BITS ? BITS : 1)));
+}
+
+constexpr int ACQ_TWL = 256;  // stages with wing <= 128 read their twiddles from an LDS copy of tw[0..254]
+
+// twiddle jj of the stage with wing HALF: tw[HALF - 1 + jj] = W_n^(jj n / (2 HALF))
+template <int HALF, bool UNIFORM>
+__device__ __forceinline__ double2 acq_tw(const double2 *TsL, const double2 *__restrict__ tsg, int jj)
+{
+    if (!UNIFORM && 2 * HALF <= ACQ_TWL) return TsL[HALF - 1 + jj];
+    return tsg[(unsigned)(HALF - 1 + jj)];
+}
+
+// G consecutive stages of the network on the 2^G values v[m] = x[base + j + HALF0 m]: the oracle's butterfly, unchanged
+template <int G, int HALF0, bool INVERSE, bool UNIFORM>
+__device__ __forceinline__ void acq_stages(double2 (&v)[1 << G], int j, const double2 *TsL, const double2 *__restrict__ tsg)
+{
+    constexpr int M = 1 << G;
+#pragma unroll
+    for (int t = 0; t < G; t++) {
+        double2 w[M / 2];
+#pragma unroll
+        for (int u = 0; u < (1 << t); u++) {
+            if (t == 0) w[u] = acq_tw<HALF0, UNIFORM>(TsL, tsg, j + HALF0 * u);
+            if (t == 1) w[u] = acq_tw<HALF0 * 2, UNIFORM>(TsL, tsg, j + HALF0 * u);
+            if (t == 2) w[u] = acq_tw<HALF0 * 4, UNIFORM>(TsL, tsg, j + HALF0 * u);
+            if (t == 3) w[u] = acq_tw<HALF0 * 8, UNIFORM>(TsL, tsg, j + HALF0 * u);
+        }
+#pragma unroll
+        for (int m = 0; m < M; m++) {
+            if ((m >> t) & 1) continue;
+            const double2 wv = w[m & ((1 << t) - 1)];
+            const double wr = wv.x;
+            const double wi = INVERSE ? -wv.y : wv.y;
+            const double2 bq = v[m + (1 << t)];
+            const double p1 = wr * bq.x, p2 = wi * bq.y, p3 = wr * bq.y, p4 = wi * bq.x;
+            const double tr = p1 - p2;
+            const double ti = p3 + p4;
+            const double2 aq = v[m];
+            v[m] = make_double2(aq.x + tr, aq.y + ti);
+            v[m + (1 << t)] = make_double2(aq.x - tr, aq.y - ti);
+        }
+    }
+}
+
+// The first FOUR stages (wings 1, 2, 4, 8) of the FORWARD transform on sixteen converted int16 samples, the multiplications by
+// the table's trivial twiddles 1 = (1, -0) and -i = (0, -1) not performed (w = 1: t = b; w = -i: t = (b.y, -b.x)).  Same
+// results to the last bit, signs of zeros included, because no value in this part of the network is ever -0.0: a converted
+// int16 sample is never -0.0, and a sum or a difference is -0.0 only if an operand already is (bpsk_fft.hip dit_first3_i16
+// has the argument in full).  Float input may hold -0.0f and takes acq_stages.
+__device__ __forceinline__ void acq_first4_i16(double2 (&v)[16], const double2 *__restrict__ tsg)
+{
+    auto bf1 = [](double2 &a, double2 &b) {
+        const double2 x = a, y = b;
+        a = make_double2(x.x + y.x, x.y + y.y);
+        b = make_double2(x.x - y.x, x.y - y.y);
+    };
+    auto bfi = [](double2 &a, double2 &b) {
+        const double2 x = a, y = b;
+        a = make_double2(x.x + y.y, x.y - y.x);
+        b = make_double2(x.x - y.y, x.y + y.x);
+    };
+    auto bfw = [](double2 &a, double2 &b, const double2 w) {
+        const double2 x = a, y = b;
+        const double p1 = w.x * y.x, p2 = w.y * y.y, p3 = w.x * y.y, p4 = w.y * y.x;
+        const double tr = p1 - p2, ti = p3 + p4;
+        a = make_double2(x.x + tr, x.y + ti);
+        b = make_double2(x.x - tr, x.y - ti);
+    };
+#pragma unroll
+    for (int h = 0; h < 16; h += 8) {
+        // wing 1: tw[0] = 1
+        bf1(v[h + 0], v[h + 1]);
+        bf1(v[h + 2], v[h + 3]);
+        bf1(v[h + 4], v[h + 5]);
+        bf1(v[h + 6], v[h + 7]);
+        // wing 2: tw[1] = 1, tw[2] = -i
+        bf1(v[h + 0], v[h + 2]);
+        bfi(v[h + 1], v[h + 3]);
+        bf1(v[h + 4], v[h + 6]);
+        bfi(v[h + 5], v[h + 7]);
+        // wing 4: tw[3] = 1, tw[4] = W8, tw[5] = -i, tw[6] = W8^3
+        bf1(v[h + 0], v[h + 4]);
+        bfw(v[h + 1], v[h + 5], tsg[4]);
+        bfi(v[h + 2], v[h + 6]);
+        bfw(v[h + 3], v[h + 7], tsg[6]);
+    }
+    // wing 8: tw[7 + j] = W16^j; j = 0: 1, j = 4: -i
+    bf1(v[0], v[8]);
+    bfw(v[1], v[9], tsg[8]);
+    bfw(v[2], v[10], tsg[9]);
+    bfw(v[3], v[11], tsg[10]);
+    bfi(v[4], v[12]);
+    bfw(v[5], v[13], tsg[12]);
+    bfw(v[6], v[14], tsg[13]);
+    bfw(v[7], v[15], tsg[14]);
+}
+
+template <int T>
+__device__ __forceinline__ void acq_barrier()
+{
+    if constexpr (T <= 64) {  // one wave per frame: its own LDS order is all there is to keep
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+        __syncthreads();
+    }
+}
+
+// one LDS round trip in the middle of a transform: G stages starting at wing HALF0 over the whole frame, in place (a thread
+// writes the slots it read)
+template <int G, int HALF0, bool INVERSE, int LOGN>
+__device__ __forceinline__ void acq_mid_pass(double2 *X, const double2 *TsL, const double2 *__restrict__ tsg, int tid)
+{
+    constexpr int N = 1 << LOGN, T = N / 16, M = 1 << G, NG = 16 >> G;
+    static_assert(HALF0 % 16 == 0, "the passes behind the first move whole rows");
+#pragma unroll
+    for (int it = 0; it < NG; it++) {
+        const int q = tid + T * it;
+        const int j = q & (HALF0 - 1);
+        const int e0 = ((q - j) << G) + j;
+        double2 v[M];
+#pragma unroll
+        for (int m = 0; m < M; m++) v[m] = X[acq_slot_hm(e0, HALF0 * m)];
+        acq_stages<G, HALF0, INVERSE, false>(v, j, TsL, tsg);
+#pragma unroll
+        for (int m = 0; m < M; m++) X[acq_slot_hm(e0, HALF0 * m)] = v[m];
+    }
+}
+
+// the grouping of a transform's stages into passes: 4 in registers first, then G2 (4), then what is left
+template <int LOGN>
+struct AcqPlan {
+    static_assert(LOGN >= 10 && LOGN <= 13, "frames of 1024 .. 8192 samples");
+    static constexpr int G3 = LOGN == 13 ? 3 : LOGN - 8;  // third pass
+    static constexpr int G4 = LOGN == 13 ? 2 : 0;         // fourth pass (8192 samples only)
+    static constexpr int GL = G4 ? G4 : G3;               // the last pass's stages
+};
+
+// what the phases hand each other, per frame id g = s * F + f (F = frames per stream in this launch)
+struct AcqPeak {
+    double maxBin;
+    int binPos;
+    int pad;
+};
+
+struct AcqArgs {
+    const int *raw;        // int16 pairs [S][stride]
+    const float2 *rawf;    // or float frames
+    long long stride_pairs;
+    int ic, qc;
+    int S, F, f0;          // streams, frames per stream in this launch, index of its first frame within the call
+    int n, do_up, decim;
+    long long first_out, nds;
+    const double2 *vco_cs;
+    const double2 *tw;
+    FftFrontState *st;
+    double2 *dm;
+    long long dm_stride;
+    double2 *spec;         // [S F][nsb]: do_up ? bins [0, 204) then [n/4 - 26, n/2 + 28) : bins [0, n/4 + 28)
+    int nsb;
+    double *aband;         // [S F][na]: boxcar sums over [beg + 75, end - 75)
+    int na;
+    AcqPeak *peak;         // [S F]
+    int *cbin;             // [S F] the frame's centre bin (phase B)
+    double *edges;         // [S F][52]: the frame's first 26 and last 26 real samples re / n (phase C)
+    int nwg;               // persistent workgroups of phases A and C
+};
+
+// where bin b of a frame sits in its spec row, or -1
+__device__ __forceinline__ int acq_spec_index(int b, int n, int do_up)
+{
+    if (!do_up) return b < n / 4 + 28 ? b : -1;
+    if (b < 204) return b;
+    const int lo = n / 4 - 26;
+    return (b >= lo && b < n / 2 + 28) ? 204 + (b - lo) : -1;
+}
+
+// ============================================================================================================= phase A
+template <int LOGN, bool F32IN>
+__global__ __launch_bounds__((1 << LOGN) / 16, 2) void k_acq_fwd(AcqArgs a)
+{
+    constexpr int N = 1 << LOGN, T = N / 16;
+    using Plan = AcqPlan<LOGN>;
+    constexpr int GL = Plan::GL, ML = 1 << GL, NGL = 16 >> GL, HL = N >> GL;  // the last pass: wings HL .. N/2
+    constexpr int NA = N / 4 - 150;                                           // boxcar outputs (:433)
+    constexpr int RB = (NA + T - 1) / T + (((NA + T - 1) / T) % 2 == 0 ? 1 : 0);  // per thread, odd: 24 / 40-byte lane strides hit distinct banks
+    extern __shared__ __align__(16) unsigned char smem[];
+    double2 *X = reinterpret_cast<double2 *>(smem);            // [N] the image
+    double2 *TsL = X + N;                                      // [ACQ_TWL]
+    double *redv = reinterpret_cast<double *>(TsL + ACQ_TWL);  // [8] per-wave best value
+    int *redi = reinterpret_cast<int *>(redv + 8);             // [8] per-wave best index
+    double *P = reinterpret_cast<double *>(smem);              // |X| over [beg + 24, end - 24): over the image, dead by then
+    const double2 *__restrict__ tsg = a.tw;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < ACQ_TWL - 1; i += T) TsL[i] = tsg[i];
+    const int beg = a.do_up ? N / 4 : 0;
+    const int end = a.do_up ? N / 2 : N / 4;
+    const int pbase = beg + 24;
+    const long long nfr = (long long)a.S * a.F;
+    // first-pass group q = brev(tid): its sixteen inputs are the frame's elements brev4(m) N/16 + tid -- coalesced loads
+    int pre[16];
+    float2 pref[16];
+    auto fetch = [&](long long g) {
+        const int s = (int)(g / a.F), f = (int)(g - (long long)s * a.F);
+        const long long off = (long long)s * a.stride_pairs + (long long)(a.f0 + f) * N + tid;
+#pragma unroll
+        for (int m = 0; m < 16; m++) {
+            if (F32IN)
+                pref[m] = a.rawf[off + acq_brev<4>(m) * (N / 16)];
+            else
+                pre[m] = a.raw[off + acq_brev<4>(m) * (N / 16)];
+        }
+    };
+    if ((long long)blockIdx.x < nfr) fetch(blockIdx.x);
+    acq_barrier<T>();
+    for (long long g = blockIdx.x; g < nfr; g += gridDim.x) {
+        // opaque per frame: nothing derived from the thread index is loop invariant, or LLVM hoists every address of every pass out
+        // of the frame loop and spills them (the same trap as in k_front_fft)
+        int tf = tid;
+        asm volatile("" : "+v"(tf));
+        // ---- forward transform (:416-423): the first four stages from the load registers
+        {
+            double2 v[16];
+#pragma unroll
+            for (int m = 0; m < 16; m++) {
+                if (F32IN) {
+                    v[m] = make_double2((double)pref[m].x, (double)pref[m].y);
+                } else {
+                    const int w = pre[m];
+                    v[m] = make_double2((double)i16_to_float_java(java_short_add((int)(short)(w & 0xffff), a.ic)),
+                                        (double)i16_to_float_java(java_short_add(w >> 16, a.qc)));
+                }
+            }
+            if (g + gridDim.x < nfr) fetch(g + gridDim.x);  // the next frame's samples are in flight during this one's passes
+            if (F32IN)
+                acq_stages<4, 1, false, true>(v, 0, TsL, tsg);
+            else
+                acq_first4_i16(v, tsg);
+            const int q1f = acq_brev<LOGN - 4>(tf);
+            const int key = acq_key(q1f);
+#pragma unroll
+            for (int m = 0; m < 16; m++) X[16 * q1f + (m ^ key)] = v[m];
+        }
+        acq_barrier<T>();
+        acq_mid_pass<4, 16, false, LOGN>(X, TsL, tsg, tf);
+        acq_barrier<T>();
+        if constexpr (Plan::G4 != 0) {
+            acq_mid_pass<Plan::G3, 256, false, LOGN>(X, TsL, tsg, tf);
+            acq_barrier<T>();
+        }
+        // ---- last pass: wings HL .. N/2, group j holds x[j + HL m] and ends as the bins j + HL m.  Only the bins somebody reads
+        // are formed in its last stage: the gather's reach (acq_spec_index) and |X| over [beg + 24, end - 24) (inside it).
+        double2 o[NGL][ML];
+        {
+#pragma unroll
+            for (int it = 0; it < NGL; it++) {
+                const int j = tf + T * it;
+#pragma unroll
+                for (int m = 0; m < ML; m++) o[it][m] = X[acq_slot_hm(j, HL * m)];
+            }
+        }
+        acq_barrier<T>();  // the image is dead: |X| goes over it
+        double2 *specg = a.spec + g * a.nsb;
+#pragma unroll
+        for (int it = 0; it < NGL; it++) {
+            const int j = tf + T * it;
+            if constexpr (GL >= 2) {
+                // all but the last stage in full
+                double2 h0[ML / 2], h1[ML / 2];
+#pragma unroll
+                for (int m = 0; m < ML / 2; m++) {
+                    h0[m] = o[it][m];
+                    h1[m] = o[it][m + ML / 2];
+                }
+                // (the two halves are the sub-groups x[j + HL m], m < ML/2 and m >= ML/2: wings HL .. N/4 never cross them)
+                acq_stages<GL - 1, HL, false, false>(h0, j, TsL, tsg);
+                acq_stages<GL - 1, HL, false, false>(h1, j, TsL, tsg);
+#pragma unroll
+                for (int m = 0; m < ML / 2; m++) {
+                    o[it][m] = h0[m];
+                    o[it][m + ML / 2] = h1[m];
+                }
+            }
+            // last stage, wing N/2: bins ba = j + HL m and bb = ba + N/2
+#pragma unroll
+            for (int m = 0; m < ML / 2; m++) {
+                const int ba = j + HL * m, bb = ba + N / 2;
+                const int ia = acq_spec_index(ba, N, a.do_up), ib = acq_spec_index(bb, N, a.do_up);
+                if (ia < 0 && ib < 0) continue;
+                const double2 wv = tsg[(unsigned)(N / 2 - 1 + ba)];
+                const double2 aq = o[it][m], bq = o[it][m + ML / 2];
+                const double p1 = wv.x * bq.x, p2 = wv.y * bq.y, p3 = wv.x * bq.y, p4 = wv.y * bq.x;
+                const double tr = p1 - p2;
+                const double ti = p3 + p4;
+                if (ia >= 0) {
+                    const double2 r = make_double2(aq.x + tr, aq.y + ti);
+                    specg[ia] = r;
+                    if (ba >= pbase && ba < end - 24) P[ba - pbase] = sqrt(r.x * r.x + r.y * r.y);  // :425-427
+                }
+                if (ib >= 0) {
+                    const double2 r = make_double2(aq.x - tr, aq.y - ti);
+                    specg[ib] = r;
+                    if (bb >= pbase && bb < end - 24) P[bb - pbase] = sqrt(r.x * r.x + r.y * r.y);
+                }
+            }
+        }
+        acq_barrier<T>();
+        // ---- 100-wide boxcar, summed j ascending for every i (:433-437); first maximum (:439-442).  A thread owns RB consecutive
+        // outputs i0 .. i0 + RB - 1: their windows P[i - 50 .. i + 49] are one run of 99 + RB values, each output its own
+        // ascending chain.
+        double bestv = 0.0;  // maxBin starts at 0.0, binPos at -1
+        int besti = -1;
+        {
+            const int i0 = beg + 75 + RB * tf;
+            if (i0 < end - 75) {
+                const double *w = P + (i0 - 50 - pbase);
+                double acc[RB];
+                constexpr int NV = 99 + RB, CH = 8, NCH = (NV + CH - 1) / CH;
+                double cur[CH], nxt[CH];
+#pragma unroll
+                for (int u = 0; u < CH; u++) cur[u] = w[u];
+#pragma unroll
+                for (int c = 0; c < NCH; c++) {
+                    if (c + 1 < NCH) {
+#pragma unroll
+                        for (int u = 0; u < CH; u++)
+                            if ((c + 1) * CH + u < NV) nxt[u] = w[(c + 1) * CH + u];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < CH; u++) {
+                        const int k = c * CH + u;
+                        if (k < NV) {
+#pragma unroll
+                            for (int r = 0; r < RB; r++) {
+                                if (k == r) acc[r] = cur[u];  // 0.0 + x == x for the |X| values (never -0.0)
+                                if (k > r && k < r + 100) acc[r] += cur[u];
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < CH; u++) cur[u] = nxt[u];
+                }
+                double *ab = a.aband + g * a.na + (i0 - (beg + 75));
+#pragma unroll
+                for (int r = 0; r < RB; r++) {
+                    if (i0 + r < end - 75) {
+                        ab[r] = acc[r];
+                        if (bestv < acc[r]) {  // i ascends within a thread: strict '<' keeps the first maximum
+                            bestv = acc[r];
+                            besti = i0 + r;
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const double ov = __shfl_xor(bestv, off, 64);
+            const int oi = __shfl_xor(besti, off, 64);
+            if (oi >= 0 && (ov > bestv || (ov == bestv && (besti < 0 || oi < besti)))) {
+                bestv = ov;
+                besti = oi;
+            }
+        }
+        if constexpr (T > 64) {
+            if (lane == 0) {
+                redv[wave] = bestv;
+                redi[wave] = besti;
+            }
+            __syncthreads();
+            if (tid == 0) {
+                double mv = 0.0;
+                int mi = -1;
+#pragma unroll
+                for (int w = 0; w < T / 64; w++) {
+                    const double ov = redv[w];
+                    const int oi = redi[w];
+                    if (oi >= 0 && (ov > mv || (ov == mv && (mi < 0 || oi < mi)))) {
+                        mv = ov;
+                        mi = oi;
+                    }
+                }
+                AcqPeak pk;
+                pk.maxBin = mv;
+                pk.binPos = mi;
+                pk.pad = 0;
+                a.peak[g] = pk;
+            }
+        } else {
+            if (tid == 0) {
+                AcqPeak pk;
+                pk.maxBin = bestv;
+                pk.binPos = besti;
+                pk.pad = 0;
+                a.peak[g] = pk;
+            }
+            acq_barrier<T>();  // P is read before the next frame's first pass stores over it
+        }
+    }
+}
+
+// ============================================================================================================= phase B
+// One wave per stream.  Lane l holds frame f0' + l of a block of 64: avePsd[centreBin] read under the centre bin the block
+// STARTS with (64 loads in flight instead of one dependent load per frame).  The rule runs over the block in order, every lane
+// on the same values; when a frame moves the centre bin, the frames behind it are re-read under the new one.  In the steady
+// state (a locked carrier's centre bin moves rarely) a block is one round trip to memory.
+__global__ __launch_bounds__(64) void k_acq_scan(AcqArgs a)
+{
+    const int s = blockIdx.x, lane = threadIdx.x;
+    const int n = a.n;
+    const int beg = a.do_up ? n / 4 : 0;
+    const int end = a.do_up ? n / 2 : n / 4;
+    FftFrontState *sp = &a.st[s];
+    double avePeakPower = sp->avePeakPower, aveCentreBin = sp->aveCentreBin;
+    int centreBin = sp->centreBin;
+    // :399-402 -- float expressions widened to double
+    const double CFREQ_INV = (double)(1.0F - (2.0F / (1 + 1))), CFREQ_AVG = (double)(2.0F / (1 + 1));
+    const double PSD_INV = (double)(1.0F - (2.0F / (10 + 1))), PSD_AVG = (double)(2.0F / (10 + 1));
+    const long long g0 = (long long)s * a.F;
+    int f = 0;
+    while (f < a.F) {
+        // :444-445 for the block's first frame; the lanes behind it assume the centre bin stays
+        int cb = centreBin;
+        if (cb < 0) cb = 0;
+        if (cb > end - 1) cb = end - 1;
+        const int fl = f + lane;
+        double atc = 0.0, mb = 0.0;
+        int bp = -1;
+        if (fl < a.F) {
+            const AcqPeak pk = a.peak[g0 + fl];
+            mb = pk.maxBin;
+            bp = pk.binPos;
+            // avePsd is cleared per frame (:431) and only [beg + 75, end - 75) is filled
+            if (cb >= beg + 75 && cb < end - 75) atc = a.aband[(g0 + fl) * a.na + (cb - (beg + 75))];
+        }
+        const int cnt = (a.F - f) < 64 ? (a.F - f) : 64;
+        int done = 0;
+        for (int l = 0; l < cnt; l++) {
+            const double atc_l = __shfl(atc, l, 64), mb_l = __shfl(mb, l, 64);
+            const int bp_l = __shfl(bp, l, 64);
+            if (centreBin < 0) centreBin = 0;
+            if (centreBin > end - 1) centreBin = end - 1;
+            avePeakPower = (PSD_AVG * atc_l) + (PSD_INV * avePeakPower);
+            if (mb_l > (avePeakPower / 4) * 5 && bp_l > 0) {
+                aveCentreBin = (CFREQ_AVG * (double)(float)bp_l) + (CFREQ_INV * aveCentreBin);
+                centreBin = (int)(aveCentreBin + (double)1.0F);
+            }
+            if (centreBin < 102) centreBin = 102;
+            if (lane == 0) a.cbin[g0 + f + l] = centreBin;
+            done = l + 1;
+            // the next frame reads avePsd under THIS frame's centre bin (after its own clamps): if that is not what the block
+            // was loaded under, reload from the next frame on
+            int cn = centreBin;
+            if (cn > end - 1) cn = end - 1;
+            if (cn != cb) break;
+        }
+        f += done;
+    }
+    if (lane == 0) {
+        sp->avePeakPower = avePeakPower;
+        sp->aveCentreBin = aveCentreBin;
+        sp->centreBin = centreBin;
+    }
+}
+
+// ============================================================================================================= phase C
+constexpr int ACQ_RB0 = 32;  // the compact real samples start at double slot ACQ_RB0 (as k_front_fft's FF_RB0)
+
+template <int LOGN>
+__global__ __launch_bounds__((1 << LOGN) / 16, 2) void k_acq_inv(AcqArgs a)
+{
+    constexpr int N = 1 << LOGN, T = N / 16;
+    using Plan = AcqPlan<LOGN>;
+    constexpr int GL = Plan::GL, ML = 1 << GL, NGL = 16 >> GL, HL = N >> GL;
+    constexpr int JB = (N / 4 + 1 + T - 1) / T;  // RxDownSample outputs per thread and frame (decimation >= 4)
+    extern __shared__ __align__(16) unsigned char smem[];
+    double2 *X = reinterpret_cast<double2 *>(smem);  // [N] the image; afterwards the compact real samples
+    double2 *TsL = X + N;                            // [ACQ_TWL]
+    double2 *B = TsL + ACQ_TWL;                      // [204] the gathered bins (everything behind them is zero, :414-415)
+    const double2 *__restrict__ tsg = a.tw;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < ACQ_TWL - 1; i += T) TsL[i] = tsg[i];
+    const int D = a.decim;
+    const double norm = 1.0 / (double)N;
+    const double HOWARD = 0.9 * 32768.0;
+    const long long nfr = (long long)a.S * a.F;
+    const int lo1 = a.do_up ? N / 4 - 26 : 0;
+    for (long long g = blockIdx.x; g < nfr; g += gridDim.x) {
+        int tf = tid;  // opaque per frame (see k_acq_fwd)
+        asm volatile("" : "+v"(tf));
+        const int s = (int)(g / a.F), f = (int)(g - (long long)s * a.F);
+        const long long t0 = (long long)(a.f0 + f) * N;  // call-relative index of the frame's first sample
+        // VCO factors of this frame's first round of outputs: in flight during the transform
+        long long jlo = (t0 - a.first_out + D - 1) / D;
+        if (t0 <= a.first_out) jlo = 0;
+        double2 cs0 = make_double2(0.0, 0.0);
+        {
+            const long long j = jlo + tf;
+            const long long te = (long long)a.first_out + (long long)D * j;
+            if (te < t0 + N && j < a.nds) cs0 = a.vco_cs[j];
+        }
+        // ---- the 204 bins around the centre to bin 0 of a zeroed array (:458)
+        {
+            const int c = a.cbin[g];
+            // phase A's rows hold bins [0, n/4 + 28) (lower band) or [0, 204) + [n/4 - 26, n/2 + 28) (upper band): every
+            // centre bin the rule can produce (102, or binPos + 1 with binPos in [beg + 75, end - 75)) gathers inside them
+            int off = c - 102;
+            if (a.do_up) off = (c == 102) ? 0 : 204 + (c - 102 - lo1);
+            if (off < 0) off = 0;
+            if (off + 204 > a.nsb) off = a.nsb - 204;
+            const double2 *src = a.spec + g * a.nsb + off;
+            for (int k = tf; k < 204; k += T) B[k] = src[k];
+        }
+        acq_barrier<T>();
+        // ---- inverse transform (:459).  Slot 16 q + m of the bit-reversed array holds input brev4(m) N/16 + brev(q): below 204 only
+        // for m = 0 (N >= 2048; and m = 8 at N = 2048), so the first three stages of a group are broadcasts of its slots 0 and 8
+        // -- a butterfly whose second operand is +0 returns its first operand twice, unless that holds a -0.0 (IEEE: (-0) + (+0) =
+        // +0): such a group takes the four stages in full -- and stage four is out[j'] = v0 + w v8, out[j' + 8] = v0 - w v8.  The
+        // second pass (wings 16 .. 128) needs slot j of sixteen groups: it forms them itself from the bins, no LDS round trip.
+        if constexpr (LOGN >= 11) {
+            const int j = tf & 15, hi = tf >> 4;
+            const double2 wq = tsg[7 + (j & 7)];
+            const double wr = wq.x, wi = -wq.y;
+            double2 x[16];
+            bool negz = false;
+            const long long NEGZ = (long long)0x8000000000000000ull;
+#pragma unroll
+            for (int m = 0; m < 16; m++) {
+                const int k0 = acq_brev<LOGN - 4>(16 * hi + m);
+                const double2 v0 = k0 < 204 ? B[k0] : make_double2(0.0, 0.0);
+                const double2 v8 = (N / 16 + k0 < 204) ? B[N / 16 + k0] : make_double2(0.0, 0.0);
+                negz = negz || __double_as_longlong(v0.x) == NEGZ || __double_as_longlong(v0.y) == NEGZ ||
+                       __double_as_longlong(v8.x) == NEGZ || __double_as_longlong(v8.y) == NEGZ;
+                const double p1 = wr * v8.x, p2 = wi * v8.y, p3 = wr * v8.y, p4 = wi * v8.x;
+                const double tr = p1 - p2;
+                const double ti = p3 + p4;
+                x[m] = (j < 8) ? make_double2(v0.x + tr, v0.y + ti) : make_double2(v0.x - tr, v0.y - ti);
+            }
+            if (negz) {
+                // a bin with a -0.0 component somewhere in this thread's sixteen groups: those groups in full (one body, not sixteen)
+#pragma unroll 1
+                for (int m = 0; m < 16; m++) {
+                    const int k0 = acq_brev<LOGN - 4>(16 * hi + m);
+                    double2 t[16];
+#pragma unroll
+                    for (int i = 0; i < 16; i++) t[i] = make_double2(0.0, 0.0);
+                    if (k0 < 204) t[0] = B[k0];
+                    if (N / 16 + k0 < 204) t[8] = B[N / 16 + k0];
+                    acq_stages<4, 1, true, true>(t, 0, TsL, tsg);
+                    double2 r = t[0];
+#pragma unroll
+                    for (int i = 1; i < 16; i++)
+                        if (j == i) r = t[i];
+#pragma unroll
+                    for (int i = 0; i < 16; i++)
+                        if (i == m) x[i] = r;
+                }
+            }
+            acq_stages<4, 16, true, false>(x, j, TsL, tsg);
+            const int e0 = (hi << 8) + j;
+#pragma unroll
+            for (int m = 0; m < 16; m++) X[acq_slot_hm(e0, 16 * m)] = x[m];
+        } else {
+            // N = 1024: four inputs of a first-pass group can be non-zero; the first pass runs in full on registers
+            const int q = tf;  // (natural order: the bins come from LDS)
+            double2 v[16];
+#pragma unroll
+            for (int m = 0; m < 16; m++) {
+                const int k = acq_brev<4>(m) * (N / 16) + acq_brev<LOGN - 4>(q);
+                v[m] = k < 204 ? B[k] : make_double2(0.0, 0.0);
+            }
+            acq_stages<4, 1, true, true>(v, 0, TsL, tsg);
+            const int key = acq_key(q);
+#pragma unroll
+            for (int m = 0; m < 16; m++) X[16 * q + (m ^ key)] = v[m];
+            acq_barrier<T>();
+            acq_mid_pass<4, 16, true, LOGN>(X, TsL, tsg, tf);
+        }
+        acq_barrier<T>();
+        if constexpr (Plan::G4 != 0) {
+            acq_mid_pass<Plan::G3, 256, true, LOGN>(X, TsL, tsg, tf);
+            acq_barrier<T>();
+        }
+        // ---- last pass: RxDownSample reads nothing but re / n (:461-463) -- the imaginary halves of the last stage have no reader
+        double o[NGL][ML];
+#pragma unroll
+        for (int it = 0; it < NGL; it++) {
+            const int j = tf + T * it;
+            double2 v[ML];
+#pragma unroll
+            for (int m = 0; m < ML; m++) v[m] = X[acq_slot_hm(j, HL * m)];
+            acq_stages<GL, HL, true, false>(v, j, TsL, tsg);
+#pragma unroll
+            for (int m = 0; m < ML; m++) o[it][m] = v[m].x * norm;
+        }
+        acq_barrier<T>();  // every butterfly of the pass is in registers: the compact samples go over the image
+        double *Rb = reinterpret_cast<double *>(smem);
+#pragma unroll
+        for (int it = 0; it < NGL; it++) {
+            const int j = tf + T * it;
+#pragma unroll
+            for (int m = 0; m < ML; m++) Rb[ACQ_RB0 + j + HL * m] = o[it][m];
+        }
+        acq_barrier<T>();
+        // ---- the frame's first and last 26 samples for the windows that cross into / out of it (k_acq_edges)
+        if (tf < 26) {
+            double *eg = a.edges + g * 52;
+            eg[tf] = Rb[ACQ_RB0 + tf];
+            eg[26 + tf] = Rb[ACQ_RB0 + N - 26 + tf];
+        }
+        // ---- RxDownSample(re, re) (:461-463, :470-492) for the outputs whose 27-sample window lies inside this frame
+        {
+            const bool even_d = (D & 1) == 0;  // then every window of the call ends on the same parity (N is even)
+            const int par = (int)((a.first_out - t0) & 1);
+#pragma unroll
+            for (int b = 0; b < JB; b++) {
+                const long long j = jlo + tf + T * b;
+                const long long te = (long long)a.first_out + (long long)D * j;  // window end, call-relative
+                if (te < t0 + N && j < a.nds) {
+                    const int e = (int)(te - t0);
+                    if (e >= 26) {
+                        double fi = 0.0;
+                        if (even_d) {
+                            // the 27 samples e-26 .. e as 14 aligned 16-byte reads
+                            const double2 *w2 = reinterpret_cast<const double2 *>(Rb + ((e + ACQ_RB0 - 26) & ~1));
+                            double d[28];
+#pragma unroll
+                            for (int i = 0; i < 14; i++) {
+                                const double2 t = w2[i];
+                                d[2 * i] = t.x;
+                                d[2 * i + 1] = t.y;
+                            }
+                            if (par) {
+#pragma unroll
+                                for (int k = 0; k < 27; k++) fi += d[27 - k] * ds_tap(k);  // newest first (:479-483)
+                            } else {
+#pragma unroll
+                                for (int k = 0; k < 27; k++) fi += d[26 - k] * ds_tap(k);
+                            }
+                        } else {
+                            const double *w = Rb + (ACQ_RB0 + e);
+#pragma unroll
+                            for (int k = 0; k < 27; k++) fi += w[-k] * ds_tap(k);
+                        }
+                        const double ov = fi * HOWARD;  // fi == fq: both rails get the same samples
+                        const double2 cs = (b == 0) ? cs0 : a.vco_cs[j];
+                        a.dm[(long long)s * a.dm_stride + 64 + j] = make_double2(ov * cs.x, ov * cs.y);  // :515-516
+                    }
+                }
+            }
+        }
+        acq_barrier<T>();  // every window is read before the next frame's passes store over the image
+    }
+}
+
+// ============================================================================================================= edges
+// One workgroup per stream.  The windows of a frame that begin in the frame before it: at most ceil(26 / D) per frame.  The
+// call's first frame reaches into the stream's history (FftFrontState::hist: the last 26 samples of the previous call, zeros
+// before the first), which this kernel also brings up to date -- after every thread has read it.
+__global__ __launch_bounds__(256) void k_acq_edges(AcqArgs a)
+{
+    const int s = blockIdx.x, tid = threadIdx.x;
+    const int n = a.n, D = a.decim;
+    const int EO = 26 / D + 2;  // upper bound of the windows per frame that end within its first 26 samples
+    const double HOWARD = 0.9 * 32768.0;
+    FftFrontState *sp = &a.st[s];
+    __shared__ double hist0[26];
+    if (tid < 26) hist0[tid] = sp->hist[tid];
+    __syncthreads();
+    const long long g0 = (long long)s * a.F;
+    for (int it = tid; it < a.F * EO; it += 256) {
+        const int f = it / EO, r = it - f * EO;
+        const long long t0 = (long long)(a.f0 + f) * n;
+        long long jlo = (t0 - a.first_out + D - 1) / D;
+        if (t0 <= a.first_out) jlo = 0;
+        const long long j = jlo + r;
+        const long long te = (long long)a.first_out + (long long)D * j;
+        if (te >= t0 + n || j >= a.nds) continue;
+        const int e = (int)(te - t0);
+        if (e < 0 || e >= 26) continue;
+        // sample e - k of the frame, k = 0 .. 26, newest first (:479-483): from the frame's own first 26 samples, or from the 26
+        // before it (the previous frame's last ones; the stream's history for the call's first frame)
+        const double *head = a.edges + (g0 + f) * 52;
+        const double *prev = a.edges + (g0 + f - 1) * 52 + 26;
+        double fi = 0.0;
+#pragma unroll
+        for (int k = 0; k < 27; k++) {
+            const int i = e - k;
+            const double x = i >= 0 ? head[i] : (f == 0 ? hist0[26 + i] : prev[26 + i]);
+            fi += x * ds_tap(k);
+        }
+        const double ov = fi * HOWARD;
+        const double2 cs = a.vco_cs[j];
+        a.dm[(long long)s * a.dm_stride + 64 + j] = make_double2(ov * cs.x, ov * cs.y);
+    }
+    if (tid < 26) sp->hist[tid] = a.edges[(g0 + a.F - 1) * 52 + 26 + tid];
+}
+
+
+// ============================================================================================================= host
+extern int g_acq_last_grid[4];
+// bytes of scratch one frame needs between the phases (spec row, boxcar band, peak, centre bin, edges), 16-byte aligned parts
+static void acq3_layout(int n, int do_up, int *nsb, int *na)
+{
+    *nsb = do_up ? 204 + (n / 4 + 54) : n / 4 + 28;
+    *na = ((n / 4 - 150) + 1) & ~1;
+}
+
+bool acq3_supported(int n)
+{
+    return n == 1024 || n == 2048 || n == 4096 || n == 8192;
+}
+
+size_t acq3_frame_bytes(int n, int do_up)
+{
+    int nsb, na;
+    acq3_layout(n, do_up, &nsb, &na);
+    return sizeof(double2) * (size_t)nsb + sizeof(double) * (size_t)na + sizeof(AcqPeak) + 16 + sizeof(double) * 52;
+}
+
+template <int LOGN>
+static int launch_acq3_t(AcqArgs &a, bool f32, int num_cu, hipStream_t st, const AcqProf &prof)
+{
+    constexpr int N = 1 << LOGN, T = N / 16;
+    constexpr size_t lds_fwd = sizeof(double2) * ((size_t)N + ACQ_TWL) + 8 * sizeof(double) + 8 * sizeof(int);
+    constexpr size_t lds_inv = sizeof(double2) * ((size_t)N + ACQ_TWL + 204);
+    const long long nfr = (long long)a.S * a.F;
+    int per_cu_f = 1, per_cu_i = 1;
+    if (f32) {
+        JSDR_LDS_ATTR((k_acq_fwd<LOGN, true>), lds_fwd);
+        JSDR_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_f, k_acq_fwd<LOGN, true>, T, lds_fwd));
+    } else {
+        JSDR_LDS_ATTR((k_acq_fwd<LOGN, false>), lds_fwd);
+        JSDR_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_f, k_acq_fwd<LOGN, false>, T, lds_fwd));
+    }
+    JSDR_LDS_ATTR((k_acq_inv<LOGN>), lds_inv);
+    JSDR_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_i, k_acq_inv<LOGN>, T, lds_inv));
+    if (per_cu_f < 1) per_cu_f = 1;
+    if (per_cu_i < 1) per_cu_i = 1;
+    long long gf = (long long)per_cu_f * num_cu, gi = (long long)per_cu_i * num_cu;
+    if (gf > nfr) gf = nfr;
+    if (gi > nfr) gi = nfr;
+    g_acq_last_grid[0] = (int)gf;
+    g_acq_last_grid[1] = (int)gi;
+    g_acq_last_grid[2] = per_cu_f;
+    g_acq_last_grid[3] = per_cu_i;
+    auto mark = [&](int phase, bool begin) {
+        if (prof.mark) prof.mark(prof.ctx, phase, begin, st);
+    };
+    mark(0, true);
+    if (f32)
+        hipLaunchKernelGGL((k_acq_fwd<LOGN, true>), dim3((unsigned)gf), dim3(T), lds_fwd, st, a);
+    else
+        hipLaunchKernelGGL((k_acq_fwd<LOGN, false>), dim3((unsigned)gf), dim3(T), lds_fwd, st, a);
+    mark(0, false);
+    JSDR_LAUNCH_CHECK();
+    mark(1, true);
+    hipLaunchKernelGGL(k_acq_scan, dim3((unsigned)a.S), dim3(64), 0, st, a);
+    mark(1, false);
+    JSDR_LAUNCH_CHECK();
+    mark(2, true);
+    hipLaunchKernelGGL((k_acq_inv<LOGN>), dim3((unsigned)gi), dim3(T), lds_inv, st, a);
+    mark(2, false);
+    JSDR_LAUNCH_CHECK();
+    mark(3, true);
+    hipLaunchKernelGGL(k_acq_edges, dim3((unsigned)a.S), dim3(256), 0, st, a);
+    mark(3, false);
+    JSDR_LAUNCH_CHECK();
+    return JSDR_OK;
+}
+
+int g_acq_last_grid[4] = {0, 0, 0, 0};
+
+// The call's frames in launches of at most chunk_frames per stream (the scratch holds S * chunk_frames frames)
+int launch_acq3(const FftFrontArgs &fa, int nstreams, unsigned char *scratch, size_t scratch_bytes, int chunk_frames, int num_cu,
+                hipStream_t st, const AcqProf &prof)
+{
+    JSDR_REQUIRE(acq3_supported(fa.n), "bpsk: the three-phase FFT-acquire front end takes frames of 1024 .. 8192 samples (2^k), not %d", fa.n);
+    int nsb, na;
+    acq3_layout(fa.n, fa.do_up, &nsb, &na);
+    if (chunk_frames < 1) chunk_frames = 1;
+    const size_t nf = (size_t)nstreams * (size_t)chunk_frames;
+    JSDR_REQUIRE(nf * acq3_frame_bytes(fa.n, fa.do_up) <= scratch_bytes, "bpsk: FFT-acquire scratch too small (%zu frames)", nf);
+    AcqArgs a;
+    a.raw = fa.raw;
+    a.rawf = fa.rawf;
+    a.stride_pairs = fa.stride_pairs;
+    a.ic = fa.ic;
+    a.qc = fa.qc;
+    a.S = nstreams;
+    a.n = fa.n;
+    a.do_up = fa.do_up;
+    a.decim = fa.decim;
+    a.first_out = fa.first_out;
+    a.nds = fa.nds;
+    a.vco_cs = fa.vco_cs;
+    a.tw = fa.tw;
+    a.st = fa.st;
+    a.dm = fa.dm;
+    a.dm_stride = fa.dm_stride;
+    a.nsb = nsb;
+    a.na = na;
+    unsigned char *p = scratch;
+    a.spec = reinterpret_cast<double2 *>(p);
+    p += sizeof(double2) * nf * (size_t)nsb;
+    a.aband = reinterpret_cast<double *>(p);
+    p += sizeof(double) * nf * (size_t)na;
+    a.peak = reinterpret_cast<AcqPeak *>(p);
+    p += sizeof(AcqPeak) * nf;
+    a.edges = reinterpret_cast<double *>(p);
+    p += sizeof(double) * 52 * nf;
+    a.cbin = reinterpret_cast<int *>(p);
+    a.nwg = 0;
+    for (int f0 = 0; f0 < fa.nframes; f0 += chunk_frames) {
+        a.f0 = f0;
+        a.F = fa.nframes - f0 < chunk_frames ? fa.nframes - f0 : chunk_frames;
+        int rc;
+        switch (fa.logn) {
+            case 10: rc = launch_acq3_t<10>(a, fa.rawf != nullptr, num_cu, st, prof); break;
+            case 11: rc = launch_acq3_t<11>(a, fa.rawf != nullptr, num_cu, st, prof); break;
+            case 12: rc = launch_acq3_t<12>(a, fa.rawf != nullptr, num_cu, st, prof); break;
+            default: rc = launch_acq3_t<13>(a, fa.rawf != nullptr, num_cu, st, prof); break;
+        }
+        if (rc != JSDR_OK) return rc;
+    }
+    return JSDR_OK;
+}
+
+}  // namespace jsdr

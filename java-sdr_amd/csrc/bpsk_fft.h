@@ -90,6 +90,18 @@ __device__ __forceinline__ void boxcar_pair(const double2 *w, double &a0, double
 }
 
 int launch_front_fft(const FftFrontArgs &a, int nstreams, hipStream_t st);
+// round 6 (bpsk_acq.hip): the same front end in three phases -- forward transform + boxcar per frame, one scan per stream,
+// inverse transform + RxDownSample per frame -- for calls of two or more frames per stream; frames of 1024 .. 8192 samples
+bool acq3_supported(int n);
+size_t acq3_frame_bytes(int n, int do_up);  // scratch per (stream, frame) of one launch
+// per-phase timing hook (bench.py's per-kernel figures): phase 0..3 = k_acq_fwd, k_acq_scan, k_acq_inv, k_acq_edges
+struct AcqProf {
+    void *ctx = nullptr;
+    void (*mark)(void *ctx, int phase, bool begin, hipStream_t st) = nullptr;
+};
+int launch_acq3(const FftFrontArgs &a, int nstreams, unsigned char *scratch, size_t scratch_bytes, int chunk_frames, int num_cu,
+                hipStream_t st, const AcqProf &prof);
+extern int g_acq_last_grid[4];  // workgroups of the last k_acq_fwd / k_acq_inv launch, and how many of each a CU holds
 // frames that are not a power of two (bpsk_fftm.hip): any n with 416 <= n <= 9600 (2^a 3^b 5^c 7^d through the radix passes, any
 // other prime factor through a pass that is the DFT's definition and needs fftm_scratch(n) elements of scratch per stream)
 bool fftm_supported(int n);

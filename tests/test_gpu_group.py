@@ -151,8 +151,14 @@ def test_group_block_of_a_recording_shorter_than_the_block(tmp_path):
         g.batch_i16([buf], 2 * n, n)
     g.sync()
     padded = [np.concatenate([iq[s][:2 * short], np.zeros(2 * (n - short), np.int16)]) for s in range(2)]
-    _, info, ref = reference_slots(padded, n, [n, n, n])
-    assert np.array_equal(g.gathered(0).reshape(2, info["slot_bytes"]), ref[2])
+    d = J.Bpsk(nstreams=2, max_batch_samples=n)  # a plain handle fed the zero-padded block three times
+    d_iq = J.DeviceBuffer.from_host(np.concatenate(padded))
+    for trial in range(3):
+        d.batch_i16(d_iq, 2 * n, n)
+    info = d.slot_info()
+    slots = J.DeviceBuffer(2 * info["slot_bytes"])
+    d.pack_slots(slots)
+    assert np.array_equal(g.gathered(0).reshape(2, info["slot_bytes"]), slots.to_host(np.uint8).reshape(2, info["slot_bytes"]))
 
 
 # ------------------------------------------------------------------ the C++ harness's --gpus mode: config 5 with no Python in the process
