@@ -3246,7 +3246,7 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
                 if (chunk < 1) chunk = 1;
                 if (chunk > fmax) chunk = fmax;
                 if (const char *e = knob("JSDR_ACQ_CHUNK")) chunk = atoll(e) > 0 && atoll(e) < chunk ? atoll(e) : chunk;
-                if (h->acq_scratch.alloc(per * (size_t)S * (size_t)chunk) != JSDR_OK) return JSDR_ERR;
+                if (h->acq_scratch.alloc(per * (size_t)S * (size_t)chunk + 512) != JSDR_OK) return JSDR_ERR;
                 h->acq_chunk = (int)chunk;
                 int dev = 0, cus = 0;
                 JSDR_HIP_TRY(hipGetDevice(&dev));
@@ -3590,7 +3590,7 @@ int jsdr_bpsk_create(jsdr_bpsk **out, int rate, int nsamples_per_frame, int tuni
         }
         if (const char *e = knob("JSDR_ACQ3")) h->acq_mode = atoi(e) != 0 ? 1 : 0;
         if (const char *e = knob("JSDR_FFT_PHASECLK"))
-            if (atoi(e) != 0 && (h->phase_clk.alloc(8) != JSDR_OK || h->phase_clk.zero() != JSDR_OK)) h->phase_clk.release();
+            if (atoi(e) != 0 && (h->phase_clk.alloc(16 + 2 * 4096) != JSDR_OK || h->phase_clk.zero() != JSDR_OK)) h->phase_clk.release();
     }
     if (hipMemcpy(h->ds_taps_dev.p, bc.ds_taps, sizeof(double) * 27, hipMemcpyHostToDevice) != hipSuccess) {
         set_error("jsdr_bpsk_create: tap upload failed");
@@ -3741,9 +3741,38 @@ int jsdr_bpsk_destroy(jsdr_bpsk *h)
         static const char *const names_mx[8] = {"load", "forward FFT", "centre-bin rule", "gather/zero/place", "inverse FFT",
                                                 "RxDownSample", "|X|", "boxcar+argmax"};
         const char *const *names = h->fft_mixed ? names_mx : names_p2;
-        long long c[8] = {0};
+        long long c[16] = {0};
         if (hipDeviceSynchronize() == hipSuccess &&
             hipMemcpy(c, h->phase_clk.p, sizeof(c), hipMemcpyDeviceToHost) == hipSuccess) {
+            if (h->acq_chunk > 0) {  // the three-phase front end ran: the last launch's workgroup 0 of k_acq_fwd / k_acq_inv
+                static const char *const nf[6] = {"convert+pass 1", "pass 2", "last pass: loads", "last pass+|X|+spec", "boxcar", "argmax+peak"};
+                static const char *const ni[5] = {"gather", "passes 1+2 fused", "last pass", "compact store", "edges+RxDownSample"};
+                long long tf = 0, ti = 0;
+                for (int k = 0; k < 6; k++) tf += c[k];
+                for (int k = 0; k < 5; k++) ti += c[8 + k];
+                for (int k = 0; k < 6; k++)
+                    fprintf(stderr, "[jsdr] k_acq_fwd phase %-20s %12lld ticks  %5.1f %%\n", nf[k], c[k], tf ? 100.0 * (double)c[k] / (double)tf : 0.0);
+                for (int k = 0; k < 5; k++)
+                    fprintf(stderr, "[jsdr] k_acq_inv phase %-20s %12lld ticks  %5.1f %%\n", ni[k], c[8 + k], ti ? 100.0 * (double)c[8 + k] / (double)ti : 0.0);
+                memset(c, 0, sizeof(c));
+                // every k_acq_fwd workgroup's first and last tick (100 MHz): how many ran from the start, how far apart they ended
+                std::vector<long long> w(2 * 4096);
+                if (hipMemcpy(w.data(), h->phase_clk.p + 16, sizeof(long long) * w.size(), hipMemcpyDeviceToHost) == hipSuccess) {
+                    long long t0 = 0, e0 = 0, e1 = 0;
+                    int n = 0, late = 0;
+                    for (int i = 0; i < 4096; i++)
+                        if (w[2 * i + 1]) {
+                            if (!n || w[2 * i] < t0) t0 = w[2 * i];
+                            if (!n || w[2 * i + 1] < e0) e0 = w[2 * i + 1];
+                            if (!n || w[2 * i + 1] > e1) e1 = w[2 * i + 1];
+                            n++;
+                        }
+                    for (int i = 0; i < 4096; i++)
+                        if (w[2 * i + 1] && w[2 * i] - t0 > (e1 - t0) / 10) late++;
+                    fprintf(stderr, "[jsdr] k_acq_fwd %d workgroups: %d started late (> 10 %% into the launch); first end %.3f ms, last end %.3f ms after the first start\n",
+                            n, late, (double)(e0 - t0) / 1e5, (double)(e1 - t0) / 1e5);
+                }
+            }
             long long tot = 0;
             for (int k = 0; k < 8; k++) tot += c[k];
             for (int k = 0; k < 8; k++)

@@ -55,6 +55,11 @@ template <int HALF, bool UNIFORM>
 __device__ __forceinline__ double2 acq_tw(const double2 *TsL, const double2 *__restrict__ tsg, int jj)
 {
     if (!UNIFORM && 2 * HALF <= ACQ_TWL) return TsL[HALF - 1 + jj];
+    if (UNIFORM) {  // the same entry in every lane: a scalar load
+        typedef const __attribute__((address_space(4))) double *ctab_t;
+        ctab_t t = (ctab_t)tsg;
+        return make_double2(t[2 * (HALF - 1 + jj)], t[2 * (HALF - 1 + jj) + 1]);
+    }
     return tsg[(unsigned)(HALF - 1 + jj)];
 }
 
@@ -65,6 +70,9 @@ __device__ __forceinline__ void acq_stages(double2 (&v)[1 << G], int j, const do
     constexpr int M = 1 << G;
 #pragma unroll
     for (int t = 0; t < G; t++) {
+#ifdef JSDR_ACQ_STAGE_FENCE
+        if (!UNIFORM) __builtin_amdgcn_sched_barrier(0);  // a stage's twiddles are requested when the stage before is done, not all up front
+#endif
         double2 w[M / 2];
 #pragma unroll
         for (int u = 0; u < (1 << t); u++) {
@@ -95,7 +103,7 @@ __device__ __forceinline__ void acq_stages(double2 (&v)[1 << G], int j, const do
 // results to the last bit, signs of zeros included, because no value in this part of the network is ever -0.0: a converted
 // int16 sample is never -0.0, and a sum or a difference is -0.0 only if an operand already is (bpsk_fft.hip dit_first3_i16
 // has the argument in full).  Float input may hold -0.0f and takes acq_stages.
-__device__ __forceinline__ void acq_first4_i16(double2 (&v)[16], const double2 *__restrict__ tsg)
+__device__ __forceinline__ void acq_first4_i16(double2 (&v)[16], const double2 (&w)[8])  // w = tw[4], tw[6], tw[8..10], tw[12..14]
 {
     auto bf1 = [](double2 &a, double2 &b) {
         const double2 x = a, y = b;
@@ -128,30 +136,38 @@ __device__ __forceinline__ void acq_first4_i16(double2 (&v)[16], const double2 *
         bfi(v[h + 5], v[h + 7]);
         // wing 4: tw[3] = 1, tw[4] = W8, tw[5] = -i, tw[6] = W8^3
         bf1(v[h + 0], v[h + 4]);
-        bfw(v[h + 1], v[h + 5], tsg[4]);
+        bfw(v[h + 1], v[h + 5], w[0]);
         bfi(v[h + 2], v[h + 6]);
-        bfw(v[h + 3], v[h + 7], tsg[6]);
+        bfw(v[h + 3], v[h + 7], w[1]);
     }
     // wing 8: tw[7 + j] = W16^j; j = 0: 1, j = 4: -i
     bf1(v[0], v[8]);
-    bfw(v[1], v[9], tsg[8]);
-    bfw(v[2], v[10], tsg[9]);
-    bfw(v[3], v[11], tsg[10]);
+    bfw(v[1], v[9], w[2]);
+    bfw(v[2], v[10], w[3]);
+    bfw(v[3], v[11], w[4]);
     bfi(v[4], v[12]);
-    bfw(v[5], v[13], tsg[12]);
-    bfw(v[6], v[14], tsg[13]);
-    bfw(v[7], v[15], tsg[14]);
+    bfw(v[5], v[13], w[5]);
+    bfw(v[6], v[14], w[6]);
+    bfw(v[7], v[15], w[7]);
 }
 
+// The workgroup barrier of these kernels orders LDS traffic ONLY.  __syncthreads() is a workgroup-scope release / acquire
+// fence pair around s_barrier, and the release half waits for EVERY outstanding memory operation of the wave (s_waitcnt
+// vmcnt(0)): the next frame's samples requested a moment ago, the spectrum rows and boxcar sums just stored -- a round trip to
+// HBM at every barrier, with two waves a SIMD to cover it.  Nothing a thread of these kernels writes to global memory is read
+// by another thread of the same launch, so the barrier waits for the wave's LDS operations and nothing else.
 template <int T>
 __device__ __forceinline__ void acq_barrier()
 {
     if constexpr (T <= 64) {  // one wave per frame: its own LDS order is all there is to keep
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     } else {
-        __syncthreads();
+#ifdef JSDR_X_ACQ_NOBAR  // (timing probe only, wrong data: what lock-step at the barriers costs)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
     }
 }
 
@@ -213,7 +229,18 @@ struct AcqArgs {
     int *cbin;             // [S F] the frame's centre bin (phase B)
     double *edges;         // [S F][52]: the frame's first 26 and last 26 real samples re / n (phase C)
     int nwg;               // persistent workgroups of phases A and C
+    unsigned *tickets;     // [2] run counters of k_acq_fwd / k_acq_inv, zero at launch: a workgroup takes its frames in runs of `run`
+    int run;               // consecutive frames per ticket (>= 2)
+    long long *clk;        // diagnostics (JSDR_FFT_PHASECLK=1): [16] clock ticks per phase of workgroup 0, k_acq_fwd [0..7], k_acq_inv [8..15]; or null
 };
+
+// thread 0 of workgroup 0 accumulates the clock ticks of every phase in LDS (never in the product's default path: clk is null)
+#define ACQ_PHASE(k)                                 \
+    if (timing) {                                    \
+        const long long now_ = (long long)clock64(); \
+        clkL[k] += now_ - tprev;                     \
+        tprev = now_;                                \
+    }
 
 // where bin b of a frame sits in its spec row, or -1
 __device__ __forceinline__ int acq_spec_index(int b, int n, int do_up)
@@ -222,6 +249,81 @@ __device__ __forceinline__ int acq_spec_index(int b, int n, int do_up)
     if (b < 204) return b;
     const int lo = n / 4 - 26;
     return (b >= lo && b < n / 2 + 28) ? 204 + (b - lo) : -1;
+}
+
+// ---- twiddles a thread keeps in registers for the whole launch: the G stages of a pass that starts at wing HALF0, for group
+// position j -- stage t, entry u at w[(1 << t) - 1 + u] = tw[(HALF0 << t) - 1 + j + HALF0 u].  The frame loop then holds no
+// global load but the samples' own: on this part VMEM operations return in order, so a wait for a twiddle requested after the
+// next frame's samples is a wait for those samples (a round trip to HBM at two waves a SIMD).
+template <int G, int HALF0>
+__device__ __forceinline__ void acq_load_tw(double2 (&w)[(1 << G) - 1], int j, const double2 *tsg_)
+{
+    // through a pointer the compiler cannot see through: loads it can prove invariant are sunk to their first use, below the
+    // barrier's memory clobber and below the next frame's samples -- the very order these requests are here to avoid
+    // (as an integer, and back into the GLOBAL address space: a laundered generic pointer gives flat loads, which count as LDS
+    //  operations too and make every wait a wait for everything)
+    typedef double d2v_ __attribute__((ext_vector_type(2)));
+    typedef __attribute__((address_space(1))) const d2v_ gbl_d2v_;
+    unsigned long long ta = (unsigned long long)tsg_;
+    asm volatile("" : "+s"(ta));
+    gbl_d2v_ *tsg = (gbl_d2v_ *)ta;
+#pragma unroll
+    for (int t = 0; t < G; t++)
+#pragma unroll
+        for (int u = 0; u < (1 << t); u++) {
+            const d2v_ x = tsg[(unsigned)((HALF0 << t) - 1 + j + HALF0 * u)];
+            w[(1 << t) - 1 + u] = make_double2(x.x, x.y);
+        }
+}
+// stages [T0, T1) of such a pass on v[m] = x[base + j + HALF0 m], twiddles from the thread's registers
+template <int G, int T0, int T1, bool INVERSE>
+__device__ __forceinline__ void acq_stages_w(double2 (&v)[1 << G], const double2 (&w)[(1 << G) - 1])
+{
+    constexpr int M = 1 << G;
+#pragma unroll
+    for (int t = T0; t < T1; t++) {
+#pragma unroll
+        for (int m = 0; m < M; m++) {
+            if ((m >> t) & 1) continue;
+            const double2 wv = w[(1 << t) - 1 + (m & ((1 << t) - 1))];
+            const double wr = wv.x;
+            const double wi = INVERSE ? -wv.y : wv.y;
+            const double2 bq = v[m + (1 << t)];
+            const double p1 = wr * bq.x, p2 = wi * bq.y, p3 = wr * bq.y, p4 = wi * bq.x;
+            const double tr = p1 - p2;
+            const double ti = p3 + p4;
+            const double2 aq = v[m];
+            v[m] = make_double2(aq.x + tr, aq.y + ti);
+            v[m + (1 << t)] = make_double2(aq.x - tr, aq.y - ti);
+        }
+    }
+}
+
+// the largest of the wave's non-negative doubles, in every lane: row shifts and row broadcasts on the two halves (DPP moves
+// cost an instruction each; the shuffle form goes through the LDS crossbar, ~100 cycles a step with nothing to cover it)
+__device__ __forceinline__ double acq_wave_max(double v)
+{
+#define ACQ_DPP_MAX(ctrl, rmask)                                                                                  \
+    {                                                                                                             \
+        const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), ctrl, rmask, 0xf, false); \
+        const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), ctrl, rmask, 0xf, false); \
+        v = fmax(v, __hiloint2double(hi, lo));                                                                    \
+    }
+    ACQ_DPP_MAX(0x111, 0xf)  // row_shr:1
+    ACQ_DPP_MAX(0x112, 0xf)  // row_shr:2
+    ACQ_DPP_MAX(0x114, 0xf)  // row_shr:4
+    ACQ_DPP_MAX(0x118, 0xf)  // row_shr:8 -- lane 15 of every row holds its row's maximum
+    ACQ_DPP_MAX(0x142, 0xa)  // row_bcast:15 into rows 1 and 3
+    ACQ_DPP_MAX(0x143, 0xc)  // row_bcast:31 into rows 2 and 3 -- lane 63 holds the wave's
+#undef ACQ_DPP_MAX
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+
+typedef const __attribute__((address_space(4))) double *acq_ctab_t;  // constant address space: uniform entries become scalar loads
+__device__ __forceinline__ double2 acq_tw_s(const double2 *tsg, int i)
+{
+    acq_ctab_t t = (acq_ctab_t)tsg;
+    return make_double2(t[2 * i], t[2 * i + 1]);
 }
 
 // ============================================================================================================= phase A
@@ -239,13 +341,26 @@ __global__ __launch_bounds__((1 << LOGN) / 16, 2) void k_acq_fwd(AcqArgs a)
     double *redv = reinterpret_cast<double *>(TsL + ACQ_TWL);  // [8] per-wave best value
     int *redi = reinterpret_cast<int *>(redv + 8);             // [8] per-wave best index
     double *P = reinterpret_cast<double *>(smem);              // |X| over [beg + 24, end - 24): over the image, dead by then
+    long long *clkL = reinterpret_cast<long long *>(redi + 8);  // [8]
+    const bool timing = a.clk != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
+    long long tprev = 0;
+    if (timing)
+        for (int k = 0; k < 8; k++) clkL[k] = 0;
     const double2 *__restrict__ tsg = a.tw;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long wg_t0 = a.clk != nullptr ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
     for (int i = tid; i < ACQ_TWL - 1; i += T) TsL[i] = tsg[i];
     const int beg = a.do_up ? N / 4 : 0;
     const int end = a.do_up ? N / 2 : N / 4;
     const int pbase = beg + 24;
     const long long nfr = (long long)a.S * a.F;
+    // the first pass's non-trivial twiddles tw[4], tw[6] (wing 4) and tw[8..10], tw[12..14] (wing 8): uniform, scalar registers
+    double2 w1[8];
+    {
+        constexpr int idx[8] = {4, 6, 8, 9, 10, 12, 13, 14};
+#pragma unroll
+        for (int i = 0; i < 8; i++) w1[i] = acq_tw_s(tsg, idx[i]);
+    }
     // first-pass group q = brev(tid): its sixteen inputs are the frame's elements brev4(m) N/16 + tid -- coalesced loads
     int pre[16];
     float2 pref[16];
@@ -260,9 +375,29 @@ __global__ __launch_bounds__((1 << LOGN) / 16, 2) void k_acq_fwd(AcqArgs a)
                 pre[m] = a.raw[off + acq_brev<4>(m) * (N / 16)];
         }
     };
-    if ((long long)blockIdx.x < nfr) fetch(blockIdx.x);
+    // Frames are handed out in RUNS of a.run consecutive frames, a ticket each from one counter: with an equal share per workgroup
+    // (all 1024 resident from the start, two waves a SIMD) the workgroups of one launch ended between 3.3 and 5.0 ms -- a wave's
+    // pace depends on whom it shares its SIMD with -- and the launch took as long as the slowest.  The next run's ticket is taken in
+    // the current run's first frame (thread 0, handed round through LDS), so the request for the next frame's samples never waits
+    // for it.
+    const int K = a.run;
+    const long long nruns = (nfr + K - 1) / K;
+    int *tkL = reinterpret_cast<int *>(clkL + 8);  // [2]
+    if (tid == 0) tkL[0] = (int)atomicAdd(a.tickets + 0, 1u);
     acq_barrier<T>();
-    for (long long g = blockIdx.x; g < nfr; g += gridDim.x) {
+    long long r_next = tkL[0];
+    long long g = 0, gb = 0;
+    bool have = r_next < nruns;
+    if (have) {
+        g = r_next * K;
+        gb = g + K < nfr ? g + K : nfr;
+        fetch(g);
+    }
+    if (timing) tprev = (long long)clock64();
+    while (have) {
+        const bool first = (g % K) == 0;  // the first frame of a run: take the next run's ticket
+        unsigned tk = 0;
+        if (first && tid == 0) tk = atomicAdd(a.tickets + 0, 1u);
         // opaque per frame: nothing derived from the thread index is loop invariant, or LLVM hoists every address of every pass out
         // of the frame loop and spills them (the same trap as in k_front_fft)
         int tf = tid;
@@ -275,85 +410,90 @@ __global__ __launch_bounds__((1 << LOGN) / 16, 2) void k_acq_fwd(AcqArgs a)
                 if (F32IN) {
                     v[m] = make_double2((double)pref[m].x, (double)pref[m].y);
                 } else {
-                    const int w = pre[m];
-                    v[m] = make_double2((double)i16_to_float_java(java_short_add((int)(short)(w & 0xffff), a.ic)),
-                                        (double)i16_to_float_java(java_short_add(w >> 16, a.qc)));
+                    double di, dq;
+                    fm_convert(pre[m], a.ic, a.qc, true, di, dq);  // both rails on the packed FP32 pipe (common.h)
+                    v[m] = make_double2(di, dq);
                 }
             }
-            if (g + gridDim.x < nfr) fetch(g + gridDim.x);  // the next frame's samples are in flight during this one's passes
             if (F32IN)
                 acq_stages<4, 1, false, true>(v, 0, TsL, tsg);
             else
-                acq_first4_i16(v, tsg);
+                acq_first4_i16(v, w1);
             const int q1f = acq_brev<LOGN - 4>(tf);
             const int key = acq_key(q1f);
 #pragma unroll
             for (int m = 0; m < 16; m++) X[16 * q1f + (m ^ key)] = v[m];
         }
         acq_barrier<T>();
+        ACQ_PHASE(0)
+        // The last pass's twiddles (wings >= 256: no room in LDS) are requested HERE, a whole pass ahead of their use and ahead of
+        // the next frame's samples: VMEM operations return in order on this part, so a wait for a twiddle requested after the
+        // samples would be a wait for the samples (a round trip to HBM at two waves a SIMD).
+        double2 twl[NGL][ML - 1];
+#pragma unroll
+        for (int it = 0; it < NGL; it++) acq_load_tw<GL, HL>(twl[it], tf + T * it, tsg);
+        __builtin_amdgcn_sched_barrier(0);
         acq_mid_pass<4, 16, false, LOGN>(X, TsL, tsg, tf);
+        if (first && tid == 0) tkL[1] = (int)tk;
         acq_barrier<T>();
+        ACQ_PHASE(1)
+        r_next = tkL[1];
+        const long long gn = g + 1 < gb ? g + 1 : (r_next < nruns ? r_next * K : g);  // the frame this workgroup takes next (or this one again)
         if constexpr (Plan::G4 != 0) {
             acq_mid_pass<Plan::G3, 256, false, LOGN>(X, TsL, tsg, tf);
             acq_barrier<T>();
         }
         // ---- last pass: wings HL .. N/2, group j holds x[j + HL m] and ends as the bins j + HL m.  Only the bins somebody reads
         // are formed in its last stage: the gather's reach (acq_spec_index) and |X| over [beg + 24, end - 24) (inside it).
+        // The next frame's samples are requested behind the frame's last request for a twiddle; from here to the next frame's first
+        // pass no wait for a global load is left.
         double2 o[NGL][ML];
-        {
 #pragma unroll
-            for (int it = 0; it < NGL; it++) {
-                const int j = tf + T * it;
+        for (int it = 0; it < NGL; it++) {
+            const int j = tf + T * it;
 #pragma unroll
-                for (int m = 0; m < ML; m++) o[it][m] = X[acq_slot_hm(j, HL * m)];
-            }
+            for (int m = 0; m < ML; m++) o[it][m] = X[acq_slot_hm(j, HL * m)];
         }
+        // (unconditional: under a branch the wait counts of everything behind it are the minimum over both paths, i.e. a wait for
+        //  a twiddle becomes a wait for these samples again; the workgroup's last frame requests itself once more)
+        fetch(gn);
+        __builtin_amdgcn_sched_barrier(0);
         acq_barrier<T>();  // the image is dead: |X| goes over it
+        ACQ_PHASE(2)
         double2 *specg = a.spec + g * a.nsb;
 #pragma unroll
         for (int it = 0; it < NGL; it++) {
             const int j = tf + T * it;
-            if constexpr (GL >= 2) {
-                // all but the last stage in full
-                double2 h0[ML / 2], h1[ML / 2];
-#pragma unroll
-                for (int m = 0; m < ML / 2; m++) {
-                    h0[m] = o[it][m];
-                    h1[m] = o[it][m + ML / 2];
-                }
-                // (the two halves are the sub-groups x[j + HL m], m < ML/2 and m >= ML/2: wings HL .. N/4 never cross them)
-                acq_stages<GL - 1, HL, false, false>(h0, j, TsL, tsg);
-                acq_stages<GL - 1, HL, false, false>(h1, j, TsL, tsg);
-#pragma unroll
-                for (int m = 0; m < ML / 2; m++) {
-                    o[it][m] = h0[m];
-                    o[it][m + ML / 2] = h1[m];
-                }
-            }
+            acq_stages_w<GL, 0, GL - 1, false>(o[it], twl[it]);  // all but the last stage in full
             // last stage, wing N/2: bins ba = j + HL m and bb = ba + N/2
 #pragma unroll
             for (int m = 0; m < ML / 2; m++) {
                 const int ba = j + HL * m, bb = ba + N / 2;
                 const int ia = acq_spec_index(ba, N, a.do_up), ib = acq_spec_index(bb, N, a.do_up);
                 if (ia < 0 && ib < 0) continue;
-                const double2 wv = tsg[(unsigned)(N / 2 - 1 + ba)];
+                const double2 wv = twl[it][ML / 2 - 1 + m];
                 const double2 aq = o[it][m], bq = o[it][m + ML / 2];
                 const double p1 = wv.x * bq.x, p2 = wv.y * bq.y, p3 = wv.x * bq.y, p4 = wv.y * bq.x;
                 const double tr = p1 - p2;
                 const double ti = p3 + p4;
                 if (ia >= 0) {
                     const double2 r = make_double2(aq.x + tr, aq.y + ti);
+#ifndef JSDR_X_ACQ_NOSPEC  // (timing probe only: the spectrum rows not stored)
                     specg[ia] = r;
+#endif
                     if (ba >= pbase && ba < end - 24) P[ba - pbase] = sqrt(r.x * r.x + r.y * r.y);  // :425-427
                 }
                 if (ib >= 0) {
                     const double2 r = make_double2(aq.x - tr, aq.y - ti);
+#ifndef JSDR_X_ACQ_NOSPEC
                     specg[ib] = r;
+#endif
                     if (bb >= pbase && bb < end - 24) P[bb - pbase] = sqrt(r.x * r.x + r.y * r.y);
                 }
             }
         }
         acq_barrier<T>();
+        ACQ_PHASE(3)
         // ---- 100-wide boxcar, summed j ascending for every i (:433-437); first maximum (:439-442).  A thread owns RB consecutive
         // outputs i0 .. i0 + RB - 1: their windows P[i - 50 .. i + 49] are one run of 99 + RB values, each output its own
         // ascending chain.
@@ -361,7 +501,11 @@ __global__ __launch_bounds__((1 << LOGN) / 16, 2) void k_acq_fwd(AcqArgs a)
         int besti = -1;
         {
             const int i0 = beg + 75 + RB * tf;
+#ifdef JSDR_X_ACQ_NOBOX  // (timing probe only: no boxcar)
+            if (false) {
+#else
             if (i0 < end - 75) {
+#endif
                 const double *w = P + (i0 - 50 - pbase);
                 double acc[RB];
                 constexpr int NV = 99 + RB, CH = 8, NCH = (NV + CH - 1) / CH;
@@ -404,21 +548,25 @@ __global__ __launch_bounds__((1 << LOGN) / 16, 2) void k_acq_fwd(AcqArgs a)
                 }
             }
         }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            const double ov = __shfl_xor(bestv, off, 64);
-            const int oi = __shfl_xor(besti, off, 64);
-            if (oi >= 0 && (ov > bestv || (ov == bestv && (besti < 0 || oi < besti)))) {
-                bestv = ov;
-                besti = oi;
+        ACQ_PHASE(4)
+        // the wave's first maximum: the largest value (sums of |X| are never negative), and of the lanes that hold it the
+        // lowest -- outputs ascend with the lane, and a lane kept the first of its own
+        {
+            const double mv = acq_wave_max(bestv);
+            int mi = -1;
+            if (mv > 0.0) {
+                const unsigned long long bal = __ballot(bestv == mv && besti >= 0);
+                mi = __builtin_amdgcn_readlane(besti, (int)__builtin_ctzll(bal));
             }
+            bestv = mv;
+            besti = mi;
         }
         if constexpr (T > 64) {
             if (lane == 0) {
                 redv[wave] = bestv;
                 redi[wave] = besti;
             }
-            __syncthreads();
+            acq_barrier<T>();
             if (tid == 0) {
                 double mv = 0.0;
                 int mi = -1;
@@ -440,13 +588,28 @@ __global__ __launch_bounds__((1 << LOGN) / 16, 2) void k_acq_fwd(AcqArgs a)
         } else {
             if (tid == 0) {
                 AcqPeak pk;
-                pk.maxBin = bestv;
+                pk.maxBin = besti >= 0 ? bestv : 0.0;
                 pk.binPos = besti;
                 pk.pad = 0;
                 a.peak[g] = pk;
             }
             acq_barrier<T>();  // P is read before the next frame's first pass stores over it
         }
+        ACQ_PHASE(5)
+        if (g + 1 < gb) {
+            g++;
+        } else if (r_next < nruns) {
+            g = r_next * K;
+            gb = g + K < nfr ? g + K : nfr;
+        } else {
+            have = false;
+        }
+    }
+    if (timing)
+        for (int k = 0; k < 8; k++) a.clk[k] = clkL[k];
+    if (a.clk != nullptr && threadIdx.x == 0 && blockIdx.x < 4096) {  // every workgroup's first and last tick (residency / balance)
+        a.clk[16 + 2 * blockIdx.x] = wg_t0;
+        a.clk[16 + 2 * blockIdx.x + 1] = (long long)__builtin_amdgcn_s_memrealtime();
     }
 }
 
@@ -524,71 +687,137 @@ __global__ __launch_bounds__((1 << LOGN) / 16, 2) void k_acq_inv(AcqArgs a)
     using Plan = AcqPlan<LOGN>;
     constexpr int GL = Plan::GL, ML = 1 << GL, NGL = 16 >> GL, HL = N >> GL;
     constexpr int JB = (N / 4 + 1 + T - 1) / T;  // RxDownSample outputs per thread and frame (decimation >= 4)
+    constexpr int NB = (204 + T - 1) / T;        // gathered bins a thread brings in
     extern __shared__ __align__(16) unsigned char smem[];
     double2 *X = reinterpret_cast<double2 *>(smem);  // [N] the image; afterwards the compact real samples
     double2 *TsL = X + N;                            // [ACQ_TWL]
     double2 *B = TsL + ACQ_TWL;                      // [204] the gathered bins (everything behind them is zero, :414-415)
+    long long *clkL = reinterpret_cast<long long *>(B + 204);  // [8]
+    int *negzL = reinterpret_cast<int *>(clkL + 8);            // [2] a gathered bin of the frame holds a -0.0 (by frame parity)
+    const bool timing = a.clk != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
+    long long tprev = 0;
+    if (timing) {
+        for (int k = 0; k < 8; k++) clkL[k] = 0;
+        tprev = (long long)clock64();
+    }
     const double2 *__restrict__ tsg = a.tw;
     const int tid = threadIdx.x;
     for (int i = tid; i < ACQ_TWL - 1; i += T) TsL[i] = tsg[i];
+    if (tid < 2) negzL[tid] = 0;
     const int D = a.decim;
     const double norm = 1.0 / (double)N;
     const double HOWARD = 0.9 * 32768.0;
     const long long nfr = (long long)a.S * a.F;
     const int lo1 = a.do_up ? N / 4 - 26 : 0;
-    for (long long g = blockIdx.x; g < nfr; g += gridDim.x) {
+    // in registers for the whole launch: the wing-8 twiddle of this thread's slot of a first-pass group, negated for the slots
+    // 8 .. 15 (v0 - w v8 = v0 + (-w) v8, product for product)
+    double wr8, wi8;
+    {
+        const double2 wq = tsg[7 + (tid & 7)];
+        wr8 = (tid & 8) ? -wq.x : wq.x;
+        wi8 = (tid & 8) ? wq.y : -wq.y;  // (the inverse conjugates: wi = -wq.y)
+    }
+    // where the frame's 204 bins sit in phase A's row: rows hold bins [0, n/4 + 28) (lower band) or [0, 204) + [n/4 - 26, n/2 + 28)
+    // (upper band): every centre bin the rule can produce (102, or binPos + 1 with binPos in [beg + 75, end - 75)) gathers inside them
+    auto row_off = [&](int c) {
+        int off = c - 102;
+        if (a.do_up) off = (c == 102) ? 0 : 204 + (c - 102 - lo1);
+        if (off < 0) off = 0;
+        if (off + 204 > a.nsb) off = a.nsb - 204;
+        return off;
+    };
+    // one frame ahead: the centre bin, then the bins
+    double2 bins[NB];
+    int c_next = 0;
+    auto fetch_bins = [&](long long g, int c) {
+        const double2 *src = a.spec + g * a.nsb + row_off(c);
+#pragma unroll
+        for (int i = 0; i < NB; i++) {
+            const int k = tid + T * i;
+            bins[i] = k < 204 ? src[k] : make_double2(0.0, 0.0);
+        }
+    };
+    // frames in runs of a.run, a ticket each (see k_acq_fwd); the next run's ticket is known from the run's first frame on, the next
+    // frame's centre bin is requested at the top of a frame (a run has at least two frames)
+    const int K = a.run;
+    const long long nruns = (nfr + K - 1) / K;
+    int *tkL = negzL + 2;  // [2]
+    if (tid == 0) tkL[0] = (int)atomicAdd(a.tickets + 1, 1u);
+    acq_barrier<T>();
+    long long r_next = tkL[0];
+    long long g = 0, gb = 0;
+    bool have = r_next < nruns;
+    if (have) {
+        g = r_next * K;
+        gb = g + K < nfr ? g + K : nfr;
+        fetch_bins(g, a.cbin[g]);
+    }
+    r_next = nruns;  // (unknown until the run's first frame has fetched it)
+    int par = 0;
+    for (; have; par ^= 1) {
+        const bool first = (g % K) == 0;
+        unsigned tk = 0;
+        if (first && tid == 0) tk = atomicAdd(a.tickets + 1, 1u);
         int tf = tid;  // opaque per frame (see k_acq_fwd)
         asm volatile("" : "+v"(tf));
         const int s = (int)(g / a.F), f = (int)(g - (long long)s * a.F);
         const long long t0 = (long long)(a.f0 + f) * N;  // call-relative index of the frame's first sample
-        // VCO factors of this frame's first round of outputs: in flight during the transform
-        long long jlo = (t0 - a.first_out + D - 1) / D;
-        if (t0 <= a.first_out) jlo = 0;
-        double2 cs0 = make_double2(0.0, 0.0);
-        {
-            const long long j = jlo + tf;
-            const long long te = (long long)a.first_out + (long long)D * j;
-            if (te < t0 + N && j < a.nds) cs0 = a.vco_cs[j];
-        }
         // ---- the 204 bins around the centre to bin 0 of a zeroed array (:458)
         {
-            const int c = a.cbin[g];
-            // phase A's rows hold bins [0, n/4 + 28) (lower band) or [0, 204) + [n/4 - 26, n/2 + 28) (upper band): every
-            // centre bin the rule can produce (102, or binPos + 1 with binPos in [beg + 75, end - 75)) gathers inside them
-            int off = c - 102;
-            if (a.do_up) off = (c == 102) ? 0 : 204 + (c - 102 - lo1);
-            if (off < 0) off = 0;
-            if (off + 204 > a.nsb) off = a.nsb - 204;
-            const double2 *src = a.spec + g * a.nsb + off;
-            for (int k = tf; k < 204; k += T) B[k] = src[k];
+            bool nz = false;
+            const long long NEGZ = (long long)0x8000000000000000ull;
+#pragma unroll
+            for (int i = 0; i < NB; i++) {
+                const int k = tf + T * i;
+                if (k < 204) {
+                    B[k] = bins[i];
+                    nz = nz || __double_as_longlong(bins[i].x) == NEGZ || __double_as_longlong(bins[i].y) == NEGZ;
+                }
+            }
+            if (nz) negzL[par] = 1;
         }
+        // the VCO factors of this frame's outputs and the next frame's centre bin: in flight during the transform
+        long long jlo = (t0 - a.first_out + D - 1) / D;
+        if (t0 <= a.first_out) jlo = 0;
+        double2 cs[JB];
+#pragma unroll
+        for (int b = 0; b < JB; b++) {
+            const long long j = jlo + tf + T * b;
+            const long long te = (long long)a.first_out + (long long)D * j;
+            cs[b] = (te < t0 + N && j < a.nds) ? a.vco_cs[j] : make_double2(0.0, 0.0);
+        }
+        // (unconditional requests: see k_acq_fwd; in a run's first frame the next frame is the run's second)
+        const long long gn = g + 1 < gb ? g + 1 : (!first && r_next < nruns ? r_next * K : g);
+        c_next = a.cbin[gn];
         acq_barrier<T>();
+        ACQ_PHASE(0)
         // ---- inverse transform (:459).  Slot 16 q + m of the bit-reversed array holds input brev4(m) N/16 + brev(q): below 204 only
         // for m = 0 (N >= 2048; and m = 8 at N = 2048), so the first three stages of a group are broadcasts of its slots 0 and 8
         // -- a butterfly whose second operand is +0 returns its first operand twice, unless that holds a -0.0 (IEEE: (-0) + (+0) =
-        // +0): such a group takes the four stages in full -- and stage four is out[j'] = v0 + w v8, out[j' + 8] = v0 - w v8.  The
-        // second pass (wings 16 .. 128) needs slot j of sixteen groups: it forms them itself from the bins, no LDS round trip.
+        // +0): a frame with such a bin takes the four stages in full -- and stage four is out[j'] = v0 + w v8, out[j' + 8] = v0 - w v8.
+        // The second pass (wings 16 .. 128) needs slot j of sixteen groups: it forms them itself from the bins, no LDS round trip.
         if constexpr (LOGN >= 11) {
             const int j = tf & 15, hi = tf >> 4;
-            const double2 wq = tsg[7 + (j & 7)];
-            const double wr = wq.x, wi = -wq.y;
             double2 x[16];
-            bool negz = false;
-            const long long NEGZ = (long long)0x8000000000000000ull;
+            if (negzL[par] == 0) {
 #pragma unroll
-            for (int m = 0; m < 16; m++) {
-                const int k0 = acq_brev<LOGN - 4>(16 * hi + m);
-                const double2 v0 = k0 < 204 ? B[k0] : make_double2(0.0, 0.0);
-                const double2 v8 = (N / 16 + k0 < 204) ? B[N / 16 + k0] : make_double2(0.0, 0.0);
-                negz = negz || __double_as_longlong(v0.x) == NEGZ || __double_as_longlong(v0.y) == NEGZ ||
-                       __double_as_longlong(v8.x) == NEGZ || __double_as_longlong(v8.y) == NEGZ;
-                const double p1 = wr * v8.x, p2 = wi * v8.y, p3 = wr * v8.y, p4 = wi * v8.x;
-                const double tr = p1 - p2;
-                const double ti = p3 + p4;
-                x[m] = (j < 8) ? make_double2(v0.x + tr, v0.y + ti) : make_double2(v0.x - tr, v0.y - ti);
-            }
-            if (negz) {
-                // a bin with a -0.0 component somewhere in this thread's sixteen groups: those groups in full (one body, not sixteen)
+                for (int m = 0; m < 16; m++) {
+                    const int k0 = acq_brev<LOGN - 4>(16 * hi + m);
+                    const double2 v0 = k0 < 204 ? B[k0] : make_double2(0.0, 0.0);
+                    x[m] = v0;
+                    // (a structurally zero v8 leaves v0 as it is: v0 + (+-0) = v0 for every v0 that is not -0.0)
+                    if (LOGN == 11 && acq_brev<4>(m) * 8 < 76) {  // compile time: 128 + k0 < 204 is possible
+                        if (N / 16 + k0 < 204) {
+                            const double2 v8 = B[N / 16 + k0];
+                            const double p1 = wr8 * v8.x, p2 = wi8 * v8.y, p3 = wr8 * v8.y, p4 = wi8 * v8.x;
+                            const double tr = p1 - p2;
+                            const double ti = p3 + p4;
+                            x[m] = make_double2(v0.x + tr, v0.y + ti);
+                        }
+                    }
+                }
+            } else {
+                // a bin with a -0.0 component: every group in full (one body, not sixteen)
 #pragma unroll 1
                 for (int m = 0; m < 16; m++) {
                     const int k0 = acq_brev<LOGN - 4>(16 * hi + m);
@@ -627,11 +856,22 @@ __global__ __launch_bounds__((1 << LOGN) / 16, 2) void k_acq_inv(AcqArgs a)
             acq_barrier<T>();
             acq_mid_pass<4, 16, true, LOGN>(X, TsL, tsg, tf);
         }
+        if (first && tid == 0) tkL[1] = (int)tk;
         acq_barrier<T>();
+        ACQ_PHASE(1)
+        if (tf == 0) negzL[par] = 0;  // (read by everybody before the barrier above; set again two frames on at the earliest)
         if constexpr (Plan::G4 != 0) {
             acq_mid_pass<Plan::G3, 256, true, LOGN>(X, TsL, tsg, tf);
             acq_barrier<T>();
         }
+        // the last pass's twiddles first, the next frame's bins (its centre bin arrived during the passes above) behind them: in-order
+        // returns, see k_acq_fwd (a pass earlier they cost the fused pass its registers)
+        double2 twl[NGL][ML - 1];
+#pragma unroll
+        for (int it = 0; it < NGL; it++) acq_load_tw<GL, HL>(twl[it], tf + T * it, tsg);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch_bins(gn, c_next);
+        __builtin_amdgcn_sched_barrier(0);
         // ---- last pass: RxDownSample reads nothing but re / n (:461-463) -- the imaginary halves of the last stage have no reader
         double o[NGL][ML];
 #pragma unroll
@@ -640,11 +880,12 @@ __global__ __launch_bounds__((1 << LOGN) / 16, 2) void k_acq_inv(AcqArgs a)
             double2 v[ML];
 #pragma unroll
             for (int m = 0; m < ML; m++) v[m] = X[acq_slot_hm(j, HL * m)];
-            acq_stages<GL, HL, true, false>(v, j, TsL, tsg);
+            acq_stages_w<GL, 0, GL, true>(v, twl[it]);
 #pragma unroll
             for (int m = 0; m < ML; m++) o[it][m] = v[m].x * norm;
         }
         acq_barrier<T>();  // every butterfly of the pass is in registers: the compact samples go over the image
+        ACQ_PHASE(2)
         double *Rb = reinterpret_cast<double *>(smem);
 #pragma unroll
         for (int it = 0; it < NGL; it++) {
@@ -653,6 +894,7 @@ __global__ __launch_bounds__((1 << LOGN) / 16, 2) void k_acq_inv(AcqArgs a)
             for (int m = 0; m < ML; m++) Rb[ACQ_RB0 + j + HL * m] = o[it][m];
         }
         acq_barrier<T>();
+        ACQ_PHASE(3)
         // ---- the frame's first and last 26 samples for the windows that cross into / out of it (k_acq_edges)
         if (tf < 26) {
             double *eg = a.edges + g * 52;
@@ -662,7 +904,7 @@ __global__ __launch_bounds__((1 << LOGN) / 16, 2) void k_acq_inv(AcqArgs a)
         // ---- RxDownSample(re, re) (:461-463, :470-492) for the outputs whose 27-sample window lies inside this frame
         {
             const bool even_d = (D & 1) == 0;  // then every window of the call ends on the same parity (N is even)
-            const int par = (int)((a.first_out - t0) & 1);
+            const int wpar = (int)((a.first_out - t0) & 1);
 #pragma unroll
             for (int b = 0; b < JB; b++) {
                 const long long j = jlo + tf + T * b;
@@ -681,7 +923,7 @@ __global__ __launch_bounds__((1 << LOGN) / 16, 2) void k_acq_inv(AcqArgs a)
                                 d[2 * i] = t.x;
                                 d[2 * i + 1] = t.y;
                             }
-                            if (par) {
+                            if (wpar) {
 #pragma unroll
                                 for (int k = 0; k < 27; k++) fi += d[27 - k] * ds_tap(k);  // newest first (:479-483)
                             } else {
@@ -694,14 +936,25 @@ __global__ __launch_bounds__((1 << LOGN) / 16, 2) void k_acq_inv(AcqArgs a)
                             for (int k = 0; k < 27; k++) fi += w[-k] * ds_tap(k);
                         }
                         const double ov = fi * HOWARD;  // fi == fq: both rails get the same samples
-                        const double2 cs = (b == 0) ? cs0 : a.vco_cs[j];
-                        a.dm[(long long)s * a.dm_stride + 64 + j] = make_double2(ov * cs.x, ov * cs.y);  // :515-516
+                        a.dm[(long long)s * a.dm_stride + 64 + j] = make_double2(ov * cs[b].x, ov * cs[b].y);  // :515-516
                     }
                 }
             }
         }
         acq_barrier<T>();  // every window is read before the next frame's passes store over the image
+        ACQ_PHASE(4)
+        r_next = tkL[1];
+        if (g + 1 < gb) {
+            g++;
+        } else if (gn != g) {  // (a run of ONE frame -- the launch's last -- whose successor was not known at its top ends the workgroup's
+            g = gn;            //  share only if no run was left; otherwise gn named the next run's first frame)
+            gb = g + K < nfr ? g + K : nfr;
+        } else {
+            have = false;
+        }
     }
+    if (timing)
+        for (int k = 0; k < 8; k++) a.clk[8 + k] = clkL[k];
 }
 
 // ============================================================================================================= edges
@@ -773,8 +1026,8 @@ template <int LOGN>
 static int launch_acq3_t(AcqArgs &a, bool f32, int num_cu, hipStream_t st, const AcqProf &prof)
 {
     constexpr int N = 1 << LOGN, T = N / 16;
-    constexpr size_t lds_fwd = sizeof(double2) * ((size_t)N + ACQ_TWL) + 8 * sizeof(double) + 8 * sizeof(int);
-    constexpr size_t lds_inv = sizeof(double2) * ((size_t)N + ACQ_TWL + 204);
+    constexpr size_t lds_fwd = sizeof(double2) * ((size_t)N + ACQ_TWL) + 8 * sizeof(double) + 8 * sizeof(int) + 8 * sizeof(long long) + 16;
+    constexpr size_t lds_inv = sizeof(double2) * ((size_t)N + ACQ_TWL + 204) + 8 * sizeof(long long) + 32;
     const long long nfr = (long long)a.S * a.F;
     int per_cu_f = 1, per_cu_i = 1;
     if (f32) {
@@ -788,6 +1041,10 @@ static int launch_acq3_t(AcqArgs &a, bool f32, int num_cu, hipStream_t st, const
     JSDR_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_i, k_acq_inv<LOGN>, T, lds_inv));
     if (per_cu_f < 1) per_cu_f = 1;
     if (per_cu_i < 1) per_cu_i = 1;
+#ifdef JSDR_X_ACQ_WGS  // (timing probe: fewer workgroups a CU)
+    if (per_cu_f > JSDR_X_ACQ_WGS) per_cu_f = JSDR_X_ACQ_WGS;
+    if (per_cu_i > JSDR_X_ACQ_WGS) per_cu_i = JSDR_X_ACQ_WGS;
+#endif
     long long gf = (long long)per_cu_f * num_cu, gi = (long long)per_cu_i * num_cu;
     if (gf > nfr) gf = nfr;
     if (gi > nfr) gi = nfr;
@@ -798,6 +1055,7 @@ static int launch_acq3_t(AcqArgs &a, bool f32, int num_cu, hipStream_t st, const
     auto mark = [&](int phase, bool begin) {
         if (prof.mark) prof.mark(prof.ctx, phase, begin, st);
     };
+    JSDR_HIP_TRY(hipMemsetAsync(a.tickets, 0, 2 * sizeof(unsigned), st));  // the run counters of the two frame-parallel kernels
     mark(0, true);
     if (f32)
         hipLaunchKernelGGL((k_acq_fwd<LOGN, true>), dim3((unsigned)gf), dim3(T), lds_fwd, st, a);
@@ -831,7 +1089,7 @@ int launch_acq3(const FftFrontArgs &fa, int nstreams, unsigned char *scratch, si
     acq3_layout(fa.n, fa.do_up, &nsb, &na);
     if (chunk_frames < 1) chunk_frames = 1;
     const size_t nf = (size_t)nstreams * (size_t)chunk_frames;
-    JSDR_REQUIRE(nf * acq3_frame_bytes(fa.n, fa.do_up) <= scratch_bytes, "bpsk: FFT-acquire scratch too small (%zu frames)", nf);
+    JSDR_REQUIRE(nf * acq3_frame_bytes(fa.n, fa.do_up) + 256 <= scratch_bytes, "bpsk: FFT-acquire scratch too small (%zu frames)", nf);
     AcqArgs a;
     a.raw = fa.raw;
     a.rawf = fa.rawf;
@@ -861,7 +1119,12 @@ int launch_acq3(const FftFrontArgs &fa, int nstreams, unsigned char *scratch, si
     a.edges = reinterpret_cast<double *>(p);
     p += sizeof(double) * 52 * nf;
     a.cbin = reinterpret_cast<int *>(p);
+    p += ((sizeof(int) * nf + 63) & ~(size_t)63);
+    a.tickets = reinterpret_cast<unsigned *>(p);
+    a.run = 4;
+    if (const char *e = knob("JSDR_ACQ_RUN")) a.run = atoi(e) >= 2 ? atoi(e) : 4;
     a.nwg = 0;
+    a.clk = fa.phase_clk;
     for (int f0 = 0; f0 < fa.nframes; f0 += chunk_frames) {
         a.f0 = f0;
         a.F = fa.nframes - f0 < chunk_frames ? fa.nframes - f0 : chunk_frames;

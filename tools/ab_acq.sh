@@ -12,7 +12,7 @@ import json, sys
 for l in open(f"gpurun_out/ab_{sys.argv[1]}.log"):
     if l.startswith("{"):
         d = json.loads(l); k = d["roofline"]["kernels_ms_per_step"]
-        print(sys.argv[1], "step", d["ms_per_step"], {a: b for a, b in k.items() if a.startswith("k_front")})
+        print(sys.argv[1], "step", d["ms_per_step"], {a: b for a, b in k.items() if a.startswith("k_front") or a.startswith("k_acq")})
 PY
 done
 done
