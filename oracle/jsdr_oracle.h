@@ -123,6 +123,12 @@ void jo_bpsk_fft_probe_enable(jo_bpsk_t *d, int64_t cap_frames);
 int64_t jo_bpsk_fft_probe(const jo_bpsk_t *d, double *out, int64_t cap_frames);
 void jo_bpsk_fft_perturb(jo_bpsk_t *d, double scale, uint64_t seed);
 void jo_bpsk_decision_margins(const jo_bpsk_t *d, double *out /* [8] */);
+/* round 6 instruments: other sin / cos tables (entries perturbed by an ulp: Math.sin / Math.cos are specified to 1 ulp only,
+ * FUNcubeBPSKDemod.java:159-162), and a log of what RxDemodulate decides on -- which 0: per detector instant {di, energy2}
+ * (:539-544), which 1: per bit clock {dmEnergy[dmNewPeak] - runner-up, dmNewPeak} (:586-592); returns the count */
+void jo_bpsk_set_sincos(jo_bpsk_t *d, const double sin_tab[256], const double cos_tab[256]);
+void jo_bpsk_declog_enable(jo_bpsk_t *d, int64_t cap);
+int64_t jo_bpsk_declog(const jo_bpsk_t *d, int which, double *out, int64_t cap);
 int64_t jo_bpsk_trace(const jo_bpsk_t *d, double *out, int64_t cap_pairs);
 /* optional trace of down-sampler outputs (after x HOWARD_FUDGE_FACTOR)           */
 int64_t jo_bpsk_trace_ds(const jo_bpsk_t *d, double *out, int64_t cap_pairs);

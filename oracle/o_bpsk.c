@@ -168,6 +168,10 @@ struct jo_bpsk {
     int64_t dec_count[3];
     double errE[SPB + 2];
     uint64_t dec_hash[2];   /* rolling hashes of the energy2 > 100 outcomes and of the dmNewPeak sequence */
+    /* round 6: a plain log of the quantities RxDemodulate decides on (both modes; instruments only): per detector instant
+     * {di, energy2}, per bit clock {dmEnergy[dmNewPeak] - runner-up, dmNewPeak} -- for the table-perturbation measurement */
+    double *dlog_det, *dlog_peak;
+    int64_t ndet, npeak, capdlog;
 };
 
 jo_bpsk_t *jo_bpsk_new(int rate, int blen, int size, int tuning, int do_fft, int do_up)
@@ -197,6 +201,8 @@ void jo_bpsk_free(jo_bpsk_t *d)
     free(d->trace);
     free(d->trace_ds);
     free(d->probe);
+    free(d->dlog_det);
+    free(d->dlog_peak);
     free(d);
 }
 
@@ -272,6 +278,11 @@ static void RxDemodulate(jo_bpsk_t *d, double i, double q)
         d->dmLastIQ[0] = fi;
         d->dmLastIQ[1] = fq;
         d->energy2 = sqrt(di * di + dq * dq);
+        if (d->dlog_det && d->ndet < d->capdlog) {
+            d->dlog_det[2 * d->ndet] = di;
+            d->dlog_det[2 * d->ndet + 1] = d->energy2;
+            d->ndet++;
+        }
         if (d->probe) {
             d->dec_hash[0] = (d->dec_hash[0] * 0x100000001b3ull) ^ (uint64_t)(d->energy2 > 100.0);
             if (err_d > 0.0) {
@@ -319,6 +330,14 @@ static void RxDemodulate(jo_bpsk_t *d, double i, double q)
                 d->dmNewPeak = n;
                 eMax = d->dmEnergy[n];
             }
+        }
+        if (d->dlog_peak && d->npeak < d->capdlog) {
+            int second = -1;
+            for (int n = 0; n < SPB; n++)
+                if (n != d->dmNewPeak && (second < 0 || d->dmEnergy[n] > d->dmEnergy[second])) second = n;
+            d->dlog_peak[2 * d->npeak] = d->dmEnergy[d->dmNewPeak] - d->dmEnergy[second];
+            d->dlog_peak[2 * d->npeak + 1] = (double)d->dmNewPeak;
+            d->npeak++;
         }
         if (d->probe) {
             d->dec_hash[1] = (d->dec_hash[1] * 0x100000001b3ull) ^ (uint64_t)d->dmNewPeak;
@@ -560,6 +579,32 @@ void jo_bpsk_decision_margins(const jo_bpsk_t *d, double *out)
     }
     out[6] = (double)(d->dec_hash[0] >> 11);
     out[7] = (double)(d->dec_hash[1] >> 11);
+}
+
+/* round 6 instruments: replace the sin / cos tables (to perturb their entries by an ulp), log what RxDemodulate decides on */
+void jo_bpsk_set_sincos(jo_bpsk_t *d, const double sin_tab[256], const double cos_tab[256])
+{
+    memcpy(d->sinTab, sin_tab, sizeof(d->sinTab));
+    memcpy(d->cosTab, cos_tab, sizeof(d->cosTab));
+}
+
+void jo_bpsk_declog_enable(jo_bpsk_t *d, int64_t cap)
+{
+    free(d->dlog_det);
+    free(d->dlog_peak);
+    d->dlog_det = (double *)calloc((size_t)cap * 2, sizeof(double));
+    d->dlog_peak = (double *)calloc((size_t)cap * 2, sizeof(double));
+    d->capdlog = cap;
+    d->ndet = d->npeak = 0;
+}
+
+int64_t jo_bpsk_declog(const jo_bpsk_t *d, int which, double *out, int64_t cap)
+{
+    const int64_t n = which == 0 ? d->ndet : d->npeak;
+    const double *src = which == 0 ? d->dlog_det : d->dlog_peak;
+    const int64_t m = n < cap ? n : cap;
+    if (out && src && m > 0) memcpy(out, src, sizeof(double) * 2 * (size_t)m);
+    return n;
 }
 
 void jo_bpsk_fft_perturb(jo_bpsk_t *d, double scale, uint64_t seed)

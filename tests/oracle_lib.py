@@ -398,6 +398,29 @@ class Bpsk:
         return dict(di=out[0], energy2=out[1], argmax=out[2], n_di=int(out[3]), n_energy2=int(out[4]), n_argmax=int(out[5]),
                     hash_energy2=int(out[6]), hash_peak=int(out[7]))
 
+    def set_sincos(self, sin_tab, cos_tab):
+        """instrument: other sin / cos tables (round 6: entries perturbed by an ulp)"""
+        st = np.ascontiguousarray(sin_tab, np.float64)
+        ct = np.ascontiguousarray(cos_tab, np.float64)
+        assert st.size == 256 and ct.size == 256
+        lib().jo_bpsk_set_sincos.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        lib().jo_bpsk_set_sincos.restype = None
+        lib().jo_bpsk_set_sincos(self.h, ptr(st), ptr(ct))
+
+    def declog_enable(self, cap):
+        lib().jo_bpsk_declog_enable.argtypes = [C.c_void_p, C.c_int64]
+        lib().jo_bpsk_declog_enable.restype = None
+        lib().jo_bpsk_declog_enable(self.h, int(cap))
+
+    def declog(self, which):
+        """which 0: [n, 2] (di, energy2) per detector instant; 1: [n, 2] (argmax gap, dmNewPeak) per bit clock"""
+        lib().jo_bpsk_declog.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64]
+        lib().jo_bpsk_declog.restype = C.c_int64
+        n = lib().jo_bpsk_declog(self.h, which, None, 0)
+        out = np.empty((max(n, 1), 2), np.float64)
+        lib().jo_bpsk_declog(self.h, which, ptr(out), n)
+        return out[:n]
+
     def fft_perturb(self, scale, seed):
         lib().jo_bpsk_fft_perturb.argtypes = [C.c_void_p, C.c_double, C.c_uint64]
         lib().jo_bpsk_fft_perturb(self.h, float(scale), int(seed))
