@@ -2469,6 +2469,7 @@ struct jsdr_bpsk {
     DevBuf<unsigned char> acq_scratch;
     int acq_chunk = 0;
     int acq_mode = -1;  // JSDR_ACQ3 (tests, A/B): 0 never, 1 whenever the frame size allows (also for one frame a call); -1: from two frames a call
+    int num_cu_known = 0;
     long long last_nds = 0;
     int last_y = 0;
     hipStream_t last_stream = 0;
@@ -3232,7 +3233,21 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
         xa.phase_clk = h->phase_clk.p;
         // round 6: frames of 2^k samples, two or more per stream in the call: three phases over FRAMES (bpsk_acq.hip); a call of
         // one frame per stream (a live receive()) keeps the fused kernel -- one launch instead of four
-        const bool three = !h->fft_2x && !h->fft_mixed && acq3_supported(h->nsf) && h->acq_mode != 0 && (xa.nframes >= 2 || h->acq_mode == 1);
+        // The 2^k frames' three-phase kernels are the faster ones per frame as well (n = 2048, 1024 x 2^20: 8.65 against 9.1 ms);
+        // the default mixed-radix frames' are the fused kernel's passes cut in two and cost 10-14 % more per frame at a full grid
+        // (9600: 12.6 against 11.5 ms; the spectrum rows' round trip, a ticket a frame) -- they are taken where frames fill the
+        // chip better than streams: ceil(S F / W) * 1.15 < ceil(S / W) * F, W = the workgroups the chip holds (one a CU).
+        bool three = !h->fft_2x && acq3_supported(h->nsf) && h->acq_mode != 0 && (xa.nframes >= 2 || h->acq_mode == 1);
+        if (three && h->fft_mixed && h->acq_mode < 0) {
+            if (h->num_cu_known == 0) {
+                int dev = 0, cus = 0;
+                JSDR_HIP_TRY(hipGetDevice(&dev));
+                JSDR_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+                h->num_cu_known = cus > 0 ? cus : 256;
+            }
+            const long long W = h->num_cu_known, F = xa.nframes;
+            three = (double)(((long long)S * F + W - 1) / W) * 1.15 < (double)((((long long)S + W - 1) / W) * F);
+        }
         if (three) {
             const size_t per = acq3_frame_bytes(h->nsf, h->do_up) + 64;
             if (!h->acq_scratch.p) {
@@ -3253,12 +3268,17 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
                 JSDR_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
                 h->num_cu = cus > 0 ? cus : 256;
             }
-            h->front_name = "k_acq_fwd";
+            h->front_name = h->fft_mixed ? "k_acqm_fwd" : "k_acq_fwd";
+            AcqmPlan plan;
+            plan.np = h->fm_np;
+            plan.rad = h->fm_rad;
+            plan.tw_off = h->fm_off;
+            plan.wr_off = h->fm_off1;
             AcqProfCtx pc{h, {nullptr, nullptr, nullptr, nullptr}};
             AcqProf prof;
             prof.ctx = &pc;
             prof.mark = acq_prof_mark;
-            if (launch_acq3(xa, S, h->acq_scratch.p, h->acq_scratch.n, h->acq_chunk, h->num_cu, st, prof) != JSDR_OK) return JSDR_ERR;
+            if (launch_acq3(xa, S, h->acq_scratch.p, h->acq_scratch.n, h->acq_chunk, h->num_cu, st, prof, plan) != JSDR_OK) return JSDR_ERR;
         } else {
         ProfScope ps(h, PK_FRONT, st);
         h->front_name = h->fft_2x ? "k_front_fft2x" : (h->fft_mixed ? "k_front_fftm" : "k_front_fft");

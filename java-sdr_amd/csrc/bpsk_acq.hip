@@ -201,56 +201,6 @@ struct AcqPlan {
     static constexpr int GL = G4 ? G4 : G3;               // the last pass's stages
 };
 
-// what the phases hand each other, per frame id g = s * F + f (F = frames per stream in this launch)
-struct AcqPeak {
-    double maxBin;
-    int binPos;
-    int pad;
-};
-
-struct AcqArgs {
-    const int *raw;        // int16 pairs [S][stride]
-    const float2 *rawf;    // or float frames
-    long long stride_pairs;
-    int ic, qc;
-    int S, F, f0;          // streams, frames per stream in this launch, index of its first frame within the call
-    int n, do_up, decim;
-    long long first_out, nds;
-    const double2 *vco_cs;
-    const double2 *tw;
-    FftFrontState *st;
-    double2 *dm;
-    long long dm_stride;
-    double2 *spec;         // [S F][nsb]: do_up ? bins [0, 204) then [n/4 - 26, n/2 + 28) : bins [0, n/4 + 28)
-    int nsb;
-    double *aband;         // [S F][na]: boxcar sums over [beg + 75, end - 75)
-    int na;
-    AcqPeak *peak;         // [S F]
-    int *cbin;             // [S F] the frame's centre bin (phase B)
-    double *edges;         // [S F][52]: the frame's first 26 and last 26 real samples re / n (phase C)
-    int nwg;               // persistent workgroups of phases A and C
-    unsigned *tickets;     // [2] run counters of k_acq_fwd / k_acq_inv, zero at launch: a workgroup takes its frames in runs of `run`
-    int run;               // consecutive frames per ticket (>= 2)
-    long long *clk;        // diagnostics (JSDR_FFT_PHASECLK=1): [16] clock ticks per phase of workgroup 0, k_acq_fwd [0..7], k_acq_inv [8..15]; or null
-};
-
-// thread 0 of workgroup 0 accumulates the clock ticks of every phase in LDS (never in the product's default path: clk is null)
-#define ACQ_PHASE(k)                                 \
-    if (timing) {                                    \
-        const long long now_ = (long long)clock64(); \
-        clkL[k] += now_ - tprev;                     \
-        tprev = now_;                                \
-    }
-
-// where bin b of a frame sits in its spec row, or -1
-__device__ __forceinline__ int acq_spec_index(int b, int n, int do_up)
-{
-    if (!do_up) return b < n / 4 + 28 ? b : -1;
-    if (b < 204) return b;
-    const int lo = n / 4 - 26;
-    return (b >= lo && b < n / 2 + 28) ? 204 + (b - lo) : -1;
-}
-
 // ---- twiddles a thread keeps in registers for the whole launch: the G stages of a pass that starts at wing HALF0, for group
 // position j -- stage t, entry u at w[(1 << t) - 1 + u] = tw[(HALF0 << t) - 1 + j + HALF0 u].  The frame loop then holds no
 // global load but the samples' own: on this part VMEM operations return in order, so a wait for a twiddle requested after the
@@ -1006,13 +956,16 @@ extern int g_acq_last_grid[4];
 // bytes of scratch one frame needs between the phases (spec row, boxcar band, peak, centre bin, edges), 16-byte aligned parts
 static void acq3_layout(int n, int do_up, int *nsb, int *na)
 {
-    *nsb = do_up ? 204 + (n / 4 + 54) : n / 4 + 28;
-    *na = ((n / 4 - 150) + 1) & ~1;
+    // (Java's integer n / 4 and n / 2, as the reference computes its band, :429-430)
+    const int beg = do_up ? n / 4 : 0, end = do_up ? n / 2 : n / 4;
+    *nsb = do_up ? 204 + (n / 2 + 28 - (n / 4 - 26)) : n / 4 + 28;
+    *na = ((end - beg - 150) + 1) & ~1;
+    if (*na < 2) *na = 2;
 }
 
 bool acq3_supported(int n)
 {
-    return n == 1024 || n == 2048 || n == 4096 || n == 8192;
+    return n == 1024 || n == 2048 || n == 4096 || n == 8192 || acqm_supported(n);
 }
 
 size_t acq3_frame_bytes(int n, int do_up)
@@ -1081,10 +1034,34 @@ static int launch_acq3_t(AcqArgs &a, bool f32, int num_cu, hipStream_t st, const
 int g_acq_last_grid[4] = {0, 0, 0, 0};
 
 // The call's frames in launches of at most chunk_frames per stream (the scratch holds S * chunk_frames frames)
-int launch_acq3(const FftFrontArgs &fa, int nstreams, unsigned char *scratch, size_t scratch_bytes, int chunk_frames, int num_cu,
-                hipStream_t st, const AcqProf &prof)
+// the default mixed-radix frames: k_acqm_fwd / k_acqm_inv (bpsk_fftm.hip) around the same scan and edges
+static int launch_acq3_m(AcqArgs &a, const FftFrontArgs &fa, const AcqmPlan &plan, int num_cu, hipStream_t st, const AcqProf &prof)
 {
-    JSDR_REQUIRE(acq3_supported(fa.n), "bpsk: the three-phase FFT-acquire front end takes frames of 1024 .. 8192 samples (2^k), not %d", fa.n);
+    auto mark = [&](int phase, bool begin) {
+        if (prof.mark) prof.mark(prof.ctx, phase, begin, st);
+    };
+    JSDR_HIP_TRY(hipMemsetAsync(a.tickets, 0, 2 * sizeof(unsigned), st));
+    mark(0, true);
+    if (launch_acqm(a, fa, plan.np, plan.rad, plan.tw_off, plan.wr_off, num_cu, 0, st) != JSDR_OK) return JSDR_ERR;
+    mark(0, false);
+    mark(1, true);
+    hipLaunchKernelGGL(k_acq_scan, dim3((unsigned)a.S), dim3(64), 0, st, a);
+    mark(1, false);
+    JSDR_LAUNCH_CHECK();
+    mark(2, true);
+    if (launch_acqm(a, fa, plan.np, plan.rad, plan.tw_off, plan.wr_off, num_cu, 1, st) != JSDR_OK) return JSDR_ERR;
+    mark(2, false);
+    mark(3, true);
+    hipLaunchKernelGGL(k_acq_edges, dim3((unsigned)a.S), dim3(256), 0, st, a);
+    mark(3, false);
+    JSDR_LAUNCH_CHECK();
+    return JSDR_OK;
+}
+
+int launch_acq3(const FftFrontArgs &fa, int nstreams, unsigned char *scratch, size_t scratch_bytes, int chunk_frames, int num_cu,
+                hipStream_t st, const AcqProf &prof, const AcqmPlan &plan)
+{
+    JSDR_REQUIRE(acq3_supported(fa.n), "bpsk: the three-phase FFT-acquire front end takes frames of 1024 .. 8192 samples (2^k) or 9600 / 4800 / 4410, not %d", fa.n);
     int nsb, na;
     acq3_layout(fa.n, fa.do_up, &nsb, &na);
     if (chunk_frames < 1) chunk_frames = 1;
@@ -1129,6 +1106,11 @@ int launch_acq3(const FftFrontArgs &fa, int nstreams, unsigned char *scratch, si
         a.f0 = f0;
         a.F = fa.nframes - f0 < chunk_frames ? fa.nframes - f0 : chunk_frames;
         int rc;
+        if (acqm_supported(fa.n)) {
+            rc = launch_acq3_m(a, fa, plan, num_cu, st, prof);
+            if (rc != JSDR_OK) return rc;
+            continue;
+        }
         switch (fa.logn) {
             case 10: rc = launch_acq3_t<10>(a, fa.rawf != nullptr, num_cu, st, prof); break;
             case 11: rc = launch_acq3_t<11>(a, fa.rawf != nullptr, num_cu, st, prof); break;

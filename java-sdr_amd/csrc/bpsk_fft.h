@@ -94,13 +94,72 @@ int launch_front_fft(const FftFrontArgs &a, int nstreams, hipStream_t st);
 // inverse transform + RxDownSample per frame -- for calls of two or more frames per stream; frames of 1024 .. 8192 samples
 bool acq3_supported(int n);
 size_t acq3_frame_bytes(int n, int do_up);  // scratch per (stream, frame) of one launch
+// what the phases hand each other, per frame id g = s * F + f (F = frames per stream in this launch)
+struct AcqPeak {
+    double maxBin;
+    int binPos;
+    int pad;
+};
+
+struct AcqArgs {
+    const int *raw;        // int16 pairs [S][stride]
+    const float2 *rawf;    // or float frames
+    long long stride_pairs;
+    int ic, qc;
+    int S, F, f0;          // streams, frames per stream in this launch, index of its first frame within the call
+    int n, do_up, decim;
+    long long first_out, nds;
+    const double2 *vco_cs;
+    const double2 *tw;
+    FftFrontState *st;
+    double2 *dm;
+    long long dm_stride;
+    double2 *spec;         // [S F][nsb]: do_up ? bins [0, 204) then [n/4 - 26, n/2 + 28) : bins [0, n/4 + 28)
+    int nsb;
+    double *aband;         // [S F][na]: boxcar sums over [beg + 75, end - 75)
+    int na;
+    AcqPeak *peak;         // [S F]
+    int *cbin;             // [S F] the frame's centre bin (phase B)
+    double *edges;         // [S F][52]: the frame's first 26 and last 26 real samples re / n (phase C)
+    int nwg;               // persistent workgroups of phases A and C
+    unsigned *tickets;     // [2] run counters of k_acq_fwd / k_acq_inv, zero at launch: a workgroup takes its frames in runs of `run`
+    int run;               // consecutive frames per ticket (>= 2)
+    long long *clk;        // diagnostics (JSDR_FFT_PHASECLK=1): [16] clock ticks per phase of workgroup 0, k_acq_fwd [0..7], k_acq_inv [8..15]; or null
+};
+
+// thread 0 of workgroup 0 accumulates the clock ticks of every phase in LDS (never in the product's default path: clk is null)
+#define ACQ_PHASE(k)                                 \
+    if (timing) {                                    \
+        const long long now_ = (long long)clock64(); \
+        clkL[k] += now_ - tprev;                     \
+        tprev = now_;                                \
+    }
+
+// where bin b of a frame sits in its spec row, or -1
+__device__ __forceinline__ int acq_spec_index(int b, int n, int do_up)
+{
+    if (!do_up) return b < n / 4 + 28 ? b : -1;
+    if (b < 204) return b;
+    const int lo = n / 4 - 26;
+    return (b >= lo && b < n / 2 + 28) ? 204 + (b - lo) : -1;
+}
+
+// the default mixed-radix frames (9600 / 4800 / 4410) in the same three phases: bpsk_fftm.hip has the two frame-parallel kernels
+// (which 0: k_acqm_fwd, 1: k_acqm_inv), built from k_front_fftm's passes
+bool acqm_supported(int n);
+int launch_acqm(const AcqArgs &a, const FftFrontArgs &fa, int np, const int *rad, const int *tw_off, const int *wr_off, int num_cu,
+                int which, hipStream_t st);
+struct AcqmPlan {  // the handle's mixed-radix plan (fftm_twiddles), for launch_acq3
+    int np = 0;
+    const int *rad = nullptr, *tw_off = nullptr, *wr_off = nullptr;
+};
 // per-phase timing hook (bench.py's per-kernel figures): phase 0..3 = k_acq_fwd, k_acq_scan, k_acq_inv, k_acq_edges
 struct AcqProf {
     void *ctx = nullptr;
     void (*mark)(void *ctx, int phase, bool begin, hipStream_t st) = nullptr;
 };
 int launch_acq3(const FftFrontArgs &a, int nstreams, unsigned char *scratch, size_t scratch_bytes, int chunk_frames, int num_cu,
-                hipStream_t st, const AcqProf &prof);
+                hipStream_t st, const AcqProf &prof, const AcqmPlan &plan);
 extern int g_acq_last_grid[4];  // workgroups of the last k_acq_fwd / k_acq_inv launch, and how many of each a CU holds
 // frames that are not a power of two (bpsk_fftm.hip): any n with 416 <= n <= 9600 (2^a 3^b 5^c 7^d through the radix passes, any
 // other prime factor through a pass that is the DFT's definition and needs fftm_scratch(n) elements of scratch per stream)

@@ -1341,6 +1341,261 @@ __global__ __launch_bounds__(FM_T) void k_front_fftm(FftmArgs aa)
     }
 }
 
+// ================================================================================== the default frames in three phases (round 6)
+// k_front_fftm's frame loop cut where the reference's loop carries nothing (bpsk_acq.hip has the whole story): k_acqm_fwd is
+// its forward half for ONE (stream, frame) -- transform, |X|, boxcar, first maximum -- and leaves what the scan (k_acq_scan) and
+// the inverse half need; k_acqm_inv gathers the frame's 204 bins from that row, runs the inverse half and RxDownSample for the
+// windows inside the frame (k_acq_edges does the ones that reach into the frame before).  Same passes, same tables, same
+// image -- so a workgroup still owns a CU -- but the grid is frames: a call of few streams fills the chip (one recorded stream
+// of 109 frames took 109 frame times in k_front_fftm and takes one here).  Frames of 9600 / 4800 / 4410 samples (the compact
+// passes); a workgroup takes its frames one at a time from a ticket counter.
+__device__ __forceinline__ long long acqm_ticket(unsigned *ctr, int *tkL, int tid)
+{
+    if (tid == 0) tkL[0] = (int)atomicAdd(ctr, 1u);
+    __syncthreads();
+    const long long g = tkL[0];
+    __syncthreads();
+    return g;
+}
+
+template <bool F32IN>
+__global__ __launch_bounds__(FM_T) void k_acqm_fwd(FftmArgs aa, AcqArgs a)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int n = a.n;
+    double2 *X = reinterpret_cast<double2 *>(smem);  // [n]
+    const LdsArr XL = lds_arr(smem);
+    double *hist = reinterpret_cast<double *>(X + n);  // [32] (unused here; the layout is k_front_fftm's)
+    double *redv = hist + 32;                          // [16]
+    int *redi = reinterpret_cast<int *>(redv + 16);    // [16]
+    double2 *twL = reinterpret_cast<double2 *>(redi + 16);
+    int *tkL = reinterpret_cast<int *>(twL + aa.lds_tw);  // (the 64 spare bytes behind the tables)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < aa.lds_tw; i += FM_T) twL[i] = aa.f.tw[i];
+    const int beg = a.do_up ? n / 4 : 0;
+    const int end = a.do_up ? n / 2 : n / 4;
+    const int pbase = beg + 24;
+    double *P = reinterpret_cast<double *>(X + (n / 2 + 104));
+    double *A = P + (n / 4 - 48 + 2);
+    const int abase = beg + 74;
+    const long long nfr = (long long)a.S * a.F;
+    __syncthreads();
+    for (;;) {
+        const long long g = acqm_ticket(a.tickets + 0, tkL, tid);
+        if (g >= nfr) break;
+        int tf = tid;
+        asm volatile("" : "+v"(tf));
+        const int s = (int)(g / a.F), f = (int)(g - (long long)s * a.F);
+        const long long t0 = (long long)s * a.stride_pairs + (long long)(a.f0 + f) * n;
+        if (n == 9600)
+            fm_first2_from_raw<9600, F32IN>(XL, a.raw + t0, a.rawf + t0, a.ic, a.qc, lds_arr(twL) + 4, tf);
+        else if (n == 4800)
+            fm_first_from_raw<4800, F32IN>(XL, a.raw + t0, a.rawf + t0, a.ic, a.qc, tf);
+        else {
+            // n = 4410: the frame to LDS in natural order (:416-421), all of a thread's samples in flight before the first conversion
+            constexpr int NLD = (4410 + FM_T - 1) / FM_T;
+            int w[NLD];
+            float2 wf[NLD];
+#pragma unroll
+            for (int q = 0; q < NLD; q++) {
+                int t = tf + q * FM_T;
+                t = t < n ? t : n - 1;
+                if (F32IN)
+                    wf[q] = a.rawf[t0 + t];
+                else
+                    w[q] = a.raw[t0 + t];
+            }
+#pragma unroll
+            for (int q = 0; q < NLD; q++) {
+                const int t = tf + q * FM_T;
+                if (t < n) {
+                    double di, dq;
+                    if (F32IN) {
+                        di = (double)wf[q].x;
+                        dq = (double)wf[q].y;
+                    } else {
+                        di = (double)i16_to_float_java(java_short_add((int)(short)(w[q] & 0xffff), a.ic));
+                        dq = (double)i16_to_float_java(java_short_add(w[q] >> 16, a.qc));
+                    }
+                    X[t] = make_double2(di, dq);
+                }
+            }
+            __syncthreads();
+        }
+        fm_forward<true>(XL, twL, aa, tf, n != 4410, FM_FWD_BAND, end + 102);  // :422-423; bins < end + 102 are formed
+        // ---- the bins a gather can reach, to the frame's row (layout: acq_spec_index), and |X| over the band the boxcar reads
+        {
+            double2 *specg = a.spec + g * a.nsb;
+            const int lo1 = a.do_up ? n / 4 - 26 : 0;
+            for (int i = tf; i < a.nsb; i += FM_T) {
+                const int b = a.do_up ? (i < 204 ? i : lo1 + (i - 204)) : i;
+                specg[i] = X[b];
+            }
+        }
+        for (int i = pbase + tf; i < end - 24; i += FM_T) {
+            const double2 v = X[i];
+            P[i - pbase] = sqrt(v.x * v.x + v.y * v.y);  // :425-427
+        }
+        __syncthreads();
+        // ---- 100-wide boxcar, summed j ascending for every i (:433-437); first maximum (:439-442)
+        double bestv = 0.0;
+        int besti = -1;
+        double *ab = a.aband + g * a.na;
+        for (int i = beg + 74 + 2 * tf; i < end - 75; i += 2 * FM_T) {
+            const double2 *w = reinterpret_cast<const double2 *>(P + (i - 50 - pbase));
+            double a0, a1;
+            boxcar_pair(w, a0, a1);
+            asm volatile("" : "+v"(a0), "+v"(a1));
+            if (i >= beg + 75) {
+                ab[i - (beg + 75)] = a0;
+                if (bestv < a0) {
+                    bestv = a0;
+                    besti = i;
+                }
+            }
+            if (i + 1 < end - 75) {
+                ab[i + 1 - (beg + 75)] = a1;
+                if (bestv < a1) {
+                    bestv = a1;
+                    besti = i + 1;
+                }
+            }
+        }
+        (void)A;
+        (void)abase;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const double ov = __shfl_xor(bestv, off, 64);
+            const int oi = __shfl_xor(besti, off, 64);
+            if (oi >= 0 && (ov > bestv || (ov == bestv && (besti < 0 || oi < besti)))) {
+                bestv = ov;
+                besti = oi;
+            }
+        }
+        if (lane == 0) {
+            redv[wave] = bestv;
+            redi[wave] = besti;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double mv = 0.0;
+            int mi = -1;
+            for (int w = 0; w < FM_T / 64; w++) {
+                const double ov = redv[w];
+                const int oi = redi[w];
+                if (oi >= 0 && (ov > mv || (ov == mv && (mi < 0 || oi < mi)))) {
+                    mv = ov;
+                    mi = oi;
+                }
+            }
+            AcqPeak pk;
+            pk.maxBin = mv;
+            pk.binPos = mi;
+            pk.pad = 0;
+            a.peak[g] = pk;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(FM_T) void k_acqm_inv(FftmArgs aa, AcqArgs a)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int n = a.n;
+    double2 *X = reinterpret_cast<double2 *>(smem);
+    const LdsArr XL = lds_arr(smem);
+    double *hist = reinterpret_cast<double *>(X + n);  // [32]: zeros (the windows that reach before the frame are k_acq_edges')
+    double *redv = hist + 32;
+    int *redi = reinterpret_cast<int *>(redv + 16);
+    double2 *twL = reinterpret_cast<double2 *>(redi + 16);
+    int *tkL = reinterpret_cast<int *>(twL + aa.lds_tw);
+    const int tid = threadIdx.x;
+    for (int i = tid; i < aa.lds_tw; i += FM_T) twL[i] = aa.f.tw[i];
+    if (tid < 32) hist[tid] = 0.0;
+    const int D = a.decim;
+    const double norm = 1.0 / (double)n;
+    const double HOWARD = 0.9 * 32768.0;
+    const int lo1 = a.do_up ? n / 4 - 26 : 0;
+    const long long nfr = (long long)a.S * a.F;
+    __syncthreads();
+    for (;;) {
+        const long long g = acqm_ticket(a.tickets + 1, tkL, tid);
+        if (g >= nfr) break;
+        int tf = tid;
+        asm volatile("" : "+v"(tf));
+        const int s = (int)(g / a.F), f = (int)(g - (long long)s * a.F);
+        const long long t0 = (long long)(a.f0 + f) * n;  // call-relative index of the frame's first sample
+        // ---- the 204 bins around the centre (:458) to the head of the image
+        {
+            const int c = a.cbin[g];
+            int off = c - 102;
+            if (a.do_up) off = (c == 102) ? 0 : 204 + (c - 102 - lo1);
+            if (off < 0) off = 0;
+            if (off + 204 > a.nsb) off = a.nsb - 204;
+            const double2 *src = a.spec + g * a.nsb + off;
+            if (tf < 204) X[tf] = src[tf];
+        }
+        __syncthreads();
+        // ---- inverse transform (:459) as conj o forward o conj: the first passes straight from the bins, the last one real parts
+        // only, scaled, compact (k_front_fftm's)
+        {
+            const LdsArr t64 = lds_arr(twL) + 20;
+            if (n == 9600)
+                fm_inv_blocks128_9600<true>(XL, XL, t64, lds_arr(twL) + 84, tf);
+            else if (n == 4800)
+                fm_inv_blocks<4800, true>(XL, XL, t64, 1, t64, 2, tf);
+            else
+                fm_inv_pair_from_bins<2, 3, 4410>(XL, XL, lds_arr(twL) + 2, tf);
+        }
+        fm_forward<true>(XL, twL, aa, tf, true, FM_INV_REAL, 0, norm, hist);
+        // ---- the frame's first and last 26 samples (k_acq_edges), RxDownSample for the windows inside the frame (:461-463, :470-492)
+        {
+            const double *Rb = reinterpret_cast<const double *>(smem);
+            if (tf < 26) {
+                double *eg = a.edges + g * 52;
+                eg[tf] = Rb[FM_RB0 + tf];
+                eg[26 + tf] = Rb[FM_RB0 + n - 26 + tf];
+            }
+            long long jlo = (t0 - a.first_out + D - 1) / D;
+            if (t0 <= a.first_out) jlo = 0;
+            const bool even_d = (D & 1) == 0;
+            const int par = (int)((a.first_out - t0) & 1);
+            for (long long j = jlo + tf;; j += FM_T) {
+                const long long te = (long long)a.first_out + (long long)D * j;  // window end, call-relative
+                if (te >= t0 + n || j >= a.nds) break;
+                const int e = (int)(te - t0);
+                if (e < 26) continue;
+                const double2 cs = a.vco_cs[j];
+                double fi = 0.0;
+                if (even_d) {
+                    const double2 *w2 = reinterpret_cast<const double2 *>(Rb + ((e + FM_RB0 - 26) & ~1));
+                    double d[28];
+#pragma unroll
+                    for (int i = 0; i < 14; i++) {
+                        const double2 t = w2[i];
+                        d[2 * i] = t.x;
+                        d[2 * i + 1] = t.y;
+                    }
+                    if (par) {
+#pragma unroll
+                        for (int k = 0; k < 27; k++) fi += d[27 - k] * ds_tap(k);  // newest first (:479-483)
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 27; k++) fi += d[26 - k] * ds_tap(k);
+                    }
+                } else {
+                    const double *w = Rb + (FM_RB0 + e);
+#pragma unroll
+                    for (int k = 0; k < 27; k++) fi += w[-k] * ds_tap(k);
+                }
+                const double o = fi * HOWARD;
+                a.dm[(long long)s * a.dm_stride + 64 + j] = make_double2(o * cs.x, o * cs.y);  // :515-516
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // ============================================================================================== frames of 2 m samples
 // n = 19200 (192 kHz with java-sdr's default buffer, JavaAudio.java:58-59: the FUNcube Dongle Pro+ frame): 307 KB as
 // double2, twice a workgroup's LDS.  The oracle's transform for n > 9600 starts with ONE radix-2 pass
@@ -2027,6 +2282,57 @@ int launch_front_fft2x(const FftFrontArgs &a, int np, const int *rad, const int 
         hipLaunchKernelGGL(k_front_fft2x<true>, dim3((unsigned)nstreams), dim3(FM_T), lds, st, aa);
     else
         hipLaunchKernelGGL(k_front_fft2x<false>, dim3((unsigned)nstreams), dim3(FM_T), lds, st, aa);
+    JSDR_LAUNCH_CHECK();
+    return JSDR_OK;
+}
+
+
+// ---- the three-phase form's two frame-parallel kernels for the default frames (bpsk_acq.hip launches the scan and the edges)
+bool acqm_supported(int n) { return n == 9600 || n == 4800 || n == 4410; }
+
+int launch_acqm(const AcqArgs &a, const FftFrontArgs &fa, int np, const int *rad, const int *tw_off, const int *wr_off, int num_cu,
+                int which, hipStream_t st)
+{
+    FftmArgs aa;
+    aa.f = fa;
+    aa.np = np;
+    aa.gscratch = nullptr;
+    aa.gscratch_stride = 0;
+    const size_t fixed = sizeof(double2) * (size_t)a.n + sizeof(double) * (32 + 16) + sizeof(int) * 16 + 64;
+    const size_t room = (size_t)160 * 1024 - fixed;
+    aa.lds_tw = 0;
+    int P = 1;
+    for (int p = 0; p < FM_MAXPASS; p++) {
+        aa.rad[p] = p < np ? rad[p] : 1;
+        aa.tw_off[p] = p < np ? tw_off[p] : 0;
+        aa.wr_off[p] = (p < np && wr_off) ? wr_off[p] : 0;
+        aa.pmagic[p] = (unsigned)(((1ull << 32) + (unsigned)P - 1) / (unsigned)P);
+        if (p < np) {
+            const size_t end = (size_t)tw_off[p] + (size_t)P * rad[p];
+            if (end == (size_t)aa.lds_tw + (size_t)P * rad[p] && end * sizeof(double2) <= room) aa.lds_tw = (int)end;
+            P *= rad[p];
+        }
+    }
+    JSDR_REQUIRE(acqm_supported(a.n), "launch_acqm: frame of %d samples", a.n);
+    JSDR_REQUIRE((a.n == 9600 && aa.lds_tw == FM_LDS_TW_9600) || (a.n == 4800 && aa.lds_tw == FM_LDS_TW_4800) || (a.n == 4410 && aa.lds_tw == 5156),
+                 "launch_acqm: the twiddle tables of a default frame are not where the kernel expects them");
+    const size_t lds = fixed + sizeof(double2) * (size_t)aa.lds_tw;
+    const long long nfr = (long long)a.S * a.F;
+    const int per_cu = lds > 80 * 1024 ? 1 : 2;
+    long long grid = (long long)per_cu * num_cu;
+    if (grid > nfr) grid = nfr;
+    if (which == 0) {
+        if (fa.rawf) {
+            JSDR_LDS_ATTR(k_acqm_fwd<true>, lds);
+            hipLaunchKernelGGL(k_acqm_fwd<true>, dim3((unsigned)grid), dim3(FM_T), lds, st, aa, a);
+        } else {
+            JSDR_LDS_ATTR(k_acqm_fwd<false>, lds);
+            hipLaunchKernelGGL(k_acqm_fwd<false>, dim3((unsigned)grid), dim3(FM_T), lds, st, aa, a);
+        }
+    } else {
+        JSDR_LDS_ATTR(k_acqm_inv, lds);
+        hipLaunchKernelGGL(k_acqm_inv, dim3((unsigned)grid), dim3(FM_T), lds, st, aa, a);
+    }
     JSDR_LAUNCH_CHECK();
     return JSDR_OK;
 }

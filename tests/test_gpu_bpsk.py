@@ -651,6 +651,64 @@ def test_bpsk_suite_with_the_eight_streams_per_wave_tail():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
+@pytest.mark.parametrize("mode,extra", [("1", {}), ("1", {"JSDR_ACQ_CHUNK": "3", "JSDR_ACQ_RUN": "2"}), ("0", {})])
+def test_bpsk_fft_mode_suite_with_either_front_end(mode, extra):
+    """Round 6: FFT-acquire calls of two or more frames per stream take the three-phase front end (bpsk_acq.hip: k_acq_fwd /
+    k_acq_scan / k_acq_inv / k_acq_edges; the default mixed-radix frames k_acqm_fwd / k_acqm_inv where frames fill the chip better
+    than streams), calls of one frame the fused kernels.  Every FFT-mode test once more in a child process with the choice
+    FORCED: JSDR_ACQ3=1 -- the three-phase form wherever the frame size has one, single-frame calls and the 9600 / 4800 / 4410
+    frames included, also with the call cut into launches of three frames per stream and tickets of two frames; JSDR_ACQ3=0 --
+    the fused kernels everywhere (what the default no longer exercises for 2^k frames)."""
+    if os.environ.get("JSDR_ACQ3") is not None:
+        return
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, JSDR_ACQ3=mode, **extra)
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-p", "no:cacheprovider", "-m", "gpu",
+                        os.path.join(here, "test_gpu_bpsk.py"), os.path.join(here, "test_gpu_fixtures.py"),
+                        "-k", "fft and not either_front_end and not eight_streams_per_wave"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_bpsk_fft_mode_front_end_choice():
+    """which front end serves a call: 2^k frames -- three phases from two frames a call; the default mixed-radix frames -- three
+    phases where frames fill the chip better than streams (few streams, many frames), the fused kernel at a full grid of streams
+    and for one frame a call"""
+    if os.environ.get("JSDR_ACQ3") is not None:
+        pytest.skip("the choice is forced")
+    iq = O.make_dbpsk_stream(7, 0, 2048 * 6)[0]
+    d = J.Bpsk(nstreams=1, do_fft=1, max_batch_samples=2048 * 6)
+    buf = J.DeviceBuffer.from_host(iq)
+    d.batch_i16(buf, 2 * 2048 * 6, 2048)
+    assert d.front_kernel_name() == "k_front_fft"
+    bits = [d.bits()]  # (the bits of the call)
+    d.batch_i16(buf.ptr + 4 * 2048, 2 * 2048 * 6, 2048 * 5)
+    assert d.front_kernel_name() == "k_acq_fwd"
+    bits.append(d.bits())
+    o = O.Bpsk(do_fft=1)
+    o.receive_i16(iq)
+    assert np.array_equal(np.concatenate(bits), o.bits()) and d.counters()["centreBin"] == o.counters()["centreBin"]
+    iq = O.make_dbpsk_stream(8, 0, 9600 * 4)[0]
+    d = J.Bpsk(nstreams=1, do_fft=1, blen=38400, max_batch_samples=9600 * 4)
+    buf = J.DeviceBuffer.from_host(iq)
+    d.batch_i16(buf, 2 * 9600 * 4, 9600)
+    assert d.front_kernel_name() == "k_front_fftm"
+    bits = [d.bits()]
+    d.batch_i16(buf.ptr + 4 * 9600, 2 * 9600 * 4, 9600 * 3)
+    assert d.front_kernel_name() == "k_acqm_fwd"  # one stream, three frames: frames fill the chip, streams do not
+    bits.append(d.bits())
+    o = O.Bpsk(do_fft=1, blen=38400)
+    o.receive_i16(iq)
+    assert np.array_equal(np.concatenate(bits), o.bits()) and d.counters()["centreBin"] == o.counters()["centreBin"]
+    S = 512
+    iqs = np.concatenate([O.make_dbpsk_stream(9, s % 4, 9600 * 2)[0] for s in range(S)])
+    d = J.Bpsk(nstreams=S, do_fft=1, blen=38400, max_batch_samples=9600 * 2)
+    d.batch_i16(J.DeviceBuffer.from_host(iqs), 2 * 9600 * 2, 9600 * 2)
+    assert d.front_kernel_name() == "k_front_fftm"  # a full grid of streams: the fused kernel
+
+
 @pytest.mark.parametrize("nsf,rate", [(4410, 44100), (3200, 32000), (2205, 22050), (1102, 11025), (800, 8000)])
 def test_bpsk_fft_mode_receive_at_consumer_sound_card_rates(nsf, rate):
     """the IAudioHandler form (one stream, one frame per receive()) in FFT-acquire mode at the frames a 44.1 / 32 / 22.05 kHz
