@@ -496,10 +496,11 @@ def live_traffic_table(a, samples_per_launch):
     t0 = time.perf_counter()
     try:
         dirs = {}
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-            d = os.path.join(tmp, counter)
-            with open(os.path.join(tmp, counter + ".log"), "w") as log:
-                pr = subprocess.Popen([prof, "--pmc", counter, "--output-format", "csv", "-d", d, "--", py,
+        # (third pass: the SQ counters of roofline.valu_issue_frac -- the limit that binds the exact-order step is VALU issue, not HBM)
+        for counter in ("FETCH_SIZE", "WRITE_SIZE", "SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_VALU"):
+            d = os.path.join(tmp, counter.split()[0])
+            with open(os.path.join(tmp, counter.split()[0] + ".log"), "w") as log:
+                pr = subprocess.Popen([prof, "--pmc"] + counter.split() + ["--output-format", "csv", "-d", d, "--", py,
                                        os.path.join(ROOT, "bench.py")] + child, cwd="/tmp", env=env, stdout=log, stderr=log,
                                       start_new_session=True)
                 try:
@@ -518,12 +519,16 @@ def live_traffic_table(a, samples_per_launch):
             if rc != 0:
                 tail = ""
                 try:
-                    tail = open(os.path.join(tmp, counter + ".log")).read()[-300:].replace("\n", " | ")
+                    tail = open(os.path.join(tmp, counter.split()[0] + ".log")).read()[-300:].replace("\n", " | ")
                 except OSError:
                     pass
                 return None, f"the --pmc {counter} pass exited with {rc}: {tail}"
-            dirs[counter] = d
+            dirs[counter.split()[0]] = d
         tab = pmc_traffic.table(dirs["FETCH_SIZE"], dirs["WRITE_SIZE"], samples_per_launch)
+        try:
+            tab["_valu"] = pmc_traffic.valu_table(dirs["SQ_ACTIVE_INST_VALU"], 3)  # (the child runs --steps 2 --warmup 1)
+        except Exception as ex:
+            tab["_valu"] = {"_error": f"{type(ex).__name__}: {ex}"}
         if not any(k.startswith("k_") for k in tab):
             return None, "the counter output names no kernel of this library"
         tab["_seconds"] = round(time.perf_counter() - t0, 1)
@@ -738,40 +743,50 @@ def main():
         step(i, False)
     sync()
     # Which form is faster depends on the BOX (same-session pairs of rounds 4 and 5: side by side 33.5 against 35.1, 34.2 / 35.7,
-    # 34.8 / 36.0 -- but 37.2-39.1 against 37.0 on a slow one): where the library says the split may pay, three untimed steps of
-    # each form after the warm-up decide which one the timed region runs; both figures go into the record.
+    # 34.8 / 36.0 -- but 37.2-39.1 against 37.0 on a slow one), and the gain is 0 +- 1 ms.  A few probe steps cannot decide that
+    # (round 5 timed three steps of each and BENCH_r05 ran the form that was 0.6 ms slower than the rejected one; alternating
+    # single steps measure a step WITHOUT the overlap of its tail with the next step's kernels and chose wrongly as well): where the
+    # library says the split may pay, BOTH forms run the full timed region -- K steps each, from their own steady state -- and the
+    # line is the faster one's; both figures and the choice go into the record.
     extra_calls = 0
     autotune = None
+
+    def timed_region():
+        if dem is not None:
+            dem.profile_read()
+            dem.profile_enable(True)
+        if amfm is not None:
+            amfm.profile_read()
+            amfm.profile_enable(True)
+        t0 = time.perf_counter()
+        for i in range(a.steps):
+            step(i, True)
+        sync()
+        dt_ = time.perf_counter() - t0
+        if dem is not None:
+            dem.profile_enable(False)
+        return dt_, {"fft_ms": [t.elapsed_ms() for t in fft_timer] if fft is not None else None,
+                     "dem": dem.profile_read() if dem is not None else None}
+
     if side_by_side and N == 1 and not D and not a.no_autotune:
-        def probe(sbs, k=3):
+        runs = {}
+        for sbs in (True, False):
             set_form(sbs)
-            step(0, False)
-            sync()
-            tp = time.perf_counter()
-            for _ in range(k):
+            for _ in range(2):  # into this form's steady state
                 step(0, False)
             sync()
-            return (time.perf_counter() - tp) / k * 1e3
-        t_sbs = probe(True)
-        t_ser = probe(False)
-        extra_calls = 8
-        set_form(t_sbs <= t_ser)
-        autotune = {"side_by_side_ms": round(t_sbs, 3), "one_after_the_other_ms": round(t_ser, 3),
-                    "chosen": "side by side" if form["sbs"] else "one after the other", "steps_each": 3}
-        side_by_side = form["sbs"]
-    if dem is not None:
-        dem.profile_read()
-        dem.profile_enable(True)
-    if amfm is not None:
-        amfm.profile_read()
-        amfm.profile_enable(True)
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        step(i, True)
-    sync()
-    dt = time.perf_counter() - t0
-    if dem is not None:
-        dem.profile_enable(False)
+            runs[sbs] = timed_region()
+        extra_calls = 4 + a.steps
+        best = runs[True][0] <= runs[False][0]
+        set_form(best)
+        dt, snap = runs[best]
+        autotune = {"side_by_side_ms": round(runs[True][0] / a.steps * 1e3, 4), "one_after_the_other_ms": round(runs[False][0] / a.steps * 1e3, 4),
+                    "chosen": "side by side" if best else "one after the other", "steps_each": a.steps,
+                    "decided_on": "both forms ran the full timed region (the same K steps, each from its own steady state, side by side first); "
+                                  "the line is the faster one's"}
+        side_by_side = best
+    else:
+        dt, snap = timed_region()
     per_rank_ms = None
     if D:
         per_rank = [None] * N
@@ -784,7 +799,7 @@ def main():
     # ---- per-kernel durations measured inside the timed region
     kern = {}
     if fft is not None:
-        ms = [t.elapsed_ms() for t in fft_timer]
+        ms = snap["fft_ms"]
         kern["k_fft"] = (float(np.sum(ms)), len(ms), BYTES_PER_SAMPLE["fft"])
     if fir_timer:
         ms = [t.elapsed_ms() for t in fir_timer]
@@ -801,7 +816,7 @@ def main():
         # which kernels ran under the library's timing scopes: the front end (k_front_reg / k_front_fft / k_front_fftm / ...),
         # the tail (k_tail / k_tail8), the FEC form (k_fec_bpsk, or the batch form's three kernels under one scope)
         rename = {"k_front": dem.front_kernel_name(), "k_tail": dem.tail_kernel_name(), "k_fec_bpsk": dem.fec_kernel_name()}
-        for name, (ms, cnt) in dem.profile_read().items():
+        for name, (ms, cnt) in snap["dem"].items():
             if cnt:
                 kern[rename.get(name, name)] = (ms, cnt, BYTES_PER_SAMPLE["bpsk"])
     # the dominant kernel is taken on the critical path: the tail / sync / FEC kernels run on the handle's side
@@ -912,7 +927,34 @@ def main():
     calls_made = a.warmup + a.steps + extra_calls
     if autotune is not None:
         roofline["autotune"] = autotune
-    if shares != (0, 0) and psd_stream is not None and not a.serial and not a.psd_stream and N == 1 and not D and a.compare_serial:
+    # ---- the limit that binds the exact-order step: VALU issue.  From the SQ counters of this run's own profiled child (third --pmc
+    # pass): the step's VALU issue cycles per SIMD over the cycles the timed step lasted, at the engine clock the counters imply
+    # (busy cycles per shader engine over the kernels' time under the profiler).
+    vt = (live_tab or {}).get("_valu") if live_tab is not None else None
+    if vt and "_error" not in vt:
+        # (the step's kernels: launched at least once a step -- not the synthesis / encoder kernels of the set-up)
+        kk = {k: v for k, v in vt.items() if v.get("launches_per_step", 0) >= 0.99}
+        valu = sum(v["valu_cycles_per_simd"] for v in kk.values())
+        busy = sum(v["busy_cycles_per_se"] for v in kk.values())
+        ms_prof = sum(v["ms_under_profiler"] for v in kk.values())
+        if valu > 0 and ms_prof > 0:
+            clock = busy / (ms_prof * 1e-3)
+            roofline["valu_issue_frac"] = round(valu / (dt / a.steps * clock), 4)
+            roofline["valu_issue"] = {"valu_cycles_per_simd_per_step": int(valu), "engine_clock_ghz": round(clock * 1e-9, 3),
+                                      "ms_of_pure_issue": round(valu / clock * 1e3, 3),
+                                      "per_kernel": {k: {"valu_issue_frac_alone": round(v["valu_cycles_per_simd"] / v["busy_cycles_per_se"], 4) if v["busy_cycles_per_se"] else None,
+                                                         "valu_wave_instructions_per_step": int(v["valu_wave_instructions"])}
+                                                     for k, v in sorted(kk.items(), key=lambda kv: -kv[1]["valu_cycles_per_simd"])[:8]},
+                                      "source": "this run's child under rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_VALU "
+                                                "(kernels serialised by the profiler; 1024 SIMDs, 32 shader engines)"}
+    elif vt:
+        roofline["valu_issue_frac"] = None
+        roofline["valu_issue"] = vt
+    if autotune is not None:
+        # (both forms ran the full timed region: the other form's figure is that run's)
+        roofline["side_by_side_ms_per_step" if not form["sbs"] else "one_after_the_other_ms_per_step"] = \
+            autotune["side_by_side_ms" if not form["sbs"] else "one_after_the_other_ms"]
+    elif shares != (0, 0) and psd_stream is not None and not a.serial and not a.psd_stream and N == 1 and not D and a.compare_serial:
         # the OTHER form, five steps right after the timed region
         calls_made += 7
         ran = form["sbs"]

@@ -41,6 +41,35 @@ def table(fetch_dir, write_dir, samples):
     return out
 
 
+def valu_table(d, nsteps, nsimd=1024, nse=32):
+    """per kernel and PER STEP (the pass ran nsteps steps): VALU issue cycles per SIMD (SQ_ACTIVE_INST_VALU counts quad-cycles
+    over all SIMDs), busy cycles per shader engine (SQ_BUSY_CYCLES is summed over the SEs), wave instructions, and the kernels'
+    time under the profiler (dispatch timestamps) -- what bench.py's roofline.valu_issue_frac is made of"""
+    acc = collections.defaultdict(lambda: collections.defaultdict(float))
+    seen = set()
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            m = re.search(r"(k_[a-z0-9_]+)", r["Kernel_Name"])
+            if not m:
+                continue
+            k = m.group(1)
+            acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            did = (f, r["Dispatch_Id"])
+            if did not in seen:
+                seen.add(did)
+                acc[k]["_ns"] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+                acc[k]["_launches"] += 1
+    out = {}
+    for k, v in acc.items():
+        if "SQ_ACTIVE_INST_VALU" not in v or "SQ_BUSY_CYCLES" not in v:
+            continue
+        out[k] = {"valu_cycles_per_simd": v["SQ_ACTIVE_INST_VALU"] * 4.0 / nsimd / nsteps,
+                  "busy_cycles_per_se": v["SQ_BUSY_CYCLES"] / nse / nsteps,
+                  "valu_wave_instructions": v.get("SQ_INSTS_VALU", 0.0) / nsteps,
+                  "ms_under_profiler": v["_ns"] * 1e-6 / nsteps, "launches_per_step": v["_launches"] / nsteps}
+    return out
+
+
 if __name__ == "__main__":
     samples = int(sys.argv[4]) if len(sys.argv) > 4 else 1024 * 1048576  # IQ samples one launch of the batch kernels covers
     out = table(sys.argv[1], sys.argv[2], samples)
