@@ -181,6 +181,18 @@ int jsdr_bpsk_cert_stats(jsdr_bpsk *h, int64_t *redone, int64_t *uncertified_str
  * recovered_on_an_exact_handle).  There is no automatic fallback: it would need the exact state kept beside the fast
  * one for every stream, i.e. the exact variant's cost.  ids: ascending, at most cap; *count: all of them. */
 int jsdr_bpsk_uncertified_streams(jsdr_bpsk *h, int32_t *ids, int cap, int *count);
+/* Fast variant, batch use over retained input (round 6): REPLAYS every stream the calls so far left uncertified, from the
+ * handle's first call, on an internal exact handle that serves those streams from then on -- their getters, their packed
+ * slots; the flag no longer withholds them; jsdr_bpsk_uncertified_streams / _cert_stats stop counting them; every later
+ * batch call advances the exact shadow in lock-step.  raw_dev_calls[k] / nsamples_calls[k]: the device pointer and sample
+ * count jsdr_bpsk_batch_i16 was given at call k, ALL calls since creation (checked against the handle's own counts), the
+ * buffers still holding those samples; ic / qc as in those calls.  *recovered = streams now served in exact order (0: none
+ * was uncertified).  Cost: one small exact handle's call per call replayed.  Mirrors what a caller of
+ * FUNcubeBPSKDemod.receive would do with a recording: run the doubtful streams again in the reference's own arithmetic
+ * (FUNcubeBPSKDemod.java:533-594). */
+int jsdr_bpsk_stream_recovered(jsdr_bpsk *h, int stream, int *recovered); /* 1: served by the exact shadow (replayed) */
+int jsdr_bpsk_recover_uncertified(jsdr_bpsk *h, const int16_t *const *raw_dev_calls, const int64_t *nsamples_calls, int ncalls,
+                                  int64_t stream_stride_i16, int ic, int qc, int *recovered, void *stream);
 /* receive(float[]) / raw form for stream 0 of a 1-stream handle (:357-364) */
 int jsdr_bpsk_receive_f32(jsdr_bpsk *h, const float *iq_host);
 int jsdr_bpsk_receive_i16(jsdr_bpsk *h, const int16_t *raw_host, int ic, int qc);

@@ -486,6 +486,23 @@ class Bpsk:
         _check(lib().jsdr_bpsk_batch_i16(self.h, _addr(raw_dev), C.c_int64(stride_i16), C.c_int64(nsamples), ic, qc,
                                          C.c_void_p(stream)), "jsdr_bpsk_batch_i16")
 
+    def is_recovered(self, stream):
+        """fast variant: this stream is served by the exact shadow handle (jsdr_bpsk_recover_uncertified replayed it)"""
+        v = C.c_int()
+        _check(lib().jsdr_bpsk_stream_recovered(self.h, int(stream), C.byref(v)), "jsdr_bpsk_stream_recovered")
+        return bool(v.value)
+
+    def recover_uncertified(self, raw_devs, nsamples, stride_i16, ic=0, qc=0, stream=None):
+        """fast variant: replay the streams the calls so far left uncertified on an internal exact handle that serves them from
+        then on; raw_devs / nsamples: every call since creation.  Returns the number of streams now served in exact order."""
+        n = len(raw_devs)
+        ptrs = (C.c_void_p * max(n, 1))(*[_addr(r) for r in raw_devs])
+        ns = (C.c_int64 * max(n, 1))(*[int(v) for v in nsamples])
+        rec = C.c_int()
+        _check(lib().jsdr_bpsk_recover_uncertified(self.h, ptrs, ns, n, C.c_int64(stride_i16), ic, qc, C.byref(rec), C.c_void_p(stream)),
+               "jsdr_bpsk_recover_uncertified")
+        return rec.value
+
     def set_cu_share(self, wgs_per_cu):
         _check(lib().jsdr_bpsk_set_cu_share(self.h, int(wgs_per_cu)), "jsdr_bpsk_set_cu_share")
 

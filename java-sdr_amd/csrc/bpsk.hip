@@ -2468,6 +2468,15 @@ struct jsdr_bpsk {
     // other, for nstreams x acq_chunk frames; allocated at the first such call
     DevBuf<unsigned char> acq_scratch;
     int acq_chunk = 0;
+    // round 6, fast variant: the streams jsdr_bpsk_recover_uncertified() has replayed live on in an EXACT shadow handle (lock-step
+    // with this one from then on); their getters and their packed slots come from it
+    jsdr_bpsk *shadow = nullptr;
+    std::vector<int> shadow_ids;   // ascending stream ids, index = the shadow's stream
+    std::vector<int> shadow_map;   // [nstreams] index into the shadow, or -1
+    DevBuf<int16_t> shadow_in;     // [U][2 max_batch] the shadow's rows of a call's input
+    DevBuf<unsigned char> shadow_slots;
+    long long batch_calls = 0;     // jsdr_bpsk_batch_i16 calls since creation (a recovery must be given all of them)
+    long long recovered_events = 0;
     int acq_mode = -1;  // JSDR_ACQ3 (tests, A/B): 0 never, 1 whenever the frame size allows (also for one frame a call); -1: from two frames a call
     int num_cu_known = 0;
     long long last_nds = 0;
@@ -3718,6 +3727,10 @@ int jsdr_bpsk_destroy(jsdr_bpsk *h)
     h->fft2x_ek.release();
     h->fft2x_r0.release();
     h->acq_scratch.release();
+    if (h->shadow) (void)jsdr_bpsk_destroy(h->shadow);
+    h->shadow = nullptr;
+    h->shadow_in.release();
+    h->shadow_slots.release();
     h->vco_cs.release();
 #ifdef JSDR_X_T8CLK
     {
@@ -3811,10 +3824,85 @@ int jsdr_bpsk_destroy(jsdr_bpsk *h)
     return JSDR_OK;
 }
 
+// the shadow's rows of a call's input, gathered into its own stream-major buffer
+static int shadow_stage(jsdr_bpsk *h, const int16_t *raw_dev, int64_t stride, int64_t nsamples, hipStream_t st)
+{
+    for (size_t i = 0; i < h->shadow_ids.size(); i++)
+        JSDR_HIP_TRY(hipMemcpyAsync(h->shadow_in.p + i * (size_t)(2 * h->max_batch), raw_dev + (int64_t)h->shadow_ids[i] * stride,
+                                    (size_t)nsamples * 4, hipMemcpyDeviceToDevice, st));
+    return JSDR_OK;
+}
+
 int jsdr_bpsk_batch_i16(jsdr_bpsk *h, const int16_t *raw_dev, int64_t stream_stride_i16, int64_t nsamples, int ic,
                         int qc, void *stream)
 {
-    return bpsk_run(h, raw_dev, nullptr, stream_stride_i16, nsamples, ic, qc, as_stream(stream));
+    if (bpsk_run(h, raw_dev, nullptr, stream_stride_i16, nsamples, ic, qc, as_stream(stream)) != JSDR_OK) return JSDR_ERR;
+    h->batch_calls++;
+    if (h->shadow) {  // the recovered streams, in exact order, in lock-step
+        if (shadow_stage(h, raw_dev, stream_stride_i16, nsamples, as_stream(stream)) != JSDR_OK) return JSDR_ERR;
+        if (bpsk_run(h->shadow, h->shadow_in.p, nullptr, 2 * h->max_batch, nsamples, ic, qc, as_stream(stream)) != JSDR_OK) return JSDR_ERR;
+    }
+    return JSDR_OK;
+}
+
+// Fast variant: the streams the calls so far left uncertified are REPLAYED from the handle's first call on an internal exact
+// handle (every uncertified stream at once, in lock-step), which serves them from then on: their getters and their packed slots
+// come from it, the sticky flag no longer withholds them, and every later batch call advances it beside the fast kernels.
+// raw_dev_calls[k] / nsamples_calls[k]: what jsdr_bpsk_batch_i16 was given at call k -- ALL calls since creation, with the
+// buffers still holding those samples (a batch over recordings has them; a live source does not and uses the exact variant).
+// Why from the first call: the decision that could not be certified depends on the exact energy history, and after a fast call
+// no exact state exists to restart from.  Cost: one small exact handle's call per call replayed (latency bound,
+// about a millisecond each), whatever the number of streams recovered.
+int jsdr_bpsk_recover_uncertified(jsdr_bpsk *h, const int16_t *const *raw_dev_calls, const int64_t *nsamples_calls, int ncalls,
+                                  int64_t stream_stride_i16, int ic, int qc, int *recovered, void *stream)
+{
+    JSDR_REQUIRE(h && (ncalls == 0 || (raw_dev_calls && nsamples_calls)), "jsdr_bpsk_recover_uncertified: null argument");
+    if (recovered) *recovered = 0;
+    if (h->variant == 0) return JSDR_OK;
+    JSDR_REQUIRE((long long)ncalls == h->batch_calls, "jsdr_bpsk_recover_uncertified: %d calls given, the handle has seen %lld (all of "
+                 "them are replayed)", ncalls, h->batch_calls);
+    long long total = 0;
+    for (int k = 0; k < ncalls; k++) {
+        JSDR_REQUIRE(raw_dev_calls[k] && nsamples_calls[k] >= 0 && nsamples_calls[k] <= h->max_batch, "jsdr_bpsk_recover_uncertified: call %d", k);
+        total += nsamples_calls[k];
+    }
+    JSDR_REQUIRE(total == h->n_in, "jsdr_bpsk_recover_uncertified: the calls given hold %lld samples per stream, the handle has taken %lld",
+                 total, h->n_in);
+    if (sync_last(h) != JSDR_OK) return JSDR_ERR;
+    std::vector<TailState> ts((size_t)h->nstreams);
+    JSDR_HIP_TRY(hipMemcpy(ts.data(), h->tail.p, sizeof(TailState) * ts.size(), hipMemcpyDeviceToHost));
+    std::vector<int> ids;
+    int fresh = 0;
+    for (int s = 0; s < h->nstreams; s++)
+        if (ts[(size_t)s].uncertified) {
+            ids.push_back(s);
+            if (h->shadow_map.empty() || h->shadow_map[(size_t)s] < 0) fresh++;
+        }
+    if (fresh == 0) return JSDR_OK;  // nothing new to recover (the shadow, if any, is up to date)
+    jsdr_bpsk *sh = nullptr;
+    if (jsdr_bpsk_create(&sh, h->rate, h->nsf, h->tuning, 0, h->do_up, (int)ids.size(), h->max_batch) != JSDR_OK) return JSDR_ERR;
+    if (h->shadow) (void)jsdr_bpsk_destroy(h->shadow);
+    h->shadow = nullptr;
+    h->shadow_ids = ids;
+    h->shadow_map.assign((size_t)h->nstreams, -1);
+    for (size_t i = 0; i < ids.size(); i++) h->shadow_map[(size_t)ids[i]] = (int)i;
+    int64_t sb = 0;
+    (void)jsdr_bpsk_slot_info(h, &sb, nullptr, nullptr, nullptr, nullptr);
+    if (h->shadow_in.alloc(ids.size() * (size_t)(2 * h->max_batch)) != JSDR_OK || h->shadow_slots.alloc(ids.size() * (size_t)sb) != JSDR_OK) {
+        (void)jsdr_bpsk_destroy(sh);
+        h->shadow_ids.clear();
+        h->shadow_map.clear();
+        return JSDR_ERR;
+    }
+    h->shadow = sh;
+    for (int k = 0; k < ncalls; k++) {
+        if (shadow_stage(h, raw_dev_calls[k], stream_stride_i16, nsamples_calls[k], as_stream(stream)) != JSDR_OK ||
+            bpsk_run(sh, h->shadow_in.p, nullptr, 2 * h->max_batch, nsamples_calls[k], ic, qc, as_stream(stream)) != JSDR_OK)
+            return JSDR_ERR;
+    }
+    h->recovered_events++;
+    if (recovered) *recovered = (int)ids.size();
+    return JSDR_OK;
 }
 
 int jsdr_bpsk_set_cu_share(jsdr_bpsk *h, int wgs_per_cu)
@@ -4035,8 +4123,12 @@ static int sync_last(jsdr_bpsk *h)
 {
     JSDR_HIP_TRY(hipStreamSynchronize(h->last_stream));
     if (h->tail_stream) JSDR_HIP_TRY(hipStreamSynchronize(h->tail_stream));
+    if (h->shadow) return sync_last(h->shadow);
     return JSDR_OK;
 }
+
+// a stream jsdr_bpsk_recover_uncertified() has replayed is served by the exact shadow handle
+#define JSDR_SHADOWED(h, stream) ((h)->shadow && (stream) >= 0 && (stream) < (h)->nstreams && (h)->shadow_map[(size_t)(stream)] >= 0)
 
 // a stream that overflowed its per-call capacity has an incomplete result log: every getter says so
 static int check_overflow(jsdr_bpsk *h, int stream, const char *who)
@@ -4060,6 +4152,7 @@ int jsdr_bpsk_get_counters(jsdr_bpsk *h, int stream, int32_t out[JSDR_BPSK_NCOUN
 {
     JSDR_REQUIRE(h && out, "jsdr_bpsk_get_counters: null argument");
     JSDR_REQUIRE(stream >= 0 && stream < h->nstreams, "jsdr_bpsk_get_counters: stream %d out of range", stream);
+    if (JSDR_SHADOWED(h, stream)) return jsdr_bpsk_get_counters(h->shadow, h->shadow_map[(size_t)stream], out);
     if (sync_last(h) != JSDR_OK) return JSDR_ERR;
     TailState t;
     int last[2], cdec;
@@ -4081,6 +4174,7 @@ int jsdr_bpsk_get_bits(jsdr_bpsk *h, int stream, int8_t *bits_host, int cap, int
 {
     JSDR_REQUIRE(h && nbits, "jsdr_bpsk_get_bits: null argument");
     JSDR_REQUIRE(stream >= 0 && stream < h->nstreams, "jsdr_bpsk_get_bits: stream %d out of range", stream);
+    if (JSDR_SHADOWED(h, stream)) return jsdr_bpsk_get_bits(h->shadow, h->shadow_map[(size_t)stream], bits_host, cap, nbits);
     if (sync_last(h) != JSDR_OK || check_overflow(h, stream, "jsdr_bpsk_get_bits") != JSDR_OK) return JSDR_ERR;
     int nb = 0;
     JSDR_HIP_TRY(hipMemcpy(&nb, h->nbits.p + stream, sizeof(int), hipMemcpyDeviceToHost));
@@ -4096,6 +4190,7 @@ int jsdr_bpsk_get_fec_count(jsdr_bpsk *h, int stream, int *count)
 {
     JSDR_REQUIRE(h && count, "jsdr_bpsk_get_fec_count: null argument");
     JSDR_REQUIRE(stream >= 0 && stream < h->nstreams, "jsdr_bpsk_get_fec_count: stream %d out of range", stream);
+    if (JSDR_SHADOWED(h, stream)) return jsdr_bpsk_get_fec_count(h->shadow, h->shadow_map[(size_t)stream], count);
     if (sync_last(h) != JSDR_OK || check_overflow(h, stream, "jsdr_bpsk_get_fec_count") != JSDR_OK) return JSDR_ERR;
     JSDR_HIP_TRY(hipMemcpy(count, h->trig_count.p + stream, sizeof(int), hipMemcpyDeviceToHost));
     return JSDR_OK;
@@ -4105,6 +4200,7 @@ int jsdr_bpsk_get_fec(jsdr_bpsk *h, int stream, int idx, int32_t *rc, int32_t *b
 {
     JSDR_REQUIRE(h && rc && bit_index && out_host, "jsdr_bpsk_get_fec: null argument");
     JSDR_REQUIRE(stream >= 0 && stream < h->nstreams, "jsdr_bpsk_get_fec: stream %d out of range", stream);
+    if (JSDR_SHADOWED(h, stream)) return jsdr_bpsk_get_fec(h->shadow, h->shadow_map[(size_t)stream], idx, rc, bit_index, out_host);
     int cnt = 0;
     if (jsdr_bpsk_get_fec_count(h, stream, &cnt) != JSDR_OK) return JSDR_ERR;
     JSDR_REQUIRE(idx >= 0 && idx < cnt, "jsdr_bpsk_get_fec: index %d outside the %d calls of the last batch", idx, cnt);
@@ -4120,6 +4216,7 @@ int jsdr_bpsk_get_decoded(jsdr_bpsk *h, int stream, uint8_t out_host[256])
 {
     JSDR_REQUIRE(h && out_host, "jsdr_bpsk_get_decoded: null argument");
     JSDR_REQUIRE(stream >= 0 && stream < h->nstreams, "jsdr_bpsk_get_decoded: stream %d out of range", stream);
+    if (JSDR_SHADOWED(h, stream)) return jsdr_bpsk_get_decoded(h->shadow, h->shadow_map[(size_t)stream], out_host);
     if (sync_last(h) != JSDR_OK || check_overflow(h, stream, "jsdr_bpsk_get_decoded") != JSDR_OK) return JSDR_ERR;
     JSDR_HIP_TRY(hipMemcpy(out_host, h->decoded.p + (size_t)stream * 256, 256, hipMemcpyDeviceToHost));
     return JSDR_OK;
@@ -4129,6 +4226,7 @@ int jsdr_bpsk_get_trace(jsdr_bpsk *h, int stream, double *out_host, int64_t cap_
 {
     JSDR_REQUIRE(h && npairs, "jsdr_bpsk_get_trace: null argument");
     JSDR_REQUIRE(stream >= 0 && stream < h->nstreams, "jsdr_bpsk_get_trace: stream %d out of range", stream);
+    if (JSDR_SHADOWED(h, stream)) return jsdr_bpsk_get_trace(h->shadow, h->shadow_map[(size_t)stream], out_host, cap_pairs, npairs);
     if (sync_last(h) != JSDR_OK) return JSDR_ERR;
     *npairs = h->last_nds;
     long long n = h->last_nds < cap_pairs ? h->last_nds : cap_pairs;
@@ -4142,6 +4240,7 @@ int jsdr_bpsk_get_state(jsdr_bpsk *h, int stream, double out[18])
 {
     JSDR_REQUIRE(h && out, "jsdr_bpsk_get_state: null argument");
     JSDR_REQUIRE(stream >= 0 && stream < h->nstreams, "jsdr_bpsk_get_state: stream %d out of range", stream);
+    if (JSDR_SHADOWED(h, stream)) return jsdr_bpsk_get_state(h->shadow, h->shadow_map[(size_t)stream], out);
     if (sync_last(h) != JSDR_OK) return JSDR_ERR;
     TailState t;
     JSDR_HIP_TRY(hipMemcpy(&t, h->tail.p + stream, sizeof(t), hipMemcpyDeviceToHost));
@@ -4234,9 +4333,9 @@ int jsdr_bpsk_cert_stats(jsdr_bpsk *h, int64_t *redone, int64_t *uncertified_str
     std::vector<TailState> ts((size_t)h->nstreams);
     JSDR_HIP_TRY(hipMemcpy(ts.data(), h->tail.p, sizeof(TailState) * ts.size(), hipMemcpyDeviceToHost));
     long long r = 0, u = 0;
-    for (auto &t : ts) {
-        r += t.redone;
-        u += t.uncertified ? 1 : 0;
+    for (size_t s = 0; s < ts.size(); s++) {
+        r += ts[s].redone;
+        u += (ts[s].uncertified && !JSDR_SHADOWED(h, (int)s)) ? 1 : 0;  // (a recovered stream is served in exact order: not counted)
     }
     if (redone) *redone = r;
     if (uncertified_streams) *uncertified_streams = u;
@@ -4260,11 +4359,18 @@ int jsdr_bpsk_uncertified_streams(jsdr_bpsk *h, int32_t *ids, int cap, int *coun
     JSDR_HIP_TRY(hipMemcpy(ts.data(), h->tail.p, sizeof(TailState) * ts.size(), hipMemcpyDeviceToHost));
     int n = 0;
     for (int s = 0; s < h->nstreams; s++)
-        if (ts[(size_t)s].uncertified) {
+        if (ts[(size_t)s].uncertified && !JSDR_SHADOWED(h, s)) {
             if (n < cap) ids[n] = s;
             n++;
         }
     *count = n;
+    return JSDR_OK;
+}
+
+int jsdr_bpsk_stream_recovered(jsdr_bpsk *h, int stream, int *recovered)
+{
+    JSDR_REQUIRE(h && recovered && stream >= 0 && stream < h->nstreams, "jsdr_bpsk_stream_recovered: bad argument");
+    *recovered = JSDR_SHADOWED(h, stream) ? 1 : 0;
     return JSDR_OK;
 }
 
@@ -4395,5 +4501,12 @@ extern "C" int jsdr_bpsk_pack_slots(jsdr_bpsk *h, uint8_t *slots_dev, void *stre
     // overwrite them while this kernel is still reading
     JSDR_HIP_TRY(hipEventRecord(h->ev_pack_done, as_stream(stream)));
     h->pack_pending = true;
+    if (h->shadow) {
+        // the recovered streams' slots are the exact shadow's (same slot layout: same max_batch), laid over the fast handle's
+        if (jsdr_bpsk_pack_slots(h->shadow, h->shadow_slots.p, stream) != JSDR_OK) return JSDR_ERR;
+        for (size_t i = 0; i < h->shadow_ids.size(); i++)
+            JSDR_HIP_TRY(hipMemcpyAsync(slots_dev + (size_t)h->shadow_ids[i] * (size_t)slot_bytes, h->shadow_slots.p + i * (size_t)slot_bytes,
+                                        (size_t)slot_bytes, hipMemcpyDeviceToDevice, as_stream(stream)));
+    }
     return JSDR_OK;
 }

@@ -212,6 +212,63 @@ def test_fast_variant_uncertified_streams_are_listed_and_recovered_on_an_exact_h
         assert len(fg) == len(fo) and all(a[0] == b[0] and np.array_equal(a[2], b[2]) for a, b in zip(fg, fo))
 
 
+def test_fast_variant_recovers_uncertified_streams_by_replay(monkeypatch):
+    """a batch over recorded IQ still has its input, so the streams a fast handle could not certify are
+    REPLAYED -- jsdr_bpsk_recover_uncertified: every call since creation, on an internal exact handle that serves those
+    streams from then on.  After it their bits / FEC bytes / counters / state are the oracle's, the flag no longer withholds
+    them, their packed slots are the exact ones, and later calls keep them exact (the shadow runs in lock-step)."""
+    monkeypatch.setenv("JSDR_FAST_ARGMAX_SCALE", "1e14")  # every argmax falls inside the (widened) margin: streams 0 and 2 cannot be certified
+    p = STREAMS["clean"]
+    n = 458752
+    raw = stream_input("clean")[:2 * n]
+    quiet = np.zeros(2 * n, np.int16)
+    cuts = [0, 2048 * 98, 2048 * 175, n]  # (whole frames: the oracle's receive() takes frames)
+    d = J.Bpsk(rate=p["rate"], blen=8192, tuning=p["tuning"], nstreams=3, max_batch_samples=2048 * 98, variant="fast")
+    d_in = J.DeviceBuffer.from_host(np.concatenate([raw, quiet, raw]))
+    o = O.Bpsk(rate=p["rate"], blen=8192, tuning=p["tuning"])
+    obits = [0]
+    ofec = [0]
+    for k in range(3):
+        o.receive_i16(raw[2 * cuts[k]:2 * cuts[k + 1]])
+        obits.append(len(o.bits()))
+        ofec.append(len(o.fec_results()))
+
+    def check_against_oracle(k):  # after call k (0-based) the recovered streams hold the oracle's results of that call
+        for s in (0, 2):
+            assert np.array_equal(d.bits(s), o_bits_all[obits[k]:obits[k + 1]])
+            fg = d.fec_results(s)
+            fo = o_fec_all[ofec[k]:ofec[k + 1]]
+            assert len(fg) == len(fo) and all(a[0] == b[0] and np.array_equal(a[2], b[2]) for a, b in zip(fg, fo))
+
+    o_bits_all, o_fec_all = o.bits().copy(), o.fec_results()
+    ptrs = [d_in.ptr + 4 * cuts[k] for k in range(3)]
+    lens = [cuts[k + 1] - cuts[k] for k in range(3)]
+    for k in range(2):
+        d.batch_i16(ptrs[k], 2 * n, lens[k])
+    assert d.uncertified_streams() == [0, 2]
+    with pytest.raises(J.JsdrError):
+        d.bits(0)
+    with pytest.raises(J.JsdrError, match="calls given"):
+        d.recover_uncertified(ptrs[:1], lens[:1], 2 * n)  # the whole history, or nothing
+    assert d.recover_uncertified(ptrs[:2], lens[:2], 2 * n) == 2
+    assert d.uncertified_streams() == [] and d.cert_stats()["streams_uncertified"] == 0
+    check_against_oracle(1)
+    assert len(d.bits(1)) == 0  # the certified stream is still the fast handle's
+    assert d.recover_uncertified(ptrs[:2], lens[:2], 2 * n) == 0  # nothing new
+    d.batch_i16(ptrs[2], 2 * n, lens[2])  # the shadow runs beside the fast kernels from now on
+    check_against_oracle(2)
+    c, oc = d.counters(0), o.counters()
+    assert all(c[k] == oc[k] for k in ("cntRaw", "cntDS", "cntBit", "cntFEC", "cntDec", "dmErrBits", "decodeOK")), (c, oc)
+    assert d.state(2).tobytes() == o.state().tobytes()
+    info = d.slot_info()
+    slots = J.DeviceBuffer(3 * info["slot_bytes"])
+    d.pack_slots(slots)
+    blob = slots.to_host(np.uint8).reshape(3, info["slot_bytes"])
+    assert np.array_equal(blob[0], blob[2])
+    u = J.sharding.unpack_slot(blob[0], info)
+    assert np.array_equal(u["bits"], o_bits_all[obits[2]:obits[3]]) and int(u["header"][4]) == oc["cntBit"] and int(u["header"][12]) == 0
+
+
 def test_fast_variant_is_tune_mode_only():
     with pytest.raises(J.JsdrError):
         J.Bpsk(nstreams=1, do_fft=1, variant="fast")
