@@ -1,7 +1,7 @@
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-timeout -k 10 900 python -m pytest tests/test_gpu_bpsk.py tests/test_gpu_fixtures.py -m gpu -x -q -k "fft" > gpurun_out/r06_b_tests.log 2>&1; rc=$?
+timeout -k 10 900 python -m pytest tests/test_gpu_bpsk.py tests/test_gpu_fixtures.py -m gpu -x -q -k "fft and not either_front_end" > gpurun_out/r06_b_tests.log 2>&1; rc=$?
 tail -5 gpurun_out/r06_b_tests.log
 [ $rc -eq 0 ] || exit $rc
-bash tools/r06_acq_ab.sh 9600 4800 4410@44100
-STREAMS=64 bash tools/r06_acq_ab.sh 9600 2048
+bash tools/_s3.sh
+bash tools/r06_acq_ab.sh 2048
