@@ -32,7 +32,9 @@ SOURCES = {
     "demod.hip": ["-ffp-contract=off"],
     "bpsk.hip": ["-ffp-contract=off"],
     "bpsk_fft.hip": ["-ffp-contract=off"],
-    "bpsk_acq.hip": ["-ffp-contract=off"],
+    # (no atomic optimiser: it turns the one-lane ticket atomicAdd into atomic + s_waitcnt vmcnt(0) + v_readfirstlane on the spot,
+    #  i.e. a round trip to memory at the top of a frame for a value that is wanted a pass later)
+    "bpsk_acq.hip": ["-ffp-contract=off", "-mllvm", "-amdgpu-atomic-optimizer-strategy=None"],
     "bpsk_fftm.hip": ["-ffp-contract=off"],
     "group.hip": [],
 }

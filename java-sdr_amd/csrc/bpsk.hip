@@ -3246,7 +3246,8 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
         // the default mixed-radix frames' are the fused kernel's passes cut in two and cost 10-14 % more per frame at a full grid
         // (9600: 12.6 against 11.5 ms; the spectrum rows' round trip, a ticket a frame) -- they are taken where frames fill the
         // chip better than streams: ceil(S F / W) * 1.15 < ceil(S / W) * F, W = the workgroups the chip holds (one a CU).
-        bool three = !h->fft_2x && acq3_supported(h->nsf) && h->acq_mode != 0 && (xa.nframes >= 2 || h->acq_mode == 1);
+        bool three = !h->fft_2x && acq3_supported(h->nsf) && h->acq_mode != 0 && (xa.nframes >= 2 || h->acq_mode == 1) &&
+                     L < 0x7fffffffLL && (long long)S * ((xa.nframes + 1) / 2) < 0x7fffffffLL;  // (its kernels' 32-bit frame arithmetic)
         if (three && h->fft_mixed && h->acq_mode < 0) {
             if (h->num_cu_known == 0) {
                 int dev = 0, cus = 0;

@@ -314,8 +314,7 @@ __global__ __launch_bounds__((1 << LOGN) / 16, 2) void k_acq_fwd(AcqArgs a)
     // first-pass group q = brev(tid): its sixteen inputs are the frame's elements brev4(m) N/16 + tid -- coalesced loads
     int pre[16];
     float2 pref[16];
-    auto fetch = [&](long long g) {
-        const int s = (int)(g / a.F), f = (int)(g - (long long)s * a.F);
+    auto fetch = [&](int s, int f) {
         const long long off = (long long)s * a.stride_pairs + (long long)(a.f0 + f) * N + tid;
 #pragma unroll
         for (int m = 0; m < 16; m++) {
@@ -330,22 +329,31 @@ __global__ __launch_bounds__((1 << LOGN) / 16, 2) void k_acq_fwd(AcqArgs a)
     // pace depends on whom it shares its SIMD with -- and the launch took as long as the slowest.  The next run's ticket is taken in
     // the current run's first frame (thread 0, handed round through LDS), so the request for the next frame's samples never waits
     // for it.
+    // A run lies inside ONE stream (a.rps runs a stream): (stream, frame) come from a ticket by one 32-bit division a run, and no
+    // 64-bit division is left in the frame loop (two of them a frame -- frame id / F, window index / D -- were a tenth of k_acq_inv).
     const int K = a.run;
-    const long long nruns = (nfr + K - 1) / K;
+    const int nruns = a.S * a.rps;
+    (void)nfr;
     int *tkL = reinterpret_cast<int *>(clkL + 8);  // [2]
     if (tid == 0) tkL[0] = (int)atomicAdd(a.tickets + 0, 1u);
     acq_barrier<T>();
-    long long r_next = tkL[0];
-    long long g = 0, gb = 0;
+    int r_next = tkL[0];
+    int s = 0, f = 0, fe = 0;       // this frame: stream, frame of the launch, end of the run
+    int sn = 0, fn = 0, fen = 0;    // the frame this workgroup takes next
     bool have = r_next < nruns;
+    bool first = true;              // the first frame of a run: take the next run's ticket
+    auto run_of = [&](int r, int &s_, int &f_, int &fe_) {
+        s_ = (int)((unsigned)r / (unsigned)a.rps);
+        f_ = (r - s_ * a.rps) * K;
+        fe_ = f_ + K < a.F ? f_ + K : a.F;
+    };
     if (have) {
-        g = r_next * K;
-        gb = g + K < nfr ? g + K : nfr;
-        fetch(g);
+        run_of(r_next, s, f, fe);
+        fetch(s, f);
     }
     if (timing) tprev = (long long)clock64();
     while (have) {
-        const bool first = (g % K) == 0;  // the first frame of a run: take the next run's ticket
+        const long long g = (long long)s * a.F + f;  // the frame's row in what the phases hand each other
         unsigned tk = 0;
         if (first && tid == 0) tk = atomicAdd(a.tickets + 0, 1u);
         // opaque per frame: nothing derived from the thread index is loop invariant, or LLVM hoists every address of every pass out
@@ -384,11 +392,30 @@ __global__ __launch_bounds__((1 << LOGN) / 16, 2) void k_acq_fwd(AcqArgs a)
         for (int it = 0; it < NGL; it++) acq_load_tw<GL, HL>(twl[it], tf + T * it, tsg);
         __builtin_amdgcn_sched_barrier(0);
         acq_mid_pass<4, 16, false, LOGN>(X, TsL, tsg, tf);
-        if (first && tid == 0) tkL[1] = (int)tk;
+        {
+            // (pinned HERE by an opaque zero: left alone the compiler moves this store up beside the atomic -- same condition -- and
+            //  waits for the ticket's round trip at the top of the frame; the wave's partner then waits for it at the next barrier)
+            int zlate = 0;
+            asm volatile("" : "+v"(zlate));
+            if (first && tid == 0) tkL[1] = (int)tk + zlate;
+        }
         acq_barrier<T>();
         ACQ_PHASE(1)
         r_next = tkL[1];
-        const long long gn = g + 1 < gb ? g + 1 : (r_next < nruns ? r_next * K : g);  // the frame this workgroup takes next (or this one again)
+        // the frame this workgroup takes next (or this one again)
+        bool more = true;
+        if (f + 1 < fe) {
+            sn = s;
+            fn = f + 1;
+            fen = fe;
+        } else if (r_next < nruns) {
+            run_of(r_next, sn, fn, fen);
+        } else {
+            sn = s;
+            fn = f;
+            fen = fe;
+            more = false;
+        }
         if constexpr (Plan::G4 != 0) {
             acq_mid_pass<Plan::G3, 256, false, LOGN>(X, TsL, tsg, tf);
             acq_barrier<T>();
@@ -406,7 +433,7 @@ __global__ __launch_bounds__((1 << LOGN) / 16, 2) void k_acq_fwd(AcqArgs a)
         }
         // (unconditional: under a branch the wait counts of everything behind it are the minimum over both paths, i.e. a wait for
         //  a twiddle becomes a wait for these samples again; the workgroup's last frame requests itself once more)
-        fetch(gn);
+        fetch(sn, fn);
         __builtin_amdgcn_sched_barrier(0);
         acq_barrier<T>();  // the image is dead: |X| goes over it
         ACQ_PHASE(2)
@@ -546,14 +573,11 @@ __global__ __launch_bounds__((1 << LOGN) / 16, 2) void k_acq_fwd(AcqArgs a)
             acq_barrier<T>();  // P is read before the next frame's first pass stores over it
         }
         ACQ_PHASE(5)
-        if (g + 1 < gb) {
-            g++;
-        } else if (r_next < nruns) {
-            g = r_next * K;
-            gb = g + K < nfr ? g + K : nfr;
-        } else {
-            have = false;
-        }
+        first = fn != f + 1 || sn != s;
+        have = more;
+        s = sn;
+        f = fn;
+        fe = fen;
     }
     if (timing)
         for (int k = 0; k < 8; k++) a.clk[k] = clkL[k];
@@ -600,8 +624,11 @@ __global__ __launch_bounds__(64) void k_acq_scan(AcqArgs a)
         const int cnt = (a.F - f) < 64 ? (a.F - f) : 64;
         int done = 0;
         for (int l = 0; l < cnt; l++) {
-            const double atc_l = __shfl(atc, l, 64), mb_l = __shfl(mb, l, 64);
-            const int bp_l = __shfl(bp, l, 64);
+            // (lane l's values to every lane by v_readlane -- the loop index is uniform; __shfl goes through the LDS crossbar: five
+            //  dependent ~100-cycle round trips a frame were most of this kernel)
+            const double atc_l = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(atc), l), __builtin_amdgcn_readlane(__double2loint(atc), l));
+            const double mb_l = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(mb), l), __builtin_amdgcn_readlane(__double2loint(mb), l));
+            const int bp_l = __builtin_amdgcn_readlane(bp, l);
             if (centreBin < 0) centreBin = 0;
             if (centreBin > end - 1) centreBin = end - 1;
             avePeakPower = (PSD_AVG * atc_l) + (PSD_INV * avePeakPower);
@@ -690,56 +717,84 @@ __global__ __launch_bounds__((1 << LOGN) / 16, 2) void k_acq_inv(AcqArgs a)
     // frames in runs of a.run, a ticket each (see k_acq_fwd); the next run's ticket is known from the run's first frame on, the next
     // frame's centre bin is requested at the top of a frame (a run has at least two frames)
     const int K = a.run;
-    const long long nruns = (nfr + K - 1) / K;
+    const int nruns = a.S * a.rps;
+    (void)nfr;
     int *tkL = negzL + 2;  // [2]
     if (tid == 0) tkL[0] = (int)atomicAdd(a.tickets + 1, 1u);
     acq_barrier<T>();
-    long long r_next = tkL[0];
-    long long g = 0, gb = 0;
+    int r_next = tkL[0];
+    int s = 0, f = 0, fe = 0, sn = 0, fn = 0, fen = 0;
+    bool first = true;
+    auto run_of = [&](int r, int &s_, int &f_, int &fe_) {
+        s_ = (int)((unsigned)r / (unsigned)a.rps);
+        f_ = (r - s_ * a.rps) * K;
+        fe_ = f_ + K < a.F ? f_ + K : a.F;
+    };
     bool have = r_next < nruns;
+    // a frame's bins reach LDS during the frame BEFORE it (requested before that frame's last pass, stored behind its compact samples:
+    // the image of bins is dead once the first passes have read it), so that a frame starts without a wait for memory and without
+    // a barrier of its own; the launch's first frame is the exception
+    auto store_bins = [&](int tf_, int slot) {
+        bool nz = false;
+        const long long NEGZ = (long long)0x8000000000000000ull;
+#pragma unroll
+        for (int i = 0; i < NB; i++) {
+            const int k = tf_ + T * i;
+            if (k < 204) {
+                B[k] = bins[i];
+                nz = nz || __double_as_longlong(bins[i].x) == NEGZ || __double_as_longlong(bins[i].y) == NEGZ;
+            }
+        }
+        if (nz) negzL[slot] = 1;
+    };
     if (have) {
-        g = r_next * K;
-        gb = g + K < nfr ? g + K : nfr;
-        fetch_bins(g, a.cbin[g]);
+        run_of(r_next, s, f, fe);
+        const long long g0_ = (long long)s * a.F + f;
+        fetch_bins(g0_, a.cbin[g0_]);
+        store_bins(tid, 0);
     }
+    acq_barrier<T>();
     r_next = nruns;  // (unknown until the run's first frame has fetched it)
     int par = 0;
     for (; have; par ^= 1) {
-        const bool first = (g % K) == 0;
         unsigned tk = 0;
         if (first && tid == 0) tk = atomicAdd(a.tickets + 1, 1u);
         int tf = tid;  // opaque per frame (see k_acq_fwd)
         asm volatile("" : "+v"(tf));
-        const int s = (int)(g / a.F), f = (int)(g - (long long)s * a.F);
-        const long long t0 = (long long)(a.f0 + f) * N;  // call-relative index of the frame's first sample
-        // ---- the 204 bins around the centre to bin 0 of a zeroed array (:458)
-        {
-            bool nz = false;
-            const long long NEGZ = (long long)0x8000000000000000ull;
-#pragma unroll
-            for (int i = 0; i < NB; i++) {
-                const int k = tf + T * i;
-                if (k < 204) {
-                    B[k] = bins[i];
-                    nz = nz || __double_as_longlong(bins[i].x) == NEGZ || __double_as_longlong(bins[i].y) == NEGZ;
-                }
-            }
-            if (nz) negzL[par] = 1;
-        }
+        const long long g = (long long)s * a.F + f;
+        // (a launch's samples number less than 2^31 -- launch_acq3 sees to it: 32-bit window arithmetic, one 32-bit division a frame)
+        const int t0 = (a.f0 + f) * N;  // call-relative index of the frame's first sample
+        // ---- the 204 bins around the centre at bin 0 of a zeroed array (:458): in LDS since the frame before
         // the VCO factors of this frame's outputs and the next frame's centre bin: in flight during the transform
-        long long jlo = (t0 - a.first_out + D - 1) / D;
-        if (t0 <= a.first_out) jlo = 0;
+        const int fo = (int)a.first_out;
+        const int jlo = t0 <= fo ? 0 : (int)((unsigned)(t0 - fo + D - 1) / (unsigned)D);
+        const int nds = (int)a.nds;
         double2 cs[JB];
 #pragma unroll
         for (int b = 0; b < JB; b++) {
-            const long long j = jlo + tf + T * b;
-            const long long te = (long long)a.first_out + (long long)D * j;
-            cs[b] = (te < t0 + N && j < a.nds) ? a.vco_cs[j] : make_double2(0.0, 0.0);
+            const int j = jlo + tf + T * b;
+            const int te = fo + D * j;
+            cs[b] = (te < t0 + N && j < nds) ? a.vco_cs[j] : make_double2(0.0, 0.0);
         }
-        // (unconditional requests: see k_acq_fwd; in a run's first frame the next frame is the run's second)
-        const long long gn = g + 1 < gb ? g + 1 : (!first && r_next < nruns ? r_next * K : g);
-        c_next = a.cbin[gn];
-        acq_barrier<T>();
+        // (unconditional requests: see k_acq_fwd; in a run's first frame the next frame is the run's second -- a run has two frames
+        //  or is the stream's last -- so the next run's ticket, taken in the first frame, is known whenever it is needed)
+        bool more = true;
+        if (f + 1 < fe) {
+            sn = s;
+            fn = f + 1;
+            fen = fe;
+        } else if (!first && r_next < nruns) {
+            run_of(r_next, sn, fn, fen);
+        } else {
+            sn = s;
+            fn = f;
+            fen = fe;
+            more = false;
+        }
+        const long long gn = (long long)sn * a.F + fn;
+        // (a SCALAR load: the value is uniform, and as a vector load the compiler makes it so on the spot -- global_load, s_waitcnt
+        //  vmcnt(0), v_readfirstlane: a round trip to memory, and the previous frame's stores, at the top of every frame)
+        c_next = ((const __attribute__((address_space(4))) int *)a.cbin)[gn];
         ACQ_PHASE(0)
         // ---- inverse transform (:459).  Slot 16 q + m of the bit-reversed array holds input brev4(m) N/16 + brev(q): below 204 only
         // for m = 0 (N >= 2048; and m = 8 at N = 2048), so the first three stages of a group are broadcasts of its slots 0 and 8
@@ -806,7 +861,13 @@ __global__ __launch_bounds__((1 << LOGN) / 16, 2) void k_acq_inv(AcqArgs a)
             acq_barrier<T>();
             acq_mid_pass<4, 16, true, LOGN>(X, TsL, tsg, tf);
         }
-        if (first && tid == 0) tkL[1] = (int)tk;
+        {
+            // (pinned HERE by an opaque zero: left alone the compiler moves this store up beside the atomic -- same condition -- and
+            //  waits for the ticket's round trip at the top of the frame; the wave's partner then waits for it at the next barrier)
+            int zlate = 0;
+            asm volatile("" : "+v"(zlate));
+            if (first && tid == 0) tkL[1] = (int)tk + zlate;
+        }
         acq_barrier<T>();
         ACQ_PHASE(1)
         if (tf == 0) negzL[par] = 0;  // (read by everybody before the barrier above; set again two frames on at the earliest)
@@ -843,6 +904,7 @@ __global__ __launch_bounds__((1 << LOGN) / 16, 2) void k_acq_inv(AcqArgs a)
 #pragma unroll
             for (int m = 0; m < ML; m++) Rb[ACQ_RB0 + j + HL * m] = o[it][m];
         }
+        store_bins(tf, par ^ 1);  // the NEXT frame's bins (requested before the last pass; nothing is stored to memory in between)
         acq_barrier<T>();
         ACQ_PHASE(3)
         // ---- the frame's first and last 26 samples for the windows that cross into / out of it (k_acq_edges)
@@ -857,10 +919,10 @@ __global__ __launch_bounds__((1 << LOGN) / 16, 2) void k_acq_inv(AcqArgs a)
             const int wpar = (int)((a.first_out - t0) & 1);
 #pragma unroll
             for (int b = 0; b < JB; b++) {
-                const long long j = jlo + tf + T * b;
-                const long long te = (long long)a.first_out + (long long)D * j;  // window end, call-relative
-                if (te < t0 + N && j < a.nds) {
-                    const int e = (int)(te - t0);
+                const int j = jlo + tf + T * b;
+                const int te = fo + D * j;  // window end, call-relative
+                if (te < t0 + N && j < nds) {
+                    const int e = te - t0;
                     if (e >= 26) {
                         double fi = 0.0;
                         if (even_d) {
@@ -894,14 +956,20 @@ __global__ __launch_bounds__((1 << LOGN) / 16, 2) void k_acq_inv(AcqArgs a)
         acq_barrier<T>();  // every window is read before the next frame's passes store over the image
         ACQ_PHASE(4)
         r_next = tkL[1];
-        if (g + 1 < gb) {
-            g++;
-        } else if (gn != g) {  // (a run of ONE frame -- the launch's last -- whose successor was not known at its top ends the workgroup's
-            g = gn;            //  share only if no run was left; otherwise gn named the next run's first frame)
-            gb = g + K < nfr ? g + K : nfr;
-        } else {
-            have = false;
+        if (!more && first && f + 1 >= fe && r_next < nruns) {
+            // a run of ONE frame (a stream's last, F not a multiple of the run): its successor was not known at its top -- it is now
+            run_of(r_next, sn, fn, fen);
+            more = true;
+            const long long gq = (long long)sn * a.F + fn;
+            fetch_bins(gq, a.cbin[gq]);  // (the bins requested for "this frame again" are replaced; stored before the next frame starts)
+            store_bins(tf, par ^ 1);
+            acq_barrier<T>();
         }
+        first = fn != f + 1 || sn != s;
+        have = more;
+        s = sn;
+        f = fn;
+        fe = fen;
     }
     if (timing)
         for (int k = 0; k < 8; k++) a.clk[8 + k] = clkL[k];
@@ -915,39 +983,52 @@ __global__ __launch_bounds__(256) void k_acq_edges(AcqArgs a)
 {
     const int s = blockIdx.x, tid = threadIdx.x;
     const int n = a.n, D = a.decim;
-    const int EO = 26 / D + 2;  // upper bound of the windows per frame that end within its first 26 samples
+    const int EO = 26 / D + 2;   // upper bound of the windows per frame that end within its first 26 samples
+    const int FB = 256 / EO;     // frames a block takes: one thread per (frame, window)
     const double HOWARD = 0.9 * 32768.0;
     FftFrontState *sp = &a.st[s];
-    __shared__ double hist0[26];
-    if (tid < 26) hist0[tid] = sp->hist[tid];
-    __syncthreads();
+    // rows[i] = the first / last 26 samples of frame fb - 1 + i, i = 0 .. FB: read once, coalesced (a window walks 27 of them, and from
+    // global memory that was 27 dependent loads a thread); for the call's first frame the row in front is the stream's history
+    __shared__ double rows[(256 / 2 + 1) * 52];
+    const int fb = blockIdx.y * FB;
     const long long g0 = (long long)s * a.F;
-    for (int it = tid; it < a.F * EO; it += 256) {
-        const int f = it / EO, r = it - f * EO;
-        const long long t0 = (long long)(a.f0 + f) * n;
-        long long jlo = (t0 - a.first_out + D - 1) / D;
-        if (t0 <= a.first_out) jlo = 0;
-        const long long j = jlo + r;
-        const long long te = (long long)a.first_out + (long long)D * j;
-        if (te >= t0 + n || j >= a.nds) continue;
-        const int e = (int)(te - t0);
-        if (e < 0 || e >= 26) continue;
-        // sample e - k of the frame, k = 0 .. 26, newest first (:479-483): from the frame's own first 26 samples, or from the 26
-        // before it (the previous frame's last ones; the stream's history for the call's first frame)
-        const double *head = a.edges + (g0 + f) * 52;
-        const double *prev = a.edges + (g0 + f - 1) * 52 + 26;
-        double fi = 0.0;
-#pragma unroll
-        for (int k = 0; k < 27; k++) {
-            const int i = e - k;
-            const double x = i >= 0 ? head[i] : (f == 0 ? hist0[26 + i] : prev[26 + i]);
-            fi += x * ds_tap(k);
-        }
-        const double ov = fi * HOWARD;
-        const double2 cs = a.vco_cs[j];
-        a.dm[(long long)s * a.dm_stride + 64 + j] = make_double2(ov * cs.x, ov * cs.y);
+    const int nrows = (fb + FB < a.F ? FB : a.F - fb) + 1;
+    for (int i = tid; i < nrows * 52; i += 256) {
+        const int row = i / 52, c = i - row * 52;
+        const int f = fb - 1 + row;
+        rows[i] = f >= 0 ? a.edges[(g0 + f) * 52 + c] : (c >= 26 ? sp->hist[c - 26] : 0.0);
     }
-    if (tid < 26) sp->hist[tid] = a.edges[(g0 + a.F - 1) * 52 + 26 + tid];
+    __syncthreads();
+    {
+        const int fi = tid / EO, r = tid - fi * EO;
+        const int f = fb + fi;
+        if (fi < FB && f < a.F) {
+            const int fo = (int)a.first_out;
+            const int t0 = (a.f0 + f) * n;
+            const int jlo = t0 <= fo ? 0 : (int)((unsigned)(t0 - fo + D - 1) / (unsigned)D);
+            const int j = jlo + r;
+            const int te = fo + D * j;
+            const int e = te - t0;
+            if (te < t0 + n && j < (int)a.nds && e >= 0 && e < 26) {
+                // sample e - k of the frame, k = 0 .. 26, newest first (:479-483): from the frame's own first 26 samples, or from the 26
+                // before it (the previous frame's last ones; the stream's history for the call's first frame)
+                const double *head = rows + (fi + 1) * 52;
+                const double *prev = rows + fi * 52 + 26;
+                double fiv = 0.0;
+#pragma unroll
+                for (int k = 0; k < 27; k++) {
+                    const int i = e - k;
+                    const double x = i >= 0 ? head[i] : prev[26 + i];
+                    fiv += x * ds_tap(k);
+                }
+                const double ov = fiv * HOWARD;
+                const double2 cs = a.vco_cs[j];
+                a.dm[(long long)s * a.dm_stride + 64 + j] = make_double2(ov * cs.x, ov * cs.y);
+            }
+        }
+    }
+    // the history the call leaves: by the stream's first block, which is the only one that read the old one (before the barrier above)
+    if (blockIdx.y == 0 && tid < 26) sp->hist[tid] = a.edges[(g0 + a.F - 1) * 52 + 26 + tid];
 }
 
 
@@ -973,6 +1054,12 @@ size_t acq3_frame_bytes(int n, int do_up)
     int nsb, na;
     acq3_layout(n, do_up, &nsb, &na);
     return sizeof(double2) * (size_t)nsb + sizeof(double) * (size_t)na + sizeof(AcqPeak) + 16 + sizeof(double) * 52;
+}
+
+static int acq_edge_blocks(const AcqArgs &a)
+{
+    const int fb = 256 / (26 / a.decim + 2);  // frames a block of k_acq_edges takes
+    return (a.F + fb - 1) / fb;
 }
 
 template <int LOGN>
@@ -1009,6 +1096,9 @@ static int launch_acq3_t(AcqArgs &a, bool f32, int num_cu, hipStream_t st, const
         if (prof.mark) prof.mark(prof.ctx, phase, begin, st);
     };
     JSDR_HIP_TRY(hipMemsetAsync(a.tickets, 0, 2 * sizeof(unsigned), st));  // the run counters of the two frame-parallel kernels
+    a.rps = (a.F + a.run - 1) / a.run;
+    JSDR_REQUIRE((long long)a.S * a.rps < 0x7fffffffLL && (long long)(a.f0 + a.F) * a.n < 0x7fffffffLL,
+                 "bpsk: a three-phase FFT-acquire launch of %d streams x %d frames is beyond its 32-bit frame arithmetic", a.S, a.F);
     mark(0, true);
     if (f32)
         hipLaunchKernelGGL((k_acq_fwd<LOGN, true>), dim3((unsigned)gf), dim3(T), lds_fwd, st, a);
@@ -1025,7 +1115,7 @@ static int launch_acq3_t(AcqArgs &a, bool f32, int num_cu, hipStream_t st, const
     mark(2, false);
     JSDR_LAUNCH_CHECK();
     mark(3, true);
-    hipLaunchKernelGGL(k_acq_edges, dim3((unsigned)a.S), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_acq_edges, dim3((unsigned)a.S, (unsigned)acq_edge_blocks(a)), dim3(256), 0, st, a);
     mark(3, false);
     JSDR_LAUNCH_CHECK();
     return JSDR_OK;
@@ -1052,7 +1142,7 @@ static int launch_acq3_m(AcqArgs &a, const FftFrontArgs &fa, const AcqmPlan &pla
     if (launch_acqm(a, fa, plan.np, plan.rad, plan.tw_off, plan.wr_off, num_cu, 1, st) != JSDR_OK) return JSDR_ERR;
     mark(2, false);
     mark(3, true);
-    hipLaunchKernelGGL(k_acq_edges, dim3((unsigned)a.S), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_acq_edges, dim3((unsigned)a.S, (unsigned)acq_edge_blocks(a)), dim3(256), 0, st, a);
     mark(3, false);
     JSDR_LAUNCH_CHECK();
     return JSDR_OK;

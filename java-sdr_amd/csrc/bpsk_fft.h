@@ -124,6 +124,7 @@ struct AcqArgs {
     int nwg;               // persistent workgroups of phases A and C
     unsigned *tickets;     // [2] run counters of k_acq_fwd / k_acq_inv, zero at launch: a workgroup takes its frames in runs of `run`
     int run;               // consecutive frames per ticket (>= 2)
+    int rps;               // runs per stream = ceil(F / run): a run lies inside one stream
     long long *clk;        // diagnostics (JSDR_FFT_PHASECLK=1): [16] clock ticks per phase of workgroup 0, k_acq_fwd [0..7], k_acq_inv [8..15]; or null
 };
 
