@@ -3524,6 +3524,12 @@ int jsdr_bpsk_create(jsdr_bpsk **out, int rate, int nsamples_per_frame, int tuni
     // tools/ab_overlap_acq.sh / ab_env.sh: a step 14.0 vs 14.9 ms at n = 9600, 17.5 vs 18.1 at 4800, no difference at 19200;
     // round 4: 11.4 vs 12.15 at n = 2048 -- k_sync_t takes 5.1 ms beside k_front_fft against 0.11 alone -- 11.6 vs 12.5 at 4096)
     if (do_fft) h->overlap = false;
+    // round 6: beside the three-phase front end's kernels of the 1024- and 2048-sample frames (128-thread workgroups, two waves a
+    // SIMD) the side section does overlap usefully -- the tail / sync / FEC of call k under the forward kernel of call k + 1: a step
+    // 9.97 against 11.25 ms at n = 2048 (1024 x 2^20), 10.50 / 12.28 at 1024, 1.16 / 1.61 at 64 streams; at n = 4096 it loses again
+    // (12.29 against 10.87) -- so a handle of such frames that takes calls of several frames keeps its side stream
+    if (do_fft && nstreams > 1 && (nsamples_per_frame == 1024 || nsamples_per_frame == 2048) && max_batch_samples >= 2LL * nsamples_per_frame)
+        h->overlap = true;
     if (const char *e = knob("JSDR_NO_OVERLAP")) h->overlap = atoi(e) == 0;
     if (const char *e = knob("JSDR_FM")) h->use_fm = atoi(e) != 0;
     if (const char *e = knob("JSDR_SCHED_PREFETCH")) h->prefetch_on = atoi(e) != 0;
