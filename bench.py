@@ -116,7 +116,7 @@ def parse():
                     help="--workload fir: 27 = dsFilter (FUNcubeBPSKDemod.java:27-55), 65 = dmFilter (:58-77), 21 = fir.java weights(500,1500)")
     ap.add_argument("--fir-decim", type=int, default=10, choices=[1, 10, 20], help="--workload fir: decimation")
     ap.add_argument("--fft-acquire", action="store_true", help="demodulator in FFT-acquire mode (bpsk-dofft=1) instead of tune mode")
-    ap.add_argument("--rate", type=int, default=96000, choices=[44100, 48000, 96000, 192000],
+    ap.add_argument("--rate", type=int, default=96000, choices=[44100, 48000, 96000, 176400, 192000, 384000],
                     help="--workload bpsk: sample rate of the synthetic streams and of the demodulator (audio-rate); 192000 with "
                          "--bpsk-frame 19200 --fft-acquire is the FUNcube Dongle Pro+ default configuration")
     return ap.parse_args()

@@ -36,6 +36,7 @@ SOURCES = {
     #  i.e. a round trip to memory at the top of a frame for a value that is wanted a pass later)
     "bpsk_acq.hip": ["-ffp-contract=off", "-mllvm", "-amdgpu-atomic-optimizer-strategy=None"],
     "bpsk_fftm.hip": ["-ffp-contract=off"],
+    "bpsk_acqg.hip": ["-ffp-contract=off"],
     "group.hip": [],
 }
 

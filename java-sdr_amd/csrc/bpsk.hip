@@ -2461,6 +2461,7 @@ struct jsdr_bpsk {
     int logn = 0;
     bool fft_mixed = false;  // FFT-acquire frame is not a power of two (bpsk_fftm.hip)
     bool fft_2x = false;     // ... and is 2 m with m an LDS-sized frame (n = 19200): two m-point halves per transform
+    AcqgPlan gen_plan;       // gen_plan.on: none of the LDS front ends takes the frame (or its decimation): bpsk_acqg.hip, always in three phases
     int fm_np = 0, fm_rad[12] = {0}, fm_off[12] = {0}, fm_off1[12] = {0};
     DevBuf<double2> fft2x_ek;  // per-stream scratch of the 2 m front end
     DevBuf<double> fft2x_r0;
@@ -3248,6 +3249,7 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
         // chip better than streams: ceil(S F / W) * 1.15 < ceil(S / W) * F, W = the workgroups the chip holds (one a CU).
         bool three = !h->fft_2x && acq3_supported(h->nsf) && h->acq_mode != 0 && (xa.nframes >= 2 || h->acq_mode == 1) &&
                      L < 0x7fffffffLL && (long long)S * ((xa.nframes + 1) / 2) < 0x7fffffffLL;  // (its kernels' 32-bit frame arithmetic)
+        if (h->gen_plan.on) three = true;  // (no fused kernel exists for these frames)
         if (three && h->fft_mixed && h->acq_mode < 0) {
             if (h->num_cu_known == 0) {
                 int dev = 0, cus = 0;
@@ -3259,7 +3261,7 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
             three = (double)(((long long)S * F + W - 1) / W) * 1.15 < (double)((((long long)S + W - 1) / W) * F);
         }
         if (three) {
-            const size_t per = acq3_frame_bytes(h->nsf, h->do_up) + 64;
+            const size_t per = acq3_frame_bytes(h->nsf, h->do_up) + 64 + (h->gen_plan.on ? acqg_image_bytes(h->nsf) : 0);
             if (!h->acq_scratch.p) {
                 // sized for the largest call the handle takes, capped (JSDR_ACQ_SCRATCH_MB, default 6 GiB): longer calls go in
                 // several launches of acq_chunk frames per stream
@@ -3278,7 +3280,7 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
                 JSDR_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
                 h->num_cu = cus > 0 ? cus : 256;
             }
-            h->front_name = h->fft_mixed ? "k_acqm_fwd" : "k_acq_fwd";
+            h->front_name = h->gen_plan.on ? "k_acqg_pass" : h->fft_mixed ? "k_acqm_fwd" : "k_acq_fwd";
             AcqmPlan plan;
             plan.np = h->fm_np;
             plan.rad = h->fm_rad;
@@ -3288,7 +3290,7 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
             AcqProf prof;
             prof.ctx = &pc;
             prof.mark = acq_prof_mark;
-            if (launch_acq3(xa, S, h->acq_scratch.p, h->acq_scratch.n, h->acq_chunk, h->num_cu, st, prof, plan) != JSDR_OK) return JSDR_ERR;
+            if (launch_acq3(xa, S, h->acq_scratch.p, h->acq_scratch.n, h->acq_chunk, h->num_cu, st, prof, plan, &h->gen_plan) != JSDR_OK) return JSDR_ERR;
         } else {
         ProfScope ps(h, PK_FRONT, st);
         h->front_name = h->fft_2x ? "k_front_fft2x" : (h->fft_mixed ? "k_front_fftm" : "k_front_fft");
@@ -3481,17 +3483,17 @@ int jsdr_bpsk_create(jsdr_bpsk **out, int rate, int nsamples_per_frame, int tuni
     // java-sdr has defaults for -- take the specialised front ends, everything else the one-thread-per-output kernel.
     // FFT-acquire mode: the power-of-two and the 2 m front ends size their per-thread output lists for a decimation of at
     // least 4; the mixed-radix one (any other frame up to 9600 samples) loops and takes any.
-    JSDR_REQUIRE(!do_fft || decim >= 4 || fftm_supported(nsamples_per_frame),
-                 "jsdr_bpsk_create: FFT-acquire mode with a power-of-two frame or a frame above 9600 samples needs a rate of at "
-                 "least 38400 Hz (decimation %d < 4)", decim);
+    // Round 6: whatever those refuse -- and any other frame the oracle defines -- goes through the any-frame passes (bpsk_acqg.hip).
     JSDR_REQUIRE(nsamples_per_frame > 0 && nstreams > 0 && nstreams <= 65535, "jsdr_bpsk_create: bad geometry");
     if (max_batch_samples < nsamples_per_frame) max_batch_samples = nsamples_per_frame;
     const bool fft_pow2 = nsamples_per_frame >= 1024 && nsamples_per_frame <= 8192 &&
                           (nsamples_per_frame & (nsamples_per_frame - 1)) == 0;
-    JSDR_REQUIRE(!do_fft || fft_pow2 || fftm_supported(nsamples_per_frame) || fft2x_supported(nsamples_per_frame),
-                 "jsdr_bpsk_create: FFT-acquire mode needs a frame of 1024 / 2048 / 4096 / 8192 samples, or any other frame of 416 .. 9600 "
-                 "samples (the default 9600 / 4800, a 44.1 kHz card's 4410, an 11.025 kHz card's 1102), or twice a 2^a 3^b 5^c frame "
-                 "that is a multiple of 16 (19200) (got %d)",
+    const bool fft_lds = do_fft && (fftm_supported(nsamples_per_frame) || (decim >= 4 && (fft_pow2 || fft2x_supported(nsamples_per_frame))));
+    bool fft_gen = do_fft && !fft_lds;
+    if (const char *e = knob("JSDR_ACQG")) fft_gen = do_fft && atoi(e) != 0;  // (tests: the any-frame passes for a frame the LDS kernels take)
+    JSDR_REQUIRE(!fft_gen || acqg_supported(nsamples_per_frame),
+                 "jsdr_bpsk_create: FFT-acquire mode needs a frame of 416 .. 4194304 samples (got %d): below 416 the 204 gathered bins "
+                 "(FUNcubeBPSKDemod.java:458) do not end inside the frame",
                  nsamples_per_frame);
     JSDR_REQUIRE(bit_clock_is_regular(), "jsdr_bpsk_create: bit clock schedule is not the regular 8-cycle");
     if (fec_prepare() != JSDR_OK) return JSDR_ERR;
@@ -3557,13 +3559,14 @@ int jsdr_bpsk_create(jsdr_bpsk **out, int rate, int nsamples_per_frame, int tuni
               h->stage_raw.alloc((size_t)nsamples_per_frame * 2 + (nstreams == 1 ? ((do_fft ? sizeof(double2) : 1) * (size_t)h->max_ds + sizeof(double2) * (256 + FM_TABLE_SLACK) + 256) / 4 : 0)) == JSDR_OK &&
               h->ds_taps_dev.alloc(32) == JSDR_OK &&
               h->dmh[0].alloc(S * 64) == JSDR_OK && h->dmh[1].alloc(S * 64) == JSDR_OK && h->hist_bad.alloc(1) == JSDR_OK && h->amax.alloc(S) == JSDR_OK && h->fm_edges.alloc(S * 4 * FM_EDGE) == JSDR_OK && h->snap_dev.alloc(1) == JSDR_OK && h->tcs.alloc(2 * (256 + FM_TABLE_SLACK)) == JSDR_OK &&
-              (!do_fft || (h->fft_state.alloc(S) == JSDR_OK && h->fft_tw.alloc(fft_pow2 ? (size_t)nsamples_per_frame : (size_t)65536) == JSDR_OK &&
+              (!do_fft || (h->fft_state.alloc(S) == JSDR_OK && h->fft_tw.alloc(fft_gen ? 3 * (size_t)nsamples_per_frame + 64 : fft_pow2 ? (size_t)nsamples_per_frame : (size_t)65536) == JSDR_OK &&
                             h->vco_cs.alloc((size_t)h->max_ds) == JSDR_OK)) &&
               (!(do_fft && fft2x_supported(nsamples_per_frame)) ||
+               fft_gen ||
                (h->fft2x_ek.alloc(S * fft2x_scratch_ek(nsamples_per_frame)) == JSDR_OK &&
                 h->fft2x_r0.alloc(S * fft2x_scratch_r0(nsamples_per_frame)) == JSDR_OK)) &&
               // (a mixed-radix frame with a prime factor above 7: the out-of-place pass's scratch, in the 2 m front end's slot)
-              (!(do_fft && !fft_pow2 && fftm_supported(nsamples_per_frame) && fftm_scratch(nsamples_per_frame) > 0) ||
+              (!(do_fft && !fft_gen && !fft_pow2 && fftm_supported(nsamples_per_frame) && fftm_scratch(nsamples_per_frame) > 0) ||
                h->fft2x_ek.alloc(S * fftm_scratch(nsamples_per_frame)) == JSDR_OK);
     if (ok && nstreams == 1) {
         // [frame | ktu | kvco | vco_cs | tcs] + alignment slack, then the SnapPack slot (not handed out by h2d_call)
@@ -3612,7 +3615,10 @@ int jsdr_bpsk_create(jsdr_bpsk **out, int rate, int nsamples_per_frame, int tuni
         std::vector<double2> tw;
         h->fft_mixed = !fft_pow2;
         h->fft_2x = !fft_pow2 && fft2x_supported(nsamples_per_frame);
-        if (fft_pow2)
+        if (fft_gen) {
+            h->fft_mixed = h->fft_2x = false;
+            acqg_twiddles(tw, nsamples_per_frame, &h->gen_plan);
+        } else if (fft_pow2)
             fft_twiddles_f64(tw, nsamples_per_frame);
         else if (h->fft_2x)
             fft2x_twiddles(tw, nsamples_per_frame, &h->fm_np, h->fm_rad, h->fm_off, h->fm_off1);

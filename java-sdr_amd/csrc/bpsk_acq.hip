@@ -1040,6 +1040,7 @@ static void acq3_layout(int n, int do_up, int *nsb, int *na)
     // (Java's integer n / 4 and n / 2, as the reference computes its band, :429-430)
     const int beg = do_up ? n / 4 : 0, end = do_up ? n / 2 : n / 4;
     *nsb = do_up ? 204 + (n / 2 + 28 - (n / 4 - 26)) : n / 4 + 28;
+    if (*nsb < 204) *nsb = 204;  // (frames below 704 samples, any-frame path: the gather at the clamp value 102 takes bins [0, 204))
     *na = ((end - beg - 150) + 1) & ~1;
     if (*na < 2) *na = 2;
 }
@@ -1148,15 +1149,42 @@ static int launch_acq3_m(AcqArgs &a, const FftFrontArgs &fa, const AcqmPlan &pla
     return JSDR_OK;
 }
 
-int launch_acq3(const FftFrontArgs &fa, int nstreams, unsigned char *scratch, size_t scratch_bytes, int chunk_frames, int num_cu,
-                hipStream_t st, const AcqProf &prof, const AcqmPlan &plan)
+// any other frame: the passes of bpsk_acqg.hip around the same scan and edges
+static int launch_acq3_g(AcqArgs &a, const AcqgPlan &gen, double2 *img, hipStream_t st, const AcqProf &prof)
 {
-    JSDR_REQUIRE(acq3_supported(fa.n), "bpsk: the three-phase FFT-acquire front end takes frames of 1024 .. 8192 samples (2^k) or 9600 / 4800 / 4410, not %d", fa.n);
+    auto mark = [&](int phase, bool begin) {
+        if (prof.mark) prof.mark(prof.ctx, phase, begin, st);
+    };
+    JSDR_REQUIRE((long long)(a.f0 + a.F) * a.n < 0x7fffffffLL, "bpsk: an FFT-acquire call of %d frames of %d samples is beyond k_acq_edges' 32-bit sample index",
+                 a.f0 + a.F, a.n);
+    mark(0, true);
+    if (launch_acqg(a, gen, img, 0, st) != JSDR_OK) return JSDR_ERR;
+    mark(0, false);
+    mark(1, true);
+    hipLaunchKernelGGL(k_acq_scan, dim3((unsigned)a.S), dim3(64), 0, st, a);
+    mark(1, false);
+    JSDR_LAUNCH_CHECK();
+    mark(2, true);
+    if (launch_acqg(a, gen, img, 1, st) != JSDR_OK) return JSDR_ERR;
+    mark(2, false);
+    mark(3, true);
+    hipLaunchKernelGGL(k_acq_edges, dim3((unsigned)a.S, (unsigned)acq_edge_blocks(a)), dim3(256), 0, st, a);
+    mark(3, false);
+    JSDR_LAUNCH_CHECK();
+    return JSDR_OK;
+}
+
+int launch_acq3(const FftFrontArgs &fa, int nstreams, unsigned char *scratch, size_t scratch_bytes, int chunk_frames, int num_cu,
+                hipStream_t st, const AcqProf &prof, const AcqmPlan &plan, const AcqgPlan *gen)
+{
+    const bool generic = gen != nullptr && gen->on;
+    JSDR_REQUIRE(generic || acq3_supported(fa.n), "bpsk: the three-phase FFT-acquire front end takes frames of 1024 .. 8192 samples (2^k) or 9600 / 4800 / 4410, not %d", fa.n);
     int nsb, na;
     acq3_layout(fa.n, fa.do_up, &nsb, &na);
     if (chunk_frames < 1) chunk_frames = 1;
     const size_t nf = (size_t)nstreams * (size_t)chunk_frames;
-    JSDR_REQUIRE(nf * acq3_frame_bytes(fa.n, fa.do_up) + 256 <= scratch_bytes, "bpsk: FFT-acquire scratch too small (%zu frames)", nf);
+    JSDR_REQUIRE(nf * (acq3_frame_bytes(fa.n, fa.do_up) + (generic ? acqg_image_bytes(fa.n) : 0)) + 512 <= scratch_bytes,
+                 "bpsk: FFT-acquire scratch too small (%zu frames)", nf);
     AcqArgs a;
     a.raw = fa.raw;
     a.rawf = fa.rawf;
@@ -1188,6 +1216,8 @@ int launch_acq3(const FftFrontArgs &fa, int nstreams, unsigned char *scratch, si
     a.cbin = reinterpret_cast<int *>(p);
     p += ((sizeof(int) * nf + 63) & ~(size_t)63);
     a.tickets = reinterpret_cast<unsigned *>(p);
+    p += 64;
+    double2 *img = reinterpret_cast<double2 *>(scratch + (((size_t)(p - scratch) + 255) & ~(size_t)255));  // (any-frame path only)
     a.run = 4;
     if (const char *e = knob("JSDR_ACQ_RUN")) a.run = atoi(e) >= 2 ? atoi(e) : 4;
     a.nwg = 0;
@@ -1196,6 +1226,11 @@ int launch_acq3(const FftFrontArgs &fa, int nstreams, unsigned char *scratch, si
         a.f0 = f0;
         a.F = fa.nframes - f0 < chunk_frames ? fa.nframes - f0 : chunk_frames;
         int rc;
+        if (generic) {
+            rc = launch_acq3_g(a, *gen, img, st, prof);
+            if (rc != JSDR_OK) return rc;
+            continue;
+        }
         if (acqm_supported(fa.n)) {
             rc = launch_acq3_m(a, fa, plan, num_cu, st, prof);
             if (rc != JSDR_OK) return rc;

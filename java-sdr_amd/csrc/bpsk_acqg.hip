@@ -1,0 +1,416 @@
+// bpsk_acqg.hip -- FUNcubeBPSKDemod FFT-acquire (doBufferFFT, FUNcubeBPSKDemod.java:406-464) for ANY frame (round 6).
+//
+// JTransforms takes any n (:194, :422-423) and a frame is a tenth of a second of any audio-rate (JavaAudio.java:49,58-59).  The LDS
+// front ends hold a frame as a double2 image in ONE workgroup's LDS: powers of two 1024 .. 8192 (bpsk_fft.hip / bpsk_acq.hip), any
+// other frame of 416 .. 9600 samples (bpsk_fftm.hip), twice a 16 | m, 2^a 3^b 5^c frame (19200).  Every other frame the oracle
+// defines comes here: powers of two below 1024 and above 8192, 17640 (176.4 kHz: 2 x 8820, 7^2 | 8820), 38400 (384 kHz), any
+// frame above 9600 samples, and the LDS front ends' frames at decimations they do not take (a 2^k frame below 38.4 kHz).
+//
+// Phases A and C of the three-phase front end (bpsk_acq.hip: frame-parallel forward half, one scan per stream, frame-parallel
+// inverse half, edges) with the frame's image in GLOBAL memory: one launch per pass of the transform, one thread per butterfly,
+// over all frames of the launch at once.  The transform is the oracle's, operation for operation (oracle/o_fft.c): powers of two
+// the radix-2 decimation-in-time network on jo_fft_twiddles_f64's table (inverse: conjugated twiddles), every other n the Stockham
+// passes of fft_f64_mixed (radices in jo_fft_mixed_radices' order, per-pass tables, the fixed-order butterflies of bpsk_radix.h, a
+// prime radix above 7 as the DFT's definition; inverse = conj o forward o conj) -- so centre bins, traces, bits and FEC bytes are
+// bit-identical to the oracle's.  A pass is a round trip through HBM (32 bytes a point): a correctness path for rare rates, ~10x
+// the LDS kernels' time per sample; the scan (k_acq_scan) and the windows across frame borders (k_acq_edges) are shared.
+#include "bpsk_fft.h"
+#include "bpsk_radix.h"
+#include <math.h>
+
+namespace jsdr {
+
+constexpr int AG_T = 256;
+constexpr int AG_TB = 2048;  // boxcar outputs a workgroup forms per LDS tile of |X|
+
+__device__ __forceinline__ int ag_bitrev(int x, int bits) { return (int)(__brev((unsigned)x) >> (32 - bits)); }
+
+// :416-421 -- the frame to the image, (double) of JavaAudio's float samples; powers of two at the bit-reversed position (the
+// permutation jo_fft_f64 starts with)
+template <bool F32IN>
+__global__ __launch_bounds__(AG_T) void k_acqg_load(AcqArgs a, double2 *img, int logn, int bpf)
+{
+    const unsigned g = blockIdx.x / (unsigned)bpf;
+    const int t = (int)(blockIdx.x - g * (unsigned)bpf) * AG_T + (int)threadIdx.x;
+    if (t >= a.n) return;
+    const int s = (int)(g / (unsigned)a.F), f = (int)(g - (unsigned)s * (unsigned)a.F);
+    const long long src = (long long)s * a.stride_pairs + (long long)(a.f0 + f) * a.n + t;
+    double di, dq;
+    if (F32IN) {
+        const float2 w = a.rawf[src];
+        di = (double)w.x;
+        dq = (double)w.y;
+    } else {
+        const int w = a.raw[src];
+        di = (double)i16_to_float_java(java_short_add((int)(short)(w & 0xffff), a.ic));
+        dq = (double)i16_to_float_java(java_short_add(w >> 16, a.qc));
+    }
+    img[(long long)g * a.n + (logn ? ag_bitrev(t, logn) : t)] = make_double2(di, dq);
+}
+
+// one radix-2 stage of jo_fft_f64, in place: butterfly (base + j, base + j + half), twiddle w[j * step] = stage table entry j
+template <bool INVERSE>
+__global__ __launch_bounds__(AG_T) void k_acqg_stage(double2 *img, int n, int half, const double2 *tw, int bpf)
+{
+    const unsigned g = blockIdx.x / (unsigned)bpf;
+    const int i = (int)(blockIdx.x - g * (unsigned)bpf) * AG_T + (int)threadIdx.x;
+    if (i >= n / 2) return;
+    double2 *X = img + (long long)g * n;
+    const int j = i & (half - 1);
+    const int ia = (i - j) * 2 + j, ib = ia + half;
+    const double2 w = tw[half - 1 + j];
+    const double wr = w.x, wi = INVERSE ? -w.y : w.y;
+    const double2 b = X[ib], av = X[ia];
+    const double p1 = wr * b.x, p2 = wi * b.y, p3 = wr * b.y, p4 = wi * b.x;
+    const double tr = p1 - p2, ti = p3 + p4;
+    X[ia] = make_double2(av.x + tr, av.y + ti);
+    X[ib] = make_double2(av.x - tr, av.y - ti);
+}
+
+// one Stockham pass of fft_f64_mixed_forward, out of place: butterfly b (k = b mod P) from in[b + j n/r], input j >= 1 times
+// T[k j], the r-point butterfly, output q to out[(b - k) r + k + q P]
+template <int R>
+__global__ __launch_bounds__(AG_T) void k_acqg_pass(const double2 *in, double2 *out, int n, int P, const double2 *tw, int bpf)
+{
+    const unsigned g = blockIdx.x / (unsigned)bpf;
+    const int b = (int)(blockIdx.x - g * (unsigned)bpf) * AG_T + (int)threadIdx.x;
+    const int nb = n / R;
+    if (b >= nb) return;
+    const double2 *x = in + (long long)g * n;
+    double2 *y = out + (long long)g * n;
+    const int k = b % P;
+    double2 v[R];
+#pragma unroll
+    for (int j = 0; j < R; j++) {
+        v[j] = x[b + j * nb];
+        if (j >= 1 && P > 1) v[j] = cdmul(v[j], tw[k * j]);
+    }
+    dft_r<R>(v);
+    const int j0 = (b - k) * R + k;
+#pragma unroll
+    for (int q = 0; q < R; q++) y[j0 + q * P] = v[q];
+}
+
+// a prime radix above 7: out_q = v_0 + v_1 W[q mod r] + ... + v_{r-1} W[(r-1) q mod r], every product a full complex multiply,
+// summed left to right (o_fft.c:206-228).  One thread per output; the twiddled inputs are formed again for every q (the same
+// operations on the same operands give the same values).
+__global__ __launch_bounds__(AG_T) void k_acqg_pass_prime(const double2 *in, double2 *out, int n, int P, int r, const double2 *tw,
+                                                          const double2 *wr, int bpf)
+{
+    const unsigned g = blockIdx.x / (unsigned)bpf;
+    const int i = (int)(blockIdx.x - g * (unsigned)bpf) * AG_T + (int)threadIdx.x;
+    if (i >= n) return;
+    const int nb = n / r;
+    const int q = i / nb, b = i - q * nb;
+    const double2 *x = in + (long long)g * n;
+    double2 *y = out + (long long)g * n;
+    const int k = b % P;
+    double2 acc = x[b];
+    for (int j = 1; j < r; j++) {
+        double2 v = x[b + j * nb];
+        if (P > 1) v = cdmul(v, tw[k * j]);
+        const int m = (int)(((long long)j * q) % r);
+        acc = cdadd(acc, cdmul(v, wr[m]));
+    }
+    y[(b - k) * r + k + q * P] = acc;
+}
+
+// :425-443 for one frame per workgroup: the bins a gather can reach to the frame's row (layout: acq_spec_index), |X| over the band
+// in LDS tiles, the 100-wide boxcar summed j ascending for every i (:433-437), first maximum (:439-442)
+__global__ __launch_bounds__(AG_T) void k_acqg_band(AcqArgs a, const double2 *img)
+{
+    __shared__ double Pm[AG_TB + 100];
+    __shared__ double redv[AG_T / 64];
+    __shared__ int redi[AG_T / 64];
+    const long long g = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = a.n;
+    const double2 *X = img + g * n;
+    const int beg = a.do_up ? n / 4 : 0;
+    const int end = a.do_up ? n / 2 : n / 4;
+    {
+        double2 *specg = a.spec + g * a.nsb;
+        const int lo1 = n / 4 - 26;
+        for (int i = tid; i < a.nsb; i += AG_T) {
+            const int b = a.do_up ? (i < 204 ? i : lo1 + (i - 204)) : i;
+            specg[i] = X[b];
+        }
+    }
+    double bestv = 0.0;
+    int besti = -1;
+    double *ab = a.aband + g * a.na;
+    for (int i0 = beg + 75; i0 < end - 75; i0 += AG_TB) {
+        const int cnt = end - 75 - i0 < AG_TB ? end - 75 - i0 : AG_TB;
+        for (int u = tid; u < cnt + 99; u += AG_T) {
+            const double2 v = X[i0 - 50 + u];
+            Pm[u] = sqrt(v.x * v.x + v.y * v.y);  // :425-427
+        }
+        __syncthreads();
+        for (int u = tid; u < cnt; u += AG_T) {
+            double acc = 0.0;
+#pragma unroll 4
+            for (int j = 0; j < 100; j++) acc += Pm[u + j];
+            ab[i0 + u - (beg + 75)] = acc;
+            if (bestv < acc) {
+                bestv = acc;
+                besti = i0 + u;
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const double ov = __shfl_xor(bestv, off, 64);
+        const int oi = __shfl_xor(besti, off, 64);
+        if (oi >= 0 && (ov > bestv || (ov == bestv && (besti < 0 || oi < besti)))) {
+            bestv = ov;
+            besti = oi;
+        }
+    }
+    if (lane == 0) {
+        redv[wave] = bestv;
+        redi[wave] = besti;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double mv = 0.0;
+        int mi = -1;
+        for (int w = 0; w < AG_T / 64; w++) {
+            const double ov = redv[w];
+            const int oi = redi[w];
+            if (oi >= 0 && (ov > mv || (ov == mv && (mi < 0 || oi < mi)))) {
+                mv = ov;
+                mi = oi;
+            }
+        }
+        AcqPeak pk;
+        pk.maxBin = mv;
+        pk.binPos = mi;
+        pk.pad = 0;
+        a.peak[g] = pk;
+    }
+}
+
+// :414-415, :458 -- the zeroed array with the 204 bins around the frame's centre bin at its head, as the inverse transform's input:
+// every other n conjugated (fft_f64_mixed: conj o forward o conj; the zeros become (0, -0.0)), powers of two as they are, at the
+// bit-reversed position
+__global__ __launch_bounds__(AG_T) void k_acqg_gather(AcqArgs a, double2 *img, int logn, int bpf)
+{
+    const unsigned g = blockIdx.x / (unsigned)bpf;
+    const int i = (int)(blockIdx.x - g * (unsigned)bpf) * AG_T + (int)threadIdx.x;
+    const int n = a.n;
+    if (i >= n) return;
+    double2 v = make_double2(0.0, 0.0);
+    if (i < 204) {
+        const int lo1 = n / 4 - 26;
+        const int c = a.cbin[g];
+        int off = c - 102;
+        if (a.do_up) off = (c == 102) ? 0 : 204 + (c - 102 - lo1);
+        if (off < 0) off = 0;
+        if (off + 204 > a.nsb) off = a.nsb - 204;
+        v = a.spec[(long long)g * a.nsb + off + i];
+    }
+    if (logn)
+        img[(long long)g * n + ag_bitrev(i, logn)] = v;
+    else
+        img[(long long)g * n + i] = make_double2(v.x, -v.y);
+}
+
+// :461-463, :470-492, :511-516 -- re / n of the inverse transform (both definitions scale by the product with 1.0 / n) through
+// RxDownSample for the windows that lie inside the frame, VCO mix; the frame's first and last 26 samples for k_acq_edges
+__global__ __launch_bounds__(AG_T) void k_acqg_rx(AcqArgs a, const double2 *img, int bpf)
+{
+    const unsigned g = blockIdx.x / (unsigned)bpf;
+    const int r = (int)(blockIdx.x - g * (unsigned)bpf) * AG_T + (int)threadIdx.x;
+    const int n = a.n, D = a.decim;
+    const int s = (int)(g / (unsigned)a.F), f = (int)(g - (unsigned)s * (unsigned)a.F);
+    const double2 *X = img + (long long)g * n;
+    const double norm = 1.0 / (double)n;
+    const double HOWARD = 0.9 * 32768.0;
+    if (r < 52) a.edges[(long long)g * 52 + r] = X[r < 26 ? r : n - 52 + r].x * norm;
+    const long long t0 = (long long)(a.f0 + f) * n;  // call-relative index of the frame's first sample
+    const long long jlo = t0 <= a.first_out ? 0 : (t0 - a.first_out + D - 1) / D;
+    const long long j = jlo + r;
+    const long long te = a.first_out + (long long)D * j;  // window end, call-relative
+    if (te >= t0 + n || j >= a.nds) return;
+    const int e = (int)(te - t0);
+    if (e < 26) return;
+    double fi = 0.0;
+#pragma unroll
+    for (int k = 0; k < 27; k++) fi += (X[e - k].x * norm) * ds_tap(k);  // newest first (:479-483)
+    const double o = fi * HOWARD;
+    const double2 cs = a.vco_cs[j];
+    a.dm[(long long)s * a.dm_stride + 64 + j] = make_double2(o * cs.x, o * cs.y);  // :515-516
+}
+
+// ============================================================================================================= host
+// the oracle's jo_fft_mixed_radices (o_fft.c:151-171), frames above 9600 samples starting with one radix-2 pass
+static int acqg_radices(int n, int *rad)
+{
+    int c = 0;
+    if (n < 2) return 0;
+    if (n > 9600 && n % 2 == 0) {
+        rad[c++] = 2;
+        n /= 2;
+    }
+    while (n % 4 == 0 && c < ACQG_MAXPASS) {
+        rad[c++] = 4;
+        n /= 4;
+    }
+    if (n % 2 == 0 && c < ACQG_MAXPASS) {
+        rad[c++] = 2;
+        n /= 2;
+    }
+    for (int p = 3; p <= 7; p += 2)
+        while (n % p == 0 && c < ACQG_MAXPASS) {
+            rad[c++] = p;
+            n /= p;
+        }
+    for (int p = 11; n > 1 && c < ACQG_MAXPASS; p += 2) {
+        if (p * p > n) p = n;
+        while (n % p == 0 && c < ACQG_MAXPASS) {
+            rad[c++] = p;
+            n /= p;
+        }
+    }
+    return n == 1 ? c : 0;
+}
+
+bool acqg_supported(int n)
+{
+    // below 416 samples the 204 gathered bins do not end inside the frame (the reference's own arraycopy would throw); the image
+    // index arithmetic of the kernels is 32-bit within a frame
+    if (n < 416 || n > (1 << 22)) return false;
+    if ((n & (n - 1)) == 0) return true;
+    int rad[ACQG_MAXPASS];
+    return acqg_radices(n, rad) > 0;
+}
+
+// images of a frame in the launch's scratch: a power of two is transformed in place, the Stockham passes go between two
+size_t acqg_image_bytes(int n) { return sizeof(double2) * (size_t)n * (((n & (n - 1)) == 0) ? 1 : 2); }
+
+void acqg_twiddles(std::vector<double2> &w, int n, AcqgPlan *plan)
+{
+    plan->on = true;
+    plan->logn = 0;
+    plan->np = 0;
+    if ((n & (n - 1)) == 0) {
+        while ((1 << plan->logn) < n) plan->logn++;
+        fft_twiddles_f64(w, n);
+        return;
+    }
+    plan->np = acqg_radices(n, plan->rad);
+    w.clear();
+    auto table = [&](int len) {  // jo_fft_mixed_table: long double + one rounding, exact on the axes
+        const size_t o = w.size();
+        w.resize(o + (size_t)len);
+        for (int m = 0; m < len; m++) {
+            const long double ang = 2.0L * 3.14159265358979323846264338327950288L * (long double)m / (long double)len;
+            w[o + m] = make_double2((double)cosl(ang), (double)(-sinl(ang)));
+        }
+        w[o] = make_double2(1.0, -0.0);
+        if (len % 4 == 0) {
+            w[o + len / 4] = make_double2(0.0, -1.0);
+            w[o + 3 * len / 4] = make_double2(-0.0, 1.0);
+        }
+        if (len % 2 == 0) w[o + len / 2] = make_double2(-1.0, -0.0);
+        return (int)o;
+    };
+    int P = 1;
+    for (int p = 0; p < plan->np; p++) {
+        plan->tw_off[p] = table(P * plan->rad[p]);
+        P *= plan->rad[p];
+    }
+    for (int p = 0; p < plan->np; p++) plan->wr_off[p] = plan->rad[p] > 7 ? table(plan->rad[p]) : 0;
+}
+
+// the transform of every frame of the launch: img0 -> wherever the last pass leaves it (returned)
+static double2 *acqg_transform(const AcqgPlan &pl, const double2 *tw, double2 *img0, double2 *img1, int n, long long nfr, bool inverse,
+                               hipStream_t st, int *rc)
+{
+    *rc = JSDR_OK;
+    if (pl.logn) {
+        const int bpf = (n / 2 + AG_T - 1) / AG_T;
+        for (int half = 1; half < n; half <<= 1) {
+            if (inverse)
+                hipLaunchKernelGGL(k_acqg_stage<true>, dim3((unsigned)(nfr * bpf)), dim3(AG_T), 0, st, img0, n, half, tw, bpf);
+            else
+                hipLaunchKernelGGL(k_acqg_stage<false>, dim3((unsigned)(nfr * bpf)), dim3(AG_T), 0, st, img0, n, half, tw, bpf);
+        }
+        if (hipGetLastError() != hipSuccess) *rc = JSDR_ERR;
+        return img0;
+    }
+    double2 *in = img0, *out = img1;
+    int P = 1;
+    for (int p = 0; p < pl.np; p++) {
+        const int r = pl.rad[p];
+        const double2 *t = tw + pl.tw_off[p];
+        const int bpf = ((r > 7 ? n : n / r) + AG_T - 1) / AG_T;
+        const dim3 grid((unsigned)(nfr * bpf));
+        switch (r) {
+            case 2: hipLaunchKernelGGL(k_acqg_pass<2>, grid, dim3(AG_T), 0, st, in, out, n, P, t, bpf); break;
+            case 3: hipLaunchKernelGGL(k_acqg_pass<3>, grid, dim3(AG_T), 0, st, in, out, n, P, t, bpf); break;
+            case 4: hipLaunchKernelGGL(k_acqg_pass<4>, grid, dim3(AG_T), 0, st, in, out, n, P, t, bpf); break;
+            case 5: hipLaunchKernelGGL(k_acqg_pass<5>, grid, dim3(AG_T), 0, st, in, out, n, P, t, bpf); break;
+            case 7: hipLaunchKernelGGL(k_acqg_pass<7>, grid, dim3(AG_T), 0, st, in, out, n, P, t, bpf); break;
+            default: hipLaunchKernelGGL(k_acqg_pass_prime, grid, dim3(AG_T), 0, st, in, out, n, P, r, t, tw + pl.wr_off[p], bpf); break;
+        }
+        P *= r;
+        double2 *tmp = in;
+        in = out;
+        out = tmp;
+    }
+    if (hipGetLastError() != hipSuccess) *rc = JSDR_ERR;
+    return in;
+}
+
+// phase A (which == 0) or phase C (which == 1) of one launch of the three-phase front end; img: the launch's images (S F frames of
+// acqg_image_bytes(n))
+int launch_acqg(const AcqArgs &a, const AcqgPlan &pl, double2 *img, int which, hipStream_t st)
+{
+    const int n = a.n;
+    const long long nfr = (long long)a.S * a.F;
+    const long long bpf_n = (n + AG_T - 1) / AG_T;
+    // (the grids are one dimension of workgroups: frames x blocks a frame; the prime-radix pass has a thread per output)
+    JSDR_REQUIRE(nfr * bpf_n < 0x7fffffffLL, "bpsk: an FFT-acquire launch of %d streams x %d frames of %d samples is beyond the any-frame kernels' grid",
+                 a.S, a.F, n);
+    double2 *img0 = img, *img1 = img + nfr * n;
+    int rc = JSDR_OK;
+    if (which == 0) {
+        const int bpf = (int)bpf_n;
+        if (a.rawf)
+            hipLaunchKernelGGL(k_acqg_load<true>, dim3((unsigned)(nfr * bpf)), dim3(AG_T), 0, st, a, img0, pl.logn, bpf);
+        else
+            hipLaunchKernelGGL(k_acqg_load<false>, dim3((unsigned)(nfr * bpf)), dim3(AG_T), 0, st, a, img0, pl.logn, bpf);
+        JSDR_LAUNCH_CHECK();
+        const double2 *X = acqg_transform(pl, a.tw, img0, img1, n, nfr, false, st, &rc);  // :422-423
+        if (rc != JSDR_OK) {
+            set_error("bpsk: an any-frame FFT pass failed to launch");
+            return JSDR_ERR;
+        }
+        hipLaunchKernelGGL(k_acqg_band, dim3((unsigned)nfr), dim3(AG_T), 0, st, a, X);
+        JSDR_LAUNCH_CHECK();
+        return JSDR_OK;
+    }
+    {
+        const int bpf = (int)bpf_n;
+        hipLaunchKernelGGL(k_acqg_gather, dim3((unsigned)(nfr * bpf)), dim3(AG_T), 0, st, a, img0, pl.logn, bpf);
+        JSDR_LAUNCH_CHECK();
+    }
+    const double2 *X = acqg_transform(pl, a.tw, img0, img1, n, nfr, true, st, &rc);  // :459
+    if (rc != JSDR_OK) {
+        set_error("bpsk: an any-frame FFT pass failed to launch");
+        return JSDR_ERR;
+    }
+    {
+        // a frame holds at most n / D + 1 window ends; 52 threads of every frame also copy its edge samples
+        int per = n / a.decim + 2;
+        if (per < 52) per = 52;
+        const int bpf = (per + AG_T - 1) / AG_T;
+        hipLaunchKernelGGL(k_acqg_rx, dim3((unsigned)(nfr * bpf)), dim3(AG_T), 0, st, a, X, bpf);
+        JSDR_LAUNCH_CHECK();
+    }
+    return JSDR_OK;
+}
+
+}  // namespace jsdr

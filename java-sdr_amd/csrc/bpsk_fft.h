@@ -114,7 +114,7 @@ struct AcqArgs {
     FftFrontState *st;
     double2 *dm;
     long long dm_stride;
-    double2 *spec;         // [S F][nsb]: do_up ? bins [0, 204) then [n/4 - 26, n/2 + 28) : bins [0, n/4 + 28)
+    double2 *spec;         // [S F][nsb]: do_up ? bins [0, 204) then [n/4 - 26, n/2 + 28) : bins [0, max(n/4 + 28, 204))
     int nsb;
     double *aband;         // [S F][na]: boxcar sums over [beg + 75, end - 75)
     int na;
@@ -159,8 +159,24 @@ struct AcqProf {
     void *ctx = nullptr;
     void (*mark)(void *ctx, int phase, bool begin, hipStream_t st) = nullptr;
 };
+// ANY other frame (bpsk_acqg.hip): phases A and C with the frame's image in global memory, one launch per pass of the oracle's
+// transform -- powers of two outside 1024 .. 8192, frames above 9600 samples that are not twice a 16 | m, 2^a 3^b 5^c one
+// (17640, 38400), and the LDS front ends' frames at the decimations they do not take
+constexpr int ACQG_MAXPASS = 32;
+struct AcqgPlan {
+    bool on = false;
+    int logn = 0;                // a power of two: the radix-2 network on fft_twiddles_f64's table; else the Stockham plan below
+    int np = 0;
+    int rad[ACQG_MAXPASS] = {0};
+    int tw_off[ACQG_MAXPASS] = {0};  // pass p's table T[m] = exp(-2 pi i m / (P r))
+    int wr_off[ACQG_MAXPASS] = {0};  // a prime radix above 7: W[m] = exp(-2 pi i m / r)
+};
+bool acqg_supported(int n);
+size_t acqg_image_bytes(int n);  // scratch per (stream, frame) of one launch, on top of acq3_frame_bytes
+void acqg_twiddles(std::vector<double2> &w, int n, AcqgPlan *plan);
+int launch_acqg(const AcqArgs &a, const AcqgPlan &pl, double2 *img, int which, hipStream_t st);
 int launch_acq3(const FftFrontArgs &a, int nstreams, unsigned char *scratch, size_t scratch_bytes, int chunk_frames, int num_cu,
-                hipStream_t st, const AcqProf &prof, const AcqmPlan &plan);
+                hipStream_t st, const AcqProf &prof, const AcqmPlan &plan, const AcqgPlan *gen = nullptr);
 extern int g_acq_last_grid[4];  // workgroups of the last k_acq_fwd / k_acq_inv launch, and how many of each a CU holds
 // frames that are not a power of two (bpsk_fftm.hip): any n with 416 <= n <= 9600 (2^a 3^b 5^c 7^d through the radix passes, any
 // other prime factor through a pass that is the DFT's definition and needs fftm_scratch(n) elements of scratch per stream)

@@ -404,20 +404,80 @@ def test_bpsk_fft_mode_rejects_partial_frames_and_odd_sizes():
     with pytest.raises(J.JsdrError):
         d.batch_i16(buf, 2 * 8192, 3000)
     with pytest.raises(J.JsdrError):
-        J.Bpsk(nstreams=1, do_fft=1, blen=4 * 512)  # a power of two below 1024: the oracle defines those through the radix-2 network, no kernel does
+        J.Bpsk(nstreams=1, do_fft=1, blen=4 * 400)  # below 416 samples the 204 gathered bins would not fit the frame (the reference's arraycopy :458 would throw)
     with pytest.raises(J.JsdrError):
-        J.Bpsk(nstreams=1, do_fft=1, blen=4 * 38400, rate=192000)  # n = 38400: neither an LDS-sized frame nor twice one
-    with pytest.raises(J.JsdrError):
-        J.Bpsk(nstreams=1, do_fft=1, blen=4 * 400)  # below 416 samples the 204 gathered bins would not fit the frame
-    with pytest.raises(J.JsdrError):
-        J.Bpsk(nstreams=1, do_fft=1, blen=4 * 9602)  # above 9600 samples only twice an LDS-sized 2^a 3^b 5^c frame
+        J.Bpsk(nstreams=1, do_fft=1, blen=4 * 256)
+
+
+@pytest.mark.parametrize("nsf,rate,do_up", [
+    (512, 48000, 0), (512, 5120, 1),  # powers of two below 1024 (decimations 5 and 1)
+    (16384, 163840, 0), (32768, 96000, 1),  # ... and above 8192
+    (17640, 176400, 0),  # a 176.4 kHz card's frame: 2 x 8820, 7^2 | 8820
+    (38400, 384000, 1),  # a 384 kHz card's
+    (9614, 96140, 0),  # 2 . 11 . 19 . 23: above 9600 samples with prime radices above 7
+    (11025, 110250, 0),  # odd: 3^2 5^2 7^2
+    (2048, 19200, 0), (4096, 32000, 1), (19200, 28800, 0),  # the LDS front ends' own frames at decimations they do not take (2, 3, 3)
+])
+def test_bpsk_fft_mode_any_frame(nsf, rate, do_up):
+    """Round 6: the frames no LDS front end takes -- powers of two outside 1024 .. 8192, frames above 9600 samples other than twice a
+    16 | m, 2^a 3^b 5^c frame, power-of-two / 2 m frames below 38.4 kHz -- through the any-frame passes (bpsk_acqg.hip: the oracle's
+    transform one launch per pass, the image in global memory) inside the three-phase front end: bits, traces, FEC, counters and
+    state against the oracle, chunked so that calls begin at different frames (one call of a single frame among them)"""
+    n = nsf * 10
+    carrier = rate * (0.375 if do_up else 0.125) + 333.0
+    iq = O.make_dbpsk_stream(86, 0, n, rate=rate, carrier_hz=carrier, noise_sigma=600.0)[0]
+    rng = np.random.default_rng(nsf + rate)
+    noise = rng.integers(-11000, 11000, 2 * n).astype(np.int16)
+    d, oracles = run_both([iq, noise], n, [nsf * 3, nsf, nsf * 6], rate=rate, do_fft=1, do_up=do_up, blen=4 * nsf)
+    assert d.front_kernel_name() == "k_acqg_pass"
+    if nsf >= 604:
+        assert oracles[0].counters()["centreBin"] > 102  # the carrier was acquired, not the clamp value
+
+
+def test_bpsk_fft_mode_any_frame_receive_float_and_int16_frames():
+    """the IAudioHandler form through the any-frame passes: one frame a receive(), float and int16 frames in turn (n = 512 and 17640)"""
+    for nsf, rate in ((512, 48000), (17640, 176400)):
+        nfr = 8
+        iq = O.make_dbpsk_stream(94, 0, nsf * nfr, rate=rate, carrier_hz=rate / 8.0 + 150.0, noise_sigma=600.0)[0]
+        exact = O.convert_i16(iq)
+        d = J.Bpsk(nstreams=1, do_fft=1, rate=rate, blen=4 * nsf)
+        o = O.Bpsk(do_fft=1, rate=rate, blen=4 * nsf, trace=nsf * nfr // max(1, rate // 9600) + 8)
+        bits, tr = [], []
+        for k in range(nfr):
+            fr = exact[2 * nsf * k:2 * nsf * (k + 1)].copy()
+            if k % 3 == 1:
+                d.receive(fr)
+            else:
+                d.receive_raw(iq[2 * nsf * k:2 * nsf * (k + 1)])
+            o.receive(fr)
+            bits.append(d.bits().copy())
+            tr.append(d.trace().copy())
+        assert np.array_equal(np.concatenate(tr), o.trace())
+        assert np.array_equal(np.concatenate(bits), o.bits())
+        same_counters(d.counters(), o.counters())
+        same_state(d.state(), o.state())
+
+
+def test_bpsk_fft_mode_suite_through_the_any_frame_passes():
+    """every FFT-mode test once more in a child process with JSDR_ACQG=1: the frames the LDS front ends take (2^k, 9600 / 4800 / 4410,
+    19200, the prime-radix ones, -0.0 bins, carriers at the band edges, the fixtures) through the any-frame passes instead -- two
+    independent implementations of the oracle's transform against the same expectations"""
+    if os.environ.get("JSDR_ACQG") is not None or os.environ.get("JSDR_ACQ3") is not None:
+        return
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, JSDR_ACQG="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-p", "no:cacheprovider", "-m", "gpu",
+                        os.path.join(here, "test_gpu_bpsk.py"), os.path.join(here, "test_gpu_fixtures.py"),
+                        "-k", "fft and not either_front_end and not eight_streams_per_wave and not any_frame"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
 def test_bpsk_api_errors():
     with pytest.raises(J.JsdrError):
         J.Bpsk(rate=0)
-    with pytest.raises(J.JsdrError):
-        J.Bpsk(rate=32000, do_fft=1)  # FFT-acquire mode with a power-of-two frame (2048 here) needs a decimation of at least 4
     d = J.Bpsk(nstreams=2)
     with pytest.raises(J.JsdrError):
         d.receive(np.zeros(4096, np.float32))  # receive() is the 1-stream form
@@ -676,7 +736,7 @@ def test_bpsk_fft_mode_front_end_choice():
     """which front end serves a call: 2^k frames -- three phases from two frames a call; the default mixed-radix frames -- three
     phases where frames fill the chip better than streams (few streams, many frames), the fused kernel at a full grid of streams
     and for one frame a call"""
-    if os.environ.get("JSDR_ACQ3") is not None:
+    if os.environ.get("JSDR_ACQ3") is not None or os.environ.get("JSDR_ACQG") is not None:
         pytest.skip("the choice is forced")
     iq = O.make_dbpsk_stream(7, 0, 2048 * 6)[0]
     d = J.Bpsk(nstreams=1, do_fft=1, max_batch_samples=2048 * 6)
