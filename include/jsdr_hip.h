@@ -146,8 +146,10 @@ int jsdr_fec_encode_batch(const uint8_t *data_dev, int64_t nblocks, uint8_t *sym
  *   tuning_hz       : "bpsk-tuning" (:195), do_fft "bpsk-dofft" (:199), do_up "bpsk-upper" (:200)
  * Frames: tune mode takes any frame; FFT-acquire mode (do_fft) frames of 1024 / 2048 / 4096 / 8192 samples, any other
  * n = 2^a 3^b 5^c 7^d from 1025 to 9600 (java-sdr's defaults 9600 / 4800 at 96 / 48 kHz, 4410 at 44.1 kHz, 3200 at 32 kHz)
- * and twice a 2^a 3^b 5^c frame that is a multiple of 16 (19200, the 192 kHz default).  Power-of-two frames and 2 m
- * frames need a rate of at least 38400 Hz in that mode.
+ * and twice a 2^a 3^b 5^c frame that is a multiple of 16 (19200, the 192 kHz default) through kernels that hold the frame
+ * in LDS; every other frame of 416 .. 4194304 samples (and power-of-two / 2 m frames below 38400 Hz) through passes in
+ * global memory -- the same results, about ten times the time per sample.  Below 416 samples: refused (the reference's
+ * arraycopy of 204 bins, :458, would run off the frame).
  * max_batch_samples bounds one batch call; the per-call result log holds max_batch/40 + 16 bits and
  * max(8, bits/2600 + 4) FECDecode calls per stream -- a call that exceeds either flags the stream (getters fail).  */
 typedef struct jsdr_bpsk jsdr_bpsk;
