@@ -403,8 +403,13 @@ def test_oracle_mixed_radix_f64_transform_against_numpy():
     assert L.jo_fft_mixed_radices(1102, rad.ctypes.data) == 3 and list(rad[:3]) == [2, 19, 29]  # an 11.025 kHz card's frame
     assert L.jo_fft_mixed_radices(1103, rad.ctypes.data) == 1 and list(rad[:1]) == [1103]       # a prime frame: the DFT sum itself
     assert L.jo_fft_mixed_radices(2 * 11 * 11 * 13, rad.ctypes.data) == 4 and list(rad[:4]) == [2, 11, 11, 13]
+    # round 6: frames above 9600 samples start with one radix-2 pass; the frames the any-frame passes serve (csrc/bpsk_acqg.hip)
+    assert L.jo_fft_mixed_radices(17640, rad.ctypes.data) == 7 and list(rad[:7]) == [2, 4, 3, 3, 5, 7, 7]  # a 176.4 kHz card's frame
+    assert L.jo_fft_mixed_radices(38400, rad.ctypes.data) == 8 and list(rad[:8]) == [2, 4, 4, 4, 4, 3, 5, 5]  # a 384 kHz card's
+    assert L.jo_fft_mixed_radices(9614, rad.ctypes.data) == 4 and list(rad[:4]) == [2, 11, 19, 23]
+    assert L.jo_fft_mixed_radices(11025, rad.ctypes.data) == 6 and list(rad[:6]) == [3, 3, 5, 5, 7, 7]
     rng = np.random.default_rng(12)
-    for n in (9600, 4800, 2400, 60, 15, 6, 4410, 7000, 49, 7, 2646, 1102, 1100, 1103, 3146, 11, 800, 638):
+    for n in (9600, 4800, 2400, 60, 15, 6, 4410, 7000, 49, 7, 2646, 1102, 1100, 1103, 3146, 11, 800, 638, 17640, 38400, 9614, 11025, 512, 16384):
         x = rng.standard_normal(2 * n)
         a = x.copy()
         L.jo_fft_f64(a.ctypes.data, n, 0, 0)
