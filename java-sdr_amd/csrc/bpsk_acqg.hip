@@ -7,7 +7,7 @@
 // frame above 9600 samples, and the LDS front ends' frames at decimations they do not take (a 2^k frame below 38.4 kHz).
 //
 // Phases A and C of the three-phase front end (bpsk_acq.hip: frame-parallel forward half, one scan per stream, frame-parallel
-// inverse half, edges) with the frame's image in GLOBAL memory: one launch per pass of the transform, one thread per butterfly,
+// inverse half, edges) with the frame's image in GLOBAL memory: one launch per pass of the transform (per four radix-2 stages), one thread per butterfly,
 // over all frames of the launch at once.  The transform is the oracle's, operation for operation (oracle/o_fft.c): powers of two
 // the radix-2 decimation-in-time network on jo_fft_twiddles_f64's table (inverse: conjugated twiddles), every other n the Stockham
 // passes of fft_f64_mixed (radices in jo_fft_mixed_radices' order, per-pass tables, the fixed-order butterflies of bpsk_radix.h, a
@@ -48,23 +48,40 @@ __global__ __launch_bounds__(AG_T) void k_acqg_load(AcqArgs a, double2 *img, int
     img[(long long)g * a.n + (logn ? ag_bitrev(t, logn) : t)] = make_double2(di, dq);
 }
 
-// one radix-2 stage of jo_fft_f64, in place: butterfly (base + j, base + j + half), twiddle w[j * step] = stage table entry j
-template <bool INVERSE>
-__global__ __launch_bounds__(AG_T) void k_acqg_stage(double2 *img, int n, int half, const double2 *tw, int bpf)
+// NST consecutive radix-2 stages of jo_fft_f64 (half = half0, 2 half0, ...), in place: a thread holds the 2^NST elements
+// base + j + u half0 that those stages connect -- one round trip through memory for up to four stages.  Every butterfly is the
+// oracle's: t = w b (four products, one difference, one sum), a' = a + t, b' = a - t, w = the stage table's entry for the pair's
+// position in its block (inverse: conjugated).
+template <bool INVERSE, int NST>
+__global__ __launch_bounds__(AG_T) void k_acqg_stages(double2 *img, int n, int half0, const double2 *tw, int bpf)
 {
+    constexpr int M = 1 << NST;
     const unsigned g = blockIdx.x / (unsigned)bpf;
     const int i = (int)(blockIdx.x - g * (unsigned)bpf) * AG_T + (int)threadIdx.x;
-    if (i >= n / 2) return;
+    if (i >= (n >> NST)) return;
     double2 *X = img + (long long)g * n;
-    const int j = i & (half - 1);
-    const int ia = (i - j) * 2 + j, ib = ia + half;
-    const double2 w = tw[half - 1 + j];
-    const double wr = w.x, wi = INVERSE ? -w.y : w.y;
-    const double2 b = X[ib], av = X[ia];
-    const double p1 = wr * b.x, p2 = wi * b.y, p3 = wr * b.y, p4 = wi * b.x;
-    const double tr = p1 - p2, ti = p3 + p4;
-    X[ia] = make_double2(av.x + tr, av.y + ti);
-    X[ib] = make_double2(av.x - tr, av.y - ti);
+    const int j = i & (half0 - 1);
+    const int base = ((i - j) << NST) + j;
+    double2 v[M];
+#pragma unroll
+    for (int u = 0; u < M; u++) v[u] = X[base + u * half0];
+#pragma unroll
+    for (int t = 0; t < NST; t++) {
+        const int h = half0 << t;
+#pragma unroll
+        for (int u = 0; u < M; u++) {
+            if (u & (1 << t)) continue;
+            const double2 w = tw[h - 1 + j + (u & ((1 << t) - 1)) * half0];
+            const double wr = w.x, wi = INVERSE ? -w.y : w.y;
+            const double2 b = v[u | (1 << t)], av = v[u];
+            const double p1 = wr * b.x, p2 = wi * b.y, p3 = wr * b.y, p4 = wi * b.x;
+            const double tr = p1 - p2, ti = p3 + p4;
+            v[u] = make_double2(av.x + tr, av.y + ti);
+            v[u | (1 << t)] = make_double2(av.x - tr, av.y - ti);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < M; u++) X[base + u * half0] = v[u];
 }
 
 // one Stockham pass of fft_f64_mixed_forward, out of place: butterfly b (k = b mod P) from in[b + j n/r], input j >= 1 times
@@ -330,12 +347,24 @@ static double2 *acqg_transform(const AcqgPlan &pl, const double2 *tw, double2 *i
 {
     *rc = JSDR_OK;
     if (pl.logn) {
-        const int bpf = (n / 2 + AG_T - 1) / AG_T;
-        for (int half = 1; half < n; half <<= 1) {
-            if (inverse)
-                hipLaunchKernelGGL(k_acqg_stage<true>, dim3((unsigned)(nfr * bpf)), dim3(AG_T), 0, st, img0, n, half, tw, bpf);
-            else
-                hipLaunchKernelGGL(k_acqg_stage<false>, dim3((unsigned)(nfr * bpf)), dim3(AG_T), 0, st, img0, n, half, tw, bpf);
+        for (int done = 0; done < pl.logn;) {
+            const int nst = pl.logn - done >= 4 ? 4 : pl.logn - done;
+            const int half0 = 1 << done;
+            const int bpf = ((n >> nst) + AG_T - 1) / AG_T;
+            const dim3 grid((unsigned)(nfr * bpf));
+#define AG_STAGES(NST)                                                                                              \
+    if (inverse)                                                                                                    \
+        hipLaunchKernelGGL((k_acqg_stages<true, NST>), grid, dim3(AG_T), 0, st, img0, n, half0, tw, bpf);          \
+    else                                                                                                            \
+        hipLaunchKernelGGL((k_acqg_stages<false, NST>), grid, dim3(AG_T), 0, st, img0, n, half0, tw, bpf)
+            switch (nst) {
+                case 4: AG_STAGES(4); break;
+                case 3: AG_STAGES(3); break;
+                case 2: AG_STAGES(2); break;
+                default: AG_STAGES(1); break;
+            }
+#undef AG_STAGES
+            done += nst;
         }
         if (hipGetLastError() != hipSuccess) *rc = JSDR_ERR;
         return img0;
