@@ -1,3 +1,4 @@
+# tools/ab_acq_sidestream.sh -- the FFT-acquire step with the tail / sync / FEC section on the side stream (default where the library chooses it) against JSDR_NO_OVERLAP=1, one session (profiles/r06_experiments.md 1c)
 export TMPDIR=/tmp JSDR_BENCH_LIVE_TRAFFIC=0 JSDR_KNOBS=1 JSDR_BENCH_ALLOW_KNOBS=1
 mkdir -p gpurun_out
 for CASE in "2048 1024" "4096 1024" "2048 64" "1024 1024" "2048 8192"; do
