@@ -458,6 +458,38 @@ def test_bpsk_fft_mode_any_frame_receive_float_and_int16_frames():
         same_state(d.state(), o.state())
 
 
+def _largest_prime_factor(n):
+    p, best = 2, 1
+    while p * p <= n:
+        while n % p == 0:
+            best, n = p, n // p
+        p += 1
+    return max(best, n) if n > 1 else best
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_bpsk_fft_mode_any_frame_random_sizes(seed, monkeypatch):
+    """random frames of 416 .. 24000 samples at random rates, both band halves, ragged call patterns, all through the any-frame passes
+    (JSDR_ACQG=1 also where an LDS front end would take the frame): whatever radix plan the frame has -- powers of two, 2 m, prime
+    radices up to 1500 (the oracle's O(n r) pass bounds the test's size, not the kernel) -- against the oracle"""
+    monkeypatch.setenv("JSDR_ACQG", "1")
+    rng = np.random.default_rng(7000 + seed)
+    while True:
+        nsf = int(rng.integers(416, 24001)) if seed % 3 else 1 << int(rng.integers(9, 15))
+        if _largest_prime_factor(nsf) <= 1500:
+            break
+    rate = int(rng.choice([8000, 9600, 11025, 22050, 32000, 44100, 48000, 96000, 192000, 250000, 384000]))
+    do_up = int(rng.integers(0, 2))
+    nfr = int(rng.integers(5, 9))
+    cuts = sorted(set(int(c) for c in rng.integers(1, nfr, 2)))
+    chunks = [b - a for a, b in zip([0] + cuts, cuts + [nfr])]
+    n = nsf * nfr
+    iq = O.make_dbpsk_stream(300 + seed, 0, n, rate=rate, carrier_hz=rate * (0.36 if do_up else 0.11) + 97.0, noise_sigma=500.0)[0]
+    noise = rng.integers(-9000, 9000, 2 * n).astype(np.int16)
+    d, _ = run_both([iq, noise], n, [c * nsf for c in chunks], rate=rate, do_fft=1, do_up=do_up, blen=4 * nsf)
+    assert d.front_kernel_name() == "k_acqg_pass"
+
+
 def test_bpsk_fft_mode_suite_through_the_any_frame_passes():
     """every FFT-mode test once more in a child process with JSDR_ACQG=1: the frames the LDS front ends take (2^k, 9600 / 4800 / 4410,
     19200, the prime-radix ones, -0.0 bins, carriers at the band edges, the fixtures) through the any-frame passes instead -- two

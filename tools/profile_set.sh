@@ -58,6 +58,9 @@ step b_acq4800 300 python bench.py --workload bpsk --fft-acquire --bpsk-frame 48
 step b_acq19200_192k 300 python bench.py --workload bpsk --fft-acquire --bpsk-frame 19200 --rate 192000 --streams 1024 $B;  line $O/${T}_b_acq19200_192k.log > $O/${T}_b_acq19200_192k.json
 # a 44.1 kHz sound card: frames of 4410 = 2 3^2 5 7^2 samples (radix-7 passes; checked against the oracle, not by payload)
 step b_acq4410_44k 300 python bench.py --workload bpsk --fft-acquire --bpsk-frame 4410 --rate 44100 --streams 1024 $B;  line $O/${T}_b_acq4410_44k.log > $O/${T}_b_acq4410_44k.json
+# frames no LDS front end takes (round 6: the any-frame passes in global memory): a 176.4 kHz and a 384 kHz card's, 256 streams
+step b_acqg17640 300 python bench.py --workload bpsk --fft-acquire --bpsk-frame 17640 --rate 176400 --streams 256 --steps 4 --warmup 1 $B;  line $O/${T}_b_acqg17640.log > $O/${T}_b_acqg17640.json
+step b_acqg38400 300 python bench.py --workload bpsk --fft-acquire --bpsk-frame 38400 --rate 384000 --streams 256 --steps 4 --warmup 1 $B;  line $O/${T}_b_acqg38400.log > $O/${T}_b_acqg38400.json
 # FFT-acquire at the reference's default frame, all 8192 streams, every stream validated by payload
 step b_acq9600_8k 500 python bench.py --workload bpsk --fft-acquire --bpsk-frame 9600 $B;  line $O/${T}_b_acq9600_8k.log > $O/${T}_b_acq9600_8k.json
 step b_fir65 300 python bench.py --workload fir --fir-taps 65 --streams 1024 $B;  line $O/${T}_b_fir65.log > $O/${T}_b_fir65.json
