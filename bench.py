@@ -55,7 +55,7 @@ FP64_ISSUE_TOPS = 31.2
 FP64_OPS_PER_DS_SAMPLE = {"k_fm": 368.0, "k_front_reg": 108.0, "k_front": 108.0, "k_matched": 260.0}
 # what binds each kernel, from the measurements cited in DESIGN.md 3 (not from the roofline arithmetic)
 KERNEL_BOUND = {"k_fft": "hbm", "k_fir_batch": "hbm", "k_waterfall": "hbm", "k_fm": "fp64-issue", "k_front_reg": "fp64-issue",
-                "k_front": "fp64-issue", "k_matched": "fp64-issue", "k_front_fft": "valu-issue", "k_front_fftm": "valu-issue",
+                "k_front": "fp64-issue", "k_matched": "fp64-issue", "k_front_fft": "valu-issue", "k_front_fftm": "valu-issue", "k_front_fftm2": "valu-issue",
                 "k_front_fft2x": "valu-issue", "k_acq_fwd": "valu-issue", "k_acq_inv": "valu-issue", "k_tail": "lds-issue/latency", "k_tail8": "hbm (16 B per 9600 Hz sample; a wave's latency below ~2000 streams)",
                 "k_fec_bits+k_vitq+k_fec_rs": "valu-issue",
                 "k_sync_t": "latency", "k_sync": "latency", "k_sync_fin": "latency", "k_fec_bpsk": "latency",

@@ -3293,7 +3293,7 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
             if (launch_acq3(xa, S, h->acq_scratch.p, h->acq_scratch.n, h->acq_chunk, h->num_cu, st, prof, plan, &h->gen_plan) != JSDR_OK) return JSDR_ERR;
         } else {
         ProfScope ps(h, PK_FRONT, st);
-        h->front_name = h->fft_2x ? "k_front_fft2x" : (h->fft_mixed ? "k_front_fftm" : "k_front_fft");
+        h->front_name = h->fft_2x ? "k_front_fft2x" : (h->fft_mixed ? (fftm_pairs(xa.n, xa.nframes) ? "k_front_fftm2" : "k_front_fftm") : "k_front_fft");
         const int frc = h->fft_2x ? launch_front_fft2x(xa, h->fm_np, h->fm_rad, h->fm_off, h->fm_off1, h->fft2x_ek.p, h->fft2x_r0.p, S, st)
                                   : (h->fft_mixed ? launch_front_fftm(xa, h->fm_np, h->fm_rad, h->fm_off, h->fm_off1, h->fft2x_ek.p, S, st) : launch_front_fft(xa, S, st));
         if (frc != JSDR_OK) return JSDR_ERR;

@@ -181,6 +181,7 @@ extern int g_acq_last_grid[4];  // workgroups of the last k_acq_fwd / k_acq_inv 
 // frames that are not a power of two (bpsk_fftm.hip): any n with 416 <= n <= 9600 (2^a 3^b 5^c 7^d through the radix passes, any
 // other prime factor through a pass that is the DFT's definition and needs fftm_scratch(n) elements of scratch per stream)
 bool fftm_supported(int n);
+bool fftm_pairs(int n, int nframes);  // launch_front_fftm takes the call's frames two at a time (k_front_fftm2)
 size_t fftm_scratch(int n);
 void fftm_twiddles(std::vector<double2> &w, int n, int *np_out, int *rad, int *tw_off, int *wr_off);
 int launch_front_fftm(const FftFrontArgs &a, int np, const int *rad, const int *tw_off, const int *wr_off, double2 *gscratch,

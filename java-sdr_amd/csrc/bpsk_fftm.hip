@@ -99,18 +99,22 @@ __device__ __forceinline__ GblArr gbl_arr(const double2 *g) { return GblArr{(gbl
 // NN / PP: frame size and stride as compile-time constants for the two default frames (9600, 4800): every LDS offset
 // becomes an immediate, `b mod P` a mask or a constant multiply-high, and the butterfly count per thread is the
 // frame's, not the largest frame's.  0 = run-time values (any other supported n).
-template <int R, int NN = 0, int PP = 0, class TW = const double2 *>
-__device__ __attribute__((noinline)) void fm_pass(LdsArr X, TW tw, int n_rt, int P_rt, unsigned pmagic, int tid)
+template <int R, int NN = 0, int PP = 0, class TW = const double2 *, int NIMG = 1>
+__device__ __attribute__((noinline)) void fm_pass(LdsArr X0, TW tw, int n_rt, int P_rt, unsigned pmagic, int tid)
 {
-    constexpr int ITERS = (((NN ? NN : FM_NMAX) / R) + FM_T - 1) / FM_T;
+    static_assert(NIMG == 1 || NN != 0, "several images: compile-time frame size");
+    constexpr int ITERS = ((NIMG * ((NN ? NN : FM_NMAX) / R)) + FM_T - 1) / FM_T;
     const int n = NN ? NN : n_rt;
     const int P = PP ? PP : P_rt;
     const int nb = n / R;
     double2 v[ITERS][R];
 #pragma unroll
     for (int it = 0; it < ITERS; it++) {
-        const int b = it * FM_T + tid;
-        if (b < nb) {
+        const int bb = it * FM_T + tid;
+        const int img = (NIMG > 1 && bb >= nb) ? 1 : 0;
+        const int b = bb - img * nb;
+        const LdsArr X = X0 + img * NN;
+        if (bb < NIMG * nb) {
             const int k = PP ? (b % PP) : (P == 1) ? 0 : b - (int)__umulhi((unsigned)b, pmagic) * P;  // b % P without the division sequence
 #pragma unroll
             for (int j = 0; j < R; j++) {
@@ -123,8 +127,11 @@ __device__ __attribute__((noinline)) void fm_pass(LdsArr X, TW tw, int n_rt, int
     FM_PASS_SYNC();
 #pragma unroll
     for (int it = 0; it < ITERS; it++) {
-        const int b = it * FM_T + tid;
-        if (b < nb) {
+        const int bb = it * FM_T + tid;
+        const int img = (NIMG > 1 && bb >= nb) ? 1 : 0;
+        const int b = bb - img * nb;
+        const LdsArr X = X0 + img * NN;
+        if (bb < NIMG * nb) {
             const int k = PP ? (b % PP) : (P == 1) ? 0 : b - (int)__umulhi((unsigned)b, pmagic) * P;  // (2^32/1 does not fit the magic)
             const int j0 = (b - k) * R + k;
 #pragma unroll
@@ -145,21 +152,27 @@ __device__ __attribute__((noinline)) void fm_pass(LdsArr X, TW tw, int n_rt, int
 // instead of 27 eight-byte reads at a 160-byte lane stride (16 lanes on the same banks).
 constexpr int FM_RB0 = 32;
 // COMPACT == 2: the samples go straight to an array in global memory (the even samples of a 2 m frame, k_front_fft2x)
-template <int NN, int PP, bool TT = false, int COMPACT = 0, class TW = const double2 *>
+// NIMG (round 6, here and in the passes below): the pass over NIMG images at once -- frames f and f + 1 of a stream side by side in
+// LDS, image i at X + i NN -- so that a frame of 4800 samples fills the 768 threads' work items as one of 9600 does (a pass pair of
+// ONE 4800-sample frame has 300 items)
+template <int NN, int PP, bool TT = false, int COMPACT = 0, class TW = const double2 *, int NIMG = 1>
 __device__ __attribute__((noinline)) void fm_pass5_real(LdsArr X, TW tw, double norm, int tid, const double *hist_ = nullptr,
                                                          double *gout = nullptr)
 {
-    constexpr int R = 5, nb = NN / R, ITERS = (nb + FM_T - 1) / FM_T;
+    constexpr int R = 5, nb = NN / R, ITERS = (NIMG * nb + FM_T - 1) / FM_T;
     double o[ITERS][R];
 #pragma unroll
     for (int it = 0; it < ITERS; it++) {
-        const int b = it * FM_T + tid;
-        if (b < nb) {
+        const int bb = it * FM_T + tid;
+        if (bb < NIMG * nb) {
+            const int img = (NIMG > 1 && bb >= nb) ? 1 : 0;
+            const int b = bb - img * nb;
+            const LdsArr Xi = X + img * NN;
             const int k = b % PP;
             double2 v[R];
 #pragma unroll
             for (int j = 0; j < R; j++) {
-                v[j] = X[b + j * nb];
+                v[j] = Xi[b + j * nb];
                 if (j >= 1) v[j] = cdmul(v[j], TT ? tw[(j - 1) * PP + k] : tw[k * j]);
             }
             dft_r<R>(v);
@@ -168,11 +181,15 @@ __device__ __attribute__((noinline)) void fm_pass5_real(LdsArr X, TW tw, double 
         }
     }
     FM_PASS_SYNC();
-    lds_f64 *Rb = reinterpret_cast<lds_f64 *>(X.p);
+    lds_f64 *Rb0 = reinterpret_cast<lds_f64 *>(X.p);
 #pragma unroll
     for (int it = 0; it < ITERS; it++) {
-        const int b = it * FM_T + tid;
-        if (b < nb) {
+        const int bb = it * FM_T + tid;
+        if (bb < NIMG * nb) {
+            const int img = (NIMG > 1 && bb >= nb) ? 1 : 0;
+            const int b = bb - img * nb;
+            const LdsArr Xi = X + img * NN;
+            lds_f64 *Rbi = Rb0 + img * (2 * NN);
             const int k = b % PP;
             const int j0 = (b - k) * R + k;
 #pragma unroll
@@ -180,12 +197,13 @@ __device__ __attribute__((noinline)) void fm_pass5_real(LdsArr X, TW tw, double 
                 if (COMPACT == 2)
                     gout[j0 + q * PP] = o[it][q];
                 else if (COMPACT == 1)
-                    Rb[FM_RB0 + j0 + q * PP] = o[it][q];
+                    Rbi[FM_RB0 + j0 + q * PP] = o[it][q];
                 else
-                    X[j0 + q * PP].put_x(o[it][q]);
+                    Xi[j0 + q * PP].put_x(o[it][q]);
             }
         }
     }
+    lds_f64 *Rb = Rb0;
     if (COMPACT == 1 && hist_ != nullptr) {
         const lds_f64 *hist = (const lds_f64 *)(unsigned)(unsigned long long)hist_;
         if (tid < 26) Rb[FM_RB0 - 26 + tid] = hist[tid];
@@ -200,18 +218,21 @@ __device__ __attribute__((noinline)) void fm_pass5_real(LdsArr X, TW tw, double 
 // butterfly whose only needed output is q = 0 forms (x0 + a1) + a2 alone (32 of its 72 operations); all others run in
 // full and store what is read.
 // need_end: outputs [0, need_end) of THIS transform are read (a half transform of a 2 m frame holds every second bin)
-template <int NN, int PP, bool TT = false, class TW = const double2 *>
+template <int NN, int PP, bool TT = false, class TW = const double2 *, int NIMG = 1>
 __device__ __attribute__((noinline)) void fm_pass5_band(LdsArr X, TW tw, int need_end, int tid)
 {
-    constexpr int R = 5, nb = NN / R, ITERS = (nb + FM_T - 1) / FM_T;
+    constexpr int R = 5, nb = NN / R, ITERS = (NIMG * nb + FM_T - 1) / FM_T;
     static_assert(PP == nb, "the last pass: one butterfly per k");
     double2 v[ITERS][R];
     unsigned need[ITERS];
 #pragma unroll
     for (int it = 0; it < ITERS; it++) {
-        const int b = it * FM_T + tid;  // == k
+        const int bb = it * FM_T + tid;
+        const int img = (NIMG > 1 && bb >= nb) ? 1 : 0;
+        const int b = bb - img * nb;  // == k
+        const LdsArr Xi = X + img * NN;
         need[it] = 0u;
-        if (b < nb) {
+        if (bb < NIMG * nb) {
 #pragma unroll
             for (int q = 0; q < R; q++) {
                 const int bin = b + q * PP;
@@ -219,7 +240,7 @@ __device__ __attribute__((noinline)) void fm_pass5_band(LdsArr X, TW tw, int nee
             }
 #pragma unroll
             for (int j = 0; j < R; j++) {
-                v[it][j] = X[b + j * nb];
+                v[it][j] = Xi[b + j * nb];
                 if (j >= 1) v[it][j] = cdmul(v[it][j], TT ? tw[(j - 1) * PP + b] : tw[b * j]);
             }
             if (need[it] & ~1u) {
@@ -234,11 +255,14 @@ __device__ __attribute__((noinline)) void fm_pass5_band(LdsArr X, TW tw, int nee
     FM_PASS_SYNC();
 #pragma unroll
     for (int it = 0; it < ITERS; it++) {
-        const int b = it * FM_T + tid;
-        if (b < nb) {
+        const int bb = it * FM_T + tid;
+        if (bb < NIMG * nb) {
+            const int img = (NIMG > 1 && bb >= nb) ? 1 : 0;
+            const int b = bb - img * nb;
+            const LdsArr Xi = X + img * NN;
 #pragma unroll
             for (int q = 0; q < R; q++)
-                if (need[it] & (1u << q)) X[b + q * PP] = v[it][q];
+                if (need[it] & (1u << q)) Xi[b + q * PP] = v[it][q];
         }
     }
     FM_PASS_SYNC();
@@ -258,18 +282,22 @@ __device__ __attribute__((noinline)) void fm_pass5_band(LdsArr X, TW tw, int nee
 // src / CONJ: where the 204 values z[0..203] come from -- the spectrum image itself (conjugated on the way, CONJ) or a
 // small array of already conjugated values beside the image.  tw1[k * s1], tw2[k * s2]: the pass-3 twiddles of inputs
 // 1 and 2 -- T64[k], T64[2k] for a transform with the ordinary tables, U[k], U[16 + k] for an odd half's (fm_pass_t).
-template <int NN, bool CONJ, class TW1, class TW2>
-__device__ __attribute__((noinline)) void fm_inv_blocks(LdsArr X, LdsArr src, TW1 tw1, int s1, TW2 tw2, int s2, int tid)
+// src_d1 (NIMG == 2): where the second image's 204 values start, relative to src0
+template <int NN, bool CONJ, class TW1, class TW2, int NIMG = 1>
+__device__ __attribute__((noinline)) void fm_inv_blocks(LdsArr X, LdsArr src0, TW1 tw1, int s1, TW2 tw2, int s2, int tid, int src_d1 = 0)
 {
-    constexpr int C = NN / 64, NITEM = C * 16, ITERS = (NITEM + FM_T - 1) / FM_T;
+    constexpr int C = NN / 64, NITEM = C * 16, ITERS = (NIMG * NITEM + FM_T - 1) / FM_T;
     static_assert(3 * C > 204, "at most three of a block's 64 inputs come from the 204 bins");
     double2 z0[ITERS], z1[ITERS], z2[ITERS];
 #pragma unroll
     for (int it = 0; it < ITERS; it++) {
-        const int id = it * FM_T + tid;
+        const int idd = it * FM_T + tid;
+        const int img = (NIMG > 1 && idd >= NITEM) ? 1 : 0;
+        const int id = idd - img * NITEM;
+        const LdsArr src = src0 + img * src_d1;
         const int m = id >> 4;
         z0[it] = z1[it] = z2[it] = make_double2(0.0, 0.0);
-        if (id < NITEM) {
+        if (idd < NIMG * NITEM) {
             const double2 a = src[m];
             z0[it] = make_double2(a.x, CONJ ? -a.y : a.y);
             if (m + C < 204) {
@@ -285,8 +313,10 @@ __device__ __attribute__((noinline)) void fm_inv_blocks(LdsArr X, LdsArr src, TW
     FM_PASS_SYNC();  // every bin is in registers before the image is overwritten
 #pragma unroll
     for (int it = 0; it < ITERS; it++) {
-        const int id = it * FM_T + tid;
-        if (id < NITEM) {
+        const int idd = it * FM_T + tid;
+        if (idd < NIMG * NITEM) {
+            const int img = (NIMG > 1 && idd >= NITEM) ? 1 : 0;
+            const int id = idd - img * NITEM;
             const int m = id >> 4, k = id & 15;
             double2 a = z0[it], b = z0[it];
             if (m + 2 * C < 204) {
@@ -294,7 +324,7 @@ __device__ __attribute__((noinline)) void fm_inv_blocks(LdsArr X, LdsArr src, TW
                 a = cdadd(z0[it], v2);
                 b = cdsub(z0[it], v2);
             }
-            const LdsArr o = X + (64 * m + k);
+            const LdsArr o = X + (img * NN + 64 * m + k);
             if (m + C < 204) {
                 const double2 v1 = cdmul(z1[it], tw1[k * s1]);
                 o[0] = cdadd(a, v1);
@@ -378,19 +408,23 @@ __device__ __attribute__((noinline)) void fm_inv_blocks128_9600(LdsArr X, LdsArr
 __device__ __forceinline__ int fm_swz(int s) { return s ^ ((s >> 4) & 7); }
 
 // SWZ_IN: the image read is the swizzled one
-template <int R1, int R2, int NN = 0, int PP = 0, bool SWZ_IN = false, class TW1 = const double2 *, class TW2 = const double2 *>
-__device__ __attribute__((noinline)) void fm_pass2(LdsArr X, TW1 tw1, TW2 tw2, int n_rt, int P_rt, unsigned pmagic, int tid)
+template <int R1, int R2, int NN = 0, int PP = 0, bool SWZ_IN = false, class TW1 = const double2 *, class TW2 = const double2 *, int NIMG = 1>
+__device__ __attribute__((noinline)) void fm_pass2(LdsArr X0, TW1 tw1, TW2 tw2, int n_rt, int P_rt, unsigned pmagic, int tid)
 {
     constexpr int RR = R1 * R2;
-    constexpr int ITERS = (((NN ? NN : FM_NMAX) / RR) + FM_T - 1) / FM_T;
+    static_assert(NIMG == 1 || NN != 0, "several images: compile-time frame size");
+    constexpr int ITERS = ((NIMG * ((NN ? NN : FM_NMAX) / RR)) + FM_T - 1) / FM_T;
     const int n = NN ? NN : n_rt;
     const int P = PP ? PP : P_rt;
     const int ng = n / RR, nb1 = n / R1;
     double2 v[ITERS][R2][R1];
 #pragma unroll
     for (int it = 0; it < ITERS; it++) {
-        const int g = it * FM_T + tid;
-        if (g < ng) {
+        const int gg = it * FM_T + tid;
+        const int img = (NIMG > 1 && gg >= ng) ? 1 : 0;
+        const int g = gg - img * ng;
+        const LdsArr X = X0 + img * NN;
+        if (gg < NIMG * ng) {
             const int k1 = PP ? (g % PP) : (P == 1) ? 0 : g - (int)__umulhi((unsigned)g, pmagic) * P;
 #pragma unroll
             for (int j2 = 0; j2 < R2; j2++) {
@@ -421,8 +455,11 @@ __device__ __attribute__((noinline)) void fm_pass2(LdsArr X, TW1 tw1, TW2 tw2, i
     FM_PASS_SYNC();
 #pragma unroll
     for (int it = 0; it < ITERS; it++) {
-        const int g = it * FM_T + tid;
-        if (g < ng) {
+        const int gg = it * FM_T + tid;
+        const int img = (NIMG > 1 && gg >= ng) ? 1 : 0;
+        const int g = gg - img * ng;
+        const LdsArr X = X0 + img * NN;
+        if (gg < NIMG * ng) {
             const int k1 = PP ? (g % PP) : (P == 1) ? 0 : g - (int)__umulhi((unsigned)g, pmagic) * P;
             const LdsArr z = X + ((g - k1) * RR + k1);
 #pragma unroll
@@ -469,18 +506,20 @@ __device__ __forceinline__ void fm_store4_rotated(LdsArr X, int b, const double2
 // inverse's from the 204 gathered bins (only input 0 of the butterflies b < 204 is not the zeroed array's (0, -0)).
 // Same butterflies on the same operands as fm_pass<4>; what goes away is one LDS write of the whole image, one read
 // of it and two barriers per transform.
-template <int NN, bool F32IN>
-__device__ __attribute__((noinline)) void fm_first_from_raw(LdsArr X, const int *raw_, const float2 *rawf_, int ic, int qc, int tid)
+template <int NN, bool F32IN, int NIMG = 1>
+__device__ __attribute__((noinline)) void fm_first_from_raw(LdsArr X0, const int *raw_, const float2 *rawf_, int ic, int qc, int tid)
 {
-    constexpr int nb = NN / 4, ITERS = (nb + FM_T - 1) / FM_T;
+    constexpr int nb = NN / 4, ITERS = (NIMG * nb + FM_T - 1) / FM_T;
     gbl_i32 *raw = (gbl_i32 *)(unsigned long long)raw_;
     gbl_f2v *rawf = (gbl_f2v *)(unsigned long long)rawf_;
     int w[ITERS][4];
     f2v wf[ITERS][4];
 #pragma unroll
     for (int it = 0; it < ITERS; it++) {
-        int b = it * FM_T + tid;
-        b = b < nb ? b : nb - 1;
+        int bb = it * FM_T + tid;
+        bb = bb < NIMG * nb ? bb : NIMG * nb - 1;
+        const int img = (NIMG > 1 && bb >= nb) ? 1 : 0;
+        const int b = bb - img * nb + img * NN;  // (the second image's frame follows the first in memory)
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             if (F32IN)
@@ -491,8 +530,11 @@ __device__ __attribute__((noinline)) void fm_first_from_raw(LdsArr X, const int 
     }
 #pragma unroll
     for (int it = 0; it < ITERS; it++) {
-        const int b = it * FM_T + tid;
-        if (b < nb) {
+        const int bb = it * FM_T + tid;
+        const int img = (NIMG > 1 && bb >= nb) ? 1 : 0;
+        const int b = bb - img * nb;
+        const LdsArr X = X0 + img * NN;
+        if (bb < NIMG * nb) {
             double2 v[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
@@ -689,21 +731,24 @@ __device__ __attribute__((noinline)) void fm_pass_generic(LdsArr X, const double
 
 // ---- round 5: the 4410-sample frame of a 44.1 kHz card (2 . 3 . 3 . 5 . 7 . 7, the oracle's order) with compile-time passes.
 // fm_passr_real / fm_passr_band: fm_pass5_real / fm_pass5_band for any radix (the last pass of 4410 is a radix-7 one).
-template <int R, int NN, int PP, int COMPACT, class TW>
+template <int R, int NN, int PP, int COMPACT, class TW, int NIMG = 1>
 __device__ __attribute__((noinline)) void fm_passr_real(LdsArr X, TW tw, double norm, int tid, const double *hist_)
 {
-    constexpr int nb = NN / R, ITERS = (nb + FM_T - 1) / FM_T;
+    constexpr int nb = NN / R, ITERS = (NIMG * nb + FM_T - 1) / FM_T;
     static_assert(COMPACT == 1, "compact real samples");
     double o[ITERS][R];
 #pragma unroll
     for (int it = 0; it < ITERS; it++) {
-        const int b = it * FM_T + tid;
-        if (b < nb) {
+        const int bb = it * FM_T + tid;
+        if (bb < NIMG * nb) {
+            const int img = (NIMG > 1 && bb >= nb) ? 1 : 0;
+            const int b = bb - img * nb;
+            const LdsArr Xi = X + img * NN;
             const int k = b % PP;
             double2 v[R];
 #pragma unroll
             for (int j = 0; j < R; j++) {
-                v[j] = X[b + j * nb];
+                v[j] = Xi[b + j * nb];
                 if (j >= 1) v[j] = cdmul(v[j], tw[k * j]);
             }
             dft_r<R>(v);  // (only the real parts are read: the imaginary halves have no reader and are not formed)
@@ -715,12 +760,14 @@ __device__ __attribute__((noinline)) void fm_passr_real(LdsArr X, TW tw, double 
     lds_f64 *Rb = reinterpret_cast<lds_f64 *>(X.p);
 #pragma unroll
     for (int it = 0; it < ITERS; it++) {
-        const int b = it * FM_T + tid;
-        if (b < nb) {
+        const int bb = it * FM_T + tid;
+        if (bb < NIMG * nb) {
+            const int img = (NIMG > 1 && bb >= nb) ? 1 : 0;
+            const int b = bb - img * nb;
             const int k = b % PP;
             const int j0 = (b - k) * R + k;
 #pragma unroll
-            for (int q = 0; q < R; q++) Rb[FM_RB0 + j0 + q * PP] = o[it][q];
+            for (int q = 0; q < R; q++) Rb[img * (2 * NN) + FM_RB0 + j0 + q * PP] = o[it][q];
         }
     }
     if (hist_ != nullptr) {
@@ -730,25 +777,28 @@ __device__ __attribute__((noinline)) void fm_passr_real(LdsArr X, TW tw, double 
     FM_PASS_SYNC();
 }
 
-template <int R, int NN, int PP, class TW>
+template <int R, int NN, int PP, class TW, int NIMG = 1>
 __device__ __attribute__((noinline)) void fm_passr_band(LdsArr X, TW tw, int need_end, int tid)
 {
-    constexpr int nb = NN / R, ITERS = (nb + FM_T - 1) / FM_T;
+    constexpr int nb = NN / R, ITERS = (NIMG * nb + FM_T - 1) / FM_T;
     static_assert(PP == nb, "the last pass: one butterfly per k");
     double2 v[ITERS][R];
     unsigned need[ITERS];
 #pragma unroll
     for (int it = 0; it < ITERS; it++) {
-        const int b = it * FM_T + tid;  // == k
+        const int bb = it * FM_T + tid;
+        const int img = (NIMG > 1 && bb >= nb) ? 1 : 0;
+        const int b = bb - img * nb;  // == k
+        const LdsArr Xi = X + img * NN;
         need[it] = 0u;
-        if (b < nb) {
+        if (bb < NIMG * nb) {
 #pragma unroll
             for (int q = 0; q < R; q++)
                 if (b + q * PP < need_end) need[it] |= 1u << q;
             if (need[it]) {  // (a butterfly none of whose outputs is read is not formed: its inputs are dead after this pass)
 #pragma unroll
                 for (int j = 0; j < R; j++) {
-                    v[it][j] = X[b + j * nb];
+                    v[it][j] = Xi[b + j * nb];
                     if (j >= 1) v[it][j] = cdmul(v[it][j], tw[b * j]);
                 }
                 dft_r<R>(v[it]);
@@ -758,11 +808,14 @@ __device__ __attribute__((noinline)) void fm_passr_band(LdsArr X, TW tw, int nee
     FM_PASS_SYNC();
 #pragma unroll
     for (int it = 0; it < ITERS; it++) {
-        const int b = it * FM_T + tid;
-        if (b < nb) {
+        const int bb = it * FM_T + tid;
+        if (bb < NIMG * nb) {
+            const int img = (NIMG > 1 && bb >= nb) ? 1 : 0;
+            const int b = bb - img * nb;
+            const LdsArr Xi = X + img * NN;
 #pragma unroll
             for (int q = 0; q < R; q++)
-                if (need[it] & (1u << q)) X[b + q * PP] = v[it][q];
+                if (need[it] & (1u << q)) Xi[b + q * PP] = v[it][q];
         }
     }
     FM_PASS_SYNC();
@@ -774,23 +827,25 @@ __device__ __attribute__((noinline)) void fm_passr_band(LdsArr X, TW tw, int nee
 // which is a bin only for j1 = j2 = 0 and g < 204.  The same operations on the same operand values (the zeros included: a
 // zero's sign is whatever the general pass would have produced), one LDS write of the image instead of zero-fill + scatter +
 // read + write.  src: the spectrum image itself (X + centreBin - 102); every bin is in registers before the first store.
-template <int R1, int R2, int NN, class TW2>
-__device__ __attribute__((noinline)) void fm_inv_pair_from_bins(LdsArr X, LdsArr src, TW2 tw2, int tid)
+template <int R1, int R2, int NN, class TW2, int NIMG = 1>
+__device__ __attribute__((noinline)) void fm_inv_pair_from_bins(LdsArr X, LdsArr src0, TW2 tw2, int tid, int src_d1 = 0)
 {
-    constexpr int RR = R1 * R2, ng = NN / RR, ITERS = (ng + FM_T - 1) / FM_T;
+    constexpr int RR = R1 * R2, ng = NN / RR, ITERS = (NIMG * ng + FM_T - 1) / FM_T;
     static_assert(ng >= 204 && FM_T >= 204, "item g < 204 holds bin g, in the first round");
     double2 v[ITERS][R2][R1];
 #pragma unroll
     for (int it = 0; it < ITERS; it++) {
-        const int g = it * FM_T + tid;
-        if (g < ng) {
+        const int gg = it * FM_T + tid;
+        const int img = (NIMG > 1 && gg >= ng) ? 1 : 0;
+        const int g = gg - img * ng;
+        if (gg < NIMG * ng) {
 #pragma unroll
             for (int j2 = 0; j2 < R2; j2++) {
 #pragma unroll
                 for (int j1 = 0; j1 < R1; j1++) v[it][j2][j1] = make_double2(0.0, -0.0);
             }
-            if (it == 0 && g < 204) {
-                const double2 a = src[g];
+            if ((NIMG > 1 || it == 0) && g < 204) {
+                const double2 a = (src0 + img * src_d1)[g];
                 v[it][0][0] = make_double2(a.x, -a.y);
             }
 #pragma unroll
@@ -813,9 +868,11 @@ __device__ __attribute__((noinline)) void fm_inv_pair_from_bins(LdsArr X, LdsArr
     __syncthreads();  // every bin has been read from the image
 #pragma unroll
     for (int it = 0; it < ITERS; it++) {
-        const int g = it * FM_T + tid;
-        if (g < ng) {
-            const LdsArr z = X + g * RR;
+        const int gg = it * FM_T + tid;
+        if (gg < NIMG * ng) {
+            const int img = (NIMG > 1 && gg >= ng) ? 1 : 0;
+            const int g = gg - img * ng;
+            const LdsArr z = X + (img * NN + g * RR);
 #pragma unroll
             for (int q2 = 0; q2 < R2; q2++)
 #pragma unroll
@@ -1271,6 +1328,282 @@ __global__ __launch_bounds__(FM_T) void k_front_fftm(FftmArgs aa)
         sp->centreBin = centreBin;
         if (timing)
             for (int k = 0; k < 8; k++) a.phase_clk[k] = clk[k];
+    }
+}
+
+// ================================================================================== two frames of a stream at once (round 6)
+// n = 4800 (the reference's default frame at 48 kHz) ran 30 % slower per sample than n = 9600: the same passes with half the work
+// items -- a pass pair of one frame has 300 or 320 items for 768 threads -- and the same ~900-tick LDS round trip each.  Here a
+// workgroup takes frames f and f + 1 of its stream TOGETHER: two images side by side in LDS (2 x 76.8 KB; the tables beyond the
+// first 276 entries come from L2 as the 9600 frame's do), every pass over both (the NIMG forms above), |X| / boxcar / argmax for
+// both, then the centre-bin rule (:444-453) for f and, with its result, for f + 1 -- the only sequential step -- the inverse
+// halves with each frame's own centre bin, and RxDownSample: frame f + 1's windows reach back into frame f's samples, which lie in
+// the first image.  A call's odd last frame runs as a pair whose second half is computed and dropped.  Same operations on the same
+// operands per frame as k_front_fftm.
+template <int NN, bool F32IN>
+__global__ __launch_bounds__(FM_T) void k_front_fftm2(FftmArgs aa)
+{
+    static_assert(NN == 4800 || NN == 4410, "frames of 4800 samples (48 kHz) or 4410 (44.1 kHz: passes [2,3] [3,5] [7] [7])");
+    extern __shared__ __align__(16) unsigned char smem[];
+    const FftFrontArgs &a = aa.f;
+    constexpr int n = NN;
+    double2 *X = reinterpret_cast<double2 *>(smem);  // [2 n]
+    const LdsArr XL = lds_arr(smem);
+    double *hist = reinterpret_cast<double *>(X + 2 * n);    // [32]
+    double *redv = hist + 32;                                // [2][16] per-image, per-wave best value
+    int *redi = reinterpret_cast<int *>(redv + 32);          // [2][16]
+    double2 *twL = reinterpret_cast<double2 *>(redi + 32);   // [lds_tw]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < aa.lds_tw; i += FM_T) twL[i] = aa.f.tw[i];
+    const int s = blockIdx.x;
+    const int beg = a.do_up ? n / 4 : 0;
+    const int end = a.do_up ? n / 2 : n / 4;
+    const int pbase = beg + 24;
+    const int abase = beg + 74;
+    constexpr int POFF = 2 * (NN / 2 + 104);  // |X| over [beg + 24, end - 24) in the dead upper part of each image (double slots)
+    constexpr int AOFF = POFF + (NN / 4 - 48);
+    FftFrontState *sp = &a.st[s];
+    if (tid < 26) hist[tid] = sp->hist[tid];
+    double avePeakPower = sp->avePeakPower, aveCentreBin = sp->aveCentreBin;
+    int centreBin = sp->centreBin;
+    const double CFREQ_INV = (double)(1.0F - (2.0F / (1 + 1))), CFREQ_AVG = (double)(2.0F / (1 + 1));
+    const double PSD_INV = (double)(1.0F - (2.0F / (10 + 1))), PSD_AVG = (double)(2.0F / (10 + 1));
+    const double HOWARD = 0.9 * 32768.0;
+    const int D = a.decim;
+    const double norm = 1.0 / (double)n;
+    const int *__restrict__ raw = a.raw + (long long)s * a.stride_pairs;
+    const float2 *__restrict__ rawf = a.rawf + (long long)s * a.stride_pairs;
+    double2 *dm = a.dm + (long long)s * a.dm_stride;
+    const GblArr g = gbl_arr(a.tw);
+    __syncthreads();
+
+    for (int f = 0; f < a.nframes; f += 2) {
+        const bool two = f + 1 < a.nframes;
+        int tf = tid;
+        asm volatile("" : "+v"(tf));  // (opaque per iteration: see k_front_fftm)
+        const long long t0 = (long long)f * n;  // call-relative index of frame f's first sample
+        // ---- both frames -> images (:416-421), forward transform (:422-423), the last pass for the bins below end + 102 only
+        if constexpr (NN == 4800) {
+            if (two) {
+                fm_first_from_raw<NN, F32IN, 2>(XL, raw + t0, rawf + t0, a.ic, a.qc, tf);  // (with the first pass)
+            } else {
+                fm_first_from_raw<NN, F32IN, 1>(XL, raw + t0, rawf + t0, a.ic, a.qc, tf);
+                for (int i = tf; i < n; i += FM_T) X[n + i] = X[i];  // (the pair's second half: a copy, computed and dropped)
+                __syncthreads();
+            }
+            const LdsArr t = lds_arr(twL);
+            fm_pass2<4, 4, NN, 4, false, LdsArr, LdsArr, 2>(XL, t + 4, t + 20, NN, 4, 0u, tf);
+            fm_pass2<3, 5, NN, 64, false, LdsArr, GblArr, 2>(XL, t + 84, g + 276, NN, 64, 0u, tf);
+            fm_pass5_band<NN, 960, false, GblArr, 2>(XL, g + 1236, end + 102, tf);
+        } else {
+            // natural order; frame f + 1 follows frame f in memory as image 1 follows image 0
+            constexpr int NLD = (2 * NN + FM_T - 1) / FM_T;
+            const int tot = two ? 2 * n : n;
+            int w[NLD];
+            float2 wf[NLD];
+#pragma unroll
+            for (int q = 0; q < NLD; q++) {
+                int t = tf + q * FM_T;
+                t = t < tot ? t : tot - 1;
+                if (F32IN)
+                    wf[q] = rawf[t0 + t];
+                else
+                    w[q] = raw[t0 + t];
+            }
+#pragma unroll
+            for (int q = 0; q < NLD; q++) {
+                const int t = tf + q * FM_T;
+                if (t < tot) {
+                    double di, dq;
+                    if (F32IN) {
+                        di = (double)wf[q].x;
+                        dq = (double)wf[q].y;
+                    } else {
+                        di = (double)i16_to_float_java(java_short_add((int)(short)(w[q] & 0xffff), a.ic));
+                        dq = (double)i16_to_float_java(java_short_add(w[q] >> 16, a.qc));
+                    }
+                    X[t] = make_double2(di, dq);
+                    if (!two) X[n + t] = make_double2(di, dq);
+                }
+            }
+            __syncthreads();
+            const LdsArr t = lds_arr(twL);
+            fm_pass2<2, 3, NN, 1, false, LdsArr, LdsArr, 2>(XL, t, t + 2, NN, 1, 0u, tf);
+            fm_pass2<3, 5, NN, 6, false, LdsArr, LdsArr, 2>(XL, t + 8, t + 26, NN, 6, 0u, tf);
+            fm_pass<7, NN, 90, LdsArr, 2>(XL, t + 116, NN, 90, 0u, tf);
+            fm_passr_band<7, NN, 630, GblArr, 2>(XL, g + 746, end + 102, tf);
+        }
+        // ---- |X| (:425-427) over the band the boxcar reads, both images
+        {
+            const int cnt = end - 24 - pbase;
+            for (int u = tf; u < 2 * cnt; u += FM_T) {
+                const int img = u >= cnt ? 1 : 0;
+                const int i = pbase + (u - img * cnt);
+                const double2 v = X[img * n + i];
+                reinterpret_cast<double *>(X + img * n)[POFF + (i - pbase)] = sqrt(v.x * v.x + v.y * v.y);
+            }
+        }
+        __syncthreads();
+        // ---- boxcar + first maximum per image (:433-442): a thread's items of one image ascend
+        double bestv[2] = {0.0, 0.0};
+        int besti[2] = {-1, -1};
+        {
+            const int npair = (end - 75 - (beg + 74) + 1) / 2;
+            for (int u = tf; u < 2 * npair; u += FM_T) {
+                const int img = u >= npair ? 1 : 0;
+                const int i = beg + 74 + 2 * (u - img * npair);
+                double *Pi = reinterpret_cast<double *>(X + img * n) + POFF;
+                double *Ai = reinterpret_cast<double *>(X + img * n) + AOFF;
+                const double2 *w = reinterpret_cast<const double2 *>(Pi + (i - 50 - pbase));
+                double a0, a1;
+                boxcar_pair(w, a0, a1);
+                asm volatile("" : "+v"(a0), "+v"(a1));
+                double bv = img ? bestv[1] : bestv[0];
+                int bi = img ? besti[1] : besti[0];
+                if (i >= beg + 75) {
+                    Ai[i - abase] = a0;
+                    if (bv < a0) {
+                        bv = a0;
+                        bi = i;
+                    }
+                }
+                if (i + 1 < end - 75) {
+                    Ai[i + 1 - abase] = a1;
+                    if (bv < a1) {
+                        bv = a1;
+                        bi = i + 1;
+                    }
+                }
+                if (img) {
+                    bestv[1] = bv;
+                    besti[1] = bi;
+                } else {
+                    bestv[0] = bv;
+                    besti[0] = bi;
+                }
+            }
+        }
+#pragma unroll
+        for (int im = 0; im < 2; im++) {
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const double ov = __shfl_xor(bestv[im], off, 64);
+                const int oi = __shfl_xor(besti[im], off, 64);
+                if (oi >= 0 && (ov > bestv[im] || (ov == bestv[im] && (besti[im] < 0 || oi < besti[im])))) {
+                    bestv[im] = ov;
+                    besti[im] = oi;
+                }
+            }
+            if (lane == 0) {
+                redv[im * 16 + wave] = bestv[im];
+                redi[im * 16 + wave] = besti[im];
+            }
+        }
+        __syncthreads();
+        // ---- centre-bin rule (:444-453) for frame f, then for frame f + 1, by every thread on the same values
+        int cb[2];
+#pragma unroll
+        for (int im = 0; im < 2; im++) {
+            double mv = 0.0;
+            int mi = -1;
+            if (lane < FM_T / 64) {
+                mv = redv[im * 16 + lane];
+                mi = redi[im * 16 + lane];
+            }
+#pragma unroll
+            for (int off = 8; off >= 1; off >>= 1) {
+                const double ov = __shfl_xor(mv, off, 64);
+                const int oi = __shfl_xor(mi, off, 64);
+                if (oi >= 0 && (ov > mv || (ov == mv && (mi < 0 || oi < mi)))) {
+                    mv = ov;
+                    mi = oi;
+                }
+            }
+            const double maxBin = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(mv)),
+                                                   __builtin_amdgcn_readfirstlane(__double2loint(mv)));
+            const int binPos = __builtin_amdgcn_readfirstlane(mi);
+            if (im == 0 || two) {
+                if (centreBin < 0) centreBin = 0;
+                if (centreBin > end - 1) centreBin = end - 1;
+                const double *Ai = reinterpret_cast<const double *>(X + im * n) + AOFF;
+                const double atc = (centreBin >= beg + 75 && centreBin < end - 75) ? Ai[centreBin - abase] : 0.0;
+                avePeakPower = (PSD_AVG * atc) + (PSD_INV * avePeakPower);
+                if (maxBin > (avePeakPower / 4) * 5 && binPos > 0) {
+                    aveCentreBin = (CFREQ_AVG * (double)(float)binPos) + (CFREQ_INV * aveCentreBin);
+                    centreBin = (int)(aveCentreBin + (double)1.0F);
+                }
+                if (centreBin < 102) centreBin = 102;
+            }
+            cb[im] = centreBin;
+        }
+        // ---- 204 bins around each frame's centre to bin 0 of a zeroed array (:458), inverse transform (:459): passes 1-3 from the
+        // bins, [3, 5], the last pass real parts only, scaled, compact
+        if constexpr (NN == 4800) {
+            const LdsArr t64 = lds_arr(twL) + 20;
+            fm_inv_blocks<NN, true, LdsArr, LdsArr, 2>(XL, XL + (cb[0] - 102), t64, 1, t64, 2, tf, n + cb[1] - cb[0]);
+            fm_pass2<3, 5, NN, 64, false, LdsArr, GblArr, 2>(XL, lds_arr(twL) + 84, g + 276, NN, 64, 0u, tf);
+            fm_pass5_real<NN, 960, false, 1, GblArr, 2>(XL, g + 1236, norm, tf, hist);
+        } else {
+            const LdsArr t = lds_arr(twL);
+            fm_inv_pair_from_bins<2, 3, NN, LdsArr, 2>(XL, XL + (cb[0] - 102), t + 2, tf, n + cb[1] - cb[0]);
+            fm_pass2<3, 5, NN, 6, false, LdsArr, LdsArr, 2>(XL, t + 8, t + 26, NN, 6, 0u, tf);
+            fm_pass<7, NN, 90, LdsArr, 2>(XL, t + 116, NN, 90, 0u, tf);
+            fm_passr_real<7, NN, 630, 1, GblArr, 2>(XL, g + 746, norm, tf, hist);
+        }
+        double *Rb0 = reinterpret_cast<double *>(smem);
+        double *Rb1 = Rb0 + 2 * n;
+        // (frame f + 1's windows reach back into frame f's last 26 samples)
+        if (tf < 26) Rb1[FM_RB0 - 26 + tf] = Rb0[FM_RB0 + n - 26 + tf];
+        __syncthreads();
+        // ---- RxDownSample(re, re) (:461-463, :470-492) from the compact samples of frame f, then of frame f + 1
+#pragma unroll
+        for (int im = 0; im < 2; im++) {
+            if (im == 1 && !two) break;
+            const double *Rb = im ? Rb1 : Rb0;
+            const long long tq = t0 + (long long)im * n;
+            long long jlo = (tq - a.first_out + D - 1) / D;
+            if (tq <= a.first_out) jlo = 0;
+            const bool even_d = (D & 1) == 0;
+            const int par = (int)((a.first_out - tq) & 1);
+            for (long long j = jlo + tf;; j += FM_T) {
+                const long long te = (long long)a.first_out + (long long)D * j;  // window end, call-relative
+                if (te >= tq + n || j >= a.nds) break;
+                const double2 cs = a.vco_cs[j];
+                const int e = (int)(te - tq);
+                double fi = 0.0;
+                if (even_d) {
+                    const double2 *w2 = reinterpret_cast<const double2 *>(Rb + ((e + FM_RB0 - 26) & ~1));
+                    double d[28];
+#pragma unroll
+                    for (int i = 0; i < 14; i++) {
+                        const double2 t = w2[i];
+                        d[2 * i] = t.x;
+                        d[2 * i + 1] = t.y;
+                    }
+                    if (par) {
+#pragma unroll
+                        for (int k = 0; k < 27; k++) fi += d[27 - k] * ds_tap(k);  // newest first (:479-483)
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 27; k++) fi += d[26 - k] * ds_tap(k);
+                    }
+                } else {
+                    const double *w = Rb + (FM_RB0 + e);
+#pragma unroll
+                    for (int k = 0; k < 27; k++) fi += w[-k] * ds_tap(k);
+                }
+                const double o = fi * HOWARD;
+                dm[64 + j] = make_double2(o * cs.x, o * cs.y);  // :515-516
+            }
+        }
+        if (tf < 26) hist[tf] = (two ? Rb1 : Rb0)[FM_RB0 + n - 26 + tf];
+        __syncthreads();
+    }
+    if (tid < 26) sp->hist[tid] = hist[tid];
+    if (tid == 0) {
+        sp->avePeakPower = avePeakPower;
+        sp->aveCentreBin = aveCentreBin;
+        sp->centreBin = centreBin;
     }
 }
 
@@ -2094,6 +2427,14 @@ void fftm_twiddles(std::vector<double2> &w, int n, int *np_out, int *rad, int *t
     }
 }
 
+// round 6: a call of two or more 4800- or 4410-sample frames a stream takes them in pairs (k_front_fftm2); JSDR_FFTM_PAIR=0: never
+bool fftm_pairs(int n, int nframes)
+{
+    bool pair = (n == 4800 || n == 4410) && nframes >= 2;
+    if (const char *e = knob("JSDR_FFTM_PAIR")) pair = pair && atoi(e) != 0;
+    return pair;
+}
+
 int launch_front_fftm(const FftFrontArgs &a, int np, const int *rad, const int *tw_off, const int *wr_off, double2 *gscratch,
                       int nstreams, hipStream_t st)
 {
@@ -2130,8 +2471,32 @@ int launch_front_fftm(const FftFrontArgs &a, int np, const int *rad, const int *
         set_error("launch_front_fftm: the twiddle tables of a default frame are not where the kernel expects them");
         return JSDR_ERR;
     }
-    const size_t lds = fixed + sizeof(double2) * (size_t)aa.lds_tw;
     const bool f32 = a.rawf != nullptr;
+    if (fftm_pairs(a.n, a.nframes)) {
+        // the tables of all passes but the last (4800: but the last two) stay in LDS; the rest come from L2
+        aa.lds_tw = a.n == 4800 ? 276 : 746;
+        const size_t lds2 = sizeof(double2) * 2 * (size_t)a.n + sizeof(double) * (32 + 32) + sizeof(int) * 32 + sizeof(double2) * (size_t)aa.lds_tw + 64;
+#define FM_LAUNCH2(NN, F32)                                                                                   \
+    do {                                                                                                      \
+        JSDR_LDS_ATTR((k_front_fftm2<NN, F32>), lds2);                                                        \
+        hipLaunchKernelGGL((k_front_fftm2<NN, F32>), dim3((unsigned)nstreams), dim3(FM_T), lds2, st, aa);     \
+    } while (0)
+        if (a.n == 4800) {
+            if (f32)
+                FM_LAUNCH2(4800, true);
+            else
+                FM_LAUNCH2(4800, false);
+        } else {
+            if (f32)
+                FM_LAUNCH2(4410, true);
+            else
+                FM_LAUNCH2(4410, false);
+        }
+#undef FM_LAUNCH2
+        JSDR_LAUNCH_CHECK();
+        return JSDR_OK;
+    }
+    const size_t lds = fixed + sizeof(double2) * (size_t)aa.lds_tw;
     if (f32)
         JSDR_LDS_ATTR(k_front_fftm<true>, lds);
     else
