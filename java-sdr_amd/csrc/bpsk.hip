@@ -3258,7 +3258,9 @@ static int bpsk_run(jsdr_bpsk *h, const int16_t *raw_dev, const float *rawf_dev,
                 h->num_cu_known = cus > 0 ? cus : 256;
             }
             const long long W = h->num_cu_known, F = xa.nframes;
-            three = (double)(((long long)S * F + W - 1) / W) * 1.15 < (double)((((long long)S + W - 1) / W) * F);
+            // (4800 / 4410: the fused kernel takes two frames at once and is 1.38 / 1.27 x the three-phase kernels' pace at a full grid)
+            const double pace = (h->nsf == 4800 && F >= 2) ? 1.4 : (h->nsf == 4410 && F >= 2) ? 1.3 : 1.15;
+            three = (double)(((long long)S * F + W - 1) / W) * pace < (double)((((long long)S + W - 1) / W) * F);
         }
         if (three) {
             const size_t per = acq3_frame_bytes(h->nsf, h->do_up) + 64 + (h->gen_plan.on ? acqg_image_bytes(h->nsf) : 0);

@@ -801,6 +801,55 @@ def test_bpsk_fft_mode_front_end_choice():
     assert d.front_kernel_name() == "k_front_fftm"  # a full grid of streams: the fused kernel
 
 
+@pytest.mark.parametrize("nsf,rate,do_up", [(4800, 48000, 0), (4800, 96000, 1), (4410, 44100, 0), (4410, 44100, 1)])
+def test_bpsk_fft_mode_two_frames_at_once(nsf, rate, do_up, monkeypatch):
+    """Round 6: at 4800- and 4410-sample frames a workgroup takes frames f and f + 1 of its stream together (k_front_fftm2: two images
+    in LDS, every pass over both, the centre-bin rule for f then f + 1).  Calls of 1 (the one-frame kernel), 2, 3 (a pair and a
+    dropped half), 5 and 8 frames, carriers that move the centre bin between the two frames of a pair (a noise stream), both
+    band halves -- against the oracle, and the same bits with the pairing switched off"""
+    if os.environ.get("JSDR_ACQ3") is not None or os.environ.get("JSDR_ACQG") is not None:
+        pytest.skip("another front end is forced")
+    nfr = 19
+    n = nsf * nfr
+    rng = np.random.default_rng(nsf + do_up)
+    iq = O.make_dbpsk_stream(88, 0, n, rate=rate, carrier_hz=rate * (0.36 if do_up else 0.12) + 211.0, noise_sigma=700.0)[0]
+    noise = rng.integers(-12000, 12000, 2 * n).astype(np.int16)
+    S = 256  # a full grid of streams keeps the fused kernel (fewer would take the three-phase form)
+    streams = [iq, noise] + [O.make_dbpsk_stream(88, 1 + (s % 3), n, rate=rate, carrier_hz=rate * (0.36 if do_up else 0.12) - 150.0 * (s % 5), noise_sigma=500.0)[0]
+                             for s in range(3)]
+    # (the oracle replays five streams; the rest of the grid repeats them)
+    chunks = [nsf, 2 * nsf, 3 * nsf, 5 * nsf, 8 * nsf]
+    d = J.Bpsk(rate=rate, blen=4 * nsf, do_fft=1, do_up=do_up, nstreams=S, max_batch_samples=max(chunks))
+    buf = J.DeviceBuffer.from_host(np.concatenate([streams[s % 5] for s in range(S)]))
+    bits = [[] for _ in range(5)]
+    names = []
+    pos = 0
+    for L in chunks:
+        d.batch_i16(buf.ptr + 4 * pos, 2 * n, L)
+        names.append(d.front_kernel_name())
+        for s in range(5):
+            bits[s].append(d.bits(250 + s).copy())  # (stream 250 + s repeats stream s)
+        pos += L
+    assert names == ["k_front_fftm", "k_front_fftm2", "k_front_fftm2", "k_front_fftm2", "k_front_fftm2"]
+    for s in range(5):
+        o = O.Bpsk(rate=rate, blen=4 * nsf, do_fft=1, do_up=do_up)
+        o.receive_i16(streams[s])
+        assert np.array_equal(np.concatenate(bits[s]), o.bits()), f"stream {s}"
+        same_counters(d.counters(s), o.counters())
+        same_state(d.state(s), o.state())
+        assert d.counters(s)["centreBin"] == o.counters()["centreBin"]
+    monkeypatch.setenv("JSDR_FFTM_PAIR", "0")
+    d1 = J.Bpsk(rate=rate, blen=4 * nsf, do_fft=1, do_up=do_up, nstreams=S, max_batch_samples=max(chunks))
+    pos = 0
+    for L in chunks:
+        d1.batch_i16(buf.ptr + 4 * pos, 2 * n, L)
+        assert d1.front_kernel_name() == "k_front_fftm"
+        pos += L
+    for s in range(5):
+        same_counters(d1.counters(s), d.counters(s))
+        same_state(d1.state(s), d.state(s))
+
+
 @pytest.mark.parametrize("nsf,rate", [(4410, 44100), (3200, 32000), (2205, 22050), (1102, 11025), (800, 8000)])
 def test_bpsk_fft_mode_receive_at_consumer_sound_card_rates(nsf, rate):
     """the IAudioHandler form (one stream, one frame per receive()) in FFT-acquire mode at the frames a 44.1 / 32 / 22.05 kHz
