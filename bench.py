@@ -192,6 +192,7 @@ def validate_acquire(J, dem, d_iq, S, L, ncalls, frame, rate, prefer=(), do_fft=
     import oracle_lib as O
     idx = sorted(set(list(prefer)[:3]) | set(int(v) for v in np.linspace(0, S - 1, nsample)))
     res = {}
+    O.lib()  # (loaded, and rebuilt if stale, before the threads start)
 
     def one(st):
         raw = d_iq.to_host(np.int16, 2 * L, offset_bytes=st * L * 4)

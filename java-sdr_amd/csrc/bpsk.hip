@@ -3494,8 +3494,8 @@ int jsdr_bpsk_create(jsdr_bpsk **out, int rate, int nsamples_per_frame, int tuni
     bool fft_gen = do_fft && !fft_lds;
     if (const char *e = knob("JSDR_ACQG")) fft_gen = do_fft && atoi(e) != 0;  // (tests: the any-frame passes for a frame the LDS kernels take)
     JSDR_REQUIRE(!fft_gen || acqg_supported(nsamples_per_frame),
-                 "jsdr_bpsk_create: FFT-acquire mode needs a frame of 416 .. 4194304 samples (got %d): below 416 the 204 gathered bins "
-                 "(FUNcubeBPSKDemod.java:458) do not end inside the frame",
+                 "jsdr_bpsk_create: FFT-acquire mode needs a frame of 416 .. 4194304 samples whose prime factors r above 7 keep n r within "
+                 "2^31 (got %d): below 416 the 204 gathered bins (FUNcubeBPSKDemod.java:458) do not end inside the frame",
                  nsamples_per_frame);
     JSDR_REQUIRE(bit_clock_is_regular(), "jsdr_bpsk_create: bit clock schedule is not the regular 8-cycle");
     if (fec_prepare() != JSDR_OK) return JSDR_ERR;

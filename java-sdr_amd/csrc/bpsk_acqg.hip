@@ -300,7 +300,13 @@ bool acqg_supported(int n)
     if (n < 416 || n > (1 << 22)) return false;
     if ((n & (n - 1)) == 0) return true;
     int rad[ACQG_MAXPASS];
-    return acqg_radices(n, rad) > 0;
+    const int np = acqg_radices(n, rad);
+    if (np <= 0) return false;
+    // a prime radix r above 7 is a pass of n r complex multiply-adds (one thread per output, r terms each): bounded, so that a frame
+    // with a huge prime factor is refused at create instead of occupying the GPU for minutes per call
+    for (int p = 0; p < np; p++)
+        if (rad[p] > 7 && (long long)n * rad[p] > (1LL << 31)) return false;
+    return true;
 }
 
 // images of a frame in the launch's scratch: a power of two is transformed in place, the Stockham passes go between two

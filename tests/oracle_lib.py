@@ -5,6 +5,7 @@ Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import 
 import ctypes as C
 import os
 import subprocess
+import threading
 
 import numpy as np
 
@@ -24,13 +25,20 @@ def build(force=False):
 
 
 _lib = None
+_lib_lock = threading.Lock()
 
 
 def lib():
+    """the library, built if stale, with every prototype set BEFORE it becomes visible: bench.py replays streams through the oracle
+    from several threads, and a thread that found the handle between CDLL() and _proto() called jo_* with ctypes' default int
+    arguments -- 64-bit pointers truncated, a segmentation fault in one run of thirty (round 6)"""
     global _lib
     if _lib is None:
-        _lib = C.CDLL(build())
-        _proto(_lib)
+        with _lib_lock:
+            if _lib is None:
+                L = C.CDLL(build())
+                _proto(L)
+                _lib = L
     return _lib
 
 

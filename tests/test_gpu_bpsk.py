@@ -407,6 +407,8 @@ def test_bpsk_fft_mode_rejects_partial_frames_and_odd_sizes():
         J.Bpsk(nstreams=1, do_fft=1, blen=4 * 400)  # below 416 samples the 204 gathered bins would not fit the frame (the reference's arraycopy :458 would throw)
     with pytest.raises(J.JsdrError):
         J.Bpsk(nstreams=1, do_fft=1, blen=4 * 256)
+    with pytest.raises(J.JsdrError):
+        J.Bpsk(nstreams=1, do_fft=1, blen=4 * 200006, rate=2000060)  # 2 x 100003 (prime): a pass of n r = 2e10 multiply-adds a frame
 
 
 @pytest.mark.parametrize("nsf,rate,do_up", [
