@@ -7,7 +7,7 @@
 // frame above 9600 samples, and the LDS front ends' frames at decimations they do not take (a 2^k frame below 38.4 kHz).
 //
 // Phases A and C of the three-phase front end (bpsk_acq.hip: frame-parallel forward half, one scan per stream, frame-parallel
-// inverse half, edges) with the frame's image in GLOBAL memory: one launch per pass of the transform (per four radix-2 stages), one thread per butterfly,
+// inverse half, edges) with the frame's image in GLOBAL memory: one launch per pass or pass pair of the transform (per four radix-2 stages), one thread per butterfly or group,
 // over all frames of the launch at once.  The transform is the oracle's, operation for operation (oracle/o_fft.c): powers of two
 // the radix-2 decimation-in-time network on jo_fft_twiddles_f64's table (inverse: conjugated twiddles), every other n the Stockham
 // passes of fft_f64_mixed (radices in jo_fft_mixed_radices' order, per-pass tables, the fixed-order butterflies of bpsk_radix.h, a
@@ -106,6 +106,48 @@ __global__ __launch_bounds__(AG_T) void k_acqg_pass(const double2 *in, double2 *
     const int j0 = (b - k) * R + k;
 #pragma unroll
     for (int q = 0; q < R; q++) y[j0 + q * P] = v[q];
+}
+
+// TWO consecutive Stockham passes (radix R1 at stride P, then R2 at stride P R1) in one round trip through memory: group g = m0 P + k1
+// holds the R1 R2 points both passes connect -- the R2 first-pass butterflies b1 = g + j2 n/(R1 R2), whose outputs q1 feed the R1
+// second-pass butterflies (k2 = k1 + q1 P), which write out[(g - k1) R1 R2 + k1 + q1 P + q2 P R1].  The operations of
+// k_acqg_pass<R1> followed by k_acqg_pass<R2> on the same operands in the same order (bpsk_fftm.hip's fm_pass2, out of place).
+template <int R1, int R2>
+__global__ __launch_bounds__(AG_T) void k_acqg_pass2(const double2 *in, double2 *out, int n, int P, const double2 *tw1, const double2 *tw2, int bpf)
+{
+    constexpr int RR = R1 * R2;
+    const unsigned fr = blockIdx.x / (unsigned)bpf;
+    const int g = (int)(blockIdx.x - fr * (unsigned)bpf) * AG_T + (int)threadIdx.x;
+    const int ng = n / RR, nb1 = n / R1;
+    if (g >= ng) return;
+    const double2 *x = in + (long long)fr * n;
+    double2 *y = out + (long long)fr * n;
+    const int k1 = g % P;
+    double2 v[R2][R1];
+#pragma unroll
+    for (int j2 = 0; j2 < R2; j2++) {
+        const int b1 = g + j2 * ng;
+#pragma unroll
+        for (int j1 = 0; j1 < R1; j1++) {
+            v[j2][j1] = x[b1 + j1 * nb1];
+            if (j1 >= 1 && P > 1) v[j2][j1] = cdmul(v[j2][j1], tw1[k1 * j1]);
+        }
+        dft_r<R1>(v[j2]);
+    }
+    double2 *z = y + ((g - k1) * RR + k1);
+#pragma unroll
+    for (int q1 = 0; q1 < R1; q1++) {
+        const int k2 = k1 + q1 * P;
+        double2 w[R2];
+#pragma unroll
+        for (int j2 = 0; j2 < R2; j2++) {
+            w[j2] = v[j2][q1];
+            if (j2 >= 1) w[j2] = cdmul(w[j2], tw2[k2 * j2]);
+        }
+        dft_r<R2>(w);
+#pragma unroll
+        for (int q2 = 0; q2 < R2; q2++) z[q1 * P + q2 * P * R1] = w[q2];
+    }
 }
 
 // a prime radix above 7: out_q = v_0 + v_1 W[q mod r] + ... + v_{r-1} W[(r-1) q mod r], every product a full complex multiply,
@@ -380,6 +422,34 @@ static double2 *acqg_transform(const AcqgPlan &pl, const double2 *tw, double2 *i
     for (int p = 0; p < pl.np; p++) {
         const int r = pl.rad[p];
         const double2 *t = tw + pl.tw_off[p];
+        // two passes of radices up to 7 and at most 25 points a group in one launch (JSDR_ACQG_PAIRS=0: one pass a launch)
+        const int r2 = (p + 1 < pl.np) ? pl.rad[p + 1] : 0;
+        static const bool pairs_on = [] { const char *e = knob("JSDR_ACQG_PAIRS"); return !(e && atoi(e) == 0); }();
+        if (pairs_on && r <= 7 && r2 >= 2 && r2 <= 7 && r * r2 <= 25) {
+            const double2 *t2 = tw + pl.tw_off[p + 1];
+            const int bpf = (n / (r * r2) + AG_T - 1) / AG_T;
+            const dim3 grid((unsigned)(nfr * bpf));
+            bool done = true;
+#define AG_P2(A, B)                                                                                      \
+    else if (r == A && r2 == B) hipLaunchKernelGGL((k_acqg_pass2<A, B>), grid, dim3(AG_T), 0, st, in, out, n, P, t, t2, bpf)
+            if (false) {
+            }
+            AG_P2(2, 2); AG_P2(2, 3); AG_P2(2, 4); AG_P2(2, 5); AG_P2(2, 7);
+            AG_P2(3, 2); AG_P2(3, 3); AG_P2(3, 4); AG_P2(3, 5); AG_P2(3, 7);
+            AG_P2(4, 2); AG_P2(4, 3); AG_P2(4, 4); AG_P2(4, 5);
+            AG_P2(5, 2); AG_P2(5, 3); AG_P2(5, 4); AG_P2(5, 5);
+            AG_P2(7, 2); AG_P2(7, 3);
+            else done = false;
+#undef AG_P2
+            if (done) {
+                P *= r * r2;
+                p++;
+                double2 *tmp = in;
+                in = out;
+                out = tmp;
+                continue;
+            }
+        }
         const int bpf = ((r > 7 ? n : n / r) + AG_T - 1) / AG_T;
         const dim3 grid((unsigned)(nfr * bpf));
         switch (r) {
