@@ -20,7 +20,15 @@ def build(force=False):
     srcs = [os.path.join(ODIR, f) for f in os.listdir(ODIR) if f.endswith((".c", ".h"))]
     stale = force or not os.path.exists(SO) or any(os.path.getmtime(s) > os.path.getmtime(SO) for s in srcs)
     if stale:
-        subprocess.check_call(["make", "-s", "-C", ODIR, "-B"])
+        # into a file of this process's own, then renamed over the target in one step: the ranks of an N > 1 bench run (and tests
+        # under pytest-xdist) may all find the library stale at once, and none of them may load a file another is still writing
+        tmp = "libjsdr_oracle.%d.tmp.so" % os.getpid()
+        try:
+            subprocess.check_call(["make", "-s", "-C", ODIR, "-B", "OUT=" + tmp, tmp])
+            os.replace(os.path.join(ODIR, tmp), SO)
+        finally:
+            if os.path.exists(os.path.join(ODIR, tmp)):
+                os.remove(os.path.join(ODIR, tmp))
     return SO
 
 
