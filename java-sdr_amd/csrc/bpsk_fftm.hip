@@ -1641,9 +1641,7 @@ __global__ __launch_bounds__(FM_T) void k_acqm_fwd(FftmArgs aa, AcqArgs a)
     const int beg = a.do_up ? n / 4 : 0;
     const int end = a.do_up ? n / 2 : n / 4;
     const int pbase = beg + 24;
-    double *P = reinterpret_cast<double *>(X + (n / 2 + 104));
-    double *A = P + (n / 4 - 48 + 2);
-    const int abase = beg + 74;
+    double *P = reinterpret_cast<double *>(X + (n / 2 + 104));  // (the sums go straight to the frame's row in global memory)
     const long long nfr = (long long)a.S * a.F;
     __syncthreads();
     for (;;) {
@@ -1727,8 +1725,6 @@ __global__ __launch_bounds__(FM_T) void k_acqm_fwd(FftmArgs aa, AcqArgs a)
                 }
             }
         }
-        (void)A;
-        (void)abase;
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) {
             const double ov = __shfl_xor(bestv, off, 64);
