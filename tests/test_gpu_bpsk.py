@@ -803,6 +803,62 @@ def test_bpsk_fft_mode_front_end_choice():
     assert d.front_kernel_name() == "k_front_fftm"  # a full grid of streams: the fused kernel
 
 
+@pytest.mark.parametrize("nsf,knob,first,second", [
+    (2048, "JSDR_ACQ3", "k_acq_fwd", "k_front_fft"),      # three phases (tail on the side stream) against the fused kernel
+    (9600, "JSDR_ACQ3", "k_front_fftm", "k_acqm_fwd"),    # the fused kernel against three phases
+    (4800, "JSDR_FFTM_PAIR", "k_front_fftm2", "k_front_fftm"),  # two frames at once against one
+])
+def test_bpsk_fft_mode_front_ends_agree_at_config4_size(nsf, knob, first, second, monkeypatch):
+    """BASELINE config 4's shape in FFT-acquire mode -- 1024 streams x 1,048,576 samples generated on the device, one call -- through
+    the default front end and through the other one the library has for that frame: EVERY stream's result slot (counters, the
+    call's bits, every FECDecode result, state) byte for byte equal, and two sampled streams equal to the oracle.  Size-independent
+    property at full size: two implementations, one answer."""
+    if any(os.environ.get(k) is not None for k in ("JSDR_ACQ3", "JSDR_ACQG", "JSDR_FFTM_PAIR")):
+        pytest.skip("a front end is forced")
+    S, L, sps = 1024, 1048576, 80
+    L = (L // nsf) * nsf
+    nfr = 3
+    seed = 20020111
+    pay = J.synth_payloads(seed, 0, S, nfr)
+    d_sym = J.DeviceBuffer(S * nfr * 5200)
+    J.fec_encode_dev(pay, S * nfr, d_sym)
+    d_ds = J.DeviceBuffer(S * nfr * 5200)
+    J.synth_diffsign(d_sym, nfr * 5200, S, d_ds)
+    ct, st = O.synth_tables(3000)
+    keys = np.array([O.mix64((seed * 0x9E3779B1 + s) ^ 0xA5A5A5A5) for s in range(S)], np.uint64)
+    d_iq = J.DeviceBuffer(S * L * 4)
+    gain = int(round(1500.0 / 37837.0 * 32768.0))
+    J.synth_dbpsk(d_iq, 2 * L, S, 0, L, d_ds, nfr * 5200, sps, 0, O.phase_inc_u32(13200.0, 96000),
+                  J.DeviceBuffer.from_host(ct), J.DeviceBuffer.from_host(st), gain, J.DeviceBuffer.from_host(keys))
+
+    def run(expect):
+        d = J.Bpsk(nstreams=S, max_batch_samples=L, do_fft=1, blen=4 * nsf)
+        d.batch_i16(d_iq, 2 * L, L)
+        assert d.front_kernel_name() == expect
+        info = d.slot_info()
+        slots = J.DeviceBuffer(S * info["slot_bytes"])
+        d.pack_slots(slots)
+        d.sync()
+        return d, slots.to_host(np.uint8).reshape(S, info["slot_bytes"]).copy()
+
+    d1, s1 = run(first)
+    monkeypatch.setenv(knob, "1" if (knob == "JSDR_ACQ3" and second.startswith("k_acq")) else "0")
+    d2, s2 = run(second)
+    differ = np.flatnonzero(np.any(s1 != s2, axis=1))
+    assert differ.size == 0, f"{differ.size} streams differ between {first} and {second}: first {differ[:8]}"
+    for s in range(0, S, 37):  # (the state doubles are not in the slot)
+        same_state(d1.state(s), d2.state(s))
+        assert d1.counters(s)["centreBin"] == d2.counters(s)["centreBin"]
+    for s in (0, S - 1):
+        iq = d_iq.to_host(np.int16, count=2 * L, offset_bytes=4 * (L * s))
+        o = O.Bpsk(do_fft=1, blen=4 * nsf)
+        o.receive_i16(iq)
+        assert np.array_equal(d1.bits(s), o.bits())
+        same_counters(d1.counters(s), o.counters())
+        same_state(d1.state(s), o.state())
+        assert np.array_equal(d2.bits(s), o.bits())
+
+
 @pytest.mark.parametrize("nsf,rate,do_up", [(4800, 48000, 0), (4800, 96000, 1), (4410, 44100, 0), (4410, 44100, 1)])
 def test_bpsk_fft_mode_two_frames_at_once(nsf, rate, do_up, monkeypatch):
     """Round 6: at 4800- and 4410-sample frames a workgroup takes frames f and f + 1 of its stream together (k_front_fftm2: two images
