@@ -803,12 +803,14 @@ def test_bpsk_fft_mode_front_end_choice():
     assert d.front_kernel_name() == "k_front_fftm"  # a full grid of streams: the fused kernel
 
 
-@pytest.mark.parametrize("nsf,knob,first,second", [
-    (2048, "JSDR_ACQ3", "k_acq_fwd", "k_front_fft"),      # three phases (tail on the side stream) against the fused kernel
-    (9600, "JSDR_ACQ3", "k_front_fftm", "k_acqm_fwd"),    # the fused kernel against three phases
-    (4800, "JSDR_FFTM_PAIR", "k_front_fftm2", "k_front_fftm"),  # two frames at once against one
+@pytest.mark.parametrize("nsf,knob,value,first,second", [
+    (2048, "JSDR_ACQ3", "0", "k_acq_fwd", "k_front_fft"),      # three phases (tail on the side stream) against the fused kernel
+    (9600, "JSDR_ACQ3", "1", "k_front_fftm", "k_acqm_fwd"),    # the fused kernel against three phases
+    (4800, "JSDR_FFTM_PAIR", "0", "k_front_fftm2", "k_front_fftm"),  # two frames at once against one
+    (2048, "JSDR_ACQG", "1", "k_acq_fwd", "k_acqg_pass"),      # the LDS kernels against the any-frame passes (radix-2 stages in global memory)
+    (9600, "JSDR_ACQG", "1", "k_front_fftm", "k_acqg_pass"),   # ... and the Stockham pass pairs
 ])
-def test_bpsk_fft_mode_front_ends_agree_at_config4_size(nsf, knob, first, second, monkeypatch):
+def test_bpsk_fft_mode_front_ends_agree_at_config4_size(nsf, knob, value, first, second, monkeypatch):
     """BASELINE config 4's shape in FFT-acquire mode -- 1024 streams x 1,048,576 samples generated on the device, one call -- through
     the default front end and through the other one the library has for that frame: EVERY stream's result slot (counters, the
     call's bits, every FECDecode result, state) byte for byte equal, and two sampled streams equal to the oracle.  Size-independent
@@ -842,7 +844,7 @@ def test_bpsk_fft_mode_front_ends_agree_at_config4_size(nsf, knob, first, second
         return d, slots.to_host(np.uint8).reshape(S, info["slot_bytes"]).copy()
 
     d1, s1 = run(first)
-    monkeypatch.setenv(knob, "1" if (knob == "JSDR_ACQ3" and second.startswith("k_acq")) else "0")
+    monkeypatch.setenv(knob, value)
     d2, s2 = run(second)
     differ = np.flatnonzero(np.any(s1 != s2, axis=1))
     assert differ.size == 0, f"{differ.size} streams differ between {first} and {second}: first {differ[:8]}"
