@@ -861,6 +861,27 @@ def test_bpsk_fft_mode_front_ends_agree_at_config4_size(nsf, knob, value, first,
         assert np.array_equal(d2.bits(s), o.bits())
 
 
+@pytest.mark.parametrize("nsf,rate", [(2048, 96000), (9600, 96000), (4800, 48000), (4410, 44100), (19200, 192000), (512, 48000), (17640, 176400)])
+def test_bpsk_fft_mode_degenerate_inputs(nsf, rate):
+    """what the reference's loop does with inputs that carry nothing: all-zero frames (the boxcar finds no maximum: binPos stays -1,
+    :439-442, and the centre bin sits at the clamp), full-scale square waves (+32767 / -32768: every FP64 product at its largest),
+    a DC offset that wraps the short (:282-288), one impulse in a silent call, and a carrier that switches off half way -- every
+    front end family against the oracle, frames in calls of 1, 2 and 3"""
+    nfr = 6
+    n = nsf * nfr
+    rng = np.random.default_rng(nsf)
+    zeros = np.zeros(2 * n, np.int16)
+    square = np.where((np.arange(2 * n) // 2) % 7 < 3, 32767, -32768).astype(np.int16)
+    impulse = zeros.copy()
+    impulse[2 * (nsf + 17)] = 32767
+    carrier = O.make_dbpsk_stream(401, 0, n, rate=rate, carrier_hz=rate / 8.0 + 50.0, noise_sigma=300.0)[0].copy()
+    carrier[2 * (3 * nsf + 11):] = 0
+    dc = np.full(2 * n, 30000, np.int16)  # + ic = 5000 wraps past 32767
+    for streams, ic, qc in (([zeros, square, impulse, carrier], 0, 0), ([dc, zeros], 5000, -5000)):
+        run_both(streams, n, [nsf, 2 * nsf, 3 * nsf], rate=rate, ic=ic, qc=qc, do_fft=1, blen=4 * nsf)
+        run_both(streams, n, [3 * nsf, nsf, 2 * nsf], rate=rate, ic=ic, qc=qc, do_fft=1, do_up=1, blen=4 * nsf)
+
+
 @pytest.mark.parametrize("nsf,rate,do_up", [(4800, 48000, 0), (4800, 96000, 1), (4410, 44100, 0), (4410, 44100, 1)])
 def test_bpsk_fft_mode_two_frames_at_once(nsf, rate, do_up, monkeypatch):
     """Round 6: at 4800- and 4410-sample frames a workgroup takes frames f and f + 1 of its stream together (k_front_fftm2: two images
