@@ -1375,7 +1375,20 @@ __global__ __launch_bounds__(FM_T) void k_front_fftm2(FftmArgs aa)
     const float2 *__restrict__ rawf = a.rawf + (long long)s * a.stride_pairs;
     double2 *dm = a.dm + (long long)s * a.dm_stride;
     const GblArr g = gbl_arr(a.tw);
+    // diagnostics (JSDR_FFT_PHASECLK=1): thread 0 of stream 0 accumulates the clock ticks of every phase (k_front_fftm's slots)
+    long long *clk = reinterpret_cast<long long *>(twL + aa.lds_tw);  // the 64 spare bytes behind the tables
+    long long tprev = 0;
+    const bool timing = a.phase_clk != nullptr && s == 0 && tid == 0;
+    if (timing)
+        for (int k = 0; k < 8; k++) clk[k] = 0;
+#define PHASE(k)                                     \
+    if (timing) {                                    \
+        const long long now_ = (long long)clock64(); \
+        clk[k] += now_ - tprev;                      \
+        tprev = now_;                                \
+    }
     __syncthreads();
+    if (timing) tprev = (long long)clock64();
 
     for (int f = 0; f < a.nframes; f += 2) {
         const bool two = f + 1 < a.nframes;
@@ -1433,6 +1446,7 @@ __global__ __launch_bounds__(FM_T) void k_front_fftm2(FftmArgs aa)
             fm_pass<7, NN, 90, LdsArr, 2>(XL, t + 116, NN, 90, 0u, tf);
             fm_passr_band<7, NN, 630, GblArr, 2>(XL, g + 746, end + 102, tf);
         }
+        PHASE(1)  // (with the load: the first pass comes straight from the samples)
         // ---- |X| (:425-427) over the band the boxcar reads, both images
         {
             const int cnt = end - 24 - pbase;
@@ -1444,6 +1458,7 @@ __global__ __launch_bounds__(FM_T) void k_front_fftm2(FftmArgs aa)
             }
         }
         __syncthreads();
+        PHASE(6)
         // ---- boxcar + first maximum per image (:433-442): a thread's items of one image ascend
         double bestv[2] = {0.0, 0.0};
         int besti[2] = {-1, -1};
@@ -1500,6 +1515,7 @@ __global__ __launch_bounds__(FM_T) void k_front_fftm2(FftmArgs aa)
             }
         }
         __syncthreads();
+        PHASE(7)
         // ---- centre-bin rule (:444-453) for frame f, then for frame f + 1, by every thread on the same values
         int cb[2];
 #pragma unroll
@@ -1536,6 +1552,7 @@ __global__ __launch_bounds__(FM_T) void k_front_fftm2(FftmArgs aa)
             }
             cb[im] = centreBin;
         }
+        PHASE(2)
         // ---- 204 bins around each frame's centre to bin 0 of a zeroed array (:458), inverse transform (:459): passes 1-3 from the
         // bins, [3, 5], the last pass real parts only, scaled, compact
         if constexpr (NN == 4800) {
@@ -1550,6 +1567,7 @@ __global__ __launch_bounds__(FM_T) void k_front_fftm2(FftmArgs aa)
             fm_pass<7, NN, 90, LdsArr, 2>(XL, t + 116, NN, 90, 0u, tf);
             fm_passr_real<7, NN, 630, 1, GblArr, 2>(XL, g + 746, norm, tf, hist);
         }
+        PHASE(4)
         double *Rb0 = reinterpret_cast<double *>(smem);
         double *Rb1 = Rb0 + 2 * n;
         // (frame f + 1's windows reach back into frame f's last 26 samples)
@@ -1598,12 +1616,16 @@ __global__ __launch_bounds__(FM_T) void k_front_fftm2(FftmArgs aa)
         }
         if (tf < 26) hist[tf] = (two ? Rb1 : Rb0)[FM_RB0 + n - 26 + tf];
         __syncthreads();
+        PHASE(5)
     }
+#undef PHASE
     if (tid < 26) sp->hist[tid] = hist[tid];
     if (tid == 0) {
         sp->avePeakPower = avePeakPower;
         sp->aveCentreBin = aveCentreBin;
         sp->centreBin = centreBin;
+        if (timing)
+            for (int k = 0; k < 8; k++) a.phase_clk[k] = clk[k];
     }
 }
 
