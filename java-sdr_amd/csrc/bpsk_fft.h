@@ -89,6 +89,46 @@ __device__ __forceinline__ void boxcar_pair(const double2 *w, double &a0, double
     boxcar_chunk<0>(w, first, a0, a1, prev_y);
 }
 
+// The wave's FIRST MAXIMUM of the boxcar search (:439-442): every lane brings its own best (value > 0 at index >= 0, or 0.0 at -1);
+// out comes, in every lane, the largest value and the LOWEST index that holds it (or 0.0 / -1).  DPP row shifts and row broadcasts
+// (an instruction each) instead of __shfl_xor's round trips through the LDS crossbar: a 64-lane reduction of (double, int) by
+// shuffles is 18 dependent ds_bpermute, ~2000 cycles with nothing to cover them -- twice a frame in the mixed-radix front ends.
+__device__ __forceinline__ void wave_first_max(double &bestv, int &besti)
+{
+    double v = bestv;
+#define JSDR_DPP_MAX(ctrl, rmask)                                                                                \
+    {                                                                                                             \
+        const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), ctrl, rmask, 0xf, false); \
+        const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), ctrl, rmask, 0xf, false); \
+        v = fmax(v, __hiloint2double(hi, lo));                                                                    \
+    }
+    JSDR_DPP_MAX(0x111, 0xf)  // row_shr:1
+    JSDR_DPP_MAX(0x112, 0xf)  // row_shr:2
+    JSDR_DPP_MAX(0x114, 0xf)  // row_shr:4
+    JSDR_DPP_MAX(0x118, 0xf)  // row_shr:8 -- lane 15 of every row holds its row's maximum
+    JSDR_DPP_MAX(0x142, 0xa)  // row_bcast:15 into rows 1 and 3
+    JSDR_DPP_MAX(0x143, 0xc)  // row_bcast:31 into rows 2 and 3 -- lane 63 holds the wave's
+#undef JSDR_DPP_MAX
+    const double mv = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+    // the lowest index among the lanes that hold it (a lane's index ascends with its rounds, not with the lane: no "first lane" here)
+    int c = (besti >= 0 && bestv == mv) ? besti : 0x7fffffff;
+#define JSDR_DPP_MIN(ctrl, rmask)                                                    \
+    {                                                                                 \
+        const int o = __builtin_amdgcn_update_dpp(c, c, ctrl, rmask, 0xf, false);    \
+        c = o < c ? o : c;                                                            \
+    }
+    JSDR_DPP_MIN(0x111, 0xf)
+    JSDR_DPP_MIN(0x112, 0xf)
+    JSDR_DPP_MIN(0x114, 0xf)
+    JSDR_DPP_MIN(0x118, 0xf)
+    JSDR_DPP_MIN(0x142, 0xa)
+    JSDR_DPP_MIN(0x143, 0xc)
+#undef JSDR_DPP_MIN
+    const int mi = __builtin_amdgcn_readlane(c, 63);
+    bestv = mi == 0x7fffffff ? 0.0 : mv;
+    besti = mi == 0x7fffffff ? -1 : mi;
+}
+
 int launch_front_fft(const FftFrontArgs &a, int nstreams, hipStream_t st);
 // round 6 (bpsk_acq.hip): the same front end in three phases -- forward transform + boxcar per frame, one scan per stream,
 // inverse transform + RxDownSample per frame -- for calls of two or more frames per stream; frames of 1024 .. 8192 samples

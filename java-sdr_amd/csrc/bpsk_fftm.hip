@@ -1166,15 +1166,7 @@ __global__ __launch_bounds__(FM_T) void k_front_fftm(FftmArgs aa)
                 }
             }
         }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            const double ov = __shfl_xor(bestv, off, 64);
-            const int oi = __shfl_xor(besti, off, 64);
-            if (oi >= 0 && (ov > bestv || (ov == bestv && (besti < 0 || oi < besti)))) {
-                bestv = ov;
-                besti = oi;
-            }
-        }
+        wave_first_max(bestv, besti);
         if (lane == 0) {
             redv[wave] = bestv;
             redi[wave] = besti;
@@ -1192,15 +1184,7 @@ __global__ __launch_bounds__(FM_T) void k_front_fftm(FftmArgs aa)
                 mv = redv[lane];
                 mi = redi[lane];
             }
-#pragma unroll
-            for (int off = 8; off >= 1; off >>= 1) {
-                const double ov = __shfl_xor(mv, off, 64);
-                const int oi = __shfl_xor(mi, off, 64);
-                if (oi >= 0 && (ov > mv || (ov == mv && (mi < 0 || oi < mi)))) {
-                    mv = ov;
-                    mi = oi;
-                }
-            }
+            wave_first_max(mv, mi);
             const double maxBin = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(mv)),
                                                    __builtin_amdgcn_readfirstlane(__double2loint(mv)));
             const int binPos = __builtin_amdgcn_readfirstlane(mi);
@@ -1500,15 +1484,7 @@ __global__ __launch_bounds__(FM_T) void k_front_fftm2(FftmArgs aa)
         }
 #pragma unroll
         for (int im = 0; im < 2; im++) {
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) {
-                const double ov = __shfl_xor(bestv[im], off, 64);
-                const int oi = __shfl_xor(besti[im], off, 64);
-                if (oi >= 0 && (ov > bestv[im] || (ov == bestv[im] && (besti[im] < 0 || oi < besti[im])))) {
-                    bestv[im] = ov;
-                    besti[im] = oi;
-                }
-            }
+            wave_first_max(bestv[im], besti[im]);
             if (lane == 0) {
                 redv[im * 16 + wave] = bestv[im];
                 redi[im * 16 + wave] = besti[im];
@@ -1526,15 +1502,7 @@ __global__ __launch_bounds__(FM_T) void k_front_fftm2(FftmArgs aa)
                 mv = redv[im * 16 + lane];
                 mi = redi[im * 16 + lane];
             }
-#pragma unroll
-            for (int off = 8; off >= 1; off >>= 1) {
-                const double ov = __shfl_xor(mv, off, 64);
-                const int oi = __shfl_xor(mi, off, 64);
-                if (oi >= 0 && (ov > mv || (ov == mv && (mi < 0 || oi < mi)))) {
-                    mv = ov;
-                    mi = oi;
-                }
-            }
+            wave_first_max(mv, mi);
             const double maxBin = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(mv)),
                                                    __builtin_amdgcn_readfirstlane(__double2loint(mv)));
             const int binPos = __builtin_amdgcn_readfirstlane(mi);
@@ -1747,15 +1715,7 @@ __global__ __launch_bounds__(FM_T) void k_acqm_fwd(FftmArgs aa, AcqArgs a)
                 }
             }
         }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            const double ov = __shfl_xor(bestv, off, 64);
-            const int oi = __shfl_xor(besti, off, 64);
-            if (oi >= 0 && (ov > bestv || (ov == bestv && (besti < 0 || oi < besti)))) {
-                bestv = ov;
-                besti = oi;
-            }
-        }
+        wave_first_max(bestv, besti);
         if (lane == 0) {
             redv[wave] = bestv;
             redi[wave] = besti;
@@ -2159,15 +2119,7 @@ __global__ __launch_bounds__(FM_T) void k_front_fft2x(Fft2xArgs aa)
                 }
             }
         }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            const double ov = __shfl_xor(bestv, off, 64);
-            const int oi = __shfl_xor(besti, off, 64);
-            if (oi >= 0 && (ov > bestv || (ov == bestv && (besti < 0 || oi < besti)))) {
-                bestv = ov;
-                besti = oi;
-            }
-        }
+        wave_first_max(bestv, besti);
         if (lane == 0) {
             redv[wave] = bestv;
             redi[wave] = besti;
@@ -2184,15 +2136,7 @@ __global__ __launch_bounds__(FM_T) void k_front_fft2x(Fft2xArgs aa)
                 mv = redv[lane];
                 mi = redi[lane];
             }
-#pragma unroll
-            for (int off = 8; off >= 1; off >>= 1) {
-                const double ov = __shfl_xor(mv, off, 64);
-                const int oi = __shfl_xor(mi, off, 64);
-                if (oi >= 0 && (ov > mv || (ov == mv && (mi < 0 || oi < mi)))) {
-                    mv = ov;
-                    mi = oi;
-                }
-            }
+            wave_first_max(mv, mi);
             const double maxBin = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(mv)),
                                                    __builtin_amdgcn_readfirstlane(__double2loint(mv)));
             const int binPos = __builtin_amdgcn_readfirstlane(mi);
