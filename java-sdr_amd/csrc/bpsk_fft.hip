@@ -479,15 +479,7 @@ __global__ __launch_bounds__(256, (LOGN <= 11 ? JSDR_FF_MINWG11 : (LOGN == 12 ? 
                 }
             }
         }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            const double ov = __shfl_xor(bestv, off, 64);
-            const int oi = __shfl_xor(besti, off, 64);
-            if (oi >= 0 && (ov > bestv || (ov == bestv && (besti < 0 || oi < besti)))) {
-                bestv = ov;
-                besti = oi;
-            }
-        }
+        wave_first_max(bestv, besti);  // (DPP: bpsk_fft.h)
         if (lane == 0) {
             redv[wave] = bestv;
             redi[wave] = besti;
