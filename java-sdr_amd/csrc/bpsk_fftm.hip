@@ -606,6 +606,64 @@ __device__ __attribute__((noinline)) void fm_first2_from_raw(LdsArr X, const int
     __syncthreads();
 }
 
+// The same in two steps (round 6, n = 9600): the frame's samples are REQUESTED a phase early -- at the top of the previous frame's
+// RxDownSample, whose loop runs for longer than the round trip to memory takes and waits for nothing of its own -- and the two passes
+// find them in registers.  With one workgroup a CU nothing else covers that latency: it was paid in full at the top of every frame.
+struct FmRaw16 {
+    int w[16];
+    f2v wf[16];
+};
+template <int NN, bool F32IN>
+__device__ __forceinline__ void fm_first2_request(FmRaw16 &r, const int *raw_, const float2 *rawf_, int tid)
+{
+    constexpr int ng = NN / 16, nb1 = NN / 4;
+    gbl_i32 *raw = (gbl_i32 *)(unsigned long long)raw_;
+    gbl_f2v *rawf = (gbl_f2v *)(unsigned long long)rawf_;
+    const int g = tid < ng ? tid : ng - 1;
+#pragma unroll
+    for (int j2 = 0; j2 < 4; j2++)
+#pragma unroll
+        for (int j1 = 0; j1 < 4; j1++) {
+            if (F32IN)
+                r.wf[4 * j2 + j1] = rawf[g + j2 * ng + j1 * nb1];
+            else
+                r.w[4 * j2 + j1] = raw[g + j2 * ng + j1 * nb1];
+        }
+}
+template <int NN, bool F32IN, class TW2>
+__device__ __forceinline__ void fm_first2_from_regs(LdsArr X, const FmRaw16 &r, int ic, int qc, TW2 tw2, int tid)
+{
+    constexpr int ng = NN / 16;
+    const bool dc = (ic != 0) || (qc != 0);
+    if (tid < ng) {
+        double2 v[4][4];
+#pragma unroll
+        for (int j2 = 0; j2 < 4; j2++) {
+#pragma unroll
+            for (int j1 = 0; j1 < 4; j1++) {
+                if (F32IN)
+                    v[j2][j1] = make_double2((double)r.wf[4 * j2 + j1].x, (double)r.wf[4 * j2 + j1].y);
+                else
+                    fm_convert(r.w[4 * j2 + j1], ic, qc, dc, v[j2][j1].x, v[j2][j1].y);
+            }
+            dft_r<4>(v[j2]);
+        }
+#pragma unroll
+        for (int q1 = 0; q1 < 4; q1++) {
+            double2 u[4];
+#pragma unroll
+            for (int j2 = 0; j2 < 4; j2++) {
+                u[j2] = v[j2][q1];
+                if (j2 >= 1) u[j2] = cdmul(u[j2], tw2[q1 * j2]);
+            }
+            dft_r<4>(u);
+#pragma unroll
+            for (int q2 = 0; q2 < 4; q2++) X[fm_swz(16 * tid + q1 + 4 * q2)] = u[q2];
+        }
+    }
+    __syncthreads();
+}
+
 // The same for one half of a frame of 2 NN samples (k_front_fft2x): the frame's radix-2 first pass, X_c[h] = x[h] +/- x[h + NN]
 // (dft_r<2>), feeds the half's first two passes directly -- 32 samples per thread in flight at once (as a load / convert /
 // store loop the half paid the HBM latency thirteen times).  ODD: the half of the odd bins, whose passes multiply EVERY
@@ -1084,6 +1142,8 @@ __global__ __launch_bounds__(FM_T) void k_front_fftm(FftmArgs aa)
     }
     __syncthreads();
     if (timing) tprev = (long long)clock64();
+    FmRaw16 pre;  // n = 9600: the next frame's samples, requested during RxDownSample
+    if (n == 9600) fm_first2_request<9600, F32IN>(pre, raw, rawf, tid);
 
     for (int f = 0; f < a.nframes; f++) {
         const long long t0 = (long long)f * n;  // call-relative index of the frame's first sample
@@ -1094,7 +1154,7 @@ __global__ __launch_bounds__(FM_T) void k_front_fftm(FftmArgs aa)
         const bool fused_first = (n == 9600 || n == 4800);
         const bool compact = fused_first || n == 4410;  // the inverse from the bins, compact real samples, windows as aligned runs
         if (n == 9600) {
-            fm_first2_from_raw<9600, F32IN>(XL, raw + t0, rawf + t0, a.ic, a.qc, lds_arr(twL) + 4, tf);
+            fm_first2_from_regs<9600, F32IN>(XL, pre, a.ic, a.qc, lds_arr(twL) + 4, tf);
         } else if (n == 4800) {
             fm_first_from_raw<4800, F32IN>(XL, raw + t0, rawf + t0, a.ic, a.qc, tf);
         } else {
@@ -1217,6 +1277,8 @@ __global__ __launch_bounds__(FM_T) void k_front_fftm(FftmArgs aa)
             // ---- RxDownSample(re, re) (:461-463, :470-492) from the compact samples: sample t of the frame at double slot
             // FM_RB0 + t, the previous frame's last 26 in front of them -- every window is one contiguous run
             {
+                // (the last frame asks for itself again: a request under a branch would make every later wait the minimum over both paths)
+                if (n == 9600) fm_first2_request<9600, F32IN>(pre, raw + (f + 1 < a.nframes ? t0 + n : t0), rawf + (f + 1 < a.nframes ? t0 + n : t0), tf);
                 const double *Rb = reinterpret_cast<const double *>(smem);
                 long long jlo = (t0 - a.first_out + D - 1) / D;
                 if (t0 <= a.first_out) jlo = 0;
