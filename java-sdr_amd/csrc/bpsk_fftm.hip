@@ -664,6 +664,57 @@ __device__ __forceinline__ void fm_first2_from_regs(LdsArr X, const FmRaw16 &r, 
     __syncthreads();
 }
 
+// fm_first_from_raw<NN, F32IN, 2> in the same two steps (the paired kernel): d1 = where the second image's frame starts relative to
+// the first's (NN, or 0 when the call's last frame stands alone: the second image is then a copy, computed and dropped)
+template <int NN, bool F32IN>
+__device__ __forceinline__ void fm_first_request2(FmRaw16 &r, const int *raw_, const float2 *rawf_, int d1, int tid)
+{
+    constexpr int nb = NN / 4, ITERS = (2 * nb + FM_T - 1) / FM_T;
+    static_assert(ITERS * 4 <= 16, "sixteen samples a thread");
+    gbl_i32 *raw = (gbl_i32 *)(unsigned long long)raw_;
+    gbl_f2v *rawf = (gbl_f2v *)(unsigned long long)rawf_;
+#pragma unroll
+    for (int it = 0; it < ITERS; it++) {
+        int bb = it * FM_T + tid;
+        bb = bb < 2 * nb ? bb : 2 * nb - 1;
+        const int img = bb >= nb ? 1 : 0;
+        const int b = bb - img * nb + img * d1;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (F32IN)
+                r.wf[4 * it + j] = rawf[b + j * nb];
+            else
+                r.w[4 * it + j] = raw[b + j * nb];
+        }
+    }
+}
+template <int NN, bool F32IN>
+__device__ __forceinline__ void fm_first_from_regs2(LdsArr X0, const FmRaw16 &r, int ic, int qc, int tid)
+{
+    constexpr int nb = NN / 4, ITERS = (2 * nb + FM_T - 1) / FM_T;
+#pragma unroll
+    for (int it = 0; it < ITERS; it++) {
+        const int bb = it * FM_T + tid;
+        const int img = bb >= nb ? 1 : 0;
+        const int b = bb - img * nb;
+        const LdsArr X = X0 + img * NN;
+        if (bb < 2 * nb) {
+            double2 v[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (F32IN)
+                    v[j] = make_double2((double)r.wf[4 * it + j].x, (double)r.wf[4 * it + j].y);
+                else
+                    v[j] = make_double2((double)i16_to_float_java(java_short_add((int)(short)(r.w[4 * it + j] & 0xffff), ic)),
+                                        (double)i16_to_float_java(java_short_add(r.w[4 * it + j] >> 16, qc)));
+            }
+            dft_r<4>(v);
+            fm_store4_rotated(X, b, v, tid);
+        }
+    }
+    __syncthreads();
+}
+
 // The same for one half of a frame of 2 NN samples (k_front_fft2x): the frame's radix-2 first pass, X_c[h] = x[h] +/- x[h + NN]
 // (dft_r<2>), feeds the half's first two passes directly -- 32 samples per thread in flight at once (as a load / convert /
 // store loop the half paid the HBM latency thirteen times).  ODD: the half of the odd bins, whose passes multiply EVERY
@@ -1435,6 +1486,27 @@ __global__ __launch_bounds__(FM_T) void k_front_fftm2(FftmArgs aa)
     }
     __syncthreads();
     if (timing) tprev = (long long)clock64();
+    // the next pair's samples are requested at the top of RxDownSample and found in registers here (see fm_first2_request)
+    FmRaw16 pre;
+    auto request = [&](long long t0q, bool two_q, int t_) {
+        if constexpr (NN == 4800) {
+            fm_first_request2<NN, F32IN>(pre, raw + t0q, rawf + t0q, two_q ? NN : 0, t_);
+        } else {
+            constexpr int NLD = (2 * NN + FM_T - 1) / FM_T;
+            static_assert(NLD <= 16, "sixteen samples a thread");
+#pragma unroll
+            for (int q = 0; q < NLD; q++) {
+                int t = t_ + q * FM_T;
+                t = t < 2 * NN ? t : 2 * NN - 1;
+                if (!two_q && t >= NN) t -= NN;  // (a single last frame: the second image is a copy)
+                if (F32IN)
+                    pre.wf[q] = reinterpret_cast<const f2v *>(rawf)[t0q + t];
+                else
+                    pre.w[q] = raw[t0q + t];
+            }
+        }
+    };
+    request(0, a.nframes >= 2, tid);
 
     for (int f = 0; f < a.nframes; f += 2) {
         const bool two = f + 1 < a.nframes;
@@ -1443,13 +1515,7 @@ __global__ __launch_bounds__(FM_T) void k_front_fftm2(FftmArgs aa)
         const long long t0 = (long long)f * n;  // call-relative index of frame f's first sample
         // ---- both frames -> images (:416-421), forward transform (:422-423), the last pass for the bins below end + 102 only
         if constexpr (NN == 4800) {
-            if (two) {
-                fm_first_from_raw<NN, F32IN, 2>(XL, raw + t0, rawf + t0, a.ic, a.qc, tf);  // (with the first pass)
-            } else {
-                fm_first_from_raw<NN, F32IN, 1>(XL, raw + t0, rawf + t0, a.ic, a.qc, tf);
-                for (int i = tf; i < n; i += FM_T) X[n + i] = X[i];  // (the pair's second half: a copy, computed and dropped)
-                __syncthreads();
-            }
+            fm_first_from_regs2<NN, F32IN>(XL, pre, a.ic, a.qc, tf);  // (with the first pass; a single last frame comes twice)
             const LdsArr t = lds_arr(twL);
             fm_pass2<4, 4, NN, 4, false, LdsArr, LdsArr, 2>(XL, t + 4, t + 20, NN, 4, 0u, tf);
             fm_pass2<3, 5, NN, 64, false, LdsArr, GblArr, 2>(XL, t + 84, g + 276, NN, 64, 0u, tf);
@@ -1457,32 +1523,19 @@ __global__ __launch_bounds__(FM_T) void k_front_fftm2(FftmArgs aa)
         } else {
             // natural order; frame f + 1 follows frame f in memory as image 1 follows image 0
             constexpr int NLD = (2 * NN + FM_T - 1) / FM_T;
-            const int tot = two ? 2 * n : n;
-            int w[NLD];
-            float2 wf[NLD];
-#pragma unroll
-            for (int q = 0; q < NLD; q++) {
-                int t = tf + q * FM_T;
-                t = t < tot ? t : tot - 1;
-                if (F32IN)
-                    wf[q] = rawf[t0 + t];
-                else
-                    w[q] = raw[t0 + t];
-            }
 #pragma unroll
             for (int q = 0; q < NLD; q++) {
                 const int t = tf + q * FM_T;
-                if (t < tot) {
+                if (t < 2 * n) {
                     double di, dq;
                     if (F32IN) {
-                        di = (double)wf[q].x;
-                        dq = (double)wf[q].y;
+                        di = (double)pre.wf[q].x;
+                        dq = (double)pre.wf[q].y;
                     } else {
-                        di = (double)i16_to_float_java(java_short_add((int)(short)(w[q] & 0xffff), a.ic));
-                        dq = (double)i16_to_float_java(java_short_add(w[q] >> 16, a.qc));
+                        di = (double)i16_to_float_java(java_short_add((int)(short)(pre.w[q] & 0xffff), a.ic));
+                        dq = (double)i16_to_float_java(java_short_add(pre.w[q] >> 16, a.qc));
                     }
                     X[t] = make_double2(di, dq);
-                    if (!two) X[n + t] = make_double2(di, dq);
                 }
             }
             __syncthreads();
@@ -1604,6 +1657,11 @@ __global__ __launch_bounds__(FM_T) void k_front_fftm2(FftmArgs aa)
         if (tf < 26) Rb1[FM_RB0 - 26 + tf] = Rb0[FM_RB0 + n - 26 + tf];
         __syncthreads();
         // ---- RxDownSample(re, re) (:461-463, :470-492) from the compact samples of frame f, then of frame f + 1
+        {
+            // (the last pair asks for itself again: a request under a branch would make every later wait the minimum over both paths)
+            const bool more = f + 2 < a.nframes;
+            request(more ? t0 + 2 * (long long)n : t0, more ? f + 3 < a.nframes : two, tf);
+        }
 #pragma unroll
         for (int im = 0; im < 2; im++) {
             if (im == 1 && !two) break;
